@@ -1,0 +1,202 @@
+"""numpy front-end of the C oracle (``oracle/moss_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
+
+``forward()`` / ``backward()`` compose the stage functions in the order of the reference's
+``CudaRasterizer::Rasterizer::forward`` / ``::backward``
+(submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu:198-341, :345-447) with the
+allocation / zero-fill / P==0 behaviour of ``RasterizeGaussiansCUDA`` / ``RasterizeGaussiansBackwardCUDA``
+(submodules/diff-gaussian-rasterization/rasterize_points.cu:35-119, :121-206).
+Every intermediate (radii, tiles_touched, offsets, unsorted/sorted keys, ranges, final_T, n_contrib ...)
+is returned so the HIP path can be compared stage by stage.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmoss_oracle.so")
+_lib = None
+
+BLOCK_X = 16
+BLOCK_Y = 16
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds).  Returns the path of the shared object."""
+    src = os.path.join(_HERE, "moss_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_preprocess.restype = C.c_int
+        _lib.oracle_inclusive_sum.restype = C.c_int
+        _lib.oracle_get_higher_msb.restype = C.c_uint32
+        _lib.oracle_get_higher_msb.argtypes = [C.c_uint32]
+    return _lib
+
+
+def _p(a):
+    """ctypes pointer of a numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _opt(a):
+    """reference convention: an absent tensor is an EMPTY tensor whose data pointer is null
+    (submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py:200-210)."""
+    if a is None:
+        return None
+    a = np.asarray(a)
+    return None if a.size == 0 else _f32(a)
+
+
+def tile_grid(W, H):
+    return (W + BLOCK_X - 1) // BLOCK_X, (H + BLOCK_Y - 1) // BLOCK_Y
+
+
+def get_higher_msb(n: int) -> int:
+    return int(lib().oracle_get_higher_msb(C.c_uint32(n)))
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    present = np.zeros(P, dtype=np.uint8)
+    if P:
+        lib().oracle_mark_visible(C.c_int(P), _p(means3D), _p(_f32(viewmatrix)), _p(_f32(projmatrix)), _p(present))
+    return present.astype(bool)
+
+
+def dist2(points):
+    points = _f32(points)
+    P = points.shape[0]
+    out = np.zeros(P, dtype=np.float32)
+    if P:
+        lib().oracle_dist2(C.c_int(P), _p(points), _p(out))
+    return out
+
+
+def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+            viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered=False,
+            want_margin=True):
+    """Returns a namespace with the reference's outputs (color (3,H,W), depth (1,H,W), alpha (1,H,W),
+    radii (P,), num_rendered) and every intermediate."""
+    L = lib()
+    bg = _f32(bg); means3D = _f32(means3D); opacities = _f32(opacities)
+    viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
+    colors_precomp = _opt(colors_precomp); scales = _opt(scales); rotations = _opt(rotations)
+    cov3D_precomp = _opt(cov3D_precomp); sh = _opt(sh)
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise ValueError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:57-59
+    P = means3D.shape[0]
+    M = 0 if sh is None else sh.shape[1]
+    N = W * H
+    gx, gy = tile_grid(W, H)
+    o = SimpleNamespace(P=P, W=W, H=H, M=M, D=degree, grid=(gx, gy))
+    o.color = np.zeros((3, H, W), np.float32)
+    o.depth = np.zeros((1, H, W), np.float32)
+    o.alpha = np.zeros((1, H, W), np.float32)
+    o.radii = np.zeros(P, np.int32)
+    o.num_rendered = 0
+    if P == 0:                                                              # rasterize_points.cu:83
+        return o
+    o.means2D = np.zeros((P, 2), np.float32)
+    o.depths = np.zeros(P, np.float32)
+    o.cov3D = np.zeros((P, 6), np.float32)
+    o.rgb = np.zeros((P, 3), np.float32)
+    o.conic_opacity = np.zeros((P, 4), np.float32)
+    o.tiles_touched = np.zeros(P, np.uint32)
+    o.clamped = np.zeros((P, 3), np.uint8)
+    err = L.oracle_preprocess(
+        C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D), _p(scales), C.c_float(scale_modifier), _p(rotations),
+        _p(opacities), _p(sh), _p(cov3D_precomp), _p(colors_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
+        C.c_int(W), C.c_int(H), C.c_float(tan_fovx), C.c_float(tan_fovy), C.c_int(int(prefiltered)),
+        _p(o.radii), _p(o.means2D), _p(o.depths), _p(o.cov3D), _p(o.rgb), _p(o.conic_opacity),
+        _p(o.tiles_touched), _p(o.clamped))
+    if err:
+        raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    o.point_offsets = np.zeros(P, np.uint32)
+    R = L.oracle_inclusive_sum(C.c_int(P), _p(o.tiles_touched), _p(o.point_offsets))
+    o.num_rendered = R
+    o.keys_unsorted = np.zeros(R, np.uint64)
+    o.values_unsorted = np.zeros(R, np.uint32)
+    L.oracle_duplicate_with_keys(C.c_int(P), _p(o.means2D), _p(o.depths), _p(o.point_offsets),
+                                 _p(o.keys_unsorted), _p(o.values_unsorted), _p(o.radii), C.c_int(W), C.c_int(H))
+    o.sort_bits = 32 + get_higher_msb(gx * gy)
+    o.point_list_keys = np.zeros(R, np.uint64)
+    o.point_list = np.zeros(R, np.uint32)
+    L.oracle_sort_pairs(C.c_int(R), _p(o.keys_unsorted), _p(o.values_unsorted), _p(o.point_list_keys),
+                        _p(o.point_list), C.c_int(o.sort_bits))
+    o.ranges = np.zeros((gx * gy, 2), np.uint32)
+    L.oracle_identify_tile_ranges(C.c_int(R), _p(o.point_list_keys), _p(o.ranges), C.c_int(gx * gy))
+    o.final_T = np.zeros(N, np.float32)
+    o.n_contrib = np.zeros(N, np.uint32)
+    o.margin = np.ones(N, np.float32) if want_margin else None
+    o.features = colors_precomp if colors_precomp is not None else o.rgb    # rasterizer_impl.cu:323
+    L.oracle_render_forward(C.c_int(W), C.c_int(H), _p(o.ranges), _p(o.point_list), _p(o.means2D),
+                            _p(np.ascontiguousarray(o.features)), _p(o.depths), _p(o.conic_opacity), _p(bg),
+                            _p(o.color), _p(o.depth), _p(o.alpha), _p(o.final_T), _p(o.n_contrib), _p(o.margin))
+    return o
+
+
+def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+             projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos):
+    """``fw`` is the namespace returned by :func:`forward`.  Returns the reference's 8 gradient arrays
+    (rasterize_points.cu:205) plus dL_dconic as a namespace."""
+    L = lib()
+    bg = _f32(bg); means3D = _f32(means3D)
+    viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
+    colors_precomp = _opt(colors_precomp); scales = _opt(scales); rotations = _opt(rotations)
+    cov3D_precomp = _opt(cov3D_precomp); sh = _opt(sh)
+    P = means3D.shape[0]
+    M = 0 if sh is None else sh.shape[1]
+    H, W = fw.H, fw.W
+    g = SimpleNamespace()
+    g.dL_dmeans3D = np.zeros((P, 3), np.float32)                            # rasterize_points.cu:158-166
+    g.dL_dmeans2D = np.zeros((P, 3), np.float32)
+    g.dL_dcolors = np.zeros((P, 3), np.float32)
+    g.dL_dconic = np.zeros((P, 2, 2), np.float32)
+    g.dL_dopacity = np.zeros((P, 1), np.float32)
+    g.dL_dcov3D = np.zeros((P, 6), np.float32)
+    g.dL_dsh = np.zeros((P, M, 3), np.float32)
+    g.dL_dscales = np.zeros((P, 3), np.float32)
+    g.dL_drotations = np.zeros((P, 4), np.float32)
+    if P == 0:
+        return g
+    dpix = _f32(dL_dout_color).reshape(3, H, W)
+    ddep = _f32(dL_dout_depth).reshape(H * W)
+    dalp = _f32(dL_dout_alpha).reshape(H * W)
+    color_ptr = colors_precomp if colors_precomp is not None else fw.rgb    # rasterizer_impl.cu:397
+    L.oracle_render_backward(C.c_int(P), C.c_int(W), C.c_int(H), _p(fw.ranges), _p(fw.point_list), _p(bg),
+                             _p(fw.means2D), _p(fw.conic_opacity), _p(np.ascontiguousarray(color_ptr)), _p(fw.depths),
+                             _p(fw.final_T), _p(fw.n_contrib), _p(dpix), _p(ddep), _p(dalp),
+                             _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors))
+    cov3D_ptr = cov3D_precomp if cov3D_precomp is not None else fw.cov3D    # rasterizer_impl.cu:424
+    focal_y = np.float32(H) / (np.float32(2.0) * np.float32(tan_fovy))      # rasterizer_impl.cu:388-389
+    focal_x = np.float32(W) / (np.float32(2.0) * np.float32(tan_fovx))
+    L.oracle_compute_cov2d_backward(C.c_int(P), _p(means3D), _p(fw.radii), _p(np.ascontiguousarray(cov3D_ptr)),
+                                    C.c_float(focal_x), C.c_float(focal_y), C.c_float(tan_fovx), C.c_float(tan_fovy),
+                                    _p(viewmatrix), _p(g.dL_dconic), _p(g.dL_dmeans3D), _p(g.dL_dcov3D))
+    L.oracle_preprocess_backward(C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D), _p(fw.radii), _p(sh),
+                                 _p(fw.clamped), _p(scales), _p(rotations), C.c_float(scale_modifier), _p(projmatrix),
+                                 _p(campos), _p(g.dL_dmeans2D), _p(g.dL_dmeans3D), _p(g.dL_dcolors), _p(g.dL_dcov3D),
+                                 _p(g.dL_dsh), _p(g.dL_dscales), _p(g.dL_drotations))
+    return g
