@@ -1,0 +1,178 @@
+/*
+ * moss_raster.h -- C ABI of the MI355X (gfx950) differentiable Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function of the reference's native API
+ * (3DHumanRehab/MOSS, submodules/diff-gaussian-rasterization = "DGR/", submodules/simple-knn = "SKNN/"),
+ * with the same arguments in the same order and the same meaning; only C++-isms are flattened:
+ *   - std::function<char*(size_t)> buffer growers  ->  a C callback + user pointer (moss_alloc_fn),
+ *   - exceptions                                    ->  negative return code + moss_last_error(),
+ *   - the implicit CUDA legacy default stream       ->  an explicit hipStream_t passed as void*.
+ * All pointers are DEVICE pointers to contiguous fp32 (int32 for radii) unless stated otherwise; an absent
+ * optional input is NULL (DGR/rasterize_points.cu passes the null data_ptr() of an empty tensor).
+ * No torch types appear here; the Python side (moss_amd/diff_gaussian_rasterization) binds it with ctypes.
+ *
+ * The three scratch buffers are opaque to the caller exactly as in the reference (their internal layout is
+ * this library's own); the caller must keep them alive and unmodified between forward and
+ * backward, as the reference's autograd ctx does (DGR/diff_gaussian_rasterization/__init__.py:97).
+ */
+#ifndef MOSS_RASTER_H
+#define MOSS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOSS_ABI_VERSION 1
+
+/* error codes (negative returns) */
+#define MOSS_ERR_INVALID_ARG   (-1)   /* bad shape / null where required (AT_ERROR in DGR/rasterize_points.cu:57-59) */
+#define MOSS_ERR_HIP           (-2)   /* a HIP runtime call or kernel failed (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:166-173) */
+#define MOSS_ERR_ALLOC         (-3)   /* an allocation callback returned NULL */
+#define MOSS_ERR_PREFILTERED   (-4)   /* a point was culled although `prefiltered` was set (__trap in auxiliary.h:156-160) */
+#define MOSS_ERR_UNSUPPORTED   (-5)   /* e.g. no colours for NUM_CHANNELS != 3 (DGR/cuda_rasterizer/rasterizer_impl.cu:244-247) */
+
+/* Replaces std::function<char*(size_t)> (DGR/cuda_rasterizer/rasterizer.h:32-34; grown by resizeFunctional,
+ * DGR/rasterize_points.cu:27-33).  Must return a device pointer to at least nbytes, 256-byte aligned, or NULL. */
+typedef char* (*moss_alloc_fn)(void* user, size_t nbytes);
+
+int moss_abi_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* moss_last_error(void);
+
+/*
+ * Replaces CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer.h:31-55,
+ * DGR/cuda_rasterizer/rasterizer_impl.cu:198-341).
+ *   P  number of Gaussians, D active SH degree (0..3), M stored SH coefficients per Gaussian (0 if shs==NULL).
+ *   background (3), means3D (P,3), shs (P,M,3) | colors_precomp (P,3), opacities (P),
+ *   scales (P,3) + rotations (P,4) | cov3D_precomp (P,6), viewmatrix/projmatrix (16, transposed = column-major),
+ *   cam_pos (3).   Outputs: out_color (3,H,W), out_depth (H,W), out_alpha (H,W), radii (P) int32 (may be NULL).
+ *   Outputs need NOT be pre-zeroed (the reference requires zero-filled tensors; every element is written here).
+ * Returns num_rendered >= 0 (the number of (Gaussian, tile) instances), or a negative error code.
+ * Performs ONE stream synchronisation (to size the binning buffer), like the reference's blocking read
+ * at rasterizer_impl.cu:283.  With debug != 0 the stream is synchronised and checked after every launch.
+ */
+int moss_raster_forward(
+    moss_alloc_fn geometry_alloc, void* geometry_user,
+    moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* opacities,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    float* out_color,
+    float* out_depth,
+    float* out_alpha,
+    int* radii,
+    int debug,
+    void* stream);
+
+/*
+ * Replaces CudaRasterizer::Rasterizer::backward (DGR/cuda_rasterizer/rasterizer.h:57-89,
+ * DGR/cuda_rasterizer/rasterizer_impl.cu:345-447).  R is the value forward returned.
+ *   dL_dpix (3,H,W), dL_ddepths (H,W), dL_dalphas (H,W): incoming gradients.
+ *   Gradient outputs: dL_dmean2D (P,3), dL_dconic (P,4 = 2x2), dL_dopacity (P), dL_dcolor (P,3),
+ *   dL_dmean3D (P,3), dL_dcov3D (P,6), dL_dsh (P,M,3) (may be NULL if M==0), dL_dscale (P,3), dL_drot (P,4).
+ *   Every element of every output is written (zeros for culled Gaussians, for dL_dscale/dL_drot when
+ *   scales==NULL and for SH coefficients above the active degree), so outputs need NOT be pre-zeroed.
+ *   `alphas` and `radii` are accepted for signature parity and ignored (the reference ignores alphas too,
+ *   DGR/cuda_rasterizer/backward.cu:410).
+ * Gradients are bitwise reproducible run to run (no float atomics), unlike the reference.
+ * Returns 0 or a negative error code.
+ */
+int moss_raster_backward(
+    int P, int D, int M, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* alphas,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    char* geom_buffer,
+    char* binning_buffer,
+    char* image_buffer,
+    const float* dL_dpix,
+    const float* dL_ddepths,
+    const float* dL_dalphas,
+    float* dL_dmean2D,
+    float* dL_dconic,
+    float* dL_dopacity,
+    float* dL_dcolor,
+    float* dL_dmean3D,
+    float* dL_dcov3D,
+    float* dL_dsh,
+    float* dL_dscale,
+    float* dL_drot,
+    int debug,
+    void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (DGR/cuda_rasterizer/rasterizer.h:24-29,
+ * rasterizer_impl.cu:141-153).  present: (P) bytes, 1 if z_view > 0.2. */
+int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                             uint8_t* present, void* stream);
+
+/*
+ * Replaces SimpleKNN::knn (SKNN/simple_knn.h:16-19, SKNN/simple_knn.cu:185-221) behind distCUDA2
+ * (SKNN/spatial.cu:16-25): mean_dists[i] = mean of the squared distances from point i to its 3 nearest
+ * other points.  points (P,3), mean_dists (P).  workspace: device scratch of moss_knn_workspace_bytes(P).
+ * Synchronises the stream twice (scene bounding box), like the reference's two blocking copies.
+ */
+size_t moss_knn_workspace_bytes(int P);
+int moss_knn_dist2(int P, const float* points, float* mean_dists, char* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- inspection entry points (used by the parity tests; not needed by a caller of the op) ---------------- */
+
+/* Scratch sizes this library will request for a given problem (host-only arithmetic, no GPU touched). */
+size_t moss_raster_geometry_bytes(int P);
+size_t moss_raster_image_bytes(int width, int height);
+size_t moss_raster_binning_bytes(int R);
+
+/*
+ * Re-express the opaque geometry buffer in the reference's GeometryState terms
+ * (DGR/cuda_rasterizer/rasterizer_impl.cu:155-170); any output pointer may be NULL.
+ *   depths (P), means2D (P,2), conic_opacity (P,4), rgb (P,3), tiles_touched (P) u32, clamped (P,3) bytes,
+ *   cov3D (P,6; only meaningful when forward computed it from scales/rotations).
+ * Entries of culled Gaussians read as zero.
+ */
+int moss_raster_export_geometry(const char* geom_buffer, int P,
+    float* depths, float* means2D, float* conic_opacity, float* rgb, uint32_t* tiles_touched,
+    uint8_t* clamped, float* cov3D, void* stream);
+
+/*
+ * Re-express the opaque binning + image buffers in the reference's BinningState / ImageState terms
+ * (rasterizer_impl.cu:172-194): the SORTED 64-bit keys (tile << 32 | depth bits), the sorted Gaussian ids,
+ * the per-tile ranges (tiles,2) u32, and per pixel final_T / n_contrib.  Any output pointer may be NULL.
+ */
+int moss_raster_export_binning(const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    int P, int R, int width, int height,
+    uint64_t* point_list_keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib,
+    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOSS_RASTER_H */

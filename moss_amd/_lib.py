@@ -1,0 +1,89 @@
+"""ctypes binding of libmoss_raster.so (the C ABI declared in include/moss_raster.h).
+
+There is NO fallback: if the HIP library is missing the import of any op fails loudly.  PyTorch is used for
+device memory and streams only; every tensor crosses the boundary as a raw device pointer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmoss_raster.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_lib = None
+_lock = threading.Lock()
+
+ERR_NAMES = {-1: "invalid argument", -2: "HIP error", -3: "allocation failed", -4: "prefiltered point culled", -5: "unsupported"}
+
+_f = C.c_float
+_i = C.c_int
+_p = C.c_void_p
+
+
+def _declare(lib):
+    lib.moss_abi_version.restype = _i
+    lib.moss_last_error.restype = C.c_char_p
+    lib.moss_raster_geometry_bytes.restype = C.c_size_t
+    lib.moss_raster_geometry_bytes.argtypes = [_i]
+    lib.moss_raster_image_bytes.restype = C.c_size_t
+    lib.moss_raster_image_bytes.argtypes = [_i, _i]
+    lib.moss_raster_binning_bytes.restype = C.c_size_t
+    lib.moss_raster_binning_bytes.argtypes = [_i]
+    lib.moss_raster_forward.restype = _i
+    lib.moss_raster_forward.argtypes = [
+        ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p,          # geometry / binning / image allocators
+        _i, _i, _i,                                        # P, D, M
+        _p, _i, _i,                                        # background, width, height
+        _p, _p, _p, _p,                                    # means3D, shs, colors_precomp, opacities
+        _p, _f, _p, _p,                                    # scales, scale_modifier, rotations, cov3D_precomp
+        _p, _p, _p,                                        # viewmatrix, projmatrix, cam_pos
+        _f, _f, _i,                                        # tan_fovx, tan_fovy, prefiltered
+        _p, _p, _p, _p, _i, _p]                            # out_color, out_depth, out_alpha, radii, debug, stream
+    lib.moss_raster_backward.restype = _i
+    lib.moss_raster_backward.argtypes = [
+        _i, _i, _i, _i,                                    # P, D, M, R
+        _p, _i, _i,                                        # background, width, height
+        _p, _p, _p, _p,                                    # means3D, shs, colors_precomp, alphas
+        _p, _f, _p, _p,                                    # scales, scale_modifier, rotations, cov3D_precomp
+        _p, _p, _p, _f, _f,                                # viewmatrix, projmatrix, campos, tan_fovx, tan_fovy
+        _p, _p, _p, _p,                                    # radii, geom, binning, image buffers
+        _p, _p, _p,                                        # dL_dpix, dL_ddepths, dL_dalphas
+        _p, _p, _p, _p, _p, _p, _p, _p, _p,                # dL_dmean2D .. dL_drot
+        _i, _p]                                            # debug, stream
+    lib.moss_raster_mark_visible.restype = _i
+    lib.moss_raster_mark_visible.argtypes = [_i, _p, _p, _p, _p, _p]
+    lib.moss_knn_workspace_bytes.restype = C.c_size_t
+    lib.moss_knn_workspace_bytes.argtypes = [_i]
+    lib.moss_knn_dist2.restype = _i
+    lib.moss_knn_dist2.argtypes = [_i, _p, _p, _p, C.c_size_t, _p]
+    lib.moss_raster_export_geometry.restype = _i
+    lib.moss_raster_export_geometry.argtypes = [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p]
+    lib.moss_raster_export_binning.restype = _i
+    lib.moss_raster_export_binning.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library.  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+                        "(run `python -m moss_amd.build`); there is no CPU/PyTorch fallback for this op")
+                handle = C.CDLL(LIB_PATH)
+                _declare(handle)
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = lib().moss_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what}: {ERR_NAMES.get(rc, rc)}: {msg}")
+    return rc

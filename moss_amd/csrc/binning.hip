@@ -1,0 +1,259 @@
+// binning.hip -- (Gaussian, tile) instance binning and the per-tile depth sort.
+//
+// What the reference does (DGR/cuda_rasterizer/rasterizer_impl.cu:279-320): inclusive scan of tiles_touched,
+// duplicateWithKeys writes one (tile<<32|depth_bits, gaussian_id) pair per instance grouped by Gaussian, a
+// device-wide 64-bit CUB radix sort (6 passes over 12-byte pairs) orders them by (tile, depth) -- stable, so ties
+// keep ascending Gaussian id -- and identifyTileRanges finds the tile boundaries.
+//
+// What this file does instead (same result, bit for bit, see moss_raster_export_binning):
+//   1. the per-tile instance COUNTS are already known (histogram filled by the preprocess kernel), so an exclusive
+//      scan over the tiles gives every tile's [start,end) range directly -- no boundary search, and the tile id
+//      never has to be part of a sort key;
+//   2. scatter: each instance is dropped into its tile's bucket (slot order inside a bucket is arbitrary) as a
+//      64-bit key (depth_bits << 32 | gaussian_id);
+//   3. each tile sorts its own bucket IN LDS with a bitonic network on those 64-bit keys.  (depth_bits, id) is a
+//      total order, so the result is unique and equals the reference's stable sort regardless of scatter order.
+//   Sorting 8-byte keys once in LDS replaces 6 global passes over 12-byte pairs: algorithmic HBM traffic of the
+//   sort falls from >= 24 B/instance/pass to 8 B write + 8 B read + 4 B write per instance in total.
+#include "common.h"
+
+namespace moss {
+
+namespace {
+
+// Exclusive scan of one value per thread across a 1024-thread block; returns this thread's offset, `total` = sum.
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave /* >= 16 */, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();                 // s_wave may still be read from a previous call
+    if (lane == 63) s_wave[w] = x;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t t = lane < 16 ? s_wave[lane] : 0u;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t y = __shfl_up(t, d);
+            if (lane >= d) t += y;
+        }
+        if (lane < 16) s_wave[lane] = t;
+    }
+    __syncthreads();
+    const uint32_t base = w ? s_wave[w - 1] : 0u;
+    total = s_wave[15];
+    return base + x - v;
+}
+
+// One 1024-thread block: (a) point_offsets = exclusive scan of tiles_touched over the P Gaussians,
+// (b) ranges[t] = [start,end) from the exclusive scan of tile_count, header[0] = R, header[1] = longest tile list.
+__global__ void __launch_bounds__(1024)
+scan_kernel(int P, const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ point_offsets,
+            int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ header)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    {   // (a)
+        const int chunk = (P + 1023) / 1024;
+        const int b = tid * chunk, e = min(P, b + chunk);
+        uint32_t sum = 0;
+        for (int i = b; i < e; i++) sum += tiles_touched[i];
+        uint32_t total;
+        uint32_t off = block_scan_1024(sum, s_wave, total);
+        for (int i = b; i < e; i++) { const uint32_t v = tiles_touched[i]; point_offsets[i] = off; off += v; }
+    }
+    {   // (b)
+        const int chunk = (T + 1023) / 1024;
+        const int b = tid * chunk, e = min(T, b + chunk);
+        uint32_t sum = 0, mx = 0;
+        for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); }
+        uint32_t total;
+        uint32_t off = block_scan_1024(sum, s_wave, total);
+        for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; ranges[i] = make_uint2(off, off + v); off += v; }
+        if (mx) atomicMax(&s_max, mx);
+        __syncthreads();
+        if (tid == 0) { header[0] = total; header[1] = s_max; }
+    }
+}
+
+// duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
+// with ONE returning global atomic (after counting its own instances in LDS) and hands the slots out with LDS atomics.
+__global__ void __launch_bounds__(256)
+scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
+               uint64_t* __restrict__ keys, int lds_hist)
+{
+    extern __shared__ uint32_t s_mem[];
+    uint32_t* s_cnt = s_mem;
+    uint32_t* s_base = s_mem + T;
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < T; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
+            const uint2 r = g.rect[idx];
+            const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+            for (int ty = y0; ty < y1; ty++)
+                for (int tx = x0; tx < x1; tx++) atomicAdd(&s_cnt[ty * gx + tx], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += blockDim.x) {
+            const uint32_t c = s_cnt[i];
+            if (c) { s_base[i] = ranges[i].x + atomicAdd(&tile_cursor[i], c); s_cnt[i] = 0; }
+        }
+        __syncthreads();
+    }
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
+        const uint2 r = g.rect[idx];
+        const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+        if (x1 <= x0 || y1 <= y0) continue;
+        const uint64_t key = ((uint64_t)__float_as_uint(g.geo_b[idx].z) << 32) | (uint32_t)idx;
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) {
+                const int t = ty * gx + tx;
+                uint32_t pos;
+                if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+                else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
+                keys[pos] = key;
+            }
+    }
+}
+
+// Bitonic sorting network ("flip" form: every comparator leaves the minimum at the lower index, so elements past n
+// behave as +infinity without being stored and comparators touching them are skipped).
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr a, uint32_t n)
+{
+    uint32_t npad = 1;
+    while (npad < n) npad <<= 1;
+    const uint32_t half = npad >> 1;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {        // flip step
+            const uint32_t blk = t / hk, off = t % hk;
+            const uint32_t lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                const uint64_t x = a[lo], y = a[hi];
+                if (x > y) { a[lo] = y; a[hi] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = hk >> 1; j >= 1; j >>= 1) {                       // half-cleaners
+            for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+                const uint32_t lo = ((t / j) * 2u * j) + (t % j), hi = lo + j;
+                if (hi < n) {
+                    const uint64_t x = a[lo], y = a[hi];
+                    if (x > y) { a[lo] = y; a[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One block per tile.  Handles tiles whose list length n satisfies lo_excl < n <= hi_incl (size classes share the grid).
+template <bool IN_LDS>
+__global__ void tile_sort_kernel(int gx, uint32_t lo_excl, uint32_t hi_incl, GeomView g, const uint2* __restrict__ ranges,
+                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+    const int tile = blockIdx.x;
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= lo_excl || n > hi_incl) return;
+    uint64_t* gk = keys + rg.x;
+    if (IN_LDS) {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = gk[i];
+        __syncthreads();
+        bitonic_sort(s_keys, n);
+    } else {
+        __syncthreads();
+        bitonic_sort(gk, n);        // one workgroup owns the segment; __syncthreads orders its global accesses
+    }
+    const int tx = tile % gx, ty = tile / gx;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t id = (uint32_t)(IN_LDS ? s_keys[i] : gk[i]);
+        point_list[rg.x + i] = id;
+        const uint2 r = g.rect[id];
+        const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
+        const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+        inst_pos[g.point_offsets[id] + k] = rg.x + i;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+export_binning_kernel(int T, GeomView g, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ list_out, uint32_t* __restrict__ ranges_out)
+{
+    const int tile = blockIdx.x;
+    if (tile >= T) return;
+    const uint2 rg = ranges[tile];
+    if (ranges_out && threadIdx.x == 0) {
+        // the reference memsets ranges to 0 and only touches tiles that own instances (rasterizer_impl.cu:312-320)
+        ranges_out[2 * tile] = (rg.y > rg.x) ? rg.x : 0u;
+        ranges_out[2 * tile + 1] = (rg.y > rg.x) ? rg.y : 0u;
+    }
+    for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x) {
+        const uint32_t id = point_list[i];
+        if (list_out) list_out[i] = id;
+        if (keys_out) keys_out[i] = ((uint64_t)(uint32_t)tile << 32) | (uint64_t)__float_as_uint(g.geo_b[id].z);
+    }
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // anonymous namespace
+
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, num_tiles,
+                       im.tile_count, im.ranges, im.header);
+}
+
+void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
+{
+    const int T = fp.gx * fp.gy;
+    const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
+    static const int per_thread = env_int("MOSS_SCATTER_ITEMS", 4);
+    int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
+    if (blocks < 1) blocks = 1;
+    const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys, lds_hist);
+}
+
+void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int max_len, hipStream_t s)
+{
+    (void)R;
+    const int T = fp.gx * fp.gy;
+    if (max_len <= 0) return;
+    // class 0: n <= 2048 (16 KB LDS, 256 threads) -- class 1: n <= 8192 (64 KB LDS, 1024 threads) -- class 2: in global memory
+    hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(T), dim3(256), 2048 * sizeof(uint64_t), s, fp.gx, 0u, 2048u, g, im.ranges,
+                       b.keys, b.point_list, b.inst_pos);
+    if (max_len > 2048)
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(T), dim3(1024), 8192 * sizeof(uint64_t), s, fp.gx, 2048u, 8192u, g, im.ranges,
+                           b.keys, b.point_list, b.inst_pos);
+    if (max_len > 8192)
+        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(T), dim3(1024), 0, s, fp.gx, 8192u, 0xffffffffu, g, im.ranges,
+                           b.keys, b.point_list, b.inst_pos);
+}
+
+void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
+                           uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s)
+{
+    (void)R;
+    const int T = fp.gx * fp.gy;
+    hipLaunchKernelGGL(export_binning_kernel, dim3(T), dim3(256), 0, s, T, g, im.ranges, b.point_list, keys, point_list, ranges);
+    const size_t N = (size_t)fp.W * fp.H;
+    if (final_T) (void)hipMemcpyAsync(final_T, im.final_T, N * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (n_contrib) (void)hipMemcpyAsync(n_contrib, im.n_contrib, N * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+}
+
+}  // namespace moss

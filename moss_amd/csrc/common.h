@@ -1,0 +1,140 @@
+// common.h -- internal declarations shared by the HIP translation units of libmoss_raster.so (gfx950 only).
+//
+// Data layout in HBM (all sub-arrays 256-byte aligned inside the three caller-owned scratch buffers; the
+// reference's layout is rasterizer_impl.cu:155-194, ours differs on purpose -- see DESIGN.md "Data layout"):
+//
+//   geometry buffer (per Gaussian, P entries)
+//     geo_a  float4 {pix.x, pix.y, conic.A, conic.B}        16 B  } three 16-byte records so that the blend
+//     geo_b  float4 {conic.C, opacity, depth, cull_hx}      16 B  } kernels gather a tile entry with three
+//     geo_c  float4 {r, g, b, cull_hy}                      16 B  } coalescable dwordx4 loads (48 B / instance)
+//     rect   uint2  {min.x | min.y<<16, max.x | max.y<<16}   8 B    tile rectangle (getRect result)
+//     tiles_touched u32, point_offsets u32 (exclusive scan), radius i32, clamped u8 (bit c = channel c),
+//     cov3D float[6] (only written when computed from scale/rotation)
+//   image buffer
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags
+//     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
+//   binning buffer (per (Gaussian,tile) instance, R entries)
+//     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id)
+//     inst_pos   u32[R]   for Gaussian g, its k-th tile (row-major inside its rect): position in point_list
+//     scratch    48 B * R  forward: 64-bit sort keys (depth<<32|id) in the first 8R bytes;
+//                          backward: per-instance partial gradients, 3 float4 per instance
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "moss_raster.h"
+
+namespace moss {
+
+constexpr int TILE = 16;                 // BLOCK_X = BLOCK_Y = 16, DGR/cuda_rasterizer/config.h:15-16
+constexpr int TILE_PIX = TILE * TILE;
+constexpr size_t BUF_ALIGN = 256;
+constexpr int MAX_LDS_TILES = 8192;      // tile histograms are privatised in LDS up to this many tiles
+constexpr uint32_t ERRFLAG_PREFILTERED = 1u;
+
+inline size_t align_up(size_t v, size_t a = BUF_ALIGN) { return (v + a - 1) / a * a; }
+
+template <typename T>
+inline T* carve(char*& p, size_t count)
+{
+    T* r = reinterpret_cast<T*>(p);
+    p += align_up(count * sizeof(T));
+    return r;
+}
+
+struct GeomView {
+    float4* geo_a; float4* geo_b; float4* geo_c;
+    uint2* rect;
+    uint32_t* tiles_touched; uint32_t* point_offsets;
+    int* radius;
+    uint8_t* clamped;
+    float* cov3D;
+    static GeomView at(char* base, int P)
+    {
+        GeomView g; char* p = base; size_t n = (size_t)P;
+        g.geo_a = carve<float4>(p, n); g.geo_b = carve<float4>(p, n); g.geo_c = carve<float4>(p, n);
+        g.rect = carve<uint2>(p, n);
+        g.tiles_touched = carve<uint32_t>(p, n); g.point_offsets = carve<uint32_t>(p, n);
+        g.radius = carve<int>(p, n);
+        g.clamped = carve<uint8_t>(p, n);
+        g.cov3D = carve<float>(p, 6 * n);
+        return g;
+    }
+    static size_t bytes(int P) { char* z = nullptr; GeomView g = at(z, P); return (size_t)((char*)g.cov3D - z) + align_up(6 * (size_t)P * 4); }
+};
+
+struct ImageView {
+    uint32_t* header;
+    uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges;
+    float* final_T; uint32_t* n_contrib;
+    static ImageView at(char* base, int W, int H)
+    {
+        ImageView v; char* p = base;
+        size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
+        v.header = carve<uint32_t>(p, 16);
+        v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
+        v.ranges = carve<uint2>(p, T);
+        v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
+        return v;
+    }
+    static size_t bytes(int W, int H) { char* z = nullptr; ImageView v = at(z, W, H); return (size_t)((char*)v.n_contrib - z) + align_up((size_t)W * H * 4); }
+    // header + tile_count + tile_cursor are contiguous: one memset clears them
+    size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
+};
+
+struct BinView {
+    uint32_t* point_list; uint32_t* inst_pos;
+    uint64_t* keys;          // aliases inst_grad (dead after the sort)
+    float4* inst_grad;       // 3 float4 per instance
+    static BinView at(char* base, int R)
+    {
+        BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
+        b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n);
+        b.inst_grad = carve<float4>(p, 3 * n);
+        b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);
+        return b;
+    }
+    static size_t bytes(int R) { char* z = nullptr; BinView b = at(z, R); size_t n = (size_t)(R > 0 ? R : 1); return (size_t)((char*)b.inst_grad - z) + align_up(3 * n * 16); }
+};
+
+// Per-call constants.  The camera matrices stay on the device (the boundary hands over device pointers, exactly
+// like the reference); kernels read them through wave-uniform (scalar) loads, so no host copy / sync is needed.
+struct FrameParams {
+    int P, D, M, W, H, gx, gy;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int prefiltered;
+    const float* view_dev; const float* proj_dev; const float* campos_dev; const float* bg_dev;
+};
+
+// ---- launchers (each defined in exactly one .hip file; all enqueue on `s`, none synchronises) -------------
+void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                               GeomView g, ImageView im, int* radii_out, hipStream_t s);
+void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* scales, const float* rotations, const float* cov3D_precomp,
+                                GeomView g, BinView b,
+                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
+
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s);                 // offsets, ranges, header
+void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);  // duplicateWithKeys
+void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int max_len, hipStream_t s);
+void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
+                           uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);
+void launch_export_geometry(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,
+                            uint32_t* tiles_touched, uint8_t* clamped, float* cov3D, hipStream_t s);
+
+void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
+                          float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
+void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
+                           const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, hipStream_t s);
+
+// shared device helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rect_area(uint2 r)
+{
+    uint32_t w = (r.y & 0xffffu) - (r.x & 0xffffu), h = (r.y >> 16) - (r.x >> 16);
+    return w * h;
+}
+
+}  // namespace moss

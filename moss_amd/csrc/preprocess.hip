@@ -1,0 +1,614 @@
+// preprocess.hip -- per-Gaussian kernels: forward preprocess (+ per-tile histogram), fused backward
+// (instance-gradient gather + conic/cov2D backward + projection/SH/cov3D backward), markVisible.
+//
+// COMPILED WITH -ffp-contract=off (see moss_amd/build.py): everything that decides an integer result
+// (radius, tile rectangle, depth bits = sort key) is evaluated with one rounding per source operation, in the
+// operation order of the reference's source text, so those results are bit-identical to the CPU oracle:
+//   frustum test      DGR/cuda_rasterizer/auxiliary.h:139-164
+//   projection        DGR/cuda_rasterizer/forward.cu:196-200, auxiliary.h:41-44 (ndc2Pix in double), :46-56 (getRect)
+//   cov3D             forward.cu:118-152         cov2D (EWA)  forward.cu:74-113
+//   conic / radius    forward.cu:218-237         SH -> RGB    forward.cu:20-71
+// These kernels stream ~100-300 B per Gaussian and are HBM-bound; contraction would buy nothing.
+#include "common.h"
+
+namespace moss {
+
+namespace {
+
+struct M3 { float m[3][3]; };   // m[c][r], the column-major convention of the reference's glm matrices
+
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B)
+{
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A)
+{
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[r][c];
+    return R;
+}
+__device__ __forceinline__ M3 m3_cols(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2, float z2)
+{
+    M3 R;
+    R.m[0][0] = x0; R.m[0][1] = y0; R.m[0][2] = z0;
+    R.m[1][0] = x1; R.m[1][1] = y1; R.m[1][2] = z1;
+    R.m[2][0] = x2; R.m[2][1] = y2; R.m[2][2] = z2;
+    return R;
+}
+
+__device__ __forceinline__ int sat_int(float v)   // float->int with saturation, NaN -> 0 (v_cvt_i32_f32 semantics, spelled out)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+__device__ __forceinline__ float3 xform4x3(float3 p, const float* m)
+{
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(float3 p, const float* m)
+{
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+                       m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+__device__ __forceinline__ M3 quat_to_R(float r, float x, float y, float z)   // quaternion used un-normalised (forward.cu:127)
+{
+    return m3_cols(
+        1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* sc, float mod, const float* q, float* cov)
+{
+    M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    S.m[0][0] = mod * sc[0]; S.m[1][1] = mod * sc[1]; S.m[2][2] = mod * sc[2];
+    M3 R = quat_to_R(q[0], q[1], q[2], q[3]);
+    M3 M = m3_mul(S, R);
+    M3 Sigma = m3_mul(m3_t(M), M);
+    cov[0] = Sigma.m[0][0]; cov[1] = Sigma.m[0][1]; cov[2] = Sigma.m[0][2];
+    cov[3] = Sigma.m[1][1]; cov[4] = Sigma.m[1][2]; cov[5] = Sigma.m[2][2];
+}
+
+struct Cov2DSetup { float3 t; float txtz, tytz; M3 W, T, Vrk; };
+
+__device__ __forceinline__ Cov2DSetup cov2d_setup(float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                                  const float* cov3D, const float* view)
+{
+    Cov2DSetup s;
+    float3 t = xform4x3(mean, view);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    s.txtz = t.x / t.z; s.tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, s.txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, s.tytz)) * t.z;
+    M3 J = m3_cols(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z),
+                   0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z),
+                   0, 0, 0);
+    s.W = m3_cols(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    s.T = m3_mul(s.W, J);
+    s.Vrk = m3_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    s.t = t;
+    return s;
+}
+
+__constant__ const float SH_C0 = 0.28209479177387814f;
+__constant__ const float SH_C1 = 0.4886025119029199f;
+__constant__ const float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                      -1.0925484305920792f, 0.5462742152960396f };
+__constant__ const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                      -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: forward preprocess, one thread per Gaussian (grid-stride).  Also counts instances per tile: lanes add into
+// an LDS-private histogram and the block flushes its non-zero bins with one global atomic each.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
+                          float tan_fovx, float tan_fovy, float focal_x, float focal_y, float scale_modifier, int prefiltered,
+                          const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                          const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
+                          const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+                          const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
+                          GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header,
+                          int* __restrict__ radii_out, int lds_hist)
+{
+    extern __shared__ uint32_t s_hist[];
+    const int T = gx * gy;
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+    }
+    float view[16], proj[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { view[i] = viewmatrix[i]; proj[i] = projmatrix[i]; }
+    const float3 campos = make_float3(cam_pos[0], cam_pos[1], cam_pos[2]);
+
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
+        int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
+        do {
+            const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+            const float3 p_view = xform4x3(p_orig, view);
+            if (p_view.z <= 0.2f) {                                   // in_frustum, auxiliary.h:154
+                if (prefiltered) atomicOr(&header[2], ERRFLAG_PREFILTERED);
+                break;
+            }
+            const float4 p_hom = xform4x4(p_orig, proj);
+            const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+            const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
+
+            float cov3D[6];
+            if (cov3D_precomp != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+            } else {
+                float sc[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
+                float q[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
+                cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
+#pragma unroll
+                for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = cov3D[i];
+            }
+
+            const Cov2DSetup cs = cov2d_setup(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view);
+            M3 cov = m3_mul(m3_mul(m3_t(cs.T), m3_t(cs.Vrk)), cs.T);
+            cov.m[0][0] += 0.3f;
+            cov.m[1][1] += 0.3f;
+            const float cx = cov.m[0][0], cy = cov.m[0][1], cz = cov.m[1][1];
+
+            const float det = (cx * cz - cy * cy);
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+
+            const float mid = 0.5f * (cx + cz);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float2 pix = make_float2(ndc2pix(p_proj.x, W), ndc2pix(p_proj.y, H));
+            const int rad = sat_int(my_radius);
+            const int x0 = min(gx, max(0, sat_int((pix.x - rad) / TILE)));
+            const int y0 = min(gy, max(0, sat_int((pix.y - rad) / TILE)));
+            const int x1 = min(gx, max(0, sat_int((pix.x + rad + TILE - 1) / TILE)));
+            const int y1 = min(gy, max(0, sat_int((pix.y + rad + TILE - 1) / TILE)));
+            if ((uint32_t)(x1 - x0) * (uint32_t)(y1 - y0) == 0u) break;
+
+            float3 rgb;
+            uint8_t clamp_bits = 0;
+            if (colors_precomp == nullptr) {
+                const float* sh = shs + (size_t)idx * M * 3;
+                float3 dir = make_float3(p_orig.x - campos.x, p_orig.y - campos.y, p_orig.z - campos.z);
+                const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+                dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+                const float x = dir.x, y = dir.y, z = dir.z;
+                float res[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+#define SH(k) sh[3 * (k) + c]
+                    float result = SH_C0 * SH(0);
+                    if (D > 0) {
+                        result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+                        if (D > 1) {
+                            const float xx = x * x, yy = y * y, zz = z * z;
+                            const float xy = x * y, yz = y * z, xz = x * z;
+                            result = result +
+                                SH_C2[0] * xy * SH(4) +
+                                SH_C2[1] * yz * SH(5) +
+                                SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                                SH_C2[3] * xz * SH(7) +
+                                SH_C2[4] * (xx - yy) * SH(8);
+                            if (D > 2) {
+                                result = result +
+                                    SH_C3[0] * y * (3.0f * xx - yy) * SH(9) +
+                                    SH_C3[1] * xy * z * SH(10) +
+                                    SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                                    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                                    SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) +
+                                    SH_C3[5] * z * (xx - yy) * SH(14) +
+                                    SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                            }
+                        }
+                    }
+#undef SH
+                    result += 0.5f;
+                    if (result < 0) clamp_bits |= (uint8_t)(1u << c);
+                    res[c] = fmaxf(result, 0.0f);
+                }
+                rgb = make_float3(res[0], res[1], res[2]);
+            } else {
+                rgb = make_float3(colors_precomp[3 * (size_t)idx], colors_precomp[3 * (size_t)idx + 1], colors_precomp[3 * (size_t)idx + 2]);
+            }
+
+            // Conservative extent of the region where this Gaussian can reach alpha >= 1/255 (power >= -tau,
+            // tau = ln(255*opacity)): half-widths sqrt(2*tau*cov_xx), sqrt(2*tau*cov_yy) of the ellipse's bounding box,
+            // widened by 1e-4 relative + 0.01 px against rounding.  Used only to SKIP work in the blend kernels.
+            const float opa = opacities[idx];
+            float hx = __builtin_huge_valf(), hy = __builtin_huge_valf();
+            if (opa == opa) {
+                if (!(opa > 0.0f)) { hx = -1.0f; hy = -1.0f; }
+                else if (det > 0.0f && cx > 0.0f && cz > 0.0f) {
+                    const float tau = logf(255.0f * opa);
+                    if (tau != tau || tau == __builtin_huge_valf()) { /* keep inf */ }
+                    else if (tau <= 0.0f) { hx = -1.0f; hy = -1.0f; }
+                    else {
+                        hx = sqrtf(2.0f * tau * cx) * 1.0001f + 0.01f;
+                        hy = sqrtf(2.0f * tau * cz) * 1.0001f + 0.01f;
+                    }
+                }
+            }
+
+            g.geo_a[idx] = make_float4(pix.x, pix.y, conic.x, conic.y);
+            g.geo_b[idx] = make_float4(conic.z, opa, p_view.z, hx);
+            g.geo_c[idx] = make_float4(rgb.x, rgb.y, rgb.z, hy);
+            g.clamped[idx] = clamp_bits;
+            out_radius = rad;
+            out_tiles = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+            out_rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+
+            for (int ty = y0; ty < y1; ty++)
+                for (int tx = x0; tx < x1; tx++) {
+                    if (lds_hist) atomicAdd(&s_hist[ty * gx + tx], 1u);
+                    else atomicAdd(&tile_count[ty * gx + tx], 1u);
+                }
+        } while (0);
+        g.radius[idx] = out_radius;
+        g.tiles_touched[idx] = out_tiles;
+        g.rect[idx] = out_rect;
+        if (radii_out) radii_out[idx] = out_radius;
+    }
+    if (lds_hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += blockDim.x) {
+            const uint32_t v = s_hist[i];
+            if (v) atomicAdd(&tile_count[i], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K8+K9 fused: per-Gaussian backward.  Sums this Gaussian's per-instance partial gradients (written by the
+// blend-backward kernel, one 48-byte record per (Gaussian, tile) instance, found through inst_pos) in a FIXED
+// order -> bitwise reproducible; then conic->cov2D->cov3D/mean (backward.cu:144-274), projection of the 2-D mean
+// gradient (:370-387), SH (:20-139) and scale/rotation (:278-341).  Writes every output element exactly once.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv)   // auxiliary.h:107-117
+{
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    float3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float scale_modifier,
+                           const float* __restrict__ means3D, const float* __restrict__ shs,
+                           const float* __restrict__ scales, const float* __restrict__ rotations,
+                           const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
+                           GeomView g, const uint32_t* __restrict__ inst_pos, const float4* __restrict__ inst_grad,
+                           float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                           float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+                           float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const uint32_t n_inst = g.tiles_touched[idx];
+    float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
+    float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
+    const bool visible = n_inst > 0;            // <=> radii > 0 (backward.cu:156,367)
+
+    if (visible) {
+        const uint32_t off = g.point_offsets[idx];
+        for (uint32_t k = 0; k < n_inst; k++) {
+            const uint32_t pos = inst_pos[off + k];
+            const float4 r0 = inst_grad[3 * (size_t)pos], r1 = inst_grad[3 * (size_t)pos + 1], r2 = inst_grad[3 * (size_t)pos + 2];
+            gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
+            gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
+            gop += r2.x;
+        }
+    }
+    dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
+    reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
+    dL_dopacity[idx] = gop;
+    dL_dcolor[3 * (size_t)idx] = gcol.x; dL_dcolor[3 * (size_t)idx + 1] = gcol.y; dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
+
+    float* dsh = (M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr;
+
+    if (visible) {
+        float view[16], proj[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { view[i] = viewmatrix[i]; proj[i] = projmatrix[i]; }
+        const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+        float cov3D[6];
+        const float* csrc = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3D[i] = csrc[i];
+
+        // ---- computeCov2DCUDA, backward.cu:144-274
+        const Cov2DSetup cs = cov2d_setup(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view);
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float x_grad_mul = cs.txtz < -limx || cs.txtz > limx ? 0 : 1;
+        const float y_grad_mul = cs.tytz < -limy || cs.tytz > limy ? 0 : 1;
+        const M3& T = cs.T; const M3& V = cs.Vrk; const M3& Wm = cs.W;
+        M3 cov2D = m3_mul(m3_mul(m3_t(T), m3_t(V)), T);
+        const float a = cov2D.m[0][0] += 0.3f;
+        const float b = cov2D.m[0][1];
+        const float c = cov2D.m[1][1] += 0.3f;
+        const float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        const float3 dcon = make_float3(gca, gcb, gcc);
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dcon.x + 2 * b * c * dcon.y + (denom - a * c) * dcon.z);
+            dL_dc = denom2inv * (-a * a * dcon.z + 2 * a * b * dcon.y + (denom - a * c) * dcon.x);
+            dL_db = denom2inv * 2 * (b * c * dcon.x - (denom + 2 * b * b) * dcon.y + a * b * dcon.z);
+            dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+            dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+            dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+            dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
+            dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
+            dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+        }
+        const float dL_dT00 = 2 * (T.m[0][0] * V.m[0][0] + T.m[0][1] * V.m[0][1] + T.m[0][2] * V.m[0][2]) * dL_da +
+            (T.m[1][0] * V.m[0][0] + T.m[1][1] * V.m[0][1] + T.m[1][2] * V.m[0][2]) * dL_db;
+        const float dL_dT01 = 2 * (T.m[0][0] * V.m[1][0] + T.m[0][1] * V.m[1][1] + T.m[0][2] * V.m[1][2]) * dL_da +
+            (T.m[1][0] * V.m[1][0] + T.m[1][1] * V.m[1][1] + T.m[1][2] * V.m[1][2]) * dL_db;
+        const float dL_dT02 = 2 * (T.m[0][0] * V.m[2][0] + T.m[0][1] * V.m[2][1] + T.m[0][2] * V.m[2][2]) * dL_da +
+            (T.m[1][0] * V.m[2][0] + T.m[1][1] * V.m[2][1] + T.m[1][2] * V.m[2][2]) * dL_db;
+        const float dL_dT10 = 2 * (T.m[1][0] * V.m[0][0] + T.m[1][1] * V.m[0][1] + T.m[1][2] * V.m[0][2]) * dL_dc +
+            (T.m[0][0] * V.m[0][0] + T.m[0][1] * V.m[0][1] + T.m[0][2] * V.m[0][2]) * dL_db;
+        const float dL_dT11 = 2 * (T.m[1][0] * V.m[1][0] + T.m[1][1] * V.m[1][1] + T.m[1][2] * V.m[1][2]) * dL_dc +
+            (T.m[0][0] * V.m[1][0] + T.m[0][1] * V.m[1][1] + T.m[0][2] * V.m[1][2]) * dL_db;
+        const float dL_dT12 = 2 * (T.m[1][0] * V.m[2][0] + T.m[1][1] * V.m[2][1] + T.m[1][2] * V.m[2][2]) * dL_dc +
+            (T.m[0][0] * V.m[2][0] + T.m[0][1] * V.m[2][1] + T.m[0][2] * V.m[2][2]) * dL_db;
+        const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+        const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+        const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+        const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+        const float tz = 1.f / cs.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * cs.t.x) * tz3 * dL_dJ02 + (2 * h_y * cs.t.y) * tz3 * dL_dJ12;
+        dmean[0] = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;       // transformVec4x3Transpose
+        dmean[1] = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
+        dmean[2] = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+
+        // ---- preprocessCUDA backward, backward.cu:370-387
+        const float4 m_hom = xform4x4(mean, proj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gmx + (proj[1] * m_w - proj[3] * mul2) * gmy;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gmx + (proj[5] * m_w - proj[7] * mul2) * gmy;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gmx + (proj[9] * m_w - proj[11] * mul2) * gmy;
+
+        // ---- SH backward, backward.cu:20-139
+        if (shs != nullptr) {
+            const float* sh = shs + (size_t)idx * M * 3;
+            const float3 dir_orig = make_float3(mean.x - cam_pos[0], mean.y - cam_pos[1], mean.z - cam_pos[2]);
+            const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+            const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+            const uint8_t cl = g.clamped[idx];
+            const float dRGB[3] = { (cl & 1) ? 0.0f : gcol.x, (cl & 2) ? 0.0f : gcol.y, (cl & 4) ? 0.0f : gcol.z };
+            float ddir[3] = { 0, 0, 0 };
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+#define SH(k) sh[3 * (k) + ch]
+#define DSH(k) dsh[3 * (k) + ch]
+                float dx_ = 0, dy_ = 0, dz_ = 0;
+                const float gch = dRGB[ch];
+                DSH(0) = SH_C0 * gch;
+                if (D > 0) {
+                    DSH(1) = (-SH_C1 * y) * gch;
+                    DSH(2) = (SH_C1 * z) * gch;
+                    DSH(3) = (-SH_C1 * x) * gch;
+                    dx_ = -SH_C1 * SH(3);
+                    dy_ = -SH_C1 * SH(1);
+                    dz_ = SH_C1 * SH(2);
+                    if (D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z;
+                        const float xy = x * y, yz = y * z, xz = x * z;
+                        DSH(4) = (SH_C2[0] * xy) * gch;
+                        DSH(5) = (SH_C2[1] * yz) * gch;
+                        DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * gch;
+                        DSH(7) = (SH_C2[3] * xz) * gch;
+                        DSH(8) = (SH_C2[4] * (xx - yy)) * gch;
+                        dx_ += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+                        dy_ += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+                        dz_ += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+                        if (D > 2) {
+                            DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * gch;
+                            DSH(10) = (SH_C3[1] * xy * z) * gch;
+                            DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * gch;
+                            DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * gch;
+                            DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * gch;
+                            DSH(14) = (SH_C3[5] * z * (xx - yy)) * gch;
+                            DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * gch;
+                            dx_ += (SH_C3[0] * SH(9) * 3.f * 2.f * xy +
+                                    SH_C3[1] * SH(10) * yz +
+                                    SH_C3[2] * SH(11) * -2.f * xy +
+                                    SH_C3[3] * SH(12) * -3.f * 2.f * xz +
+                                    SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                    SH_C3[5] * SH(14) * 2.f * xz +
+                                    SH_C3[6] * SH(15) * 3.f * (xx - yy));
+                            dy_ += (SH_C3[0] * SH(9) * 3.f * (xx - yy) +
+                                    SH_C3[1] * SH(10) * xz +
+                                    SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                                    SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                                    SH_C3[4] * SH(13) * -2.f * xy +
+                                    SH_C3[5] * SH(14) * -2.f * yz +
+                                    SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                            dz_ += (SH_C3[1] * SH(10) * xy +
+                                    SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                                    SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                                    SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                                    SH_C3[5] * SH(14) * (xx - yy));
+                        }
+                    }
+                }
+                const int used = (D + 1) * (D + 1);
+                for (int k = used; k < M; k++) DSH(k) = 0.0f;      // coefficients above the active degree get no gradient
+#undef SH
+#undef DSH
+                ddir[0] += dx_ * gch; ddir[1] += dy_ * gch; ddir[2] += dz_ * gch;
+            }
+            const float3 dm = dnormvdv(dir_orig, make_float3(ddir[0], ddir[1], ddir[2]));
+            dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+        }
+
+        // ---- scale / rotation backward, backward.cu:278-341
+        if (scales != nullptr) {
+            const float r = rotations[4 * (size_t)idx], x = rotations[4 * (size_t)idx + 1], y = rotations[4 * (size_t)idx + 2], z = rotations[4 * (size_t)idx + 3];
+            const M3 R = quat_to_R(r, x, y, z);
+            const float s[3] = { scale_modifier * scales[3 * (size_t)idx], scale_modifier * scales[3 * (size_t)idx + 1], scale_modifier * scales[3 * (size_t)idx + 2] };
+            M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+            const M3 Mm = m3_mul(S, R);
+            const M3 dSigma = m3_cols(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2],
+                                      0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                                      0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+            M3 M2;
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) M2.m[cc][rr] = 2.0f * Mm.m[cc][rr];
+            const M3 dL_dM = m3_mul(M2, dSigma);
+            const M3 Rt = m3_t(R);
+            M3 dMt = m3_t(dL_dM);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dscale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) dMt.m[k][rr] *= s[k];
+#define DM(c_, r_) dMt.m[c_][r_]
+            drot[0] = 2 * z * (DM(0,1) - DM(1,0)) + 2 * y * (DM(2,0) - DM(0,2)) + 2 * x * (DM(1,2) - DM(2,1));
+            drot[1] = 2 * y * (DM(1,0) + DM(0,1)) + 2 * z * (DM(2,0) + DM(0,2)) + 2 * r * (DM(1,2) - DM(2,1)) - 4 * x * (DM(2,2) + DM(1,1));
+            drot[2] = 2 * x * (DM(1,0) + DM(0,1)) + 2 * r * (DM(2,0) - DM(0,2)) + 2 * z * (DM(1,2) + DM(2,1)) - 4 * y * (DM(2,2) + DM(0,0));
+            drot[3] = 2 * r * (DM(0,1) - DM(1,0)) + 2 * x * (DM(2,0) + DM(0,2)) + 2 * y * (DM(1,2) + DM(2,1)) - 4 * z * (DM(1,1) + DM(0,0));
+#undef DM
+        }
+    } else if (dsh != nullptr) {
+        for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
+    }
+    if (visible && dsh != nullptr && shs == nullptr) {
+        for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 3; i++) dL_dmean3D[3 * (size_t)idx + i] = dmean[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
+    reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ viewmatrix, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    float view[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) view[i] = viewmatrix[i];
+    const float3 p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    const float3 pv = xform4x3(p, view);
+    present[idx] = (pv.z <= 0.2f) ? 0 : 1;      // rasterizer_impl.cu:54-66, auxiliary.h:154
+}
+
+__global__ void __launch_bounds__(256)
+export_geometry_kernel(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,
+                       uint32_t* tiles_touched, uint8_t* clamped, float* cov3D)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const bool vis = g.tiles_touched[idx] > 0;
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    const float4 a = vis ? g.geo_a[idx] : z4, b = vis ? g.geo_b[idx] : z4, c = vis ? g.geo_c[idx] : z4;
+    if (depths) depths[idx] = b.z;
+    if (means2D) { means2D[2 * (size_t)idx] = a.x; means2D[2 * (size_t)idx + 1] = a.y; }
+    if (conic_opacity) reinterpret_cast<float4*>(conic_opacity)[idx] = make_float4(a.z, a.w, b.x, b.y);
+    if (rgb) { rgb[3 * (size_t)idx] = c.x; rgb[3 * (size_t)idx + 1] = c.y; rgb[3 * (size_t)idx + 2] = c.z; }
+    if (tiles_touched) tiles_touched[idx] = g.tiles_touched[idx];
+    if (clamped) {
+        const uint8_t cl = vis ? g.clamped[idx] : 0;
+        clamped[3 * (size_t)idx] = cl & 1; clamped[3 * (size_t)idx + 1] = (cl >> 1) & 1; clamped[3 * (size_t)idx + 2] = (cl >> 2) & 1;
+    }
+    if (cov3D) for (int i = 0; i < 6; i++) cov3D[6 * (size_t)idx + i] = g.cov3D[6 * (size_t)idx + i];
+}
+
+}  // anonymous namespace
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                               GeomView g, ImageView im, int* radii_out, hipStream_t s)
+{
+    const int T = fp.gx * fp.gy;
+    const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
+    // Gaussians per thread: more -> better aggregation of the tile-histogram atomics, fewer -> more waves in flight.
+    static const int per_thread = env_int("MOSS_PREPROCESS_ITEMS", 2);
+    int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
+    if (blocks < 1) blocks = 1;
+    const size_t lds = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
+    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
+                       fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
+                       fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
+                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist);
+}
+
+void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* scales, const float* rotations, const float* cov3D_precomp,
+                                GeomView g, BinView b,
+                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s)
+{
+    (void)colors_precomp;
+    const int blocks = (fp.P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, s,
+                       fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,
+                       means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,
+                       g, b.inst_pos, b.inst_grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                       dL_dsh, dL_dscale, dL_drot);
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view16_dev, present);
+}
+
+void launch_export_geometry(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,
+                            uint32_t* tiles_touched, uint8_t* clamped, float* cov3D, hipStream_t s)
+{
+    hipLaunchKernelGGL(export_geometry_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g, depths, means2D, conic_opacity, rgb,
+                       tiles_touched, clamped, cov3D);
+}
+
+}  // namespace moss

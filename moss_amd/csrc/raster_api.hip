@@ -1,0 +1,227 @@
+// raster_api.hip -- the extern "C" entry points declared in include/moss_raster.h (host orchestration only).
+// Stage order follows CudaRasterizer::Rasterizer::forward / ::backward
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:198-341, :345-447); the stages themselves are this library's own.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+using namespace moss;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(MOSS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// CHECK_CUDA equivalent (auxiliary.h:166-173): with debug, synchronise and surface errors after every launch.
+#define STAGE_CHECK(name)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = hipGetLastError();                                                             \
+        if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(s);                                   \
+        if (e_ != hipSuccess) return fail(MOSS_ERR_HIP, "stage '%s' failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// Small pinned host block for the header read-back, one per host thread.
+struct Pinned {
+    uint32_t* p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+};
+thread_local Pinned g_pinned;
+
+FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float tan_fovy, float scale_modifier, int prefiltered,
+                        const float* view, const float* proj, const float* campos, const float* bg)
+{
+    FrameParams fp;
+    fp.P = P; fp.D = D; fp.M = M; fp.W = W; fp.H = H;
+    fp.gx = (W + TILE - 1) / TILE; fp.gy = (H + TILE - 1) / TILE;
+    fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
+    fp.focal_y = H / (2.0f * tan_fovy);         // rasterizer_impl.cu:224-225
+    fp.focal_x = W / (2.0f * tan_fovx);
+    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered;
+    fp.view_dev = view; fp.proj_dev = proj; fp.campos_dev = campos; fp.bg_dev = bg;
+    return fp;
+}
+
+}  // namespace
+
+extern "C" {
+
+int moss_abi_version(void) { return MOSS_ABI_VERSION; }
+const char* moss_last_error(void) { return g_err; }
+
+size_t moss_raster_geometry_bytes(int P) { return GeomView::bytes(P > 0 ? P : 1); }
+size_t moss_raster_image_bytes(int width, int height) { return ImageView::bytes(width, height); }
+size_t moss_raster_binning_bytes(int R) { return BinView::bytes(R); }
+
+int moss_raster_forward(
+    moss_alloc_fn geometry_alloc, void* geometry_user,
+    moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream)
+{
+    g_err[0] = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) return fail(MOSS_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
+    if (!out_color || !out_depth || !out_alpha || !background) return fail(MOSS_ERR_INVALID_ARG, "null output/background pointer");
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(MOSS_ERR_INVALID_ARG, "null allocator callback");
+    if ((width + TILE - 1) / TILE > 65535 || (height + TILE - 1) / TILE > 65535) return fail(MOSS_ERR_UNSUPPORTED, "image too large");
+    const size_t N = (size_t)width * height;
+
+    if (P == 0) {
+        // rasterize_points.cu:68-83: zero-filled outputs, nothing else happens.  (Outputs here are caller-allocated
+        // and possibly uninitialised, so fill them; the background is NOT composited in the reference either.)
+        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(out_depth, 0, N * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(out_alpha, 0, N * sizeof(float), s));
+        return 0;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) return fail(MOSS_ERR_INVALID_ARG, "null required input");
+    if (!colors_precomp && !shs) return fail(MOSS_ERR_UNSUPPORTED, "provide SHs or precomputed colours");
+    if (!colors_precomp && (M <= 0 || (D + 1) * (D + 1) > M || D < 0 || D > 3)) return fail(MOSS_ERR_INVALID_ARG, "SH degree %d does not fit M=%d", D, M);
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(MOSS_ERR_INVALID_ARG, "provide scales+rotations or cov3D_precomp");
+
+    char* geom_ptr = geometry_alloc(geometry_user, GeomView::bytes(P));
+    if (!geom_ptr) return fail(MOSS_ERR_ALLOC, "geometry allocator returned NULL");
+    char* img_ptr = image_alloc(image_user, ImageView::bytes(width, height));
+    if (!img_ptr) return fail(MOSS_ERR_ALLOC, "image allocator returned NULL");
+    GeomView g = GeomView::at(geom_ptr, P);
+    ImageView im = ImageView::at(img_ptr, width, height);
+    const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, prefiltered,
+                                       viewmatrix, projmatrix, cam_pos, background);
+    const int T = fp.gx * fp.gy;
+
+    HIP_TRY(hipMemsetAsync(im.header, 0, im.clear_bytes(), s));        // header + tile histogram + tile cursors
+    launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, im, radii, s);
+    STAGE_CHECK("preprocess");
+    launch_scan(P, g, im, T, s);
+    STAGE_CHECK("scan");
+
+    // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
+    if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int R = (int)g_pinned.p[0];
+    const int max_len = (int)g_pinned.p[1];
+    if (g_pinned.p[2] & ERRFLAG_PREFILTERED)
+        return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+
+    char* bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
+    if (!bin_ptr) return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL");
+    BinView b = BinView::at(bin_ptr, R);
+
+    if (R > 0) {
+        launch_scatter(fp, g, im, b, s);
+        STAGE_CHECK("scatter");
+        launch_tile_sort(fp, g, im, b, R, max_len, s);
+        STAGE_CHECK("tile_sort");
+    }
+    launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s);
+    STAGE_CHECK("blend_forward");
+    return R;
+}
+
+int moss_raster_backward(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    (void)alphas; (void)radii;
+    g_err[0] = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(MOSS_ERR_INVALID_ARG, "bad sizes");
+    if (P == 0) return 0;                                                 // rasterize_points.cu:168
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(MOSS_ERR_INVALID_ARG, "null scratch buffer");
+    if (!dL_dpix || !dL_ddepths || !dL_dalphas) return fail(MOSS_ERR_INVALID_ARG, "null incoming gradient");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail(MOSS_ERR_INVALID_ARG, "null gradient output");
+    if (shs && !dL_dsh) return fail(MOSS_ERR_INVALID_ARG, "dL_dsh is NULL although shs is given");
+    if (!means3D || !viewmatrix || !projmatrix || !campos || !background) return fail(MOSS_ERR_INVALID_ARG, "null required input");
+
+    GeomView g = GeomView::at(geom_buffer, P);
+    ImageView im = ImageView::at(image_buffer, width, height);
+    BinView b = BinView::at(binning_buffer, R);
+    const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, 0,
+                                       viewmatrix, projmatrix, campos, background);
+    if (R > 0) {
+        launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s);
+        STAGE_CHECK("blend_backward");
+    }
+    launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b,
+                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s);
+    STAGE_CHECK("preprocess_backward");
+    return 0;
+}
+
+int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                             uint8_t* present, void* stream)
+{
+    (void)projmatrix;
+    g_err[0] = 0;
+    if (P < 0) return fail(MOSS_ERR_INVALID_ARG, "bad P");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(MOSS_ERR_INVALID_ARG, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    launch_mark_visible(P, means3D, viewmatrix, present, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOSS_ERR_HIP, "mark_visible launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int moss_raster_export_geometry(const char* geom_buffer, int P,
+    float* depths, float* means2D, float* conic_opacity, float* rgb, uint32_t* tiles_touched,
+    uint8_t* clamped, float* cov3D, void* stream)
+{
+    g_err[0] = 0;
+    if (P <= 0 || !geom_buffer) return fail(MOSS_ERR_INVALID_ARG, "bad arguments");
+    GeomView g = GeomView::at(const_cast<char*>(geom_buffer), P);
+    launch_export_geometry(P, g, depths, means2D, conic_opacity, rgb, tiles_touched, clamped, cov3D, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOSS_ERR_HIP, "export_geometry launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int moss_raster_export_binning(const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    int P, int R, int width, int height,
+    uint64_t* point_list_keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, void* stream)
+{
+    g_err[0] = 0;
+    if (P <= 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(MOSS_ERR_INVALID_ARG, "bad arguments");
+    GeomView g = GeomView::at(const_cast<char*>(geom_buffer), P);
+    ImageView im = ImageView::at(const_cast<char*>(image_buffer), width, height);
+    BinView b = BinView::at(const_cast<char*>(binning_buffer), R);
+    const FrameParams fp = make_params(P, 0, 0, width, height, 1.f, 1.f, 1.f, 0, nullptr, nullptr, nullptr, nullptr);
+    launch_export_binning(fp, g, im, b, R, point_list_keys, point_list, ranges, final_T, n_contrib, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MOSS_ERR_HIP, "export_binning launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""Drop-in for the reference's compiled ``diff_gaussian_rasterization._C`` module (pybind11 exports at
+submodules/diff-gaussian-rasterization/ext.cpp:15-18; torch glue in rasterize_points.cu / rasterize_points.h).
+
+Same three callables, same positional arguments, same return tuples.  Each one unwraps the tensors to raw device
+pointers and calls the C ABI of ``include/moss_raster.h`` through ctypes on the CURRENT torch HIP stream
+(the reference launches on the legacy default stream -- a wart, not a contract).  Tensors are only used for what the
+reference's glue uses them for: allocating outputs and the three opaque scratch buffers.
+"""
+from __future__ import annotations
+
+import threading
+
+import torch
+
+from .._lib import ALLOC_FN, check, lib
+
+NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/config.h:14
+
+_tls = threading.local()
+
+lib()   # fail at import time if the HIP library is missing: there is no fallback
+
+
+@ALLOC_FN
+def _grow(user, nbytes):
+    """Replaces resizeFunctional (rasterize_points.cu:27-33): grow scratch tensor number `user` and hand back its pointer."""
+    t = _tls.buffers[int(user or 0)]
+    t.resize_(int(nbytes))
+    return t.data_ptr()
+
+
+def _ptr(t: torch.Tensor, name: str, dtype=torch.float32):
+    """Raw device pointer of an optional tensor; an EMPTY tensor means "absent" and maps to NULL
+    (diff_gaussian_rasterization/__init__.py:200-210, rasterize_points.cu:96-108)."""
+    if t is None or t.numel() == 0:
+        return None, t
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); this op has no CPU path")
+    t = t.contiguous()
+    return t.data_ptr(), t
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA, rasterize_points.cu:35-119.
+    Returns (num_rendered, out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P,), geomBuffer,
+    binningBuffer, imgBuffer)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")          # rasterize_points.cu:57-59
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must live on the GPU; this op has no CPU path")
+    L = lib()
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    fopts = dict(dtype=torch.float32, device=dev)
+    # every element is written by the kernels (or memset by the library when P == 0): no zero-fill pass needed
+    out_color = torch.empty((NUM_CHANNELS, H, W), **fopts)
+    out_depth = torch.empty((1, H, W), **fopts)
+    out_alpha = torch.empty((1, H, W), **fopts)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty((0,), dtype=torch.uint8, device=dev)
+    binning = torch.empty((0,), dtype=torch.uint8, device=dev)
+    img = torch.empty((0,), dtype=torch.uint8, device=dev)
+
+    M = int(sh.size(1)) if sh.numel() != 0 else 0                                   # rasterize_points.cu:85-89
+    keep = []
+    def p(t, name):
+        ptr, c = _ptr(t, name)
+        keep.append(c)
+        return ptr
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _tls.buffers = (geom, binning, img)
+        try:
+            rc = L.moss_raster_forward(
+                _grow, 0, _grow, 1, _grow, 2,
+                P, int(degree), M,
+                p(background, "background"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"), p(opacity, "opacity"),
+                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr() if P else None,
+                int(bool(debug)), stream)
+        finally:
+            _tls.buffers = None
+    rendered = check(rc, "rasterize_gaussians")
+    return rendered, out_color, out_depth, out_alpha, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug):
+    """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:121-206.
+    Returns (dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P,1), dL_dmeans3D (P,3), dL_dcov3D (P,6),
+    dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4))."""
+    L = lib()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.numel() != 0 else 0
+    fopts = dict(dtype=torch.float32, device=dev)
+    # The reference zero-fills nine tensors here (300 B per Gaussian, rasterize_points.cu:158-166); the HIP backward
+    # writes every element exactly once, so plain allocations suffice.  P == 0 keeps the reference's zeros.
+    alloc = torch.zeros if P == 0 else torch.empty
+    dL_dmeans3D = alloc((P, 3), **fopts)
+    dL_dmeans2D = alloc((P, 3), **fopts)
+    dL_dcolors = alloc((P, NUM_CHANNELS), **fopts)
+    dL_dconic = alloc((P, 2, 2), **fopts)
+    dL_dopacity = alloc((P, 1), **fopts)
+    dL_dcov3D = alloc((P, 6), **fopts)
+    dL_dsh = alloc((P, M, 3), **fopts)
+    dL_dscales = alloc((P, 3), **fopts)
+    dL_drotations = alloc((P, 4), **fopts)
+    if P != 0:
+        keep = []
+        def p(t, name, dtype=torch.float32):
+            ptr, c = _ptr(t, name, dtype)
+            keep.append(c)
+            return ptr
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.moss_raster_backward(
+                P, int(degree), M, int(R),
+                p(background, "background"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"), p(alphas, "alphas"),
+                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tan_fovx), float(tan_fovy),
+                p(radii, "radii", torch.int32), p(geomBuffer, "geomBuffer", torch.uint8),
+                p(binningBuffer, "binningBuffer", torch.uint8), p(imageBuffer, "imageBuffer", torch.uint8),
+                p(dL_dout_color, "dL_dout_color"), p(dL_dout_depth, "dL_dout_depth"), p(dL_dout_alpha, "dL_dout_alpha"),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None,
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)), stream)
+        check(rc, "rasterize_gaussians_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible, rasterize_points.cu:208-227: bool (P,), True where z_view > 0.2."""
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must live on the GPU; this op has no CPU path")
+    L = lib()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m, _m = _ptr(means3D, "means3D")
+        v, _v = _ptr(viewmatrix, "viewmatrix")
+        pr, _pr = _ptr(projmatrix, "projmatrix")
+        with torch.cuda.device(dev):
+            rc = L.moss_raster_mark_visible(P, m, v, pr, present.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        check(rc, "mark_visible")
+    return present

@@ -1,0 +1,127 @@
+"""Python op surface of the MI355X Gaussian rasterizer -- a drop-in for the reference package
+``diff_gaussian_rasterization`` (submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py).
+
+Same public names, signatures, argument meaning, outputs and error behaviour:
+
+=============================  ==========================================================  =================
+name                           role                                                        reference lines
+=============================  ==========================================================  =================
+GaussianRasterizationSettings  per-view constants (NamedTuple, 12 fields)                  __init__.py:160-172
+GaussianRasterizer             nn.Module; ``forward`` validates inputs, ``markVisible``     __init__.py:174-223
+rasterize_gaussians            functional entry                                            __init__.py:21-42
+_RasterizeGaussians            autograd.Function: 4 outputs (color, radii, depth, alpha),  __init__.py:44-158
+                               3 incoming grads, 9 returned grads
+=============================  ==========================================================  =================
+
+MOSS imports it as ``from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer``
+(gaussian_renderer/__init__.py:16); the repo-root package ``diff_gaussian_rasterization`` re-exports this module
+under that name.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    """Host copies of every tensor argument, taken BEFORE a debug-mode native call so that a failing call can be
+    replayed from ``snapshot_fw.dump`` / ``snapshot_bw.dump`` (reference __init__.py:17-19, :83-90, :135-142)."""
+    return tuple(a.cpu().clone() if isinstance(a, torch.Tensor) else a for a in input_tuple)
+
+
+def _call_native(fn, args, debug, dump_name, what):
+    if not debug:
+        return fn(*args)
+    snapshot = cpu_deep_copy_tuple(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(snapshot, dump_name)
+        print(f"\nAn error occured in {what}. Please forward {dump_name} for debugging.")
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        native_args = (
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
+            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        (num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_native(
+            _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              geomBuffer, binningBuffer, imgBuffer, alpha)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+         geomBuffer, binningBuffer, imgBuffer, alpha) = ctx.saved_tensors
+        native_args = (
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,
+            sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+         grad_scales, grad_rotations) = _call_native(
+            _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
+        # one gradient per forward() input, in forward()'s order; raster_settings gets None
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean (P,) mask of the points that pass the near-plane test of this camera."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        # an absent optional is handed to the native side as an empty tensor (null data pointer)
+        absent = torch.Tensor([])
+        shs = absent if shs is None else shs
+        colors_precomp = absent if colors_precomp is None else colors_precomp
+        scales = absent if scales is None else scales
+        rotations = absent if rotations is None else rotations
+        cov3D_precomp = absent if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

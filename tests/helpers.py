@@ -1,0 +1,146 @@
+"""Shared test plumbing: run the CPU oracle and the HIP library on the same inputs and expose both in the
+reference's own terms (GeometryState / BinningState / ImageState fields), so every stage can be compared."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+def inputs_of(scene, mode="scale_rot", degree=None, colors=False, bg=None):
+    """Select the op's input mode like gaussian_renderer/__init__.py:85-109 does.
+    mode: 'scale_rot' (scales+rotations) or 'precomp' (cov3D_precomp).  colors=True feeds colours instead of SHs."""
+    d = SimpleNamespace()
+    d.P = scene.means3D.shape[0]
+    d.means3D = scene.means3D.float().contiguous()
+    d.opacities = scene.opacities.float().contiguous()
+    d.scale_modifier = 1.0
+    if mode == "scale_rot":
+        d.scales, d.rotations, d.cov3D_precomp = scene.scales.float().contiguous(), scene.rotations.float().contiguous(), None
+    else:
+        d.scales, d.rotations, d.cov3D_precomp = None, None, scene.cov3D_precomp.float().contiguous()
+    d.degree = scene.sh_degree if degree is None else degree
+    if colors:
+        g = torch.Generator().manual_seed(11)
+        d.colors_precomp, d.shs = torch.rand(d.P, 3, generator=g), None
+    else:
+        d.colors_precomp, d.shs = None, scene.shs.float().contiguous()
+    d.bg = scene.bg.float() if bg is None else torch.tensor(bg, dtype=torch.float32)
+    c = scene.camera
+    d.cam = c
+    d.W, d.H = c.W, c.H
+    return d
+
+
+def oracle_forward(d):
+    c = d.cam
+    return oracle.forward(d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), d.opacities.numpy(), _np(d.scales),
+                          _np(d.rotations), d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(),
+                          c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy())
+
+
+def oracle_backward(d, fw, dc, dd, da):
+    c = d.cam
+    return oracle.backward(fw, d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), _np(d.scales), _np(d.rotations),
+                           d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(), c.tanfovx,
+                           c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy())
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def _dev(t, device):
+    return torch.Tensor([]) if t is None else t.to(device)
+
+
+def hip_forward(d, device, debug=False, prefiltered=False):
+    """Call the drop-in `_C.rasterize_gaussians` and export its opaque buffers in reference terms."""
+    from moss_amd.diff_gaussian_rasterization import _C
+    c = d.cam
+    t = SimpleNamespace()
+    t.args = dict(bg=d.bg.to(device), means3D=d.means3D.to(device), colors=_dev(d.colors_precomp, device),
+                  opacity=d.opacities.to(device), scales=_dev(d.scales, device), rotations=_dev(d.rotations, device),
+                  cov3D=_dev(d.cov3D_precomp, device), view=c.viewmatrix.to(device), proj=c.projmatrix.to(device),
+                  sh=_dev(d.shs, device), campos=c.campos.to(device))
+    a = t.args
+    (t.R, t.color, t.depth, t.alpha, t.radii, t.geom, t.binning, t.img) = _C.rasterize_gaussians(
+        a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"], a["rotations"], d.scale_modifier, a["cov3D"],
+        a["view"], a["proj"], c.tanfovx, c.tanfovy, c.H, c.W, a["sh"], d.degree, a["campos"], prefiltered, debug)
+    return t
+
+
+def hip_export(d, t, device):
+    """GeometryState / BinningState / ImageState views of the HIP buffers (numpy)."""
+    L = _lib()
+    P, R, W, H = d.P, t.R, d.W, d.H
+    e = SimpleNamespace()
+    f32 = dict(dtype=torch.float32, device=device)
+    depths = torch.zeros(P, **f32); means2D = torch.zeros(P, 2, **f32); conic = torch.zeros(P, 4, **f32)
+    rgb = torch.zeros(P, 3, **f32); tiles = torch.zeros(P, dtype=torch.int32, device=device)
+    clamped = torch.zeros(P, 3, dtype=torch.uint8, device=device); cov3D = torch.zeros(P, 6, **f32)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rc = L.moss_raster_export_geometry(t.geom.data_ptr(), P, depths.data_ptr(), means2D.data_ptr(), conic.data_ptr(),
+                                       rgb.data_ptr(), tiles.data_ptr(), clamped.data_ptr(), cov3D.data_ptr(), stream)
+    assert rc == 0
+    gx, gy = oracle.tile_grid(W, H)
+    keys = torch.zeros(max(R, 1), dtype=torch.int64, device=device)
+    plist = torch.zeros(max(R, 1), dtype=torch.int32, device=device)
+    ranges = torch.zeros(gx * gy, 2, dtype=torch.int32, device=device)
+    final_T = torch.zeros(W * H, **f32); n_contrib = torch.zeros(W * H, dtype=torch.int32, device=device)
+    rc = L.moss_raster_export_binning(t.geom.data_ptr(), t.binning.data_ptr(), t.img.data_ptr(), P, R, W, H,
+                                      keys.data_ptr(), plist.data_ptr(), ranges.data_ptr(), final_T.data_ptr(),
+                                      n_contrib.data_ptr(), stream)
+    assert rc == 0
+    torch.cuda.synchronize(device)
+    e.depths = depths.cpu().numpy(); e.means2D = means2D.cpu().numpy(); e.conic_opacity = conic.cpu().numpy()
+    e.rgb = rgb.cpu().numpy(); e.tiles_touched = tiles.cpu().numpy().view(np.uint32); e.clamped = clamped.cpu().numpy()
+    e.cov3D = cov3D.cpu().numpy()
+    e.point_list_keys = keys.cpu().numpy().view(np.uint64)[:R]; e.point_list = plist.cpu().numpy().view(np.uint32)[:R]
+    e.ranges = ranges.cpu().numpy().view(np.uint32); e.final_T = final_T.cpu().numpy()
+    e.n_contrib = n_contrib.cpu().numpy().view(np.uint32)
+    e.radii = t.radii.cpu().numpy(); e.color = t.color.cpu().numpy(); e.depth = t.depth.cpu().numpy(); e.alpha = t.alpha.cpu().numpy()
+    return e
+
+
+def hip_backward(d, t, dc, dd, da, device, debug=False):
+    from moss_amd.diff_gaussian_rasterization import _C
+    c = d.cam
+    a = t.args
+    out = _C.rasterize_gaussians_backward(
+        a["bg"], a["means3D"], t.radii, a["colors"], a["scales"], a["rotations"], d.scale_modifier, a["cov3D"], a["view"],
+        a["proj"], c.tanfovx, c.tanfovy, dc.to(device), dd.to(device), da.to(device), a["sh"], d.degree, a["campos"],
+        t.geom, t.R, t.binning, t.img, t.alpha, debug)
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+    return SimpleNamespace(**{n: o for n, o in zip(names, out)})
+
+
+def _lib():
+    from moss_amd import _lib as m
+    return m.lib()
+
+
+def image_grads(H, W, seed=5, zero_depth=False):
+    g = torch.Generator().manual_seed(seed)
+    dc = torch.randn(3, H, W, generator=g)
+    dd = torch.zeros(1, H, W) if zero_depth else torch.randn(1, H, W, generator=g)
+    da = torch.randn(1, H, W, generator=g)
+    return dc, dd, da
+
+
+def rel_err(a, b):
+    """max |a-b| relative to the largest magnitude of the reference b (scale-aware infinity norm)."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)) if a.size else 0.0
+
+
+def replace_forward_state(fw, e):
+    """Oracle forward namespace whose image state (final_T, n_contrib) is taken from the HIP forward, so that the
+    backward arithmetic can be compared in isolation from forward threshold decisions."""
+    import copy
+    f2 = copy.copy(fw)
+    f2.final_T = e.final_T.copy(); f2.n_contrib = e.n_contrib.copy()
+    return f2
