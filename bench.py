@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- train iters/sec of the rasterizer hot path (BASELINE.json metric) on N MI355X of one node.
+
+One STEP = one training iteration on one view of the `configs[2]` workload (100k Gaussians, 512x512, SH degree 3):
+  render() -> HIP rasterizer forward -> L1 + 0.2*(1-SSIM) + 0.5*maskL2 -> backward (HIP rasterizer backward, down to the raw
+  Gaussian parameters) -> [N>1: one RCCL all-reduce of the flat gradient bucket] -> AdamW step.
+Inputs are resident in HBM before the timed region.  N>1 is frame-parallel (one camera per rank, replicas of the
+Gaussians, weak scaling): value = N * steps / max-over-ranks time.
+
+Launch: python bench.py [--gpus 1 --steps K --warmup W]      or, for N>1,
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
+    """bytes that MUST cross HBM per fwd+bwd step, from the measured P, Pv, R, N."""
+    c = 28 if scale_rot_mode else 24
+    fwd = {
+        "preprocess_fwd": P * (12 + c + 4) + Pv * 12 * K + P * 8 + Pv * 43,
+        "scan": 8 * P,
+        "scatter": Pv * 24 + 12 * R,
+        "tile_sort": 24 * R + 8 * R + 8 * tiles,
+        "blend_fwd": 44 * R + 28 * N,
+    }
+    bwd = {
+        "blend_bwd": 44 * R + 28 * N + 36 * Pv,
+        "preprocess_bwd": 36 * Pv + Pv * (12 + 4 + 24 + 12 * K + 3) + Pv * (12 + 24 + 12 * K + 4) + (28 * Pv if scale_rot_mode else 0) + P * 12,
+    }
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--mode", default="precomp", choices=["precomp", "scale_rot"],
+                    help="precomp = MOSS as shipped (cov3D computed in Python, arguments/__init__.py:60); scale_rot = in-kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    from moss_amd import dist as mdist
+    from moss_amd import scenes, _lib
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    from moss_amd.loss import training_loss
+    from types import SimpleNamespace
+
+    rank, world, local_rank = mdist.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- workload (identical Gaussians on every rank, one camera per rank) ---------------------------------
+    poses = scenes.look_at_ring(max(world, 8))
+    maker = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[args.config]
+    scene = maker()
+    if world > 1:
+        R_, t_ = poses[rank % len(poses)]
+        c0 = scene.camera
+        scene.camera = scenes.make_camera(c0.W, c0.H, float(c0.K[0, 0]), float(c0.K[1, 1]), float(c0.K[0, 2]), float(c0.K[1, 2]), R_, t_)
+    cam = camera_view(scene.camera, dev)
+    H, W = scene.camera.H, scene.camera.W
+    pc = GaussianSet(scene, sh_degree=3, device=dev)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode == "precomp"), debug=False)
+    bg = torch.zeros(3, device=dev)
+    gt = scenes.synthetic_target(H, W).to(dev)
+    gt_mask = (gt.mean(0, keepdim=True) > 0.5).float()
+    try:
+        opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, fused=True)      # gaussian_model.py:226
+    except Exception:
+        opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, foreach=True)
+    bucket = mdist.GradBucket(list(pc.parameters()))
+
+    def step():
+        bucket.attach()
+        out = render(cam, pc, pipe, bg)
+        loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
+        loss.backward()
+        bucket.all_reduce_mean(loss, world)
+        opt.step()
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # ---- warmup (also finds the dominant kernel with all stages timed) -------------------------------------
+    _lib.profile_enable(None)
+    out = None
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize(dev)
+    prof = _lib.profile_read()
+    stage_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+    dominant = max(stage_ms, key=stage_ms.get)
+    _lib.profile_enable([dominant])          # two events per step around the dominant kernel only
+
+    # ---- timed region: EXACTLY K steps between barrier+sync pairs -------------------------------------------
+    barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev); barrier()
+    elapsed = time.perf_counter() - t0
+    dom_ms, dom_n = _lib.profile_read()[dominant]
+    dom_ms = dom_ms / max(dom_n, 1)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-stage device times of the same step (separate pass, all stages timed; not part of `value`) ----
+    _lib.profile_enable(None)
+    n_prof = min(args.steps, 50)
+    for _ in range(n_prof):
+        out = step()
+    torch.cuda.synchronize(dev)
+    prof = _lib.profile_read()
+    _lib.profile_enable([])
+    stage_ms = {k: round(v[0] / v[1], 5) if v[1] else 0.0 for k, v in prof.items()}
+
+    if rank != 0:
+        return
+
+    # ---- measured problem statistics and the roofline -------------------------------------------------------
+    radii = out["radii"]
+    P = int(radii.numel()); Pv = int((radii > 0).sum().item())
+    from moss_amd.diff_gaussian_rasterization import _C
+    R = int(_C.last_num_rendered)
+    N = H * W
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode == "scale_rot")
+    all_b = dict(fwd_b); all_b.update(bwd_b)
+    dom_bytes = all_b[dominant]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    total_bytes = sum(all_b.values())
+    iters_per_s = world * args.steps / elapsed
+    raster_ms = sum(stage_ms.values())
+
+    result = {
+        "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)" if args.config == "cfg3" else f"train iters/sec ({args.config})",
+        "value": round(iters_per_s, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {P} Gaussians on a synthetic capsule body, {W}x{H}, SH degree 3, "
+                               f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
+                   if args.config == "cfg3" else args.config,
+                   "input_mode": args.mode, "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
+                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": _pmc_traffic(dominant),
+                     "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
+                     "timing": "hipEvent pairs on the launch stream inside the timed region"},
+        "stages_ms": stage_ms,
+        "rasterizer_ms_per_step": round(raster_ms, 4),
+        "step_algorithmic_bytes": int(total_bytes),
+        "step_hbm_frac": round(total_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
+    print(json.dumps(result))
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/pmc_latest.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(scene, args, gt, gt_mask):
+    """The CPU oracle (single-threaded C port of the reference algorithm) + the same loss in torch on ONE thread, timed on
+    this box's host cores on a bounded sample of the same workload.  A reported baseline, never the product path."""
+    import numpy as np
+    import torch
+    from moss_amd.loss import training_loss
+    from tests import helpers as hp
+    torch.set_num_threads(1)
+    d = hp.inputs_of(scene, args.mode)
+    gt_c, mask_c = gt.cpu(), gt_mask.cpu()
+    n = max(1, args.cpu_iters)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fw = hp.oracle_forward(d)
+        img = torch.from_numpy(fw.color).requires_grad_(True)
+        alpha = torch.from_numpy(fw.alpha).requires_grad_(True)
+        loss = training_loss(img, alpha, gt_c, mask_c)
+        loss.backward()
+        hp.oracle_backward(d, fw, img.grad, torch.zeros(1, d.H, d.W), alpha.grad)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{n} full iterations of the same workload (C oracle fwd+bwd + torch loss, 1 thread) in {dt:.1f} s",
+            "host_cores_available": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -139,7 +139,8 @@ int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatri
  * Replaces SimpleKNN::knn (SKNN/simple_knn.h:16-19, SKNN/simple_knn.cu:185-221) behind distCUDA2
  * (SKNN/spatial.cu:16-25): mean_dists[i] = mean of the squared distances from point i to its 3 nearest
  * other points.  points (P,3), mean_dists (P).  workspace: device scratch of moss_knn_workspace_bytes(P).
- * Synchronises the stream twice (scene bounding box), like the reference's two blocking copies.
+ * Fully asynchronous on `stream` (the reference blocks twice to fetch the scene bounding box, simple_knn.cu:197,200;
+ * here the box is reduced and consumed on the device).
  */
 size_t moss_knn_workspace_bytes(int P);
 int moss_knn_dist2(int P, const float* points, float* mean_dists, char* workspace, size_t workspace_bytes, void* stream);
@@ -171,6 +172,22 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
     int P, int R, int width, int height,
     uint64_t* point_list_keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib,
     void* stream);
+
+/*
+ * Per-stage device timing, measured with HIP events recorded on the stream each stage is launched on (so it sees exactly
+ * what a profiler's kernel trace sees, minus nothing).  Enable a set of stages (bit i = stage i), run, then read:
+ * ms_sum[i] = summed duration of stage i over count[i] executions since the last read; reading synchronises those events.
+ */
+#define MOSS_STAGE_PREPROCESS_FWD 0
+#define MOSS_STAGE_SCAN           1
+#define MOSS_STAGE_SCATTER        2
+#define MOSS_STAGE_TILE_SORT      3
+#define MOSS_STAGE_BLEND_FWD      4
+#define MOSS_STAGE_BLEND_BWD      5
+#define MOSS_STAGE_PREPROCESS_BWD 6
+#define MOSS_NUM_STAGES           8
+void moss_raster_profile_enable(uint32_t stage_mask);
+int moss_raster_profile_read(float* ms_sum /* [MOSS_NUM_STAGES] */, uint32_t* count /* [MOSS_NUM_STAGES] */);
 
 #ifdef __cplusplus
 }

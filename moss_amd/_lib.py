@@ -60,6 +60,10 @@ def _declare(lib):
     lib.moss_knn_workspace_bytes.argtypes = [_i]
     lib.moss_knn_dist2.restype = _i
     lib.moss_knn_dist2.argtypes = [_i, _p, _p, _p, C.c_size_t, _p]
+    lib.moss_raster_profile_enable.restype = None
+    lib.moss_raster_profile_enable.argtypes = [C.c_uint32]
+    lib.moss_raster_profile_read.restype = _i
+    lib.moss_raster_profile_read.argtypes = [_p, _p]
     lib.moss_raster_export_geometry.restype = _i
     lib.moss_raster_export_geometry.argtypes = [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p]
     lib.moss_raster_export_binning.restype = _i
@@ -80,6 +84,26 @@ def lib() -> C.CDLL:
                 _declare(handle)
                 _lib = handle
     return _lib
+
+
+STAGES = ["preprocess_fwd", "scan", "scatter", "tile_sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+
+
+def profile_enable(stages=None):
+    """Enable HIP-event timing for the named stages (None = all, [] = off)."""
+    names = STAGES if stages is None else stages
+    mask = 0
+    for n in names:
+        mask |= 1 << STAGES.index(n)
+    lib().moss_raster_profile_enable(mask)
+
+
+def profile_read():
+    """{stage: (total_ms, count)} since the last read (synchronises the recorded events)."""
+    ms = (C.c_float * 8)()
+    cnt = (C.c_uint32 * 8)()
+    check(lib().moss_raster_profile_read(ms, cnt), "profile_read")
+    return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(STAGES)}
 
 
 def check(rc: int, what: str) -> int:

@@ -49,37 +49,25 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave
     return base + x - v;
 }
 
-// One 1024-thread block: (a) point_offsets = exclusive scan of tiles_touched over the P Gaussians,
-// (b) ranges[t] = [start,end) from the exclusive scan of tile_count, header[0] = R, header[1] = longest tile list.
+// One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram,
+// header[0] = R (num_rendered), header[1] = longest tile list.  (The per-Gaussian offsets are produced by the preprocess kernel.)
 __global__ void __launch_bounds__(1024)
-scan_kernel(int P, const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ point_offsets,
-            int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ header)
+scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ header)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x;
     if (tid == 0) s_max = 0;
-    {   // (a)
-        const int chunk = (P + 1023) / 1024;
-        const int b = tid * chunk, e = min(P, b + chunk);
-        uint32_t sum = 0;
-        for (int i = b; i < e; i++) sum += tiles_touched[i];
-        uint32_t total;
-        uint32_t off = block_scan_1024(sum, s_wave, total);
-        for (int i = b; i < e; i++) { const uint32_t v = tiles_touched[i]; point_offsets[i] = off; off += v; }
-    }
-    {   // (b)
-        const int chunk = (T + 1023) / 1024;
-        const int b = tid * chunk, e = min(T, b + chunk);
-        uint32_t sum = 0, mx = 0;
-        for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); }
-        uint32_t total;
-        uint32_t off = block_scan_1024(sum, s_wave, total);
-        for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; ranges[i] = make_uint2(off, off + v); off += v; }
-        if (mx) atomicMax(&s_max, mx);
-        __syncthreads();
-        if (tid == 0) { header[0] = total; header[1] = s_max; }
-    }
+    const int chunk = (T + 1023) / 1024;
+    const int b = tid * chunk, e = min(T, b + chunk);
+    uint32_t sum = 0, mx = 0;
+    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); }
+    uint32_t total;
+    uint32_t off = block_scan_1024(sum, s_wave, total);
+    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; ranges[i] = make_uint2(off, off + v); off += v; }
+    if (mx) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (tid == 0) { header[0] = total; header[1] = s_max; }
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
@@ -128,23 +116,24 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr a, uint32_t n)
 {
-    uint32_t npad = 1;
-    while (npad < n) npad <<= 1;
-    const uint32_t half = npad >> 1;
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
-        const uint32_t hk = k >> 1;
+    uint32_t lpad = 0;
+    while ((1u << lpad) < n) lpad++;
+    const uint32_t half = (1u << lpad) >> 1;
+    for (uint32_t lk = 1; lk <= lpad; lk++) {                              // k = 2^lk
+        const uint32_t lhk = lk - 1, hkm = (1u << lhk) - 1u;
         for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {        // flip step
-            const uint32_t blk = t / hk, off = t % hk;
-            const uint32_t lo = blk * k + off, hi = blk * k + k - 1 - off;
+            const uint32_t blk = t >> lhk, off = t & hkm;
+            const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + ((1u << lk) - 1u) - off;
             if (hi < n) {
                 const uint64_t x = a[lo], y = a[hi];
                 if (x > y) { a[lo] = y; a[hi] = x; }
             }
         }
         __syncthreads();
-        for (uint32_t j = hk >> 1; j >= 1; j >>= 1) {                       // half-cleaners
+        for (int lj = (int)lhk - 1; lj >= 0; lj--) {                        // half-cleaners, j = 2^lj
+            const uint32_t j = 1u << lj;
             for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-                const uint32_t lo = ((t / j) * 2u * j) + (t % j), hi = lo + j;
+                const uint32_t lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u)), hi = lo + j;
                 if (hi < n) {
                     const uint64_t x = a[lo], y = a[hi];
                     if (x > y) { a[lo] = y; a[hi] = x; }
@@ -157,7 +146,7 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, uint32_t n)
 
 // One block per tile.  Handles tiles whose list length n satisfies lo_excl < n <= hi_incl (size classes share the grid).
 template <bool IN_LDS>
-__global__ void tile_sort_kernel(int gx, uint32_t lo_excl, uint32_t hi_incl, GeomView g, const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(1024) tile_sort_kernel(int gx, uint32_t lo_excl, uint32_t hi_incl, GeomView g, const uint2* __restrict__ ranges,
                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
@@ -214,8 +203,8 @@ int env_int(const char* name, int dflt)
 
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, num_tiles,
-                       im.tile_count, im.ranges, im.header);
+    (void)P; (void)g;
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.header);
 }
 
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
@@ -234,12 +223,9 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     (void)R;
     const int T = fp.gx * fp.gy;
     if (max_len <= 0) return;
-    // class 0: n <= 2048 (16 KB LDS, 256 threads) -- class 1: n <= 8192 (64 KB LDS, 1024 threads) -- class 2: in global memory
-    hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(T), dim3(256), 2048 * sizeof(uint64_t), s, fp.gx, 0u, 2048u, g, im.ranges,
+    // one 1024-thread workgroup per tile, keys in LDS (64 KB = 8192 keys); longer lists are sorted in global memory
+    hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(T), dim3(1024), 8192 * sizeof(uint64_t), s, fp.gx, 0u, 8192u, g, im.ranges,
                        b.keys, b.point_list, b.inst_pos);
-    if (max_len > 2048)
-        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(T), dim3(1024), 8192 * sizeof(uint64_t), s, fp.gx, 2048u, 8192u, g, im.ranges,
-                           b.keys, b.point_list, b.inst_pos);
     if (max_len > 8192)
         hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(T), dim3(1024), 0, s, fp.gx, 8192u, 0xffffffffu, g, im.ranges,
                            b.keys, b.point_list, b.inst_pos);

@@ -1,27 +1,40 @@
 // blend.hip -- the 16x16-tile alpha blend, forward (DGR/cuda_rasterizer/forward.cu:261-383) and backward
-// (DGR/cuda_rasterizer/backward.cu:399-587), written for wave64 / CDNA4.
+// (DGR/cuda_rasterizer/backward.cu:399-587), designed for wave64 / CDNA4.
 //
-// Shape of both kernels: one 256-thread workgroup per tile = 4 wavefronts, wave w owns the 8x8-pixel quadrant
-// (w&1, w>>1) of the tile (an 8x8 block has a smaller bounding box than the reference's 16x4 thread rows, which
-// is what makes the per-wave culling below effective).  The tile's sorted entry list is walked in batches:
-//   * the whole workgroup stages a batch (three 16-byte records per entry: position+conic, conic/opacity/depth,
-//     colour -- ALL per-entry data, the reference leaves colour and depth in global memory in its forward loop,
-//     forward.cu:360,362) into LDS with coalescable dwordx4 gathers;
-//   * each wave tests 64 entries at a time, ONE ENTRY PER LANE, against its quadrant (conservative bounding box of
-//     the alpha >= 1/255 ellipse computed by the preprocess kernel), __ballot()s the result into a 64-bit scalar
-//     mask and then visits only the set bits in order (s_ff1): entries that cannot touch the quadrant cost one
-//     lane-test instead of 64 lane-evaluations;
-//   * LDS reads of the visited entry are wave-uniform broadcasts.
-// Early out: a wave stops visiting when all its 64 pixels are done; the workgroup leaves when all four waves are.
+// WHY NOT "one thread per pixel, 256 threads per tile" (the reference's shape): a training view of a human puts
+// ~100k Gaussians into ~180 of 1024 tiles, 1-5k entries per tile.  The blend is a serial recurrence over a tile's
+// entry list, so with 4 waves per tile the kernel time is (longest list) x (instructions per entry) at ONE wave per
+// SIMD (one instruction per ~4-5 cycles, every LDS/exp latency exposed) while 3/4 of the chip idles.
+//
+// Shape used here: a wavefront owns a 4x4-pixel block; lane l = (pixel l>>2, slot l&3): the FOUR lanes of a pixel
+// evaluate FOUR consecutive list entries at once, and the order-dependent parts (transmittance T, the backward's
+// suffix blend) are carried across the four slots with quad-permute DPP moves in exactly the sequential order
+// (forward T is bit-identical to a one-entry-at-a-time loop).  A workgroup is NW waves (NW=16: a whole tile, NW=4: an
+// 8x8 quadrant, so that one long tile spreads over four CUs); it stages each batch of entries ONCE into LDS (three
+// 16-byte records per entry with coalescable dwordx4 gathers -- colour and depth included, which the reference re-reads
+// from global memory per pixel, forward.cu:360,362 -- plus a packed {x, y, hx, hy} record for the cull test).
+//   * per-wave culling: each wave tests 64 staged entries at a time, one entry per lane, against its 4x4 block
+//     (conservative bounding box of the alpha >= 1/255 ellipse, from the preprocess kernel), __ballot()s the hits and
+//     compacts their indices into a per-wave LDS list (v_mbcnt prefix); the blend loop then walks that list four
+//     entries per iteration with the next iteration's records prefetched.  A 4x4 block is touched by roughly half as
+//     many entries as an 8x8 block and a quarter as many as the tile;
+//   * the inner loops are written to stay on the VECTOR unit: per-lane conditions are float selects, not lane-mask
+//     algebra -- the scalar unit is shared by every wave of a CU and was the measured bottleneck of an earlier version
+//     (SQ_INSTS_SALU > SQ_INSTS_VALU, profiles/r01_notes.md);
+//   * early out: a wave stops when its 16 pixels are done, the workgroup when all its waves are (forward).
 //
 // Backward: the reference issues 9 global float atomics per (pixel, Gaussian) pair (backward.cu:538,574-584).  Here the
-// 9 partial gradients are summed across the wave's 64 pixels with DPP row operations (6 v_add_f32_dpp per value),
-// the four wave sums are combined through LDS in a fixed order, and each (tile, entry) instance stores ONE 48-byte
-// record with plain coalesced stores; the per-Gaussian kernel (preprocess.hip) gathers a Gaussian's records in a
-// fixed order.  No float atomics anywhere => gradients are bitwise reproducible, and no accumulator needs zeroing.
+// 9 partial gradients of FOUR entries are summed over a wave's 16 pixels by a reduce-scatter: v_permlane32_swap and
+// v_permlane16_swap each fold TWO values one level (5+3 swaps), two DPP row rotations finish (22 instructions per four
+// entries); the wave sums are combined through LDS in a fixed order and each (tile, entry) instance stores ONE 48-byte
+// record with plain coalesced stores.  The per-Gaussian kernel (preprocess.hip) gathers a Gaussian's records in a
+// fixed order.  No float atomics => gradients are bitwise reproducible and no accumulator needs zero-filling.
+// The five suffix blends of backward.cu:529-549 (colour x3, depth, alpha) enter dL/dalpha only through
+// sum_k (x_k - accum_k) * g_k with per-pixel constants g, so ONE running scalar Q = sum_k accum_k g_k is carried
+// instead of five.
 //
-// Arithmetic: the power/alpha evaluation is ONE shared inline function used by both kernels (explicit fmaf chain),
-// so forward and backward take bit-identical skip decisions for every (pixel, entry) pair.
+// Arithmetic: power/alpha of a (pixel, entry) pair is ONE inline function shared by both kernels (explicit fmaf chain),
+// so forward and backward take bit-identical skip decisions.
 #include "common.h"
 
 namespace moss {
@@ -29,155 +42,258 @@ namespace moss {
 namespace {
 
 constexpr int FWD_BATCH = 256;
-constexpr int BWD_BATCH = 128;
+constexpr int BWD_BATCH = 64;
 constexpr int NPART = 12;           // 9 partial gradients padded to 12 floats (48 B) per (wave, entry)
+constexpr int LIST_PAD = 16;
 
-struct PairEval { float power, G, alpha; bool ok; };
+struct PairEval { float power, G, alpha; };
 
-// alpha of one (pixel, entry) pair; `ok` == the pair passes both skip tests of forward.cu:340-350 / backward.cu:507-514.
+// alpha of one (pixel, entry) pair, 0 if the pair fails either skip test of forward.cu:340-350 / backward.cu:507-514
 __device__ __forceinline__ PairEval eval_pair(float dx, float dy, float A, float B, float C, float opacity)
 {
     PairEval r;
-    // power = -0.5*(A dx^2 + C dy^2) - B dx dy
-    const float q = __fmaf_rn(A * dx, dx, (C * dy) * dy);
+    const float q = __fmaf_rn(A * dx, dx, (C * dy) * dy);      // power = -0.5*(A dx^2 + C dy^2) - B dx dy
     r.power = __fmaf_rn(-0.5f, q, -(B * dx) * dy);
     r.G = __expf(r.power);
-    r.alpha = fminf(0.99f, opacity * r.G);
-    r.ok = (r.power <= 0.0f) && (r.alpha >= 1.0f / 255.0f);
+    float al = fminf(0.99f, opacity * r.G);
+    al = (r.power <= 0.0f) ? al : 0.0f;
+    r.alpha = (al >= 1.0f / 255.0f) ? al : 0.0f;
     return r;
 }
 
-__device__ __forceinline__ bool quad_hit(float4 a, float hx, float hy, float bx0, float by0)
+// bounding box of an entry's alpha >= 1/255 region {x, y, hx, hy} vs. the wave's 4x4 pixel block [bx0,bx0+3] x [by0,by0+3]
+__device__ __forceinline__ bool block_hit(float4 d, float bx0, float by0)
 {
-    // bounding box of the entry's alpha >= 1/255 region vs. the wave's 8x8 pixel block [bx0,bx0+7] x [by0,by0+7]
-    return (a.x + hx >= bx0) && (a.x - hx <= bx0 + 7.0f) && (a.y + hy >= by0) && (a.y - hy <= by0 + 7.0f);
+    return (d.x + d.z >= bx0) && (d.x - d.z <= bx0 + 3.0f) && (d.y + d.w >= by0) && (d.y - d.w <= by0 + 3.0f);
+}
+
+// quad-permute DPP moves (lane l = 4*pixel + slot)
+#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
+#define QUAD_PREV(v)   DPP_F(v, 0x90)     // quad_perm:[0,0,1,2]  slot s reads slot s-1 (slot 0 reads itself)
+#define QUAD_BCAST3(v) DPP_F(v, 0xFF)     // quad_perm:[3,3,3,3]
+#define QUAD_XOR1(v)   DPP_F(v, 0xB1)     // quad_perm:[1,0,3,2]
+#define QUAD_XOR2(v)   DPP_F(v, 0x4E)     // quad_perm:[2,3,0,1]
+
+// which 4x4 block of the tile a wave owns
+template <int NW>
+__device__ __forceinline__ void block_of_wave(int sub, int wv, int& bx, int& by)
+{
+    if (NW == 16) { bx = wv & 3; by = wv >> 2; }
+    else { bx = 2 * (sub & 1) + (wv & 1); by = 2 * (sub >> 1) + (wv >> 1); }      // NW == 4: quadrant `sub`
+}
+
+// cooperative staging of `cnt` list entries first, first+dir, ... into LDS
+template <int BATCH, int NT>
+__device__ __forceinline__ void stage_batch(int cnt, const uint32_t* __restrict__ plist, int first, int dir,
+                                            const float4* __restrict__ geo_a, const float4* __restrict__ geo_b,
+                                            const float4* __restrict__ geo_c,
+                                            float4* s_a, float4* s_b, float4* s_c, float4* s_d)
+{
+#pragma unroll
+    for (int i = threadIdx.x; i < 4 * BATCH; i += NT) {
+        const int which = i / BATCH, e = i % BATCH;                  // BATCH is a power of two
+        if (e < cnt) {
+            const uint32_t id = plist[first + dir * e];
+            if (which == 0) s_a[e] = geo_a[id];
+            else if (which == 1) s_b[e] = geo_b[id];
+            else if (which == 2) s_c[e] = geo_c[id];
+            else { const float4 a = geo_a[id]; s_d[e] = make_float4(a.x, a.y, geo_b[id].w, geo_c[id].w); }
+        }
+    }
+}
+
+// Append the indices (c0 + lane) of the lanes with `hit` to this wave's list; returns the new length.
+__device__ __forceinline__ int append_hits(uint16_t* list, int len, bool hit, int value)
+{
+    const unsigned long long m = __ballot(hit);
+    const int pos = len + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (hit) list[pos] = (uint16_t)value;
+    return len + __popcll(m);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-blend_forward_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ geo_a, const float4* __restrict__ geo_b, const float4* __restrict__ geo_c,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                      float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int use_cull)
 {
-    __shared__ float4 s_a[FWD_BATCH];
-    __shared__ float4 s_b[FWD_BATCH];
-    __shared__ float4 s_c[FWD_BATCH];
+    constexpr int NT = NW * 64;
+    __shared__ float4 s_a[FWD_BATCH + 1];
+    __shared__ float4 s_b[FWD_BATCH + 1];
+    __shared__ float4 s_c[FWD_BATCH + 1];
+    __shared__ float4 s_d[FWD_BATCH];
+    __shared__ uint16_t s_list[NW][FWD_BATCH + LIST_PAD];
 
-    const int tile = blockIdx.x;
+    // workgroups of one tile differ by a multiple of T_pad (a multiple of 8): same XCD under round-robin placement
+    const int tile = blockIdx.x % T_pad, sub = blockIdx.x / T_pad;
+    if (tile >= T_tiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int qx = tx * TILE + (wv & 1) * 8, qy = ty * TILE + (wv >> 1) * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const int slot = lane & 3, pl = lane >> 2;
+    int bx, by;
+    block_of_wave<NW>(sub, wv, bx, by);
+    const int ox = tx * TILE + bx * 4, oy = ty * TILE + by * 4;
+    const int px = ox + (pl & 3), py = oy + (pl >> 2);
     const bool inside = px < W && py < H;
     const float pixx = (float)px, pixy = (float)py;
-    const float bx0 = (float)qx, by0 = (float)qy;
+    const float bx0 = (float)ox, by0 = (float)oy;
+    const int qshift = lane & ~3;
+    const uint32_t below_mask = (1u << slot) - 1u;
 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
 
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;
+    if (tid == 0) {                       // sentinel entry: opacity 0 -> alpha 0 -> contributes nothing
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_a[FWD_BATCH] = z4; s_b[FWD_BATCH] = z4; s_c[FWD_BATCH] = z4;
+    }
+
+    float T = 1.0f, T_stop = -1.0f;
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
     uint32_t last_contributor = 0;
-    bool done = !inside;
+    float live = inside ? 1.0f : 0.0f;
+    uint16_t* my_list = s_list[wv];
 
     for (int base = 0; base < n; base += FWD_BATCH) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(live == 0.0f)) break;
         const int cnt = min(FWD_BATCH, n - base);
-        if (tid < cnt) {
-            const uint32_t id = point_list[rg.x + base + tid];
-            s_a[tid] = geo_a[id]; s_b[tid] = geo_b[id]; s_c[tid] = geo_c[id];
-        }
+        stage_batch<FWD_BATCH, NT>(cnt, point_list, (int)rg.x + base, 1, geo_a, geo_b, geo_c, s_a, s_b, s_c, s_d);
         __syncthreads();
-        if (__ballot(!done) == 0ull) continue;          // this wave is finished; keep meeting the barriers
+        if (__ballot(live > 0.0f) == 0ull) continue;          // this wave is finished; keep meeting the barriers
+
+        int len = 0;
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             bool hit = j < cnt;
-            if (hit && use_cull) hit = quad_hit(s_a[j], s_b[j].w, s_c[j].w, bx0, by0);
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int bit = __ffsll((long long)mask) - 1;
-                mask &= mask - 1ull;
-                const int e = c0 + bit;
-                const float4 a = s_a[e], b = s_b[e], c = s_c[e];
-                if (!done) {
-                    const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, a.z, a.w, b.x, b.y);
-                    if (pe.ok) {
-                        const float test_T = T * (1.0f - pe.alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const float wgt = pe.alpha * T;
-                            Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);
-                            weight += wgt;
-                            Dacc = __fmaf_rn(b.z, wgt, Dacc);
-                            T = test_T;
-                            last_contributor = (uint32_t)(base + e + 1);
-                        }
-                    }
-                }
-                if (__ballot(!done) == 0ull) { mask = 0ull; c0 = cnt; }
-            }
+            if (hit && use_cull) hit = block_hit(s_d[j], bx0, by0);
+            len = append_hits(my_list, len, hit, j);
+        }
+        if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)FWD_BATCH;        // pad with the sentinel
+        const int niter = (len + 3) >> 2;
+
+        int lp = slot;
+        uint32_t e = my_list[lp];
+        float4 a = s_a[e], b = s_b[e], c = s_c[e];
+        uint32_t e1 = my_list[lp + 4];
+        for (int it = 0; it < niter; it++) {
+            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];            // prefetch the next iteration's records
+            const uint32_t e2 = my_list[lp + 8];
+
+            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, a.z, a.w, b.x, b.y);
+            const float al = pe.alpha * live;                                  // 0 for finished / outside pixels
+            const float f = 1.0f - al;
+            // X_s = T after the entries of slots 0..s, multiplied in list order (bit-identical to the serial loop)
+            float X = T * f, Y;
+            Y = QUAD_PREV(X); X = slot >= 1 ? Y * f : X;
+            Y = QUAD_PREV(X); X = slot >= 2 ? Y * f : X;
+            Y = QUAD_PREV(X); X = slot >= 3 ? Y * f : X;
+            Y = QUAD_PREV(X);
+            const float Tb = slot == 0 ? T : Y;                                // T in front of this slot's entry
+            const float st = (X < 0.0001f) ? al : 0.0f;                        // > 0: this entry ends the pixel (forward.cu:351-356)
+            const unsigned long long sb = __ballot(st > 0.0f);
+            const uint32_t q = (uint32_t)(sb >> qshift) & 0xFu;                // stop flags of this pixel's 4 slots
+            const uint32_t below = q & below_mask;                             // an earlier slot already stopped the pixel
+            float wgt = al * Tb;
+            wgt = (st > 0.0f) ? 0.0f : wgt;
+            wgt = (below != 0u) ? 0.0f : wgt;
+            const float ts = (st > 0.0f) ? Tb : T_stop;
+            T_stop = (below != 0u) ? T_stop : ts;                              // the first stopping slot records the final T
+            Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);
+            weight += wgt;
+            Dacc = __fmaf_rn(b.z, wgt, Dacc);
+            last_contributor = (wgt > 0.0f) ? (uint32_t)base + e + 1u : last_contributor;
+            T = QUAD_BCAST3(X);
+            live = (q != 0u) ? 0.0f : live;
+            if (__ballot(live > 0.0f) == 0ull) break;
+
+            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += 4;
         }
     }
 
-    if (inside) {
+    // combine the four slots of each pixel
+    Cr += QUAD_XOR1(Cr); Cr += QUAD_XOR2(Cr);
+    Cg += QUAD_XOR1(Cg); Cg += QUAD_XOR2(Cg);
+    Cb += QUAD_XOR1(Cb); Cb += QUAD_XOR2(Cb);
+    weight += QUAD_XOR1(weight); weight += QUAD_XOR2(weight);
+    Dacc += QUAD_XOR1(Dacc); Dacc += QUAD_XOR2(Dacc);
+    T_stop = fmaxf(T_stop, QUAD_XOR1(T_stop)); T_stop = fmaxf(T_stop, QUAD_XOR2(T_stop));
+    uint32_t lc = last_contributor;
+    lc = max(lc, (uint32_t)__builtin_amdgcn_mov_dpp((int)lc, 0xB1, 0xf, 0xf, true));
+    lc = max(lc, (uint32_t)__builtin_amdgcn_mov_dpp((int)lc, 0x4E, 0xf, 0xf, true));
+    const float Tf = T_stop >= 0.0f ? T_stop : T;
+
+    if (inside && slot == 0) {
         const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
-        final_T[pix_id] = T;
-        n_contrib[pix_id] = last_contributor;
-        out_color[pix_id] = __fmaf_rn(T, bg_color[0], Cr);
-        out_color[plane + pix_id] = __fmaf_rn(T, bg_color[1], Cg);
-        out_color[2 * plane + pix_id] = __fmaf_rn(T, bg_color[2], Cb);
+        final_T[pix_id] = Tf;
+        n_contrib[pix_id] = lc;
+        out_color[pix_id] = __fmaf_rn(Tf, bg_color[0], Cr);
+        out_color[plane + pix_id] = __fmaf_rn(Tf, bg_color[1], Cg);
+        out_color[2 * plane + pix_id] = __fmaf_rn(Tf, bg_color[2], Cb);
         out_alpha[pix_id] = weight;
         out_depth[pix_id] = Dacc;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.  6 DPP adds:
-// quad butterfly (x2), row_half_mirror, row_mirror (now every lane holds its 16-lane row sum), then row_bcast:15
-// into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+// two values, one reduction level each: lanes 0-31 get a's sum over (l, l+32), lanes 32-63 get b's
+__device__ __forceinline__ float fold32(float a, float b)
 {
-#define DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
-    DPP_ADD(0xB1, 0xf);     // quad_perm:[1,0,3,2]
-    DPP_ADD(0x4E, 0xf);     // quad_perm:[2,3,0,1]
-    DPP_ADD(0x141, 0xf);    // row_half_mirror
-    DPP_ADD(0x140, 0xf);    // row_mirror
-    DPP_ADD(0x142, 0xa);    // row_bcast:15 -> rows 1,3
-    DPP_ADD(0x143, 0xc);    // row_bcast:31 -> rows 2,3
-#undef DPP_ADD
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// even rows get a's sum over row pairs (0,1) / (2,3), odd rows get b's
+__device__ __forceinline__ float fold16(float a, float b)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the 4 lanes of a row that share l&3
+__device__ __forceinline__ float row_slot_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));   // row_ror:4
     return v;
 }
 
-__global__ void __launch_bounds__(256)
-blend_backward_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float4* __restrict__ geo_a, const float4* __restrict__ geo_b, const float4* __restrict__ geo_c,
                       const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
-                      float4* __restrict__ inst_grad, int use_cull)
+                      float* __restrict__ inst_grad /* [16/NW][R][12] */, size_t slab_stride, int use_cull)
 {
-    __shared__ float4 s_a[BWD_BATCH];
-    __shared__ float4 s_b[BWD_BATCH];
-    __shared__ float4 s_c[BWD_BATCH];
-    __shared__ __attribute__((aligned(16))) float s_part[4][BWD_BATCH][NPART];
+    constexpr int NT = NW * 64;
+    __shared__ float4 s_a[BWD_BATCH + 1];
+    __shared__ float4 s_b[BWD_BATCH + 1];
+    __shared__ float4 s_c[BWD_BATCH + 1];
+    __shared__ float4 s_d[BWD_BATCH];
+    __shared__ uint16_t s_list[NW][BWD_BATCH + LIST_PAD];
+    __shared__ __attribute__((aligned(16))) float s_part[NW][BWD_BATCH + 1][NPART];
     __shared__ uint32_t s_nmax;
 
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x % T_pad, sub = blockIdx.x / T_pad;
+    if (tile >= T_tiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int qx = tx * TILE + (wv & 1) * 8, qy = ty * TILE + (wv >> 1) * 8;
-    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const int slot = lane & 3, pl = lane >> 2;
+    int bx, by;
+    block_of_wave<NW>(sub, wv, bx, by);
+    const int ox = tx * TILE + bx * 4, oy = ty * TILE + by * 4;
+    const int px = ox + (pl & 3), py = oy + (pl >> 2);
     const bool inside = px < W && py < H;
     const float pixx = (float)px, pixy = (float)py;
-    const float bx0 = (float)qx, by0 = (float)qy;
+    const float bx0 = (float)ox, by0 = (float)oy;
     const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     if (n == 0) return;
+    float* my_grad = inst_grad + (size_t)sub * slab_stride + (size_t)rg.x * NPART;      // this workgroup's slab of the tile's records
 
     const float T_final = inside ? final_Ts[pix_id] : 0.0f;
-    float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
     float gpr = 0.f, gpg = 0.f, gpb = 0.f, gpd = 0.f, gpa = 0.f;
     if (inside) {
@@ -185,116 +301,121 @@ blend_backward_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
         gpd = dL_ddepths[pix_id]; gpa = dL_dalphas[pix_id];
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-    // entries at list positions >= n_eff are behind every pixel's last contributor: nobody visits them
-    if (tid == 0) s_nmax = 0;
-    __syncthreads();
-    {
-        int m = last_contributor;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-        if (lane == 0) atomicMax(&s_nmax, (uint32_t)m);
+    if (tid == 0) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_a[BWD_BATCH] = z4; s_b[BWD_BATCH] = z4; s_c[BWD_BATCH] = z4;
+        s_nmax = 0;
     }
     __syncthreads();
-    const int n_eff = (int)s_nmax;
+    // Pixel state, replicated in the pixel's four lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
+    // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
+    float T = T_final, Q = 0.0f;
+
+    // entries at list positions >= n_eff are behind every pixel's last contributor: nobody visits them
     int wave_max = last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wave_max = max(wave_max, __shfl_xor(wave_max, d));
+    if (lane == 0) atomicMax(&s_nmax, (uint32_t)wave_max);
+    __syncthreads();
+    const int n_eff = (int)s_nmax;
 
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pos = n_eff + tid; pos < n; pos += 256) {
-        float4* dst = inst_grad + 3 * ((size_t)rg.x + pos);
-        dst[0] = z4; dst[1] = z4; dst[2] = z4;
-    }
+    for (int i = n_eff * NPART + tid; i < n * NPART; i += NT) my_grad[i] = 0.0f;
+
+    uint16_t* my_list = s_list[wv];
+    // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
+    const int row = lane >> 4, rh = row >> 1, rp = row & 1;
+    const int m0 = 2 * rp + rh, m1 = 4 + m0;
+    const bool writer = (lane & 12) == 0;                  // lanes 16*row + slot
 
     for (int base = 0; base < n_eff; base += BWD_BATCH) {
         const int cnt = min(BWD_BATCH, n_eff - base);
         __syncthreads();                                   // previous batch fully flushed
-        if (tid < cnt) {
-            const int pos = n_eff - 1 - (base + tid);      // back to front
-            const uint32_t id = point_list[rg.x + pos];
-            s_a[tid] = geo_a[id]; s_b[tid] = geo_b[id]; s_c[tid] = geo_c[id];
-        }
+        stage_batch<BWD_BATCH, NT>(cnt, point_list, (int)rg.x + n_eff - 1 - base, -1, geo_a, geo_b, geo_c, s_a, s_b, s_c, s_d);
         {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4* zp = reinterpret_cast<float4*>(&s_part[0][0][0]);
-            for (int i = tid; i < 4 * BWD_BATCH * NPART / 4; i += 256) zp[i] = z4;
+            for (int i = tid; i < NW * (BWD_BATCH + 1) * NPART / 4; i += NT) zp[i] = z4;
         }
         __syncthreads();
 
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-            const int j = c0 + lane;
-            bool hit = (j < cnt) && (n_eff - 1 - (base + j) < wave_max);
-            if (hit && use_cull) hit = quad_hit(s_a[j], s_b[j].w, s_c[j].w, bx0, by0);
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int bit = __ffsll((long long)mask) - 1;
-                mask &= mask - 1ull;
-                const int e = c0 + bit;
-                const int pos = n_eff - 1 - (base + e);
-                const float4 a = s_a[e], b = s_b[e], c = s_c[e];
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-                bool contrib = false;
-                if (pos < last_contributor) {              // backward.cu:499-501
-                    const float dx = a.x - pixx, dy = a.y - pixy;
-                    const PairEval pe = eval_pair(dx, dy, a.z, a.w, b.x, b.y);
-                    if (pe.ok) {
-                        contrib = true;
-                        const float alpha = pe.alpha, G = pe.G;
-                        T = T / (1.f - alpha);
-                        const float dchannel_dcolor = alpha * T;
-                        // suffix blends (backward.cu:529-549)
-                        acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r; last_r = c.x;
-                        acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g; last_g = c.y;
-                        acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b; last_b = c.z;
-                        float dL_dopa = (c.x - acc_r) * gpr + (c.y - acc_g) * gpg + (c.z - acc_b) * gpb;
-                        v0 = dchannel_dcolor * gpr; v1 = dchannel_dcolor * gpg; v2 = dchannel_dcolor * gpb;
-                        acc_d = last_alpha * last_d + (1.f - last_alpha) * acc_d; last_d = b.z;
-                        dL_dopa += (b.z - acc_d) * gpd;
-                        acc_a = last_alpha + (1.f - last_alpha) * acc_a;
-                        dL_dopa += (1.f - acc_a) * gpa;
-                        dL_dopa *= T;
-                        last_alpha = alpha;
-                        dL_dopa += (-T_final / (1.f - alpha)) * bg_dot;
-                        const float dL_dG = b.y * dL_dopa;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * b.x - gdx * a.w;
-                        v3 = dL_dG * dG_ddelx * ddelx_dx;
-                        v4 = dL_dG * dG_ddely * ddely_dy;
-                        v5 = -0.5f * gdx * dx * dL_dG;
-                        v6 = -0.5f * gdx * dy * dL_dG;
-                        v7 = -0.5f * gdy * dy * dL_dG;
-                        v8 = G * dL_dopa;
-                    }
-                }
-                if (__ballot(contrib) != 0ull) {
-                    v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
-                    v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
-                    v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
-                    if (lane == 63) {
-                        float4* dst = reinterpret_cast<float4*>(&s_part[wv][e][0]);
-                        dst[0] = make_float4(v0, v1, v2, v3);
-                        dst[1] = make_float4(v4, v5, v6, v7);
-                        s_part[wv][e][8] = v8;
-                    }
+        bool hit = (lane < cnt) && (n_eff - 1 - (base + lane) < wave_max);
+        if (hit && use_cull) hit = block_hit(s_d[lane], bx0, by0);
+        const int len = append_hits(my_list, 0, hit, lane);
+        if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)BWD_BATCH;
+        const int niter = (len + 3) >> 2;
+
+        int lp = slot;
+        uint32_t e = my_list[lp];
+        float4 a = s_a[e], b = s_b[e], c = s_c[e];
+        uint32_t e1 = my_list[lp + 4];
+        for (int it = 0; it < niter; it++) {
+            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];
+            const uint32_t e2 = my_list[lp + 8];
+
+            const int pos = n_eff - 1 - (base + (int)e);                   // back to front
+            const float dx = a.x - pixx, dy = a.y - pixy;
+            const PairEval pe = eval_pair(dx, dy, a.z, a.w, b.x, b.y);
+            const float al = (pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = this pair is skipped
+            const float G = (al > 0.0f) ? pe.G : 0.0f;
+            // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
+            const float mm = 1.0f - al;
+            const float rinv = __builtin_amdgcn_rcpf(mm);
+            const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(b.z, gpd, gpa))));
+            const float kq = al * u;
+            // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
+            float Ti = T, Qi = Q;
+            float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);
+#pragma unroll
+            for (int k = 1; k <= 3; k++) {
+                const float yT = QUAD_PREV(To), yQ = QUAD_PREV(Qo);
+                Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
+                To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
+            }
+            T = QUAD_BCAST3(To); Q = QUAD_BCAST3(Qo);                      // the pixel's state after these four entries
+
+            // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
+            float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
+            dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
+            const float dchannel_dcolor = al * To;
+            const float dL_dG = b.y * dL_dopa;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * a.z - gdy * a.w;
+            const float dG_ddely = -gdy * b.x - gdx * a.w;
+            const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
+            const float v3 = dL_dG * dG_ddelx * ddelx_dx;
+            const float v4 = dL_dG * dG_ddely * ddely_dy;
+            const float hdG = -0.5f * dL_dG;
+            const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
+            const float v8 = G * dL_dopa;
+
+            if (__ballot(al > 0.0f) != 0ull) {
+                // reduce-scatter over the 16 pixels, separately per slot: after fold32 the lower/upper half-waves hold
+                // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
+                const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
+                const float s0 = row_slot_sum(fold16(r0, r1)), s1 = row_slot_sum(fold16(r2, r3)), s2 = row_slot_sum(fold16(r4, 0.0f));
+                if (writer) {
+                    float* dst = &s_part[wv][e][0];
+                    dst[m0] = s0; dst[m1] = s1;
+                    if (row == 0) dst[8] = s2;
                 }
             }
+            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += 4;
         }
         __syncthreads();
-        if (tid < cnt) {
-            // combine the four quadrant sums in a fixed order and emit this instance's record
-            float r[9];
+        // combine the wave sums in a fixed order; 16 lanes per entry write its 48-byte record contiguously
+        for (int i = tid; i < BWD_BATCH * 16; i += NT) {
+            const int ee = i >> 4, k = i & 15;
+            if (ee < cnt && k < NPART) {
+                float r = 0.f;
+                if (k < 9) {
 #pragma unroll
-            for (int k = 0; k < 9; k++)
-                r[k] = ((s_part[0][tid][k] + s_part[1][tid][k]) + s_part[2][tid][k]) + s_part[3][tid][k];
-            const int pos = n_eff - 1 - (base + tid);
-            float4* dst = inst_grad + 3 * ((size_t)rg.x + pos);
-            dst[0] = make_float4(r[0], r[1], r[2], r[3]);
-            dst[1] = make_float4(r[4], r[5], r[6], r[7]);
-            dst[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+                    for (int w = 0; w < NW; w++) r += s_part[w][ee][k];
+                }
+                const int pos = n_eff - 1 - (base + ee);
+                my_grad[(size_t)pos * NPART + k] = r;
+            }
         }
     }
 }
@@ -307,21 +428,39 @@ int env_int(const char* name, int dflt)
 
 }  // anonymous namespace
 
+int blend_subgroups()      // workgroups per tile (1: 16 waves own a tile; 4: one 4-wave workgroup per 8x8 quadrant)
+{
+    static const int nw = env_int("MOSS_BLEND_WAVES", 4);
+    return nw == 4 ? 4 : 1;
+}
+
 void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
                           float* out_color, float* out_depth, float* out_alpha, hipStream_t s)
 {
     static const int use_cull = env_int("MOSS_BLEND_CULL", 1);
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(fp.gx * fp.gy), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.ranges, b.point_list,
-                       g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
+    const int T = fp.gx * fp.gy, T_pad = (T + 7) / 8 * 8;
+    if (blend_subgroups() == 4)
+        hipLaunchKernelGGL(blend_forward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
+                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
+    else
+        hipLaunchKernelGGL(blend_forward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
+                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
                            const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, hipStream_t s)
 {
     static const int use_cull = env_int("MOSS_BLEND_CULL", 1);
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(fp.gx * fp.gy), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.ranges, b.point_list,
-                       g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
-                       b.inst_grad, use_cull);
+    const int T = fp.gx * fp.gy, T_pad = (T + 7) / 8 * 8;
+    float* ig = reinterpret_cast<float*>(b.inst_grad);
+    if (blend_subgroups() == 4)
+        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
+                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
+                           ig, b.slab_stride_floats, use_cull);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
+                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
+                           ig, b.slab_stride_floats, use_cull);
 }
 
 }  // namespace moss

@@ -11,7 +11,7 @@
 //     tiles_touched u32, point_offsets u32 (exclusive scan), radius i32, clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
-//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
 //     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id)
@@ -82,19 +82,28 @@ struct ImageView {
     size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
 };
 
+int blend_subgroups();       // workgroups per tile in the blend kernels (1 or 4), blend.hip
+
 struct BinView {
     uint32_t* point_list; uint32_t* inst_pos;
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
-    float4* inst_grad;       // 3 float4 per instance
+    float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per blend workgroup of a tile)
+    int slabs; size_t slab_stride_floats;
     static BinView at(char* base, int R)
     {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
+        b.slabs = blend_subgroups();
+        b.slab_stride_floats = align_up(3 * n * 16) / 4;
         b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n);
-        b.inst_grad = carve<float4>(p, 3 * n);
+        b.inst_grad = reinterpret_cast<float4*>(p);
         b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);
         return b;
     }
-    static size_t bytes(int R) { char* z = nullptr; BinView b = at(z, R); size_t n = (size_t)(R > 0 ? R : 1); return (size_t)((char*)b.inst_grad - z) + align_up(3 * n * 16); }
+    static size_t bytes(int R)
+    {
+        char* z = nullptr; BinView b = at(z, R);
+        return (size_t)((char*)b.inst_grad - z) + (size_t)b.slabs * b.slab_stride_floats * 4;
+    }
 };
 
 // Per-call constants.  The camera matrices stay on the device (the boundary hands over device pointers, exactly

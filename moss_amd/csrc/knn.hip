@@ -69,20 +69,21 @@ morton_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__
 __global__ void __launch_bounds__(1024)
 sort_keys_kernel(uint64_t* __restrict__ a, uint32_t n)
 {
-    uint32_t npad = 1;
-    while (npad < n) npad <<= 1;
-    const uint32_t half = npad >> 1;
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
-        const uint32_t hk = k >> 1;
+    uint32_t lpad = 0;
+    while ((1u << lpad) < n) lpad++;
+    const uint32_t half = (1u << lpad) >> 1;
+    for (uint32_t lk = 1; lk <= lpad; lk++) {
+        const uint32_t lhk = lk - 1, hkm = (1u << lhk) - 1u;
         for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-            const uint32_t blk = t / hk, off = t % hk;
-            const uint32_t lo = blk * k + off, hi = blk * k + k - 1 - off;
+            const uint32_t blk = t >> lhk, off = t & hkm;
+            const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + ((1u << lk) - 1u) - off;
             if (hi < n) { const uint64_t x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
         }
         __syncthreads();
-        for (uint32_t j = hk >> 1; j >= 1; j >>= 1) {
+        for (int lj = (int)lhk - 1; lj >= 0; lj--) {
+            const uint32_t j = 1u << lj;
             for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-                const uint32_t lo = ((t / j) * 2u * j) + (t % j), hi = lo + j;
+                const uint32_t lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u)), hi = lo + j;
                 if (hi < n) { const uint64_t x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
             }
             __syncthreads();

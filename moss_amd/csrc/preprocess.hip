@@ -132,6 +132,8 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           int* __restrict__ radii_out, int lds_hist)
 {
     extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_blockbase;
     const int T = gx * gy;
     if (lds_hist) {
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
@@ -142,9 +144,12 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
     for (int i = 0; i < 16; i++) { view[i] = viewmatrix[i]; proj[i] = projmatrix[i]; }
     const float3 campos = make_float3(cam_pos[0], cam_pos[1], cam_pos[2]);
 
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
+    // every thread runs the same number of iterations (the slot reservation below uses block barriers)
+    const int iters = (P + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (int it = 0; it < iters; it++) {
+        const int idx = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
-        do {
+        if (idx < P) do {
             const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
             const float3 p_view = xform4x3(p_orig, view);
             if (p_view.z <= 0.2f) {                                   // in_frustum, auxiliary.h:154
@@ -268,10 +273,30 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                     else atomicAdd(&tile_count[ty * gx + tx], 1u);
                 }
         } while (0);
-        g.radius[idx] = out_radius;
-        g.tiles_touched[idx] = out_tiles;
-        g.rect[idx] = out_rect;
-        if (radii_out) radii_out[idx] = out_radius;
+        // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos.  The runs only have to
+        // be disjoint, not ordered by index, so a block-level prefix sum plus ONE returning atomic per block replaces the
+        // device-wide scan of the reference (rasterizer_impl.cu:279).
+        uint32_t incl = out_tiles;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+            s_blockbase = tot ? atomicAdd(&header[3], tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t wbase = s_blockbase;
+        for (int w = 0; w < wv; w++) wbase += s_wsum[w];
+        if (idx < P) {
+            g.radius[idx] = out_radius;
+            g.tiles_touched[idx] = out_tiles;
+            g.point_offsets[idx] = wbase + incl - out_tiles;
+            g.rect[idx] = out_rect;
+            if (radii_out) radii_out[idx] = out_radius;
+        }
+        __syncthreads();
     }
     if (lds_hist) {
         __syncthreads();
@@ -306,6 +331,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                            const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                            GeomView g, const uint32_t* __restrict__ inst_pos, const float4* __restrict__ inst_grad,
+                           int slabs, size_t slab_stride_f4,
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
@@ -321,10 +347,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         const uint32_t off = g.point_offsets[idx];
         for (uint32_t k = 0; k < n_inst; k++) {
             const uint32_t pos = inst_pos[off + k];
-            const float4 r0 = inst_grad[3 * (size_t)pos], r1 = inst_grad[3 * (size_t)pos + 1], r2 = inst_grad[3 * (size_t)pos + 2];
-            gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
-            gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
-            gop += r2.x;
+            for (int sl = 0; sl < slabs; sl++) {
+                const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
+                gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
+                gop += r2.x;
+            }
         }
     }
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
@@ -595,7 +624,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, s,
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,
-                       g, b.inst_pos, b.inst_grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                       g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
                        dL_dsh, dL_dscale, dL_drot);
 }
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 using namespace moss;
 
@@ -35,6 +36,43 @@ int fail(int code, const char* fmt, ...)
         if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(s);                                   \
         if (e_ != hipSuccess) return fail(MOSS_ERR_HIP, "stage '%s' failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
+
+// ---- optional per-stage timing with HIP events recorded on the launch stream (moss_raster_profile_*) ----------
+struct ProfRec { int stage; hipEvent_t a, b; };
+struct Profiler {
+    std::mutex m;
+    uint32_t mask = 0;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Profiler g_prof;
+
+struct StageTimer {
+    int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(int stage_, hipStream_t s_) : stage(stage_), s(s_)
+    {
+        if (g_prof.mask & (1u << stage)) {
+            std::lock_guard<std::mutex> lk(g_prof.m);
+            a = g_prof.get(); b = g_prof.get();
+            if (a) (void)hipEventRecord(a, s);
+        }
+    }
+    ~StageTimer()
+    {
+        if (a && b) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof.m);
+            g_prof.recs.push_back({stage, a, b});
+        }
+    }
+};
 
 // Small pinned host block for the header read-back, one per host thread.
 struct Pinned {
@@ -112,9 +150,10 @@ int moss_raster_forward(
     const int T = fp.gx * fp.gy;
 
     HIP_TRY(hipMemsetAsync(im.header, 0, im.clear_bytes(), s));        // header + tile histogram + tile cursors
-    launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, im, radii, s);
+    { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
+      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, im, radii, s); }
     STAGE_CHECK("preprocess");
-    launch_scan(P, g, im, T, s);
+    { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, s); }
     STAGE_CHECK("scan");
 
     // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
@@ -131,12 +170,12 @@ int moss_raster_forward(
     BinView b = BinView::at(bin_ptr, R);
 
     if (R > 0) {
-        launch_scatter(fp, g, im, b, s);
+        { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, s); }
         STAGE_CHECK("scatter");
-        launch_tile_sort(fp, g, im, b, R, max_len, s);
+        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, max_len, s); }
         STAGE_CHECK("tile_sort");
     }
-    launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s);
+    { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }
     STAGE_CHECK("blend_forward");
     return R;
 }
@@ -171,11 +210,12 @@ int moss_raster_backward(
     const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, 0,
                                        viewmatrix, projmatrix, campos, background);
     if (R > 0) {
-        launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s);
+        { StageTimer tm(MOSS_STAGE_BLEND_BWD, s); launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s); }
         STAGE_CHECK("blend_backward");
     }
-    launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b,
-                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s);
+    { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
+      launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b,
+                                 dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s); }
     STAGE_CHECK("preprocess_backward");
     return 0;
 }
@@ -222,6 +262,27 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MOSS_ERR_HIP, "export_binning launch failed: %s", hipGetErrorString(e));
     return 0;
+}
+
+void moss_raster_profile_enable(uint32_t stage_mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof.m);
+    g_prof.mask = stage_mask;
+}
+
+int moss_raster_profile_read(float* ms_sum, uint32_t* count)
+{
+    std::lock_guard<std::mutex> lk(g_prof.m);
+    for (int i = 0; i < MOSS_NUM_STAGES; i++) { ms_sum[i] = 0.0f; count[i] = 0; }
+    int rc = 0;
+    for (const ProfRec& r : g_prof.recs) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = MOSS_ERR_HIP;
+        else if (r.stage >= 0 && r.stage < MOSS_NUM_STAGES) { ms_sum[r.stage] += ms; count[r.stage]++; }
+        g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
+    }
+    g_prof.recs.clear();
+    return rc;
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ from .._lib import ALLOC_FN, check, lib
 NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/config.h:14
 
 _tls = threading.local()
+last_num_rendered = 0   # num_rendered of the most recent forward call (read by bench.py for its byte accounting)
 
 lib()   # fail at import time if the HIP library is missing: there is no fallback
 
@@ -88,6 +89,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         finally:
             _tls.buffers = None
     rendered = check(rc, "rasterize_gaussians")
+    global last_num_rendered
+    last_num_rendered = rendered
     return rendered, out_color, out_depth, out_alpha, radii, geom, binning, img
 
 

@@ -1,0 +1,109 @@
+"""Counterpart of the reference's render binding, gaussian_renderer/__init__.py:21-136 -- the one Python file of
+MOSS that changes when the rasterizer is swapped (north_star).  Same call signature, same settings construction
+(:36-52), same zero ``means2D`` gradient sink (:29-33), same input-mode selection (:85-109), same output keys (:124-136).
+
+Out of scope here: the LBS / pose-refinement branch (:57-72).  If ``pc`` offers
+``coarse_deform_c2source`` it is called exactly as the reference does; otherwise the Gaussians render where they are
+(optionally moved by explicit ``transforms`` / ``translation``, the cheap branch :73-77).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+
+from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+PipelineDefaults = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=True, debug=False)  # arguments/__init__.py:57-61
+
+
+def eval_sh_rgb(deg, sh, dirs):
+    """SH -> RGB in torch for ``pipe.convert_SHs_python`` (the reference imports utils/sh_utils.eval_sh :57-112)."""
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+    C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435]
+    res = C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        res = res - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            res = (res + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5] + C2[2] * (2.0 * zz - xx - yy) * sh[..., 6]
+                   + C2[3] * xz * sh[..., 7] + C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                res = (res + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10]
+                       + C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                       + C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + C3[5] * z * (xx - yy) * sh[..., 14]
+                       + C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return res
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, return_smpl_rot=False,
+           transforms=None, translation=None):
+    """Render one view.  ``bg_color`` must be on the GPU."""
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D = xyz
+    bweights = correct_Rs = pose_out = None
+    if transforms is not None:
+        means3D = torch.matmul(transforms, means3D[..., None]).squeeze(-1) + (0 if translation is None else translation)
+    elif hasattr(pc, "coarse_deform_c2source"):
+        _, means3D, bweights, transforms, translation = pc.coarse_deform_c2source(
+            means3D[None], viewpoint_camera.smpl_param, viewpoint_camera.big_pose_smpl_param,
+            viewpoint_camera.big_pose_world_vertex[None])
+    means3D = means3D.squeeze()
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier, None if transforms is None else transforms.squeeze())
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = means3D - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh_rgb(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    rendered_image, radii, depth, alpha = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "transforms": transforms, "translation": translation, "correct_Rs": correct_Rs, "pose_out": pose_out,
+            "lbs_weights": bweights, "means3D": means3D}
+
+
+def camera_view(cam, device):
+    """Adapt a ``scenes.make_camera`` namespace to the attribute names render() reads from MOSS's Camera
+    (scene/cameras.py:17-72)."""
+    return SimpleNamespace(
+        FoVx=cam.FoVx, FoVy=cam.FoVy, image_height=cam.H, image_width=cam.W,
+        world_view_transform=cam.viewmatrix.to(device), full_proj_transform=cam.projmatrix.to(device),
+        camera_center=cam.campos.to(device))

@@ -1,0 +1,60 @@
+"""Photometric losses of the measured training step (host side, torch ops).
+
+Semantics follow the reference's utils/loss_utils.py: ``l1_loss`` (:41-42), ``l2_loss`` (:44-45), ``ssim`` with an
+11x11 Gaussian window, sigma 1.5, zero padding, depthwise (:47-87); the step combines them as
+``L1 + 0.2 * (1 - SSIM)`` (+ 0.5 * mask L2 on the alpha image), the rasterizer-facing terms of train_ZJU.py:111-131.
+Pinned by tests/golden/loss_*.npz (generated from the reference functions).
+"""
+from __future__ import annotations
+
+from math import exp
+
+import torch
+import torch.nn.functional as F
+
+_WINDOWS = {}
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def _window(window_size: int, channel: int, like: torch.Tensor) -> torch.Tensor:
+    key = (window_size, channel, like.device, like.dtype)
+    w = _WINDOWS.get(key)
+    if w is None:
+        g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+        w = w2.expand(channel, 1, window_size, window_size).contiguous().to(device=like.device, dtype=like.dtype)
+        _WINDOWS[key] = w
+    return w
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    channel = img1.size(-3)
+    window = _window(window_size, channel, img1)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    if size_average:
+        return ssim_map.mean()
+    return ssim_map.mean(1).mean(1).mean(1)
+
+
+def training_loss(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5):
+    """L1 + lambda_mask * L2(alpha, mask) + lambda_dssim * (1 - SSIM)  (train_ZJU.py:111-112,119,131)."""
+    ll1 = l1_loss(image, gt_image)
+    mask_loss = l2_loss(alpha, gt_mask)
+    s = ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
+    return ll1 + lambda_mask * mask_loss + lambda_dssim * (1.0 - s)

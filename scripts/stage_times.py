@@ -1,0 +1,30 @@
+"""Per-stage device times of the raw op (no loss / optimizer) on one config, via the library's HIP-event hooks."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from moss_amd import scenes, _lib
+from tests import helpers as hp
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="cfg3")
+ap.add_argument("--mode", default="precomp")
+ap.add_argument("--iters", type=int, default=30)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+scene = {"cfg1": scenes.config1, "cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[args.config]()
+d = hp.inputs_of(scene, args.mode)
+dc, dd, da = hp.image_grads(d.H, d.W)
+dc, dd, da = dc.to(dev), dd.to(dev), da.to(dev)
+for _ in range(5):
+    t = hp.hip_forward(d, dev); hp.hip_backward(d, t, dc, dd, da, dev)
+torch.cuda.synchronize()
+_lib.profile_enable(None)
+t0 = time.perf_counter()
+for _ in range(args.iters):
+    t = hp.hip_forward(d, dev); hp.hip_backward(d, t, dc, dd, da, dev)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / args.iters * 1e3
+prof = _lib.profile_read()
+out = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
+out["sum"] = round(sum(out.values()), 4); out["wall_ms_per_iter"] = round(wall, 4); out["R"] = t.R
+print(args.config, os.environ.get("MOSS_BLEND_CULL", "1"), json.dumps(out))
