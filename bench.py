@@ -60,7 +60,7 @@ def main():
     from moss_amd import scenes, _lib
     from moss_amd.gaussian_model import GaussianSet
     from moss_amd.gaussian_renderer import render, camera_view
-    from moss_amd.loss import training_loss
+    from moss_amd.loss import training_loss_fused as training_loss     # HIP-fused L1 + SSIM + mask loss (same value/grads)
     from types import SimpleNamespace
 
     rank, world, local_rank = mdist.init_from_env()

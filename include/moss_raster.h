@@ -145,6 +145,20 @@ int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatri
 size_t moss_knn_workspace_bytes(int P);
 int moss_knn_dist2(int P, const float* points, float* mean_dists, char* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Fused photometric loss of the training step and its gradient (the consumer side of the rasterizer's outputs):
+ *   loss = mean|image - gt| + lambda_mask * mean((alpha - mask)^2) + lambda_dssim * (1 - mean SSIM(image, gt))
+ * Replaces the torch graph built from l1_loss / l2_loss / ssim (utils/loss_utils.py:41-87) as combined in
+ * train_ZJU.py:111-112,119,131 (lambda_dssim 0.2, lambda_mask 0.5) and its autograd backward.
+ *   image, gt (C,H,W); alpha, mask (H,W) or both NULL; loss_out: 4 device floats {total, l1, ssim, mask_l2};
+ *   dL_dimage (C,H,W), dL_dalpha (H,W; NULL iff alpha NULL): gradients of `total`, every element written.
+ *   workspace: device scratch of moss_loss_workspace_bytes(C,H,W).  Asynchronous on `stream`, deterministic.
+ */
+size_t moss_loss_workspace_bytes(int C, int H, int W);
+int moss_photometric_loss(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
+                          float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage, float* dL_dalpha,
+                          char* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- inspection entry points (used by the parity tests; not needed by a caller of the op) ---------------- */
 
 /* Scratch sizes this library will request for a given problem (host-only arithmetic, no GPU touched). */

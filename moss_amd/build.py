@@ -26,6 +26,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "blend.hip": [],
+    "loss.hip": [],
     "raster_api.hip": [],
 }
 

@@ -58,3 +58,42 @@ def training_loss(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask
     mask_loss = l2_loss(alpha, gt_mask)
     s = ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
     return ll1 + lambda_mask * mask_loss + lambda_dssim * (1.0 - s)
+
+
+class _FusedPhotometricLoss(torch.autograd.Function):
+    """HIP implementation of :func:`training_loss` (include/moss_raster.h: moss_photometric_loss): the loss and its
+    gradient w.r.t. image and alpha come out of two fused kernels; backward only scales them by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask):
+        from ._lib import check, lib
+        L = lib()
+        if not image.is_cuda:
+            raise RuntimeError("fused loss needs GPU tensors; use training_loss() for the torch reference on CPU")
+        C, H, W = image.shape
+        image_c, gt_c = image.contiguous(), gt_image.contiguous()
+        alpha_c, mask_c = alpha.contiguous(), gt_mask.contiguous()
+        out = torch.empty(4, dtype=torch.float32, device=image.device)
+        d_img = torch.empty_like(image_c)
+        d_alpha = torch.empty_like(alpha_c)
+        nbytes = int(L.moss_loss_workspace_bytes(C, H, W))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+        with torch.cuda.device(image.device):
+            rc = L.moss_photometric_loss(C, H, W, image_c.data_ptr(), gt_c.data_ptr(), alpha_c.data_ptr(), mask_c.data_ptr(),
+                                         float(lambda_dssim), float(lambda_mask), out.data_ptr(), d_img.data_ptr(),
+                                         d_alpha.data_ptr(), ws.data_ptr(), nbytes,
+                                         torch.cuda.current_stream(image.device).cuda_stream)
+        check(rc, "photometric_loss")
+        ctx.save_for_backward(d_img, d_alpha)
+        ctx.terms = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        d_img, d_alpha = ctx.saved_tensors
+        return grad_out * d_img, grad_out * d_alpha, None, None, None, None
+
+
+def training_loss_fused(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5):
+    """Same value and gradients as :func:`training_loss`, computed by the fused HIP kernels."""
+    return _FusedPhotometricLoss.apply(image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask)
