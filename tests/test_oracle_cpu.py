@@ -1,0 +1,242 @@
+"""CPU tests that PIN THE ORACLE: golden vectors produced by the reference's own Python (tests/golden/make_golden.py),
+closed-form known answers, and an independent float64 autograd restatement for the explicit backward."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from moss_amd import scenes
+from oracle import autograd_rasterizer as ag
+from oracle import oracle
+from tests import helpers as hp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def _preprocess_only(means, shs, degree, campos, scales=None, rots=None, cov=None, W=64, H=64, tan=2.0, t=(0, 0, 10.0), op=None):
+    """Run just the oracle's preprocess stage on a wide camera so that nothing is culled."""
+    L = oracle.lib()
+    P = means.shape[0]
+    cam = scenes.make_camera(W, H, W / (2 * tan), H / (2 * tan), W / 2, H / 2, np.eye(3), np.array(t, dtype=float))
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    means, shs, scales, rots, cov = f(means), f(shs), f(scales), f(rots), f(cov)
+    op = np.full(P, 0.5, np.float32) if op is None else f(op)
+    view, proj, cp = f(cam.viewmatrix.numpy()), f(cam.projmatrix.numpy()), f(campos)
+    radii = np.zeros(P, np.int32); xy = np.zeros((P, 2), np.float32); depths = np.zeros(P, np.float32)
+    cov3D = np.zeros((P, 6), np.float32); rgb = np.zeros((P, 3), np.float32); conic = np.zeros((P, 4), np.float32)
+    tiles = np.zeros(P, np.uint32); clamped = np.zeros((P, 3), np.uint8)
+    M = 0 if shs is None else shs.shape[1]
+    err = L.oracle_preprocess(C.c_int(P), C.c_int(degree), C.c_int(M), p(means), p(scales), C.c_float(1.0), p(rots), p(op), p(shs),
+                              p(cov), None, p(view), p(proj), p(cp), C.c_int(W), C.c_int(H), C.c_float(cam.tanfovx),
+                              C.c_float(cam.tanfovy), C.c_int(0), p(radii), p(xy), p(depths), p(cov3D), p(rgb), p(conic), p(tiles),
+                              p(clamped))
+    assert err == 0
+    return dict(radii=radii, xy=xy, depths=depths, cov3D=cov3D, rgb=rgb, conic=conic, tiles=tiles, clamped=clamped, cam=cam)
+
+
+# ------------------------------------------------------------------------------------------------ golden: SH -> RGB
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_to_rgb_matches_reference_eval_sh(deg):
+    """oracle computeColorFromSH == clamp_min(eval_sh(reference) + 0.5, 0)  (gaussian_renderer/__init__.py:100-105)."""
+    g = _gold("sh_eval.npz")
+    dirs, sh = g["dirs"], g["sh"]                                    # sh: (P, 3, 16) reference layout
+    means = dirs * 3.0                                               # campos = 0 -> view direction == dirs
+    shs = np.ascontiguousarray(sh.transpose(0, 2, 1))                # op layout (P, 16, 3)
+    cov = np.tile(np.array([0.05, 0, 0, 0.05, 0, 0.05], np.float32), (len(means), 1))
+    r = _preprocess_only(means, shs, deg, np.zeros(3, np.float32), cov=cov)
+    assert (r["radii"] > 0).all()
+    want = g[f"rgb_deg{deg}"] + 0.5
+    np.testing.assert_allclose(r["rgb"], np.maximum(want, 0.0), rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(r["clamped"].astype(bool)[np.abs(want) > 1e-5], (want < 0)[np.abs(want) > 1e-5])
+
+
+def test_rgb2sh_constant():
+    g = _gold("sh_eval.npz")
+    np.testing.assert_allclose((g["rgb2sh_in"] - 0.5) / scenes.C0, g["rgb2sh_out"], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ golden: covariance
+def test_cov3d_from_scale_rotation_matches_reference():
+    """oracle computeCov3D (quaternion used as given) == reference build_covariance_from_scaling_rotation on the normalised
+    quaternion (the reference's Python normalises, its kernel does not: Q5 of SURVEY appendix A)."""
+    g = _gold("cov3d.npz")
+    scales, rots = g["scales"], g["rots"]
+    qn = rots / np.linalg.norm(rots, axis=1, keepdims=True)
+    means = np.zeros((len(scales), 3), np.float32)
+    shs = np.zeros((len(scales), 1, 3), np.float32)
+    r = _preprocess_only(means, shs, 0, np.array([0, 0, -5.0], np.float32), scales=scales, rots=qn)
+    np.testing.assert_allclose(r["cov3D"], g["cov_plain"], rtol=2e-5, atol=1e-9)
+
+
+def test_covariance_precomp_helper_matches_reference():
+    g = _gold("cov3d.npz")
+    s, q, T = torch.from_numpy(g["scales"]), torch.from_numpy(g["rots"]), torch.from_numpy(g["transforms"])
+    np.testing.assert_allclose(scenes.covariance_precomp(s, q).numpy(), g["cov_plain"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(scenes.covariance_precomp(s, q, 1.7).numpy(), g["cov_mod17"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(scenes.covariance_precomp(s, q, 1.0, T).numpy(), g["cov_T"], rtol=5e-5, atol=1e-9)
+    np.testing.assert_allclose(scenes.quat_to_rot(q).numpy(), g["rotmat"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ golden: cameras
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_camera_matrices_match_reference(i):
+    import math
+    g = _gold("camera.npz")
+    W, H, fx, fy, cx, cy, ang, tx, ty, tz = g[f"c{i}_params"]
+    R = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    cam = scenes.make_camera(int(W), int(H), fx, fy, cx, cy, R, np.array([tx, ty, tz]))
+    np.testing.assert_allclose(cam.viewmatrix.numpy(), g[f"c{i}_w2v"].T, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(cam.projmatrix.numpy(), g[f"c{i}_full"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cam.campos.numpy(), g[f"c{i}_campos"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([cam.FoVx, cam.FoVy], g[f"c{i}_fov"], rtol=1e-7)
+    np.testing.assert_allclose(scenes.projection_refine(cam.K, int(H), int(W)), g[f"c{i}_proj"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ golden: losses
+@pytest.mark.parametrize("i", [0, 1])
+def test_loss_functions_match_reference(i):
+    from moss_amd import loss
+    g = _gold("loss.npz")
+    a = torch.from_numpy(g[f"l{i}_a"]).requires_grad_(True); b = torch.from_numpy(g[f"l{i}_b"])
+    l1, l2, s = loss.l1_loss(a, b), loss.l2_loss(a, b), loss.ssim(a.unsqueeze(0), b.unsqueeze(0))
+    assert abs(l1.item() - g[f"l{i}_l1"]) < 1e-12 and abs(l2.item() - g[f"l{i}_l2"]) < 1e-12
+    assert abs(s.item() - g[f"l{i}_ssim"]) < 1e-7          # the reference builds its window in fp32
+    total = l1 + 0.2 * (1.0 - s)
+    total.backward()
+    np.testing.assert_allclose(a.grad.numpy(), g[f"l{i}_grad"], rtol=1e-5, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ known answers
+def _single(opacity=0.8, sigma=0.02, z=0.0, color=(0.9, 0.3, 0.1), W=64, H=64, bg=(0.0, 0.0, 0.0)):
+    s = scenes.config1(P=1, W=W, H=H)
+    s.means3D = torch.tensor([[0.0, 0.0, z]])
+    s.scales = torch.full((1, 3), sigma); s.rotations = torch.tensor([[1.0, 0, 0, 0]])
+    s.opacities = torch.tensor([[opacity]])
+    s.cov3D_precomp = scenes.covariance_precomp(s.scales, s.rotations)
+    s.camera = scenes.make_camera(W, H, 96.0, 96.0, W / 2 + 0.5, H / 2 + 0.5, np.eye(3), np.array([0.0, 0.0, 3.0]))
+    d = hp.inputs_of(s, "scale_rot", colors=True, bg=list(bg))
+    d.colors_precomp = torch.tensor([list(color)])
+    return d
+
+
+def test_single_isotropic_gaussian_closed_form():
+    """Centre projects exactly onto pixel (32,32): cov2D = (f*sigma/z)^2 + 0.3 on the diagonal, radius = ceil(3 sqrt(lambda)),
+    alpha(centre) = opacity, colour(centre) = rgb*alpha + T*bg, alpha image = alpha, depth image = z*alpha."""
+    d = _single(bg=(0.2, 0.4, 0.6))
+    fw = hp.oracle_forward(d)
+    var = (96.0 * 0.02 / 3.0) ** 2 + 0.3
+    assert abs(fw.means2D[0, 0] - 32.0) < 1e-4 and abs(fw.means2D[0, 1] - 32.0) < 1e-4
+    np.testing.assert_allclose(fw.conic_opacity[0], [1 / var, 0.0, 1 / var, 0.8], rtol=1e-5, atol=1e-7)
+    # isotropic: mid^2 - det = 0, but the reference floors it at 0.1 (forward.cu:230-231) => lambda1 = var + sqrt(0.1)
+    assert fw.radii[0] == int(np.ceil(3 * np.sqrt(var + np.sqrt(0.1))))
+    r = fw.radii[0]
+    x0, x1 = int((32 - r) / 16), int((32 + r + 15) / 16)
+    assert fw.tiles_touched[0] == (x1 - x0) ** 2 == fw.num_rendered
+    np.testing.assert_allclose(fw.alpha[0, 32, 32], 0.8, rtol=1e-5)
+    np.testing.assert_allclose(fw.color[:, 32, 32], np.array([0.9, 0.3, 0.1]) * 0.8 + 0.2 * np.array([0.2, 0.4, 0.6]), rtol=1e-5)
+    np.testing.assert_allclose(fw.depth[0, 32, 32], 3.0 * 0.8, rtol=1e-5)
+    # two pixels to the right: alpha = o * exp(-0.5 * 4 / var)
+    np.testing.assert_allclose(fw.alpha[0, 32, 34], 0.8 * np.exp(-2.0 / var), rtol=1e-4)
+    # far away: background only, n_contrib 0
+    np.testing.assert_allclose(fw.color[:, 2, 2], [0.2, 0.4, 0.6], rtol=1e-6)
+    assert fw.n_contrib.reshape(64, 64)[2, 2] == 0 and fw.n_contrib.reshape(64, 64)[32, 32] == 1
+
+
+def test_two_gaussians_blend_front_to_back_and_alpha_clamp():
+    d = _single(opacity=1.0)                      # alpha clamps at 0.99
+    d.means3D = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 0.5]]); d.P = 2
+    d.scales = torch.full((2, 3), 0.02); d.rotations = torch.tensor([[1.0, 0, 0, 0]] * 2)
+    d.opacities = torch.tensor([[1.0], [0.5]])
+    d.colors_precomp = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    fw = hp.oracle_forward(d)
+    # the nearer Gaussian (z_view 3.0) comes first in every tile it shares with the farther one
+    t = np.flatnonzero(fw.ranges[:, 1] - fw.ranges[:, 0] == 2)[0]
+    np.testing.assert_array_equal(fw.point_list[fw.ranges[t, 0]:fw.ranges[t, 1]], [0, 1])
+    a0 = 0.99
+    px = fw.means2D[1]                            # second Gaussian's centre pixel (32, 32) as well (on the optical axis)
+    var1 = (96.0 * 0.02 / 3.5) ** 2 + 0.3
+    a1 = 0.5 * np.exp(-0.5 * ((px[0] - 32) ** 2 + (px[1] - 32) ** 2) / var1)
+    np.testing.assert_allclose(fw.color[:, 32, 32], [a0, (1 - a0) * a1, 0.0], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(fw.final_T.reshape(64, 64)[32, 32], (1 - a0) * (1 - a1), rtol=1e-4)
+
+
+def test_sort_is_stable_on_equal_depth():
+    d = _single()
+    d.means3D = torch.tensor([[0.01, 0.0, 0.0], [0.0, 0.01, 0.0], [-0.01, 0.0, 0.0]]); d.P = 3      # identical view depth
+    d.scales = torch.full((3, 3), 0.02); d.rotations = torch.tensor([[1.0, 0, 0, 0]] * 3)
+    d.opacities = torch.full((3, 1), 0.3); d.colors_precomp = torch.rand(3, 3)
+    fw = hp.oracle_forward(d)
+    assert len(set(fw.depths.view(np.uint32).tolist())) == 1
+    for t in range(len(fw.ranges)):
+        seg = fw.point_list[fw.ranges[t, 0]:fw.ranges[t, 1]]
+        assert list(seg) == sorted(seg)
+    assert (np.diff(fw.point_list_keys.astype(np.uint64)) >= 0).all()
+
+
+def test_binning_invariants_cfg2():
+    fw = hp.oracle_forward(hp.inputs_of(scenes.config2(), "precomp"))
+    assert fw.num_rendered == int(fw.tiles_touched.sum()) == len(fw.point_list)
+    assert (np.diff(fw.point_list_keys) >= 0).all()                                   # sorted by (tile, depth bits)
+    lens = fw.ranges[:, 1].astype(np.int64) - fw.ranges[:, 0]
+    assert lens.sum() == fw.num_rendered and (lens >= 0).all()
+    tiles = (fw.point_list_keys >> np.uint64(32)).astype(np.int64)
+    for t in np.flatnonzero(lens > 0)[:20]:
+        assert (tiles[fw.ranges[t, 0]:fw.ranges[t, 1]] == t).all()
+    assert oracle.get_higher_msb(1024) == 11 and oracle.get_higher_msb(4096) == 13
+
+
+def test_dist2_known_answers():
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [10, 10, 10]], np.float32)
+    d = oracle.dist2(pts)
+    np.testing.assert_allclose(d[0], (1 + 4 + 9) / 3.0, rtol=1e-6)
+    np.testing.assert_allclose(d[1], (1 + 5 + 10) / 3.0, rtol=1e-6)
+    # fewer than 3 neighbours leaves a FLT_MAX term in the mean (simple_knn.cu:154,182): ~FLT_MAX/3
+    np.testing.assert_allclose(oracle.dist2(pts[:3]), np.float32(3.4028235e38) / np.float32(3.0), rtol=1e-6)
+    dup = np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0], [2, 0, 0]], np.float32)
+    np.testing.assert_allclose(oracle.dist2(dup)[0], (0 + 1 + 4) / 3.0, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ backward vs autograd
+@pytest.mark.parametrize("mode", ["scale_rot", "precomp"])
+def test_explicit_backward_matches_independent_autograd(mode):
+    """The C oracle's explicit backward (restated backward.cu) against autograd of an independent float64 forward.
+    Tolerance 2e-3 of each gradient's max: fp32 vs fp64 plus semantic (vii) above."""
+    s = scenes.config1(P=96, W=64, H=64, seed=7)
+    d = hp.inputs_of(s, mode)
+    fw = hp.oracle_forward(d)
+    dc, dd, da = hp.image_grads(d.H, d.W, seed=9)
+    ref = hp.oracle_backward(d, fw, dc, dd, da)
+    # pixels whose decisions sit on a threshold would make the two forwards differ discretely: require none
+    assert fw.margin.min() > 1e-6
+    c = d.cam
+    f64 = lambda t: None if t is None else t.double()
+    leaf = lambda t: None if t is None else t.double().clone().requires_grad_(True)
+    means, opa, shs = leaf(d.means3D), leaf(d.opacities), leaf(d.shs)
+    scales, rots, cov = leaf(d.scales), leaf(d.rotations), leaf(d.cov3D_precomp)
+    ndc = torch.zeros(d.P, 2, dtype=torch.float64, requires_grad=True)
+    col, dep, alp = ag.render(fw, means, opa, f64(c.viewmatrix), f64(c.projmatrix), f64(c.campos), c.tanfovx, c.tanfovy,
+                              f64(d.bg), d.degree, shs=shs, scales=scales, rotations=rots, cov3D_precomp=cov, ndc_offset=ndc)
+    # forward agreement first (fp32 oracle vs fp64 autograd forward)
+    assert hp.rel_err(fw.color, col.detach().numpy()) < 5e-5
+    assert hp.rel_err(fw.alpha, alp.detach().numpy()) < 5e-5
+    assert hp.rel_err(fw.depth, dep.detach().numpy()) < 5e-5
+    loss = (col * dc.double()).sum() + (dep * dd.double()).sum() + (alp * da.double()).sum()
+    loss.backward()
+    checks = [("dL_dmeans3D", means.grad), ("dL_dopacity", opa.grad), ("dL_dsh", shs.grad), ("dL_dmeans2D", ndc.grad)]
+    if mode == "scale_rot":
+        checks += [("dL_dscales", scales.grad), ("dL_drotations", rots.grad)]
+    else:
+        checks += [("dL_dcov3D", cov.grad)]
+    for name, gref in checks:
+        got = getattr(ref, name)
+        if name == "dL_dmeans2D":
+            got = got[:, :2]
+        err = hp.rel_err(got.reshape(gref.shape), gref.numpy())
+        assert err < 2e-3, (name, err)
