@@ -49,8 +49,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--mode", default="precomp", choices=["precomp", "scale_rot"],
-                    help="precomp = MOSS as shipped (cov3D computed in Python, arguments/__init__.py:60); scale_rot = in-kernel")
+    ap.add_argument("--mode", default="scale_rot", choices=["precomp", "scale_rot"],
+                    help="scale_rot = cov3D computed inside the rasterizer from scales+rotations (the reference's "
+                         "compute_cov3D_python=False path, gaussian_renderer/__init__.py:92-93); precomp = cov3D computed by "
+                         "torch ops and passed in (MOSS's shipped default, arguments/__init__.py:60)")
+    ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW instead of the flat fused HIP AdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
@@ -84,11 +87,12 @@ def main():
     bg = torch.zeros(3, device=dev)
     gt = scenes.synthetic_target(H, W).to(dev)
     gt_mask = (gt.mean(0, keepdim=True) > 0.5).float()
-    try:
-        opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, fused=True)      # gaussian_model.py:226
-    except Exception:
-        opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, foreach=True)
     bucket = mdist.GradBucket(list(pc.parameters()))
+    if args.torch_adamw:
+        opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, fused=True)      # gaussian_model.py:226
+    else:
+        from moss_amd.optim import FlatAdamW
+        opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15)                          # same rule, one kernel over the bucket
 
     def step():
         bucket.attach()

@@ -159,6 +159,15 @@ int moss_photometric_loss(int C, int H, int W, const float* image, const float* 
                           float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage, float* dL_dalpha,
                           char* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Flat fused AdamW (torch.optim.AdamW semantics, amsgrad off) over `n` contiguous fp32 parameters with their gradients and
+ * moments; up to 8 learning-rate segments: parameter i belongs to the first segment s with i < segment_end[s] (host arrays).
+ * Replaces the per-group optimizer step of scene/gaussian_model.py:215-226 for the Gaussian parameters.  `step` counts from 1.
+ */
+int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    int num_segments, const long long* segment_end, const float* segment_lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ---- inspection entry points (used by the parity tests; not needed by a caller of the op) ---------------- */
 
 /* Scratch sizes this library will request for a given problem (host-only arithmetic, no GPU touched). */

@@ -27,6 +27,7 @@ SOURCES = {
     "binning.hip": [],
     "blend.hip": [],
     "loss.hip": [],
+    "optim.hip": [],
     "raster_api.hip": [],
 }
 

@@ -1,0 +1,71 @@
+// optim.hip -- flat fused AdamW over the frame-parallel gradient bucket.
+// MOSS steps torch.optim.AdamW over 8 parameter groups (scene/gaussian_model.py:215-226); per step that is one
+// multi-tensor launch per group.  All Gaussian parameters, their gradients (moss_amd/dist.py GradBucket) and both
+// moments live in four flat fp32 buffers here, so one streaming kernel (28 B per parameter) updates everything;
+// groups differ only in learning rate, looked up from a small segment table.
+// Semantics = torch.optim.AdamW (amsgrad=False, maximize=False): decoupled weight decay, bias-corrected moments.
+#include "common.h"
+
+namespace moss {
+namespace {
+
+struct Segs { int n; long long end[8]; float lr[8]; };
+
+__global__ void __launch_bounds__(256)
+adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+             Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt)
+{
+    for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i4 * 4;
+        float pv[4], gv[4], mv[4], vv[4];
+        const bool full = i + 4 <= n;
+        if (full) {
+            const float4 a = reinterpret_cast<const float4*>(p)[i4], b = reinterpret_cast<const float4*>(g)[i4];
+            const float4 c = reinterpret_cast<const float4*>(m)[i4], d = reinterpret_cast<const float4*>(v)[i4];
+            pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+        } else {
+            for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float lr = 0.f;
+            const long long idx = i + k;
+#pragma unroll
+            for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) lr = segs.lr[s];
+            pv[k] *= 1.0f - lr * weight_decay;
+            mv[k] = beta1 * mv[k] + (1.0f - beta1) * gv[k];
+            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pv[k] -= (lr / bc1) * (mv[k] / denom);
+        }
+        if (full) {
+            reinterpret_cast<float4*>(p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            reinterpret_cast<float4*>(m)[i4] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            reinterpret_cast<float4*>(v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            for (int k = 0; k < 4; k++) if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace moss
+
+extern "C" int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               int num_segments, const long long* segment_end, const float* segment_lr,
+                               float beta1, float beta2, float eps, float weight_decay, int step, void* stream)
+{
+    if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || step < 1)
+        return MOSS_ERR_INVALID_ARG;
+    if (n == 0) return 0;
+    moss::Segs segs; segs.n = num_segments;
+    for (int i = 0; i < 8; i++) { segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f; }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(moss::adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq,
+                       segs, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+}

@@ -1,0 +1,52 @@
+"""Flat fused AdamW over the gradient bucket (C ABI ``moss_adamw_flat``, csrc/optim.hip) -- SURVEY.md section 8(f) n4.
+
+Same update rule as ``torch.optim.AdamW`` (which MOSS uses per parameter group, scene/gaussian_model.py:215-226), applied by
+ONE streaming kernel to all parameters: they are re-homed as views of one flat buffer, next to their flat gradients
+(``moss_amd.dist.GradBucket``) and flat first/second moments."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib
+
+
+class FlatAdamW:
+    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.01):
+        self.bucket = bucket
+        params = bucket.params
+        lr_of = {}
+        for gidx, grp in enumerate(param_groups):
+            for p in grp["params"]:
+                lr_of[id(p)] = float(grp["lr"])
+        total = sum(bucket.sizes)
+        dev = params[0].device
+        self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        ends, lrs = [], []
+        for p, n in zip(params, bucket.sizes):
+            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_params[off:off + n].view_as(p)              # the parameter now lives in the flat buffer
+            off += n
+            ends.append(off); lrs.append(lr_of[id(p)])
+        if len(ends) > 8:
+            raise ValueError("FlatAdamW supports at most 8 learning-rate segments")
+        self.n = total
+        self.seg_end = (C.c_longlong * len(ends))(*ends)
+        self.seg_lr = (C.c_float * len(lrs))(*lrs)
+        self.nseg = len(ends)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        dev = self.flat_params.device
+        with torch.cuda.device(dev):
+            rc = lib().moss_adamw_flat(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
+                                       float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                       self.t, torch.cuda.current_stream(dev).cuda_stream)
+        check(rc, "adamw_flat")
