@@ -11,8 +11,10 @@
 //      never has to be part of a sort key;
 //   2. scatter: each instance is dropped into its tile's bucket (slot order inside a bucket is arbitrary) as a
 //      64-bit key (depth_bits << 32 | gaussian_id);
-//   3. each tile sorts its own bucket IN LDS with a bitonic network on those 64-bit keys.  (depth_bits, id) is a
-//      total order, so the result is unique and equals the reference's stable sort regardless of scatter order.
+//   3. each bucket is sorted on those 64-bit keys in two instance-parallel steps: 1024-key chunks are sorted in LDS
+//      (bitonic network, one workgroup per chunk), then every instance finds its final rank by binary search in its
+//      tile's other chunks.  (depth_bits, id) is a total order, so the result is unique and equals the reference's
+//      stable sort regardless of scatter order -- and no workgroup ever owns more than 1024 keys (no long-tile tail).
 //   Sorting 8-byte keys once in LDS replaces 6 global passes over 12-byte pairs: algorithmic HBM traffic of the
 //   sort falls from >= 24 B/instance/pass to 8 B write + 8 B read + 4 B write per instance in total.
 #include "common.h"
@@ -49,10 +51,14 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave
     return base + x - v;
 }
 
-// One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram,
-// header[0] = R (num_rendered), header[1] = longest tile list.  (The per-Gaussian offsets are produced by the preprocess kernel.)
+constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort_kernel
+
+// One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram, chunk_base[t] = number
+// of sort chunks in front of tile t; header[0] = R (num_rendered), header[1] = longest tile list, header[4] = total chunks.
+// (The per-Gaussian offsets are produced by the preprocess kernel.)
 __global__ void __launch_bounds__(1024)
-scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ header)
+scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
+            uint32_t* __restrict__ header)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
@@ -60,21 +66,26 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
     if (tid == 0) s_max = 0;
     const int chunk = (T + 1023) / 1024;
     const int b = tid * chunk, e = min(T, b + chunk);
-    uint32_t sum = 0, mx = 0;
-    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); }
-    uint32_t total;
+    uint32_t sum = 0, mx = 0, nch = 0;
+    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); nch += (v + CHUNK - 1) / CHUNK; }
+    uint32_t total, total_chunks;
     uint32_t off = block_scan_1024(sum, s_wave, total);
-    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; ranges[i] = make_uint2(off, off + v); off += v; }
+    uint32_t coff = block_scan_1024(nch, s_wave, total_chunks);
+    for (int i = b; i < e; i++) {
+        const uint32_t v = tile_count[i];
+        ranges[i] = make_uint2(off, off + v); off += v;
+        chunk_base[i] = coff; coff += (v + CHUNK - 1) / CHUNK;
+    }
     if (mx) atomicMax(&s_max, mx);
     __syncthreads();
-    if (tid == 0) { header[0] = total; header[1] = s_max; }
+    if (tid == 0) { header[0] = total; header[1] = s_max; header[4] = total_chunks; }
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
 // with ONE returning global atomic (after counting its own instances in LDS) and hands the slots out with LDS atomics.
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ keys, int lds_hist)
+               uint64_t* __restrict__ keys, uint32_t* __restrict__ inst_tile, int lds_hist)
 {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_cnt = s_mem;
@@ -99,7 +110,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
         const uint2 r = g.rect[idx];
         const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
         if (x1 <= x0 || y1 <= y0) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(g.geo_b[idx].z) << 32) | (uint32_t)idx;
+        const uint64_t key = ((uint64_t)__float_as_uint(g.geo_c[idx].w) << 32) | (uint32_t)idx;
         for (int ty = y0; ty < y1; ty++)
             for (int tx = x0; tx < x1; tx++) {
                 const int t = ty * gx + tx;
@@ -107,6 +118,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
                 if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
                 keys[pos] = key;
+                inst_tile[pos] = (uint32_t)t;
             }
     }
 }
@@ -144,34 +156,65 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, uint32_t n)
     }
 }
 
-// One block per tile.  Handles tiles whose list length n satisfies lo_excl < n <= hi_incl (size classes share the grid).
-template <bool IN_LDS>
-__global__ void __launch_bounds__(1024) tile_sort_kernel(int gx, uint32_t lo_excl, uint32_t hi_incl, GeomView g, const uint2* __restrict__ ranges,
-                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos)
+// Stage A of the sort: one workgroup per CHUNK of a tile's bucket (a tile of n entries has ceil(n/CHUNK) chunks), keys
+// sorted in LDS and written back in place.  Every workgroup has at most 1024 keys, so there is no long-tile tail here.
+__global__ void __launch_bounds__(1024)
+chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
-    const int tile = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[CHUNK];
+    __shared__ int s_tile;
+    const uint32_t c = blockIdx.x;
+    if (threadIdx.x == 0) {         // last tile whose chunk_base <= c (tiles without entries share their successor's base)
+        int lo = 0, hi = T;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_base[mid] <= c) lo = mid; else hi = mid; }
+        s_tile = lo;
+    }
+    __syncthreads();
+    const int tile = s_tile;
     const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    if (n <= lo_excl || n > hi_incl) return;
-    uint64_t* gk = keys + rg.x;
-    if (IN_LDS) {
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = gk[i];
-        __syncthreads();
-        bitonic_sort(s_keys, n);
-    } else {
-        __syncthreads();
-        bitonic_sort(gk, n);        // one workgroup owns the segment; __syncthreads orders its global accesses
+    const uint32_t first = rg.x + (c - chunk_base[tile]) * CHUNK;
+    const uint32_t n = min((uint32_t)CHUNK, rg.y - first);
+    uint64_t* gk = keys + first;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = gk[i];
+    __syncthreads();
+    bitonic_sort(s_keys, n);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gk[i] = s_keys[i];
+}
+
+// Stage B: one thread per instance.  Its final rank inside the tile = its rank inside its own (sorted) chunk + the number
+// of smaller keys in each of the tile's other chunks (binary search; keys (depth_bits, id) are unique).  The same thread
+// then emits everything that is per-instance: the sorted id, the 48-byte record the blend kernels stream, and the
+// Gaussian -> instance back-pointer used by the backward gather.
+__global__ void __launch_bounds__(256)
+merge_gather_kernel(int R, int gx, GeomView g, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+                    const uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
+                    float4* __restrict__ inst_rec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t tile = inst_tile[i];
+    const uint2 rg = ranges[tile];
+    const uint64_t key = keys[i];
+    const uint32_t local = (uint32_t)i - rg.x, own = local / CHUNK, n = rg.y - rg.x;
+    uint32_t rank = local % CHUNK;
+    const uint32_t nch = (n + CHUNK - 1) / CHUNK;
+    for (uint32_t c = 0; c < nch; c++) {
+        if (c == own) continue;
+        const uint64_t* seg = keys + rg.x + c * CHUNK;
+        uint32_t lo = 0, hi = min((uint32_t)CHUNK, n - c * CHUNK);        // count of keys < key in this sorted chunk
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seg[mid] < key) lo = mid + 1; else hi = mid; }
+        rank += lo;
     }
-    const int tx = tile % gx, ty = tile / gx;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t id = (uint32_t)(IN_LDS ? s_keys[i] : gk[i]);
-        point_list[rg.x + i] = id;
-        const uint2 r = g.rect[id];
-        const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
-        const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-        inst_pos[g.point_offsets[id] + k] = rg.x + i;
-    }
+    const uint32_t pos = rg.x + rank;
+    const uint32_t id = (uint32_t)key;
+    point_list[pos] = id;
+    float4* rec = inst_rec + 3 * (size_t)pos;
+    rec[0] = g.geo_a[id]; rec[1] = g.geo_b[id]; rec[2] = g.geo_c[id];
+    const uint2 r = g.rect[id];
+    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
+    const int tx = (int)tile % gx, ty = (int)tile / gx;
+    const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    inst_pos[g.point_offsets[id] + k] = pos;
 }
 
 __global__ void __launch_bounds__(256)
@@ -189,7 +232,7 @@ export_binning_kernel(int T, GeomView g, const uint2* __restrict__ ranges, const
     for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x) {
         const uint32_t id = point_list[i];
         if (list_out) list_out[i] = id;
-        if (keys_out) keys_out[i] = ((uint64_t)(uint32_t)tile << 32) | (uint64_t)__float_as_uint(g.geo_b[id].z);
+        if (keys_out) keys_out[i] = ((uint64_t)(uint32_t)tile << 32) | (uint64_t)__float_as_uint(g.geo_c[id].w);
     }
 }
 
@@ -204,7 +247,7 @@ int env_int(const char* name, int dflt)
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s)
 {
     (void)P; (void)g;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.header);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.header);
 }
 
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
@@ -215,20 +258,17 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
-    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys, lds_hist);
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
+                       b.inst_tile, lds_hist);
 }
 
-void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int max_len, hipStream_t s)
+void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s)
 {
-    (void)R;
     const int T = fp.gx * fp.gy;
-    if (max_len <= 0) return;
-    // one 1024-thread workgroup per tile, keys in LDS (64 KB = 8192 keys); longer lists are sorted in global memory
-    hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(T), dim3(1024), 8192 * sizeof(uint64_t), s, fp.gx, 0u, 8192u, g, im.ranges,
-                       b.keys, b.point_list, b.inst_pos);
-    if (max_len > 8192)
-        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(T), dim3(1024), 0, s, fp.gx, 8192u, 0xffffffffu, g, im.ranges,
-                           b.keys, b.point_list, b.inst_pos);
+    if (R <= 0 || total_chunks <= 0) return;
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(1024), 0, s, T, im.ranges, im.chunk_base, b.keys);
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, fp.gx, g, im.ranges, b.keys, b.inst_tile,
+                       b.point_list, b.inst_pos, b.inst_rec);
 }
 
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

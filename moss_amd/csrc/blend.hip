@@ -42,9 +42,9 @@ namespace moss {
 namespace {
 
 constexpr int FWD_BATCH = 256;
-constexpr int BWD_BATCH = 64;
+constexpr int BWD_BATCH_QUADRANT = 128, BWD_BATCH_TILE = 64;   // entries staged per round (4-wave / 16-wave workgroups)
 constexpr int NPART = 12;           // 9 partial gradients padded to 12 floats (48 B) per (wave, entry)
-constexpr int LIST_PAD = 16;
+constexpr int LIST_PAD = 32;           // sentinel entries behind a hit list: two groups per trip + one trip of prefetch
 
 struct PairEval { float power, G, alpha; };
 
@@ -82,24 +82,27 @@ __device__ __forceinline__ void block_of_wave(int sub, int wv, int& bx, int& by)
     else { bx = 2 * (sub & 1) + (wv & 1); by = 2 * (sub >> 1) + (wv >> 1); }      // NW == 4: quadrant `sub`
 }
 
-// cooperative staging of `cnt` list entries first, first+dir, ... into LDS
-template <int BATCH, int NT>
-__device__ __forceinline__ void stage_batch(int cnt, const uint32_t* __restrict__ plist, int first, int dir,
-                                            const float4* __restrict__ geo_a, const float4* __restrict__ geo_b,
-                                            const float4* __restrict__ geo_c,
-                                            float4* s_a, float4* s_b, float4* s_c, float4* s_d)
+// Cooperative staging of a batch of list entries first, first+dir, ... : thread e < cnt owns entry e.  The gather is
+// split in two so that the loads of batch k+1 are in flight (in registers) while the workgroup processes batch k.
+struct Staged { float4 a, b, c; };
+
+__device__ __forceinline__ Staged load_entry(int cnt, const float4* __restrict__ inst_rec, int first, int dir)
 {
-#pragma unroll
-    for (int i = threadIdx.x; i < 4 * BATCH; i += NT) {
-        const int which = i / BATCH, e = i % BATCH;                  // BATCH is a power of two
-        if (e < cnt) {
-            const uint32_t id = plist[first + dir * e];
-            if (which == 0) s_a[e] = geo_a[id];
-            else if (which == 1) s_b[e] = geo_b[id];
-            else if (which == 2) s_c[e] = geo_c[id];
-            else { const float4 a = geo_a[id]; s_d[e] = make_float4(a.x, a.y, geo_b[id].w, geo_c[id].w); }
-        }
+    Staged s;
+    const int e = threadIdx.x;
+    if (e < cnt) {
+        const float4* rec = inst_rec + 3 * (size_t)(first + dir * e);      // contiguous per tile: coalesced, single level
+        s.a = rec[0]; s.b = rec[1]; s.c = rec[2];
+    } else {
+        s.a = s.b = s.c = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    return s;
+}
+
+__device__ __forceinline__ void store_entry(const Staged& s, int cnt, float4* s_a, float4* s_b, float4* s_c)
+{
+    const int e = threadIdx.x;
+    if (e < cnt) { s_a[e] = s.a; s_b[e] = s.b; s_c[e] = s.c; }     // s_a = {x, y, hx, hy} doubles as the cull record
 }
 
 // Append the indices (c0 + lane) of the lanes with `hit` to this wave's list; returns the new length.
@@ -114,8 +117,7 @@ __device__ __forceinline__ int append_hits(uint16_t* list, int len, bool hit, in
 // ---------------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
-blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ geo_a, const float4* __restrict__ geo_b, const float4* __restrict__ geo_c,
+blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                      float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int use_cull)
 {
@@ -123,7 +125,6 @@ blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* 
     __shared__ float4 s_a[FWD_BATCH + 1];
     __shared__ float4 s_b[FWD_BATCH + 1];
     __shared__ float4 s_c[FWD_BATCH + 1];
-    __shared__ float4 s_d[FWD_BATCH];
     __shared__ uint16_t s_list[NW][FWD_BATCH + LIST_PAD];
 
     // workgroups of one tile differ by a multiple of T_pad (a multiple of 8): same XCD under round-robin placement
@@ -156,10 +157,14 @@ blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* 
     float live = inside ? 1.0f : 0.0f;
     uint16_t* my_list = s_list[wv];
 
+    static_assert(NT >= FWD_BATCH, "one staging thread per batch entry");
+    Staged pre = load_entry(min(FWD_BATCH, n), inst_rec, (int)rg.x, 1);
     for (int base = 0; base < n; base += FWD_BATCH) {
-        if (__syncthreads_and(live == 0.0f)) break;
+        if (__syncthreads_and(live == 0.0f)) break;           // also: everybody is done reading the previous batch
         const int cnt = min(FWD_BATCH, n - base);
-        stage_batch<FWD_BATCH, NT>(cnt, point_list, (int)rg.x + base, 1, geo_a, geo_b, geo_c, s_a, s_b, s_c, s_d);
+        store_entry(pre, cnt, s_a, s_b, s_c);
+        if (base + FWD_BATCH < n)                             // next batch's gathers fly while this one is blended
+            pre = load_entry(min(FWD_BATCH, n - base - FWD_BATCH), inst_rec, (int)rg.x + base + FWD_BATCH, 1);
         __syncthreads();
         if (__ballot(live > 0.0f) == 0ull) continue;          // this wave is finished; keep meeting the barriers
 
@@ -167,48 +172,61 @@ blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* 
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             bool hit = j < cnt;
-            if (hit && use_cull) hit = block_hit(s_d[j], bx0, by0);
+            if (hit && (use_cull & 1)) hit = block_hit(s_a[j], bx0, by0);
+            if (use_cull & 4) hit = false;
             len = append_hits(my_list, len, hit, j);
         }
         if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)FWD_BATCH;        // pad with the sentinel
-        const int niter = (len + 3) >> 2;
+        const int niter = (use_cull & 2) ? 0 : (len + 3) >> 2;
 
+        // Two groups of four entries per trip: the two alpha evaluations (sub/mul/exp, ~25 dependent instructions each) are
+        // independent and interleave; only the short T chains run one after the other.  Records are prefetched one trip ahead.
         int lp = slot;
-        uint32_t e = my_list[lp];
-        float4 a = s_a[e], b = s_b[e], c = s_c[e];
-        uint32_t e1 = my_list[lp + 4];
-        for (int it = 0; it < niter; it++) {
-            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];            // prefetch the next iteration's records
-            const uint32_t e2 = my_list[lp + 8];
+        uint32_t eA = my_list[lp], eB = my_list[lp + 4];
+        float4 aA = s_a[eA], bA = s_b[eA], cA = s_c[eA];
+        float4 aB = s_a[eB], bB = s_b[eB], cB = s_c[eB];
+        uint32_t eA1 = my_list[lp + 8], eB1 = my_list[lp + 12];
+        for (int it = 0; it < niter; it += 2) {
+            const float4 aAn = s_a[eA1], bAn = s_b[eA1], cAn = s_c[eA1];
+            const float4 aBn = s_a[eB1], bBn = s_b[eB1], cBn = s_c[eB1];
+            const uint32_t eA2 = my_list[lp + 16], eB2 = my_list[lp + 20];
 
-            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, a.z, a.w, b.x, b.y);
-            const float al = pe.alpha * live;                                  // 0 for finished / outside pixels
-            const float f = 1.0f - al;
-            // X_s = T after the entries of slots 0..s, multiplied in list order (bit-identical to the serial loop)
-            float X = T * f, Y;
-            Y = QUAD_PREV(X); X = slot >= 1 ? Y * f : X;
-            Y = QUAD_PREV(X); X = slot >= 2 ? Y * f : X;
-            Y = QUAD_PREV(X); X = slot >= 3 ? Y * f : X;
-            Y = QUAD_PREV(X);
-            const float Tb = slot == 0 ? T : Y;                                // T in front of this slot's entry
-            const float st = (X < 0.0001f) ? al : 0.0f;                        // > 0: this entry ends the pixel (forward.cu:351-356)
-            const unsigned long long sb = __ballot(st > 0.0f);
-            const uint32_t q = (uint32_t)(sb >> qshift) & 0xFu;                // stop flags of this pixel's 4 slots
-            const uint32_t below = q & below_mask;                             // an earlier slot already stopped the pixel
-            float wgt = al * Tb;
-            wgt = (st > 0.0f) ? 0.0f : wgt;
-            wgt = (below != 0u) ? 0.0f : wgt;
-            const float ts = (st > 0.0f) ? Tb : T_stop;
-            T_stop = (below != 0u) ? T_stop : ts;                              // the first stopping slot records the final T
-            Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);
-            weight += wgt;
-            Dacc = __fmaf_rn(b.z, wgt, Dacc);
-            last_contributor = (wgt > 0.0f) ? (uint32_t)base + e + 1u : last_contributor;
-            T = QUAD_BCAST3(X);
-            live = (q != 0u) ? 0.0f : live;
+            const PairEval peA = eval_pair(aA.x - pixx, aA.y - pixy, bA.x, bA.y, bA.z, bA.w);
+            const PairEval peB = eval_pair(aB.x - pixx, aB.y - pixy, bB.x, bB.y, bB.z, bB.w);
+#define FWD_GROUP(pe, b, c, e)                                                                                              \
+            {                                                                                                               \
+                const float al = pe.alpha * live;                       /* 0 for finished / outside pixels */               \
+                const float f = 1.0f - al;                                                                                  \
+                /* X_s = T after the entries of slots 0..s, multiplied in list order (bit-identical to the serial loop) */ \
+                float X = T * f, Y;                                                                                         \
+                Y = QUAD_PREV(X); X = slot >= 1 ? Y * f : X;                                                                \
+                Y = QUAD_PREV(X); X = slot >= 2 ? Y * f : X;                                                                \
+                Y = QUAD_PREV(X); X = slot >= 3 ? Y * f : X;                                                                \
+                Y = QUAD_PREV(X);                                                                                           \
+                const float Tb = slot == 0 ? T : Y;                     /* T in front of this slot's entry */               \
+                const float st = (X < 0.0001f) ? al : 0.0f;             /* > 0: this entry ends the pixel (forward.cu:351-356) */ \
+                const unsigned long long sb = __ballot(st > 0.0f);                                                          \
+                const uint32_t q = (uint32_t)(sb >> qshift) & 0xFu;     /* stop flags of this pixel's 4 slots */            \
+                const uint32_t below = q & below_mask;                  /* an earlier slot already stopped the pixel */     \
+                float wgt = al * Tb;                                                                                        \
+                wgt = (st > 0.0f) ? 0.0f : wgt;                                                                             \
+                wgt = (below != 0u) ? 0.0f : wgt;                                                                           \
+                const float ts = (st > 0.0f) ? Tb : T_stop;                                                                 \
+                T_stop = (below != 0u) ? T_stop : ts;                   /* the first stopping slot records the final T */   \
+                Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);                   \
+                weight += wgt;                                                                                              \
+                Dacc = __fmaf_rn(c.w, wgt, Dacc);                                                                           \
+                last_contributor = (wgt > 0.0f) ? (uint32_t)base + e + 1u : last_contributor;                               \
+                T = QUAD_BCAST3(X);                                                                                         \
+                live = (q != 0u) ? 0.0f : live;                                                                             \
+            }
+            FWD_GROUP(peA, bA, cA, eA)
+            FWD_GROUP(peB, bB, cB, eB)
+#undef FWD_GROUP
             if (__ballot(live > 0.0f) == 0ull) break;
 
-            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += 4;
+            aA = aAn; bA = bAn; cA = cAn; aB = aBn; bB = bBn; cB = cBn;
+            eA = eA1; eB = eB1; eA1 = eA2; eB1 = eB2; lp += 8;
         }
     }
 
@@ -259,19 +277,18 @@ __device__ __forceinline__ float row_slot_sum(float v)
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
-blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const float4* __restrict__ geo_a, const float4* __restrict__ geo_b, const float4* __restrict__ geo_c,
+blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
                       const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
                       float* __restrict__ inst_grad /* [16/NW][R][12] */, size_t slab_stride, int use_cull)
 {
     constexpr int NT = NW * 64;
-    __shared__ float4 s_a[BWD_BATCH + 1];
-    __shared__ float4 s_b[BWD_BATCH + 1];
-    __shared__ float4 s_c[BWD_BATCH + 1];
-    __shared__ float4 s_d[BWD_BATCH];
-    __shared__ uint16_t s_list[NW][BWD_BATCH + LIST_PAD];
-    __shared__ __attribute__((aligned(16))) float s_part[NW][BWD_BATCH + 1][NPART];
+    constexpr int BB = (NW == 4) ? BWD_BATCH_QUADRANT : BWD_BATCH_TILE;      // entries staged per round
+    __shared__ float4 s_a[BB + 1];
+    __shared__ float4 s_b[BB + 1];
+    __shared__ float4 s_c[BB + 1];
+    __shared__ uint16_t s_list[NW][BB + LIST_PAD];
+    __shared__ __attribute__((aligned(16))) float s_part[NW][BB + 1][NPART];
     __shared__ uint32_t s_nmax;
 
     const int tile = blockIdx.x % T_pad, sub = blockIdx.x / T_pad;
@@ -305,7 +322,7 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
 
     if (tid == 0) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_a[BWD_BATCH] = z4; s_b[BWD_BATCH] = z4; s_c[BWD_BATCH] = z4;
+        s_a[BB] = z4; s_b[BB] = z4; s_c[BB] = z4;
         s_nmax = 0;
     }
     __syncthreads();
@@ -329,83 +346,101 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
     const int m0 = 2 * rp + rh, m1 = 4 + m0;
     const bool writer = (lane & 12) == 0;                  // lanes 16*row + slot
 
-    for (int base = 0; base < n_eff; base += BWD_BATCH) {
-        const int cnt = min(BWD_BATCH, n_eff - base);
+    static_assert(NT >= BB, "one staging thread per batch entry");
+    Staged pre = load_entry(min(BB, n_eff), inst_rec, (int)rg.x + n_eff - 1, -1);
+    for (int base = 0; base < n_eff; base += BB) {
+        const int cnt = min(BB, n_eff - base);
         __syncthreads();                                   // previous batch fully flushed
-        stage_batch<BWD_BATCH, NT>(cnt, point_list, (int)rg.x + n_eff - 1 - base, -1, geo_a, geo_b, geo_c, s_a, s_b, s_c, s_d);
+        store_entry(pre, cnt, s_a, s_b, s_c);
+        if (base + BB < n_eff)                      // next batch's gathers fly while this one is processed
+            pre = load_entry(min(BB, n_eff - base - BB), inst_rec, (int)rg.x + n_eff - 1 - base - BB, -1);
         {
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4* zp = reinterpret_cast<float4*>(&s_part[0][0][0]);
-            for (int i = tid; i < NW * (BWD_BATCH + 1) * NPART / 4; i += NT) zp[i] = z4;
+            for (int i = tid; i < NW * (BB + 1) * NPART / 4; i += NT) zp[i] = z4;
         }
         __syncthreads();
 
-        bool hit = (lane < cnt) && (n_eff - 1 - (base + lane) < wave_max);
-        if (hit && use_cull) hit = block_hit(s_d[lane], bx0, by0);
-        const int len = append_hits(my_list, 0, hit, lane);
-        if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)BWD_BATCH;
-        const int niter = (len + 3) >> 2;
+        int len = 0;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int j = c0 + lane;
+            bool hit = (j < cnt) && (n_eff - 1 - (base + j) < wave_max);
+            if (hit && (use_cull & 1)) hit = block_hit(s_a[j], bx0, by0);
+            if (use_cull & 4) hit = false;
+            len = append_hits(my_list, len, hit, j);
+        }
+        if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)BB;
+        const int niter = (use_cull & 2) ? 0 : (len + 3) >> 2;
 
+        // Two groups of four entries per trip (see the forward kernel): evaluations and gradient formulas of the two groups
+        // are independent and interleave; only the (T, Q) chains are sequential.  Records are prefetched one trip ahead.
         int lp = slot;
-        uint32_t e = my_list[lp];
-        float4 a = s_a[e], b = s_b[e], c = s_c[e];
-        uint32_t e1 = my_list[lp + 4];
-        for (int it = 0; it < niter; it++) {
-            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];
-            const uint32_t e2 = my_list[lp + 8];
+        uint32_t eA = my_list[lp], eB = my_list[lp + 4];
+        float4 aA = s_a[eA], bA = s_b[eA], cA = s_c[eA];
+        float4 aB = s_a[eB], bB = s_b[eB], cB = s_c[eB];
+        uint32_t eA1 = my_list[lp + 8], eB1 = my_list[lp + 12];
+        for (int it = 0; it < niter; it += 2) {
+            const float4 aAn = s_a[eA1], bAn = s_b[eA1], cAn = s_c[eA1];
+            const float4 aBn = s_a[eB1], bBn = s_b[eB1], cBn = s_c[eB1];
+            const uint32_t eA2 = my_list[lp + 16], eB2 = my_list[lp + 20];
 
-            const int pos = n_eff - 1 - (base + (int)e);                   // back to front
-            const float dx = a.x - pixx, dy = a.y - pixy;
-            const PairEval pe = eval_pair(dx, dy, a.z, a.w, b.x, b.y);
-            const float al = (pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = this pair is skipped
-            const float G = (al > 0.0f) ? pe.G : 0.0f;
-            // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
-            const float mm = 1.0f - al;
-            const float rinv = __builtin_amdgcn_rcpf(mm);
-            const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(b.z, gpd, gpa))));
-            const float kq = al * u;
-            // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
-            float Ti = T, Qi = Q;
-            float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);
-#pragma unroll
-            for (int k = 1; k <= 3; k++) {
-                const float yT = QUAD_PREV(To), yQ = QUAD_PREV(Qo);
-                Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
-                To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
+            const float dxA = aA.x - pixx, dyA = aA.y - pixy, dxB = aB.x - pixx, dyB = aB.y - pixy;
+            const PairEval peA = eval_pair(dxA, dyA, bA.x, bA.y, bA.z, bA.w);
+            const PairEval peB = eval_pair(dxB, dyB, bB.x, bB.y, bB.z, bB.w);
+#define BWD_GROUP(pe, dx, dy, a, b, c, e)                                                                                   \
+            {                                                                                                               \
+                const int pos = n_eff - 1 - (base + (int)e);                 /* back to front */                            \
+                const float al = (pos < last_contributor) ? pe.alpha : 0.0f; /* backward.cu:499-514; 0 = pair skipped */    \
+                const float G = (al > 0.0f) ? pe.G : 0.0f;                                                                  \
+                /* this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped) */ \
+                const float mm = 1.0f - al;                                                                                 \
+                const float rinv = __builtin_amdgcn_rcpf(mm);                                                               \
+                const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));    \
+                const float kq = al * u;                                                                                    \
+                /* run the four slots' transforms in visiting order: slot s starts from the output of slot s-1 */          \
+                float Ti = T, Qi = Q;                                                                                       \
+                float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);                                                           \
+                _Pragma("unroll") for (int k = 1; k <= 3; k++) {                                                            \
+                    const float yT = QUAD_PREV(To), yQ = QUAD_PREV(Qo);                                                     \
+                    Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;                                                     \
+                    To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);                                                             \
+                }                                                                                                           \
+                T = QUAD_BCAST3(To); Q = QUAD_BCAST3(Qo);                    /* the pixel's state after these four entries */ \
+                /* To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k */                     \
+                float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);                                          \
+                dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;                                                                     \
+                const float dchannel_dcolor = al * To;                                                                      \
+                const float dL_dG = b.w * dL_dopa;                                                                          \
+                const float gdx = G * dx, gdy = G * dy;                                                                     \
+                const float dG_ddelx = -gdx * b.x - gdy * b.y;                                                              \
+                const float dG_ddely = -gdy * b.z - gdx * b.y;                                                              \
+                const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;             \
+                const float v3 = dL_dG * dG_ddelx * ddelx_dx;                                                               \
+                const float v4 = dL_dG * dG_ddely * ddely_dy;                                                               \
+                const float hdG = -0.5f * dL_dG;                                                                            \
+                const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;                                  \
+                const float v8 = G * dL_dopa;                                                                               \
+                if (__ballot(al > 0.0f) != 0ull) {                                                                          \
+                    /* reduce-scatter over the 16 pixels, separately per slot: after fold32 the lower/upper half-waves hold \
+                       different values, after fold16 even/odd rows do; lane (row r, slot s) ends with m0, m1 (and 8 in row 0) */ \
+                    const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f); \
+                    const float s0 = row_slot_sum(fold16(r0, r1)), s1 = row_slot_sum(fold16(r2, r3)), s2 = row_slot_sum(fold16(r4, 0.0f)); \
+                    if (writer) {                                                                                           \
+                        float* dst = &s_part[wv][e][0];                                                                     \
+                        dst[m0] = s0; dst[m1] = s1;                                                                         \
+                        if (row == 0) dst[8] = s2;                                                                          \
+                    }                                                                                                       \
+                }                                                                                                           \
             }
-            T = QUAD_BCAST3(To); Q = QUAD_BCAST3(Qo);                      // the pixel's state after these four entries
-
-            // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
-            float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
-            dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
-            const float dchannel_dcolor = al * To;
-            const float dL_dG = b.y * dL_dopa;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * a.z - gdy * a.w;
-            const float dG_ddely = -gdy * b.x - gdx * a.w;
-            const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
-            const float v3 = dL_dG * dG_ddelx * ddelx_dx;
-            const float v4 = dL_dG * dG_ddely * ddely_dy;
-            const float hdG = -0.5f * dL_dG;
-            const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
-            const float v8 = G * dL_dopa;
-
-            if (__ballot(al > 0.0f) != 0ull) {
-                // reduce-scatter over the 16 pixels, separately per slot: after fold32 the lower/upper half-waves hold
-                // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
-                const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
-                const float s0 = row_slot_sum(fold16(r0, r1)), s1 = row_slot_sum(fold16(r2, r3)), s2 = row_slot_sum(fold16(r4, 0.0f));
-                if (writer) {
-                    float* dst = &s_part[wv][e][0];
-                    dst[m0] = s0; dst[m1] = s1;
-                    if (row == 0) dst[8] = s2;
-                }
-            }
-            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += 4;
+            BWD_GROUP(peA, dxA, dyA, aA, bA, cA, eA)
+            BWD_GROUP(peB, dxB, dyB, aB, bB, cB, eB)
+#undef BWD_GROUP
+            aA = aAn; bA = bAn; cA = cAn; aB = aBn; bB = bBn; cB = cBn;
+            eA = eA1; eB = eB1; eA1 = eA2; eB1 = eB2; lp += 8;
         }
         __syncthreads();
         // combine the wave sums in a fixed order; 16 lanes per entry write its 48-byte record contiguously
-        for (int i = tid; i < BWD_BATCH * 16; i += NT) {
+        for (int i = tid; i < BB * 16; i += NT) {
             const int ee = i >> 4, k = i & 15;
             if (ee < cnt && k < NPART) {
                 float r = 0.f;
@@ -440,11 +475,11 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     static const int use_cull = env_int("MOSS_BLEND_CULL", 1);
     const int T = fp.gx * fp.gy, T_pad = (T + 7) / 8 * 8;
     if (blend_subgroups() == 4)
-        hipLaunchKernelGGL(blend_forward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
-                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
+        hipLaunchKernelGGL(blend_forward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
+                           fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
     else
-        hipLaunchKernelGGL(blend_forward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
-                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
+        hipLaunchKernelGGL(blend_forward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
+                           fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
@@ -454,12 +489,12 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     const int T = fp.gx * fp.gy, T_pad = (T + 7) / 8 * 8;
     float* ig = reinterpret_cast<float*>(b.inst_grad);
     if (blend_subgroups() == 4)
-        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
-                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
+        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
+                           fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
                            ig, b.slab_stride_floats, use_cull);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.point_list,
-                           g.geo_a, g.geo_b, g.geo_c, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
+        hipLaunchKernelGGL(blend_backward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
+                           fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
                            ig, b.slab_stride_floats, use_cull);
 }
 

@@ -4,20 +4,21 @@
 // reference's layout is rasterizer_impl.cu:155-194, ours differs on purpose -- see DESIGN.md "Data layout"):
 //
 //   geometry buffer (per Gaussian, P entries)
-//     geo_a  float4 {pix.x, pix.y, conic.A, conic.B}        16 B  } three 16-byte records so that the blend
-//     geo_b  float4 {conic.C, opacity, depth, cull_hx}      16 B  } kernels gather a tile entry with three
-//     geo_c  float4 {r, g, b, cull_hy}                      16 B  } coalescable dwordx4 loads (48 B / instance)
+//     geo_a  float4 {pix.x, pix.y, cull_hx, cull_hy}        16 B  } three 16-byte records; geo_a alone is the cull record.
+//     geo_b  float4 {conic.A, conic.B, conic.C, opacity}    16 B  } The tile sort copies them, in sorted order, into the
+//     geo_c  float4 {r, g, b, depth}                        16 B  } per-instance stream the blend kernels read (inst_rec)
 //     rect   uint2  {min.x | min.y<<16, max.x | max.y<<16}   8 B    tile rectangle (getRect result)
 //     tiles_touched u32, point_offsets u32 (exclusive scan), radius i32, clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
-//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
-//     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id)
+//     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id); inst_tile u32[R] tile of a slot
 //     inst_pos   u32[R]   for Gaussian g, its k-th tile (row-major inside its rect): position in point_list
-//     scratch    48 B * R  forward: 64-bit sort keys (depth<<32|id) in the first 8R bytes;
-//                          backward: per-instance partial gradients, 3 float4 per instance
+//     inst_rec   48 B * R  the three records of every instance in sorted order (written by the tile sort)
+//     scratch    48 B * R * slabs  forward: 64-bit sort keys (depth<<32|id) in the first 8R bytes;
+//                          backward: per-instance partial gradients, 3 float4 per instance and slab
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,7 +66,7 @@ struct GeomView {
 
 struct ImageView {
     uint32_t* header;
-    uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges;
+    uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base;
     float* final_T; uint32_t* n_contrib;
     static ImageView at(char* base, int W, int H)
     {
@@ -73,7 +74,7 @@ struct ImageView {
         size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
         v.header = carve<uint32_t>(p, 16);
         v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
-        v.ranges = carve<uint2>(p, T);
+        v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T);
         v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
         return v;
     }
@@ -85,8 +86,9 @@ struct ImageView {
 int blend_subgroups();       // workgroups per tile in the blend kernels (1 or 4), blend.hip
 
 struct BinView {
-    uint32_t* point_list; uint32_t* inst_pos;
+    uint32_t* point_list; uint32_t* inst_pos; uint32_t* inst_tile;
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
+    float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
     float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per blend workgroup of a tile)
     int slabs; size_t slab_stride_floats;
     static BinView at(char* base, int R)
@@ -94,7 +96,8 @@ struct BinView {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
         b.slabs = blend_subgroups();
         b.slab_stride_floats = align_up(3 * n * 16) / 4;
-        b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n);
+        b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n); b.inst_tile = carve<uint32_t>(p, n);
+        b.inst_rec = carve<float4>(p, 3 * n);
         b.inst_grad = reinterpret_cast<float4*>(p);
         b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);
         return b;
@@ -128,7 +131,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view16_dev, u
 
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s);                 // offsets, ranges, header
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);  // duplicateWithKeys
-void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int max_len, hipStream_t s);
+void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s);
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
                            uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);
 void launch_export_geometry(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,

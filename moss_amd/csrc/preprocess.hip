@@ -259,9 +259,9 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                 }
             }
 
-            g.geo_a[idx] = make_float4(pix.x, pix.y, conic.x, conic.y);
-            g.geo_b[idx] = make_float4(conic.z, opa, p_view.z, hx);
-            g.geo_c[idx] = make_float4(rgb.x, rgb.y, rgb.z, hy);
+            g.geo_a[idx] = make_float4(pix.x, pix.y, hx, hy);                 // position + cull extents (the cull record)
+            g.geo_b[idx] = make_float4(conic.x, conic.y, conic.z, opa);
+            g.geo_c[idx] = make_float4(rgb.x, rgb.y, rgb.z, p_view.z);
             g.clamped[idx] = clamp_bits;
             out_radius = rad;
             out_tiles = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
@@ -576,9 +576,9 @@ export_geometry_kernel(int P, GeomView g, float* depths, float* means2D, float* 
     const bool vis = g.tiles_touched[idx] > 0;
     const float4 z4 = make_float4(0, 0, 0, 0);
     const float4 a = vis ? g.geo_a[idx] : z4, b = vis ? g.geo_b[idx] : z4, c = vis ? g.geo_c[idx] : z4;
-    if (depths) depths[idx] = b.z;
+    if (depths) depths[idx] = c.w;
     if (means2D) { means2D[2 * (size_t)idx] = a.x; means2D[2 * (size_t)idx + 1] = a.y; }
-    if (conic_opacity) reinterpret_cast<float4*>(conic_opacity)[idx] = make_float4(a.z, a.w, b.x, b.y);
+    if (conic_opacity) reinterpret_cast<float4*>(conic_opacity)[idx] = b;
     if (rgb) { rgb[3 * (size_t)idx] = c.x; rgb[3 * (size_t)idx + 1] = c.y; rgb[3 * (size_t)idx + 2] = c.z; }
     if (tiles_touched) tiles_touched[idx] = g.tiles_touched[idx];
     if (clamped) {

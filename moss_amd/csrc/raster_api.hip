@@ -158,10 +158,10 @@ int moss_raster_forward(
 
     // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
     if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int R = (int)g_pinned.p[0];
-    const int max_len = (int)g_pinned.p[1];
+    const int total_chunks = (int)g_pinned.p[4];
     if (g_pinned.p[2] & ERRFLAG_PREFILTERED)
         return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
 
@@ -172,7 +172,7 @@ int moss_raster_forward(
     if (R > 0) {
         { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, s); }
         STAGE_CHECK("scatter");
-        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, max_len, s); }
+        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s); }
         STAGE_CHECK("tile_sort");
     }
     { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }
