@@ -210,6 +210,9 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
 #define MOSS_STAGE_PREPROCESS_BWD 6
 #define MOSS_NUM_STAGES           8
 void moss_raster_profile_enable(uint32_t stage_mask);
+/* Diagnostics: register a device buffer of 8 x (4 * padded tile count) uint64; while set, the forward blend kernel stores per
+ * workgroup {total, barrier-1, staging, barrier-2, cull, trips} cycles of its first wave and {batches, trips} counts. NULL = off. */
+void moss_raster_debug_set_stamps(unsigned long long* device_buffer);
 int moss_raster_profile_read(float* ms_sum /* [MOSS_NUM_STAGES] */, uint32_t* count /* [MOSS_NUM_STAGES] */);
 
 #ifdef __cplusplus

@@ -58,12 +58,14 @@ constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort
 // (The per-Gaussian offsets are produced by the preprocess kernel.)
 __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
-            uint32_t* __restrict__ header)
+            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bucket[34];
     const int tid = threadIdx.x;
     if (tid == 0) s_max = 0;
+    if (tid < 34) s_bucket[tid] = 0;
     const int chunk = (T + 1023) / 1024;
     const int b = tid * chunk, e = min(T, b + chunk);
     uint32_t sum = 0, mx = 0, nch = 0;
@@ -77,8 +79,21 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
         chunk_base[i] = coff; coff += (v + CHUNK - 1) / CHUNK;
     }
     if (mx) atomicMax(&s_max, mx);
+    // tile_order: tiles grouped by floor(log2(list length)), longest class first, empty tiles last.  The blend kernels
+    // pull (tile, quadrant) work items in this order from an atomic queue (longest-processing-time-first balancing).
+    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u); }
     __syncthreads();
-    if (tid == 0) { header[0] = total; header[1] = s_max; header[4] = total_chunks; }
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 33; k++) { const uint32_t c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
+        header[0] = total; header[1] = s_max; header[4] = total_chunks;
+        header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
+    }
+    __syncthreads();
+    for (int i = b; i < e; i++) {
+        const uint32_t v = tile_count[i];
+        tile_order[atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u)] = (uint32_t)i;
+    }
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
@@ -247,7 +262,8 @@ int env_int(const char* name, int dflt)
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s)
 {
     (void)P; (void)g;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.header);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
+                       im.header);
 }
 
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)

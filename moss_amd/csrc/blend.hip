@@ -3,35 +3,35 @@
 //
 // WHY NOT "one thread per pixel, 256 threads per tile" (the reference's shape): a training view of a human puts
 // ~100k Gaussians into ~180 of 1024 tiles, 1-5k entries per tile.  The blend is a serial recurrence over a tile's
-// entry list, so with 4 waves per tile the kernel time is (longest list) x (instructions per entry) at ONE wave per
-// SIMD (one instruction per ~4-5 cycles, every LDS/exp latency exposed) while 3/4 of the chip idles.
+// entry list and a single wavefront issues at most one instruction per ~4 cycles whatever its ILP, so the kernel time is
+// (instructions executed by the busiest wave) x 4 cycles while most SIMDs idle (measured: profiles/r01_notes.md).
+// The design therefore minimises the work of the busiest WAVE, not the total work:
 //
-// Shape used here: a wavefront owns a 4x4-pixel block; lane l = (pixel l>>2, slot l&3): the FOUR lanes of a pixel
-// evaluate FOUR consecutive list entries at once, and the order-dependent parts (transmittance T, the backward's
-// suffix blend) are carried across the four slots with quad-permute DPP moves in exactly the sequential order
-// (forward T is bit-identical to a one-entry-at-a-time loop).  A workgroup is NW waves (NW=16: a whole tile, NW=4: an
-// 8x8 quadrant, so that one long tile spreads over four CUs); it stages each batch of entries ONCE into LDS (three
-// 16-byte records per entry with coalescable dwordx4 gathers -- colour and depth included, which the reference re-reads
-// from global memory per pixel, forward.cu:360,362 -- plus a packed {x, y, hx, hy} record for the cull test).
-//   * per-wave culling: each wave tests 64 staged entries at a time, one entry per lane, against its 4x4 block
+//   * a wavefront owns a small pixel block and evaluates SLOTS consecutive list entries at once:
+//         lane = pixel * SLOTS + slot,   SLOTS = 4 / 8 / 16  <->  block = 4x4 / 4x2 / 2x2 pixels;
+//     the order-dependent parts (transmittance T; the backward's suffix blend) are carried across the slots of a
+//     pixel with DPP row shifts: a log-step prefix product (SLOTS = 4: a 3-step chain that is bit-identical to the serial
+//     loop).  More slots = proportionally fewer trips through the list for the busiest wave;
+//   * a workgroup is the SLOTS waves of one 8x8 QUADRANT of the tile (4 workgroups per tile, sharing blockIdx % 8 = one
+//     XCD's L2): it stages each batch of entries ONCE into LDS, straight from the per-instance record stream the sort
+//     wrote (48 contiguous bytes per entry: coalesced, single-level loads, prefetched one batch ahead in registers);
+//   * per-wave culling: each wave tests 64 staged entries per instruction, one entry per lane, against its block
 //     (conservative bounding box of the alpha >= 1/255 ellipse, from the preprocess kernel), __ballot()s the hits and
-//     compacts their indices into a per-wave LDS list (v_mbcnt prefix); the blend loop then walks that list four
-//     entries per iteration with the next iteration's records prefetched.  A 4x4 block is touched by roughly half as
-//     many entries as an 8x8 block and a quarter as many as the tile;
-//   * the inner loops are written to stay on the VECTOR unit: per-lane conditions are float selects, not lane-mask
-//     algebra -- the scalar unit is shared by every wave of a CU and was the measured bottleneck of an earlier version
-//     (SQ_INSTS_SALU > SQ_INSTS_VALU, profiles/r01_notes.md);
-//   * early out: a wave stops when its 16 pixels are done, the workgroup when all its waves are (forward).
+//     compacts their indices into a private LDS list (v_mbcnt prefix); the blend loop walks that list SLOTS entries per trip
+//     with the next trip's records prefetched;
+//   * the inner loops stay on the VECTOR unit: per-lane conditions are float selects, not lane-mask algebra -- the
+//     scalar unit is shared by every wave of a CU and was the measured bottleneck of the first version;
+//   * early out: a wave stops when all its pixels are done, the workgroup when all its waves are (forward).
 //
 // Backward: the reference issues 9 global float atomics per (pixel, Gaussian) pair (backward.cu:538,574-584).  Here the
-// 9 partial gradients of FOUR entries are summed over a wave's 16 pixels by a reduce-scatter: v_permlane32_swap and
-// v_permlane16_swap each fold TWO values one level (5+3 swaps), two DPP row rotations finish (22 instructions per four
-// entries); the wave sums are combined through LDS in a fixed order and each (tile, entry) instance stores ONE 48-byte
-// record with plain coalesced stores.  The per-Gaussian kernel (preprocess.hip) gathers a Gaussian's records in a
-// fixed order.  No float atomics => gradients are bitwise reproducible and no accumulator needs zero-filling.
-// The five suffix blends of backward.cu:529-549 (colour x3, depth, alpha) enter dL/dalpha only through
-// sum_k (x_k - accum_k) * g_k with per-pixel constants g, so ONE running scalar Q = sum_k accum_k g_k is carried
-// instead of five.
+// 9 partial gradients of a trip's SLOTS entries are summed over the wave's pixels by a reduce-scatter (v_permlane32_swap
+// and v_permlane16_swap each fold TWO values one level, DPP row rotations finish), the wave sums are combined through LDS
+// in a fixed order and each (tile, entry) instance stores ONE 48-byte record per quadrant with plain coalesced stores.
+// The per-Gaussian kernel (preprocess.hip) gathers a Gaussian's records in a fixed order.  No float atomics =>
+// gradients are bitwise reproducible and no accumulator needs zero-filling.  The five suffix blends of
+// backward.cu:529-549 (colour x3, depth, alpha) enter dL/dalpha only through sum_k (x_k - accum_k) * g_k with per-pixel
+// constants g, so ONE running scalar Q = sum_k accum_k g_k is carried instead of five; (T, Q) advance through a trip's
+// slots as a prefix composition of the affine maps  T -> T/(1-a),  Q -> (1-a) Q + a u.
 //
 // Arithmetic: power/alpha of a (pixel, entry) pair is ONE inline function shared by both kernels (explicit fmaf chain),
 // so forward and backward take bit-identical skip decisions.
@@ -42,9 +42,17 @@ namespace moss {
 namespace {
 
 constexpr int FWD_BATCH = 256;
-constexpr int BWD_BATCH_QUADRANT = 128, BWD_BATCH_TILE = 64;   // entries staged per round (4-wave / 16-wave workgroups)
 constexpr int NPART = 12;           // 9 partial gradients padded to 12 floats (48 B) per (wave, entry)
-constexpr int LIST_PAD = 32;           // sentinel entries behind a hit list: two groups per trip + one trip of prefetch
+constexpr int LIST_PAD = 48;        // sentinel entries behind a hit list (one trip of 16 + prefetch)
+
+template <int SLOTS> struct Lay {
+    static constexpr int NW = SLOTS;                       // waves per 8x8 quadrant = workgroup size / 64
+    static constexpr int NPIX = 64 / SLOTS;                // pixels per wave
+    static constexpr int BW = (SLOTS == 16) ? 2 : 4;       // pixel block of a wave: 4x4, 4x2, 2x2
+    static constexpr int BH = NPIX / BW;
+    static constexpr int WX = 8 / BW;                      // blocks per quadrant row
+    static constexpr int BB = (SLOTS == 16) ? 64 : 128;    // backward: entries staged per round (bounds the LDS partial sums)
+};
 
 struct PairEval { float power, G, alpha; };
 
@@ -61,29 +69,59 @@ __device__ __forceinline__ PairEval eval_pair(float dx, float dy, float A, float
     return r;
 }
 
-// bounding box of an entry's alpha >= 1/255 region {x, y, hx, hy} vs. the wave's 4x4 pixel block [bx0,bx0+3] x [by0,by0+3]
-__device__ __forceinline__ bool block_hit(float4 d, float bx0, float by0)
+// bounding box of an entry's alpha >= 1/255 region {x, y, hx, hy} vs. a pixel block [bx0,bx0+w] x [by0,by0+h]
+__device__ __forceinline__ bool block_hit(float4 d, float bx0, float by0, float w, float h)
 {
-    return (d.x + d.z >= bx0) && (d.x - d.z <= bx0 + 3.0f) && (d.y + d.w >= by0) && (d.y - d.w <= by0 + 3.0f);
+    return (d.x + d.z >= bx0) && (d.x - d.z <= bx0 + w) && (d.y + d.w >= by0) && (d.y - d.w <= by0 + h);
 }
 
-// quad-permute DPP moves (lane l = 4*pixel + slot)
-#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
-#define QUAD_PREV(v)   DPP_F(v, 0x90)     // quad_perm:[0,0,1,2]  slot s reads slot s-1 (slot 0 reads itself)
-#define QUAD_BCAST3(v) DPP_F(v, 0xFF)     // quad_perm:[3,3,3,3]
-#define QUAD_XOR1(v)   DPP_F(v, 0xB1)     // quad_perm:[1,0,3,2]
-#define QUAD_XOR2(v)   DPP_F(v, 0x4E)     // quad_perm:[2,3,0,1]
+// ---- cross-lane helpers (lane = pixel * SLOTS + slot; the SLOTS lanes of a pixel are contiguous inside a 16-lane DPP row)
+#define DPP_MOV(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
+// lane - k inside the 16-lane row; lanes without a source keep `fill`
+#define ROW_SHR(v, k, fill) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x110 + (k), 0xf, 0xf, false))
 
-// which 4x4 block of the tile a wave owns
-template <int NW>
-__device__ __forceinline__ void block_of_wave(int sub, int wv, int& bx, int& by)
+// value of slot s-K (K compile-time) of the same pixel, `fill` if s < K
+template <int SLOTS, int K>
+__device__ __forceinline__ float from_slot_minus(float v, float fill, int slot)
 {
-    if (NW == 16) { bx = wv & 3; by = wv >> 2; }
-    else { bx = 2 * (sub & 1) + (wv & 1); by = 2 * (sub >> 1) + (wv >> 1); }      // NW == 4: quadrant `sub`
+    float r = ROW_SHR(v, K, fill);
+    if (SLOTS < 16) r = (slot >= K) ? r : fill;          // a 16-lane row holds 16/SLOTS pixels: do not read the neighbour's slots
+    return r;
 }
 
-// Cooperative staging of a batch of list entries first, first+dir, ... : thread e < cnt owns entry e.  The gather is
-// split in two so that the loads of batch k+1 are in flight (in registers) while the workgroup processes batch k.
+// inclusive prefix product over the slots of a pixel (list order)
+template <int SLOTS>
+__device__ __forceinline__ float prefix_mul(float x, int slot)
+{
+    x *= from_slot_minus<SLOTS, 1>(x, 1.0f, slot);
+    x *= from_slot_minus<SLOTS, 2>(x, 1.0f, slot);
+    if (SLOTS > 4) x *= from_slot_minus<SLOTS, 4>(x, 1.0f, slot);
+    if (SLOTS > 8) x *= from_slot_minus<SLOTS, 8>(x, 1.0f, slot);
+    return x;
+}
+
+// butterfly all-reduce over the slots of a pixel: every lane ends with bit-identical results (commutative ops, symmetric tree)
+#define GROUP_ALLREDUCE(SLOTS, v, OP)                                          \
+    {                                                                          \
+        v = OP(v, DPP_MOV(v, 0xB1));                      /* quad_perm:[1,0,3,2] */ \
+        v = OP(v, DPP_MOV(v, 0x4E));                      /* quad_perm:[2,3,0,1] */ \
+        if (SLOTS > 4) v = OP(v, DPP_MOV(v, 0x141));      /* row_half_mirror     */ \
+        if (SLOTS > 8) v = OP(v, DPP_MOV(v, 0x140));      /* row_mirror          */ \
+    }
+#define OP_MUL(a, b) ((a) * (b))
+#define OP_ADD(a, b) ((a) + (b))
+#define OP_MAX(a, b) fmaxf((a), (b))
+
+// value held by the LAST slot of this lane's pixel
+template <int SLOTS>
+__device__ __forceinline__ float from_last_slot(float v, int lane)
+{
+    if (SLOTS == 4) return DPP_MOV(v, 0xFF);              // quad_perm:[3,3,3,3]
+    return __shfl(v, (lane | (SLOTS - 1)));
+}
+
+// Cooperative staging of a batch of list entries first, first+dir, ... : thread e < cnt owns entry e.  The loads of batch
+// k+1 are in flight (in registers) while the workgroup processes batch k.
 struct Staged { float4 a, b, c; };
 
 __device__ __forceinline__ Staged load_entry(int cnt, const float4* __restrict__ inst_rec, int first, int dir)
@@ -105,7 +143,7 @@ __device__ __forceinline__ void store_entry(const Staged& s, int cnt, float4* s_
     if (e < cnt) { s_a[e] = s.a; s_b[e] = s.b; s_c[e] = s.c; }     // s_a = {x, y, hx, hy} doubles as the cull record
 }
 
-// Append the indices (c0 + lane) of the lanes with `hit` to this wave's list; returns the new length.
+// Append the indices of the lanes with `hit` to this wave's list; returns the new length.
 __device__ __forceinline__ int append_hits(uint16_t* list, int len, bool hit, int value)
 {
     const unsigned long long m = __ballot(hit);
@@ -114,34 +152,65 @@ __device__ __forceinline__ int append_hits(uint16_t* list, int len, bool hit, in
     return len + __popcll(m);
 }
 
+// geometry of this lane inside the tile
+template <int SLOTS>
+struct LaneGeom {
+    int slot, px, py, ox, oy, gbase;
+    __device__ __forceinline__ LaneGeom(int tile, int sub, int gx, int lane, int wv)
+    {
+        using L = Lay<SLOTS>;
+        const int tx = tile % gx, ty = tile / gx;
+        slot = lane % SLOTS;
+        const int pl = lane / SLOTS;
+        ox = tx * TILE + (sub & 1) * 8 + (wv % L::WX) * L::BW;
+        oy = ty * TILE + (sub >> 1) * 8 + (wv / L::WX) * L::BH;
+        px = ox + pl % L::BW; py = oy + pl / L::BW;
+        gbase = lane - slot;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
+template <int SLOTS>
+__global__ void __launch_bounds__(SLOTS * 64)
+blend_forward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
+                     uint32_t* __restrict__ queue_head,
+                     const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
-                     float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int use_cull)
+                     float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
+                     unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per workgroup, else NULL */)
 {
-    constexpr int NT = NW * 64;
+    using L = Lay<SLOTS>;
+    constexpr int NW = L::NW, NT = NW * 64;
     __shared__ float4 s_a[FWD_BATCH + 1];
     __shared__ float4 s_b[FWD_BATCH + 1];
     __shared__ float4 s_c[FWD_BATCH + 1];
     __shared__ uint16_t s_list[NW][FWD_BATCH + LIST_PAD];
+    __shared__ int s_done[NW];
+    __shared__ int s_item;
 
-    // workgroups of one tile differ by a multiple of T_pad (a multiple of 8): same XCD under round-robin placement
-    const int tile = blockIdx.x % T_pad, sub = blockIdx.x / T_pad;
-    if (tile >= T_tiles) return;
-    const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int slot = lane & 3, pl = lane >> 2;
-    int bx, by;
-    block_of_wave<NW>(sub, wv, bx, by);
-    const int ox = tx * TILE + bx * 4, oy = ty * TILE + by * 4;
-    const int px = ox + (pl & 3), py = oy + (pl >> 2);
-    const bool inside = px < W && py < H;
-    const float pixx = (float)px, pixy = (float)py;
-    const float bx0 = (float)ox, by0 = (float)oy;
-    const int qshift = lane & ~3;
-    const uint32_t below_mask = (1u << slot) - 1u;
+    const int n_items = 4 * (int)header[5];                  // tile_order lists the tiles that own instances first
+    // Persistent workgroups: a fixed number per CU pull (tile, quadrant) work items from an atomic queue, tiles with the
+    // longest lists first (tile_order).  Static blockIdx -> tile placement left some CUs with 6-8 heavy workgroups and others
+    // with none (measured with in-kernel stamps: 42 % of the slowest workgroups' time was barrier wait, 11 cycles/instruction).
+    int next_item = 0;
+    if (tid == 0) next_item = (int)atomicAdd(queue_head, 1u);
+    for (;;) {
+    __syncthreads();                                         // the previous item is completely finished (LDS is reused)
+    if (tid == 0) {
+        s_item = next_item;
+        if (next_item < n_items) next_item = (int)atomicAdd(queue_head, 1u);   // returns while this item is processed
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item >= n_items) break;
+    const int tile = (int)tile_order[item >> 2], sub = item & 3;
+    const LaneGeom<SLOTS> lg(tile, sub, gx, lane, wv);
+    const int slot = lg.slot;
+    const bool inside = lg.px < W && lg.py < H;
+    const float pixx = (float)lg.px, pixy = (float)lg.py;
+    const float bx0 = (float)lg.ox, by0 = (float)lg.oy;
+    const uint32_t slot_bits = (1u << SLOTS) - 1u, below_mask = (1u << slot) - 1u;
 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
@@ -150,107 +219,138 @@ blend_forward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* 
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         s_a[FWD_BATCH] = z4; s_b[FWD_BATCH] = z4; s_c[FWD_BATCH] = z4;
     }
+    if (tid < NW) s_done[tid] = 0;
 
     float T = 1.0f, T_stop = -1.0f;
     float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
-    uint32_t last_contributor = 0;
+    float last_contributor = 0.0f;                                       // list positions < 2^24: exact in fp32
     float live = inside ? 1.0f : 0.0f;
     uint16_t* my_list = s_list[wv];
+
+    // diagnostics only (moss_raster_debug_set_stamps): cycles wave 0 spends in each phase of a batch
+#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
+    unsigned long long d_top = 0, d_stage = 0, d_bar = 0, d_cull = 0, d_trip = 0, n_batches = 0, n_trips = 0;
+    const unsigned long long t_begin = STAMP();
 
     static_assert(NT >= FWD_BATCH, "one staging thread per batch entry");
     Staged pre = load_entry(min(FWD_BATCH, n), inst_rec, (int)rg.x, 1);
     for (int base = 0; base < n; base += FWD_BATCH) {
-        if (__syncthreads_and(live == 0.0f)) break;           // also: everybody is done reading the previous batch
+        const unsigned long long t0 = STAMP();
+        __syncthreads();                                      // everybody is done reading the previous batch; s_done is current
+        bool all_done = true;
+#pragma unroll
+        for (int w = 0; w < NW; w++) all_done = all_done && (s_done[w] != 0);
+        if (all_done) break;
+        const unsigned long long t1 = STAMP();
         const int cnt = min(FWD_BATCH, n - base);
         store_entry(pre, cnt, s_a, s_b, s_c);
-        if (base + FWD_BATCH < n)                             // next batch's gathers fly while this one is blended
+        if (base + FWD_BATCH < n)                             // next batch's loads fly while this one is blended
             pre = load_entry(min(FWD_BATCH, n - base - FWD_BATCH), inst_rec, (int)rg.x + base + FWD_BATCH, 1);
+        const unsigned long long t2 = STAMP();
         __syncthreads();
-        if (__ballot(live > 0.0f) == 0ull) continue;          // this wave is finished; keep meeting the barriers
+        const unsigned long long t3 = STAMP();
+        d_top += t1 - t0; d_stage += t2 - t1; d_bar += t3 - t2; n_batches++;
+        if (__ballot(live > 0.0f) == 0ull) {                  // this wave is finished; keep meeting the barriers
+            if (lane == 0) s_done[wv] = 1;
+            continue;
+        }
 
         int len = 0;
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             bool hit = j < cnt;
-            if (hit && (use_cull & 1)) hit = block_hit(s_a[j], bx0, by0);
-            if (use_cull & 4) hit = false;
+            if (hit && (flags & 1)) hit = block_hit(s_a[j], bx0, by0, (float)(L::BW - 1), (float)(L::BH - 1));
             len = append_hits(my_list, len, hit, j);
         }
         if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)FWD_BATCH;        // pad with the sentinel
-        const int niter = (use_cull & 2) ? 0 : (len + 3) >> 2;
+        const int ntrip = (flags & 2) ? 0 : (len + SLOTS - 1) / SLOTS;
+        const unsigned long long t4 = STAMP();
+        d_cull += t4 - t3; n_trips += ntrip;
 
-        // Two groups of four entries per trip: the two alpha evaluations (sub/mul/exp, ~25 dependent instructions each) are
-        // independent and interleave; only the short T chains run one after the other.  Records are prefetched one trip ahead.
         int lp = slot;
-        uint32_t eA = my_list[lp], eB = my_list[lp + 4];
-        float4 aA = s_a[eA], bA = s_b[eA], cA = s_c[eA];
-        float4 aB = s_a[eB], bB = s_b[eB], cB = s_c[eB];
-        uint32_t eA1 = my_list[lp + 8], eB1 = my_list[lp + 12];
-        for (int it = 0; it < niter; it += 2) {
-            const float4 aAn = s_a[eA1], bAn = s_b[eA1], cAn = s_c[eA1];
-            const float4 aBn = s_a[eB1], bBn = s_b[eB1], cBn = s_c[eB1];
-            const uint32_t eA2 = my_list[lp + 16], eB2 = my_list[lp + 20];
+        uint32_t e = my_list[lp];
+        float4 a = s_a[e], b = s_b[e], c = s_c[e];
+        uint32_t e1 = my_list[lp + SLOTS];
+        for (int it = 0; it < ntrip; it++) {
+            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];            // prefetch the next trip's records
+            const uint32_t e2 = my_list[lp + 2 * SLOTS];
 
-            const PairEval peA = eval_pair(aA.x - pixx, aA.y - pixy, bA.x, bA.y, bA.z, bA.w);
-            const PairEval peB = eval_pair(aB.x - pixx, aB.y - pixy, bB.x, bB.y, bB.z, bB.w);
-#define FWD_GROUP(pe, b, c, e)                                                                                              \
-            {                                                                                                               \
-                const float al = pe.alpha * live;                       /* 0 for finished / outside pixels */               \
-                const float f = 1.0f - al;                                                                                  \
-                /* X_s = T after the entries of slots 0..s, multiplied in list order (bit-identical to the serial loop) */ \
-                float X = T * f, Y;                                                                                         \
-                Y = QUAD_PREV(X); X = slot >= 1 ? Y * f : X;                                                                \
-                Y = QUAD_PREV(X); X = slot >= 2 ? Y * f : X;                                                                \
-                Y = QUAD_PREV(X); X = slot >= 3 ? Y * f : X;                                                                \
-                Y = QUAD_PREV(X);                                                                                           \
-                const float Tb = slot == 0 ? T : Y;                     /* T in front of this slot's entry */               \
-                const float st = (X < 0.0001f) ? al : 0.0f;             /* > 0: this entry ends the pixel (forward.cu:351-356) */ \
-                const unsigned long long sb = __ballot(st > 0.0f);                                                          \
-                const uint32_t q = (uint32_t)(sb >> qshift) & 0xFu;     /* stop flags of this pixel's 4 slots */            \
-                const uint32_t below = q & below_mask;                  /* an earlier slot already stopped the pixel */     \
-                float wgt = al * Tb;                                                                                        \
-                wgt = (st > 0.0f) ? 0.0f : wgt;                                                                             \
-                wgt = (below != 0u) ? 0.0f : wgt;                                                                           \
-                const float ts = (st > 0.0f) ? Tb : T_stop;                                                                 \
-                T_stop = (below != 0u) ? T_stop : ts;                   /* the first stopping slot records the final T */   \
-                Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);                   \
-                weight += wgt;                                                                                              \
-                Dacc = __fmaf_rn(c.w, wgt, Dacc);                                                                           \
-                last_contributor = (wgt > 0.0f) ? (uint32_t)base + e + 1u : last_contributor;                               \
-                T = QUAD_BCAST3(X);                                                                                         \
-                live = (q != 0u) ? 0.0f : live;                                                                             \
+            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.x, b.y, b.z, b.w);
+            const float al = pe.alpha * live;                                  // 0 for finished / outside pixels
+            const float f = 1.0f - al;
+            float X, Tb;                                                       // T behind / in front of this slot's entry
+            if (SLOTS == 4) {
+                // multiplied in list order: bit-identical to the serial loop
+                float Y;
+                X = T * f;
+                Y = DPP_MOV(X, 0x90); X = slot >= 1 ? Y * f : X;               // quad_perm:[0,0,1,2]
+                Y = DPP_MOV(X, 0x90); X = slot >= 2 ? Y * f : X;
+                Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y * f : X;
+                Y = DPP_MOV(X, 0x90);
+                Tb = slot == 0 ? T : Y;
+            } else {
+                const float Pm = prefix_mul<SLOTS>(f, slot);
+                X = T * Pm;
+                Tb = T * from_slot_minus<SLOTS, 1>(Pm, 1.0f, slot);
             }
-            FWD_GROUP(peA, bA, cA, eA)
-            FWD_GROUP(peB, bB, cB, eB)
-#undef FWD_GROUP
+            const float st = (X < 0.0001f) ? al : 0.0f;                        // > 0: this entry ends the pixel (forward.cu:351-356)
+            const unsigned long long sb = __ballot(st > 0.0f);
+            const uint32_t q = (uint32_t)(sb >> lg.gbase) & slot_bits;         // stop flags of this pixel's slots
+            const uint32_t below = q & below_mask;                             // an earlier slot already stopped the pixel
+            float wgt = al * Tb;
+            wgt = (st > 0.0f) ? 0.0f : wgt;
+            wgt = (below != 0u) ? 0.0f : wgt;
+            const float ts = (st > 0.0f) ? Tb : T_stop;
+            T_stop = (below != 0u) ? T_stop : ts;                              // the first stopping slot records the final T
+            Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);
+            weight += wgt;
+            Dacc = __fmaf_rn(c.w, wgt, Dacc);
+            last_contributor = (wgt > 0.0f) ? (float)(base + (int)e + 1) : last_contributor;
+            if (SLOTS == 4) T = DPP_MOV(X, 0xFF);
+            else { float Pall = f; GROUP_ALLREDUCE(SLOTS, Pall, OP_MUL) T *= Pall; }
+            live = (q != 0u) ? 0.0f : live;
             if (__ballot(live > 0.0f) == 0ull) break;
 
-            aA = aAn; bA = bAn; cA = cAn; aB = aBn; bB = bBn; cB = cBn;
-            eA = eA1; eB = eB1; eA1 = eA2; eB1 = eB2; lp += 8;
+            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += SLOTS;
         }
+        const bool wave_done = __ballot(live > 0.0f) == 0ull;          // all lanes vote (outside the lane-0 branch)
+        if (lane == 0) s_done[wv] = wave_done ? 1 : 0;
+        d_trip += STAMP() - t4;
     }
 
-    // combine the four slots of each pixel
-    Cr += QUAD_XOR1(Cr); Cr += QUAD_XOR2(Cr);
-    Cg += QUAD_XOR1(Cg); Cg += QUAD_XOR2(Cg);
-    Cb += QUAD_XOR1(Cb); Cb += QUAD_XOR2(Cb);
-    weight += QUAD_XOR1(weight); weight += QUAD_XOR2(weight);
-    Dacc += QUAD_XOR1(Dacc); Dacc += QUAD_XOR2(Dacc);
-    T_stop = fmaxf(T_stop, QUAD_XOR1(T_stop)); T_stop = fmaxf(T_stop, QUAD_XOR2(T_stop));
-    uint32_t lc = last_contributor;
-    lc = max(lc, (uint32_t)__builtin_amdgcn_mov_dpp((int)lc, 0xB1, 0xf, 0xf, true));
-    lc = max(lc, (uint32_t)__builtin_amdgcn_mov_dpp((int)lc, 0x4E, 0xf, 0xf, true));
+    if (stamps && tid == 0) {
+        unsigned long long* o = stamps + (size_t)item * 8;
+        o[0] = STAMP() - t_begin; o[1] = d_top; o[2] = d_stage; o[3] = d_bar; o[4] = d_cull; o[5] = d_trip; o[6] = n_batches; o[7] = n_trips;
+    }
+#undef STAMP
+    // combine the slots of each pixel
+    GROUP_ALLREDUCE(SLOTS, Cr, OP_ADD) GROUP_ALLREDUCE(SLOTS, Cg, OP_ADD) GROUP_ALLREDUCE(SLOTS, Cb, OP_ADD)
+    GROUP_ALLREDUCE(SLOTS, weight, OP_ADD) GROUP_ALLREDUCE(SLOTS, Dacc, OP_ADD)
+    GROUP_ALLREDUCE(SLOTS, T_stop, OP_MAX) GROUP_ALLREDUCE(SLOTS, last_contributor, OP_MAX)
     const float Tf = T_stop >= 0.0f ? T_stop : T;
 
     if (inside && slot == 0) {
-        const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
+        const size_t pix_id = (size_t)W * lg.py + lg.px, plane = (size_t)W * H;
         final_T[pix_id] = Tf;
-        n_contrib[pix_id] = lc;
+        n_contrib[pix_id] = (uint32_t)last_contributor;
         out_color[pix_id] = __fmaf_rn(Tf, bg_color[0], Cr);
         out_color[plane + pix_id] = __fmaf_rn(Tf, bg_color[1], Cg);
         out_color[2 * plane + pix_id] = __fmaf_rn(Tf, bg_color[2], Cb);
         out_alpha[pix_id] = weight;
         out_depth[pix_id] = Dacc;
+    }
+    }   // work-item loop
+
+    // Tiles without instances get the background only (forward.cu:374-382 with an empty range).  Done AFTER the queue so that
+    // the heavy items start immediately; workgroups that run out of queued work fill these while the stragglers finish.
+    for (int i = n_items + (int)blockIdx.x; i < 4 * T_tiles; i += (int)gridDim.x) {
+        const LaneGeom<SLOTS> lg(tile_order[i >> 2], i & 3, gx, lane, wv);
+        if (lg.px < W && lg.py < H && lg.slot == 0) {
+            const size_t pix_id = (size_t)W * lg.py + lg.px, plane = (size_t)W * H;
+            final_T[pix_id] = 1.0f; n_contrib[pix_id] = 0u;
+            out_color[pix_id] = bg_color[0]; out_color[plane + pix_id] = bg_color[1]; out_color[2 * plane + pix_id] = bg_color[2];
+            out_alpha[pix_id] = 0.0f; out_depth[pix_id] = 0.0f;
+        }
     }
 }
 
@@ -267,48 +367,59 @@ __device__ __forceinline__ float fold16(float a, float b)
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// sum over the 4 lanes of a row that share l&3
+// sum over the lanes of a row that share the slot (lane % SLOTS)
+template <int SLOTS>
 __device__ __forceinline__ float row_slot_sum(float v)
 {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));   // row_ror:4
+    if (SLOTS < 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
+    if (SLOTS < 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));    // row_ror:4
     return v;
 }
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
+template <int SLOTS>
+__global__ void __launch_bounds__(SLOTS * 64)
+blend_backward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
+                      uint32_t* __restrict__ queue_head,
+                      const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
                       const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
-                      float* __restrict__ inst_grad /* [16/NW][R][12] */, size_t slab_stride, int use_cull)
+                      float* __restrict__ inst_grad /* [4][R][12] */, size_t slab_stride, int flags)
 {
-    constexpr int NT = NW * 64;
-    constexpr int BB = (NW == 4) ? BWD_BATCH_QUADRANT : BWD_BATCH_TILE;      // entries staged per round
+    using L = Lay<SLOTS>;
+    constexpr int NW = L::NW, NT = NW * 64, BB = L::BB;
     __shared__ float4 s_a[BB + 1];
     __shared__ float4 s_b[BB + 1];
     __shared__ float4 s_c[BB + 1];
     __shared__ uint16_t s_list[NW][BB + LIST_PAD];
     __shared__ __attribute__((aligned(16))) float s_part[NW][BB + 1][NPART];
     __shared__ uint32_t s_nmax;
+    __shared__ int s_item;
 
-    const int tile = blockIdx.x % T_pad, sub = blockIdx.x / T_pad;
-    if (tile >= T_tiles) return;
-    const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int slot = lane & 3, pl = lane >> 2;
-    int bx, by;
-    block_of_wave<NW>(sub, wv, bx, by);
-    const int ox = tx * TILE + bx * 4, oy = ty * TILE + by * 4;
-    const int px = ox + (pl & 3), py = oy + (pl >> 2);
-    const bool inside = px < W && py < H;
-    const float pixx = (float)px, pixy = (float)py;
-    const float bx0 = (float)ox, by0 = (float)oy;
-    const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
+    const int n_items = 4 * (int)header[5];                  // only tiles that own instances
+    int next_item = 0;
+    if (tid == 0) next_item = (int)atomicAdd(queue_head, 1u);
+    for (;;) {                                               // persistent workgroup: see the forward kernel
+    __syncthreads();
+    if (tid == 0) {
+        s_item = next_item;
+        if (next_item < n_items) next_item = (int)atomicAdd(queue_head, 1u);
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item >= n_items) break;
+    const int tile = (int)tile_order[item >> 2], sub = item & 3;
+    const LaneGeom<SLOTS> lg(tile, sub, gx, lane, wv);
+    const int slot = lg.slot;
+    const bool inside = lg.px < W && lg.py < H;
+    const float pixx = (float)lg.px, pixy = (float)lg.py;
+    const float bx0 = (float)lg.ox, by0 = (float)lg.oy;
+    const size_t pix_id = (size_t)W * lg.py + lg.px, plane = (size_t)W * H;
 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
-    if (n == 0) return;
-    float* my_grad = inst_grad + (size_t)sub * slab_stride + (size_t)rg.x * NPART;      // this workgroup's slab of the tile's records
+    if (n == 0) continue;
+    float* my_grad = inst_grad + (size_t)sub * slab_stride + (size_t)rg.x * NPART;      // this quadrant's slab of the tile's records
 
     const float T_final = inside ? final_Ts[pix_id] : 0.0f;
     const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
@@ -326,7 +437,7 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
         s_nmax = 0;
     }
     __syncthreads();
-    // Pixel state, replicated in the pixel's four lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
+    // Pixel state, replicated in the pixel's lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
     // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
     float T = T_final, Q = 0.0f;
 
@@ -344,7 +455,7 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
     // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
     const int row = lane >> 4, rh = row >> 1, rp = row & 1;
     const int m0 = 2 * rp + rh, m1 = 4 + m0;
-    const bool writer = (lane & 12) == 0;                  // lanes 16*row + slot
+    const bool writer = (lane & 15) < SLOTS;               // one lane per (row, slot)
 
     static_assert(NT >= BB, "one staging thread per batch entry");
     Staged pre = load_entry(min(BB, n_eff), inst_rec, (int)rg.x + n_eff - 1, -1);
@@ -352,7 +463,7 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
         const int cnt = min(BB, n_eff - base);
         __syncthreads();                                   // previous batch fully flushed
         store_entry(pre, cnt, s_a, s_b, s_c);
-        if (base + BB < n_eff)                      // next batch's gathers fly while this one is processed
+        if (base + BB < n_eff)                             // next batch's loads fly while this one is processed
             pre = load_entry(min(BB, n_eff - base - BB), inst_rec, (int)rg.x + n_eff - 1 - base - BB, -1);
         {
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -365,78 +476,93 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             bool hit = (j < cnt) && (n_eff - 1 - (base + j) < wave_max);
-            if (hit && (use_cull & 1)) hit = block_hit(s_a[j], bx0, by0);
-            if (use_cull & 4) hit = false;
+            if (hit && (flags & 1)) hit = block_hit(s_a[j], bx0, by0, (float)(L::BW - 1), (float)(L::BH - 1));
             len = append_hits(my_list, len, hit, j);
         }
         if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)BB;
-        const int niter = (use_cull & 2) ? 0 : (len + 3) >> 2;
+        const int ntrip = (flags & 2) ? 0 : (len + SLOTS - 1) / SLOTS;
 
-        // Two groups of four entries per trip (see the forward kernel): evaluations and gradient formulas of the two groups
-        // are independent and interleave; only the (T, Q) chains are sequential.  Records are prefetched one trip ahead.
         int lp = slot;
-        uint32_t eA = my_list[lp], eB = my_list[lp + 4];
-        float4 aA = s_a[eA], bA = s_b[eA], cA = s_c[eA];
-        float4 aB = s_a[eB], bB = s_b[eB], cB = s_c[eB];
-        uint32_t eA1 = my_list[lp + 8], eB1 = my_list[lp + 12];
-        for (int it = 0; it < niter; it += 2) {
-            const float4 aAn = s_a[eA1], bAn = s_b[eA1], cAn = s_c[eA1];
-            const float4 aBn = s_a[eB1], bBn = s_b[eB1], cBn = s_c[eB1];
-            const uint32_t eA2 = my_list[lp + 16], eB2 = my_list[lp + 20];
+        uint32_t e = my_list[lp];
+        float4 a = s_a[e], b = s_b[e], c = s_c[e];
+        uint32_t e1 = my_list[lp + SLOTS];
+        for (int it = 0; it < ntrip; it++) {
+            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];
+            const uint32_t e2 = my_list[lp + 2 * SLOTS];
 
-            const float dxA = aA.x - pixx, dyA = aA.y - pixy, dxB = aB.x - pixx, dyB = aB.y - pixy;
-            const PairEval peA = eval_pair(dxA, dyA, bA.x, bA.y, bA.z, bA.w);
-            const PairEval peB = eval_pair(dxB, dyB, bB.x, bB.y, bB.z, bB.w);
-#define BWD_GROUP(pe, dx, dy, a, b, c, e)                                                                                   \
-            {                                                                                                               \
-                const int pos = n_eff - 1 - (base + (int)e);                 /* back to front */                            \
-                const float al = (pos < last_contributor) ? pe.alpha : 0.0f; /* backward.cu:499-514; 0 = pair skipped */    \
-                const float G = (al > 0.0f) ? pe.G : 0.0f;                                                                  \
-                /* this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped) */ \
-                const float mm = 1.0f - al;                                                                                 \
-                const float rinv = __builtin_amdgcn_rcpf(mm);                                                               \
-                const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));    \
-                const float kq = al * u;                                                                                    \
-                /* run the four slots' transforms in visiting order: slot s starts from the output of slot s-1 */          \
-                float Ti = T, Qi = Q;                                                                                       \
-                float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);                                                           \
-                _Pragma("unroll") for (int k = 1; k <= 3; k++) {                                                            \
-                    const float yT = QUAD_PREV(To), yQ = QUAD_PREV(Qo);                                                     \
-                    Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;                                                     \
-                    To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);                                                             \
-                }                                                                                                           \
-                T = QUAD_BCAST3(To); Q = QUAD_BCAST3(Qo);                    /* the pixel's state after these four entries */ \
-                /* To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k */                     \
-                float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);                                          \
-                dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;                                                                     \
-                const float dchannel_dcolor = al * To;                                                                      \
-                const float dL_dG = b.w * dL_dopa;                                                                          \
-                const float gdx = G * dx, gdy = G * dy;                                                                     \
-                const float dG_ddelx = -gdx * b.x - gdy * b.y;                                                              \
-                const float dG_ddely = -gdy * b.z - gdx * b.y;                                                              \
-                const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;             \
-                const float v3 = dL_dG * dG_ddelx * ddelx_dx;                                                               \
-                const float v4 = dL_dG * dG_ddely * ddely_dy;                                                               \
-                const float hdG = -0.5f * dL_dG;                                                                            \
-                const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;                                  \
-                const float v8 = G * dL_dopa;                                                                               \
-                if (__ballot(al > 0.0f) != 0ull) {                                                                          \
-                    /* reduce-scatter over the 16 pixels, separately per slot: after fold32 the lower/upper half-waves hold \
-                       different values, after fold16 even/odd rows do; lane (row r, slot s) ends with m0, m1 (and 8 in row 0) */ \
-                    const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f); \
-                    const float s0 = row_slot_sum(fold16(r0, r1)), s1 = row_slot_sum(fold16(r2, r3)), s2 = row_slot_sum(fold16(r4, 0.0f)); \
-                    if (writer) {                                                                                           \
-                        float* dst = &s_part[wv][e][0];                                                                     \
-                        dst[m0] = s0; dst[m1] = s1;                                                                         \
-                        if (row == 0) dst[8] = s2;                                                                          \
-                    }                                                                                                       \
-                }                                                                                                           \
+            const int pos = n_eff - 1 - (base + (int)e);                   // back to front
+            const float dx = a.x - pixx, dy = a.y - pixy;
+            const PairEval pe = eval_pair(dx, dy, b.x, b.y, b.z, b.w);
+            const float al = (pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = this pair is skipped
+            const float G = (al > 0.0f) ? pe.G : 0.0f;
+            // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
+            const float mm = 1.0f - al;
+            const float rinv = __builtin_amdgcn_rcpf(mm);
+            const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));
+            const float kq = al * u;
+            float Ti, Qi, To;
+            if (SLOTS == 4) {
+                // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
+                Ti = T; Qi = Q;
+                To = Ti * rinv; float Qo = __fmaf_rn(mm, Qi, kq);
+#pragma unroll
+                for (int k = 1; k <= 3; k++) {
+                    const float yT = DPP_MOV(To, 0x90), yQ = DPP_MOV(Qo, 0x90);
+                    Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
+                    To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
+                }
+                T = DPP_MOV(To, 0xFF); Q = DPP_MOV(Qo, 0xFF);               // the pixel's state after these four entries
+            } else {
+                // inclusive prefix composition of the slots' maps: (Rp, M, K) of slots 0..s, later o earlier:
+                //   Rp = prod rinv,   M = prod mm,   K <- M_self * K_earlier + K_self
+                float Rp = rinv, M = mm, K = kq;
+#define COMPOSE_STEP(k)                                                                                  \
+                {                                                                                        \
+                    const float Re = from_slot_minus<SLOTS, k>(Rp, 1.0f, slot), Me = from_slot_minus<SLOTS, k>(M, 1.0f, slot), \
+                                Ke = from_slot_minus<SLOTS, k>(K, 0.0f, slot);                           \
+                    K = __fmaf_rn(M, Ke, K); M *= Me; Rp *= Re;                                          \
+                }
+                COMPOSE_STEP(1) COMPOSE_STEP(2) COMPOSE_STEP(4)
+                if (SLOTS > 8) COMPOSE_STEP(8)
+#undef COMPOSE_STEP
+                // state in front of this slot = maps of slots 0..s-1 applied to the pixel state
+                const float Rx = from_slot_minus<SLOTS, 1>(Rp, 1.0f, slot), Mx = from_slot_minus<SLOTS, 1>(M, 1.0f, slot),
+                            Kx = from_slot_minus<SLOTS, 1>(K, 0.0f, slot);
+                Ti = T * Rx; Qi = __fmaf_rn(Mx, Q, Kx);
+                To = Ti * rinv;
+                // the pixel's state after this trip = the last slot's inclusive maps applied to it
+                const float Rl = from_last_slot<SLOTS>(Rp, lane), Ml = from_last_slot<SLOTS>(M, lane), Kl = from_last_slot<SLOTS>(K, lane);
+                T = T * Rl; Q = __fmaf_rn(Ml, Q, Kl);
             }
-            BWD_GROUP(peA, dxA, dyA, aA, bA, cA, eA)
-            BWD_GROUP(peB, dxB, dyB, aB, bB, cB, eB)
-#undef BWD_GROUP
-            aA = aAn; bA = bAn; cA = cAn; aB = aBn; bB = bBn; cB = cBn;
-            eA = eA1; eB = eB1; eA1 = eA2; eB1 = eB2; lp += 8;
+
+            // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
+            float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
+            dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
+            const float dchannel_dcolor = al * To;
+            const float dL_dG = b.w * dL_dopa;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * b.x - gdy * b.y;
+            const float dG_ddely = -gdy * b.z - gdx * b.y;
+            const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
+            const float v3 = dL_dG * dG_ddelx * ddelx_dx;
+            const float v4 = dL_dG * dG_ddely * ddely_dy;
+            const float hdG = -0.5f * dL_dG;
+            const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
+            const float v8 = G * dL_dopa;
+
+            if (__ballot(al > 0.0f) != 0ull) {
+                // reduce-scatter over the wave's pixels, separately per slot: after fold32 the lower/upper half-waves hold
+                // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
+                const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
+                const float s0 = row_slot_sum<SLOTS>(fold16(r0, r1)), s1 = row_slot_sum<SLOTS>(fold16(r2, r3)),
+                            s2 = row_slot_sum<SLOTS>(fold16(r4, 0.0f));
+                if (writer) {
+                    float* dst = &s_part[wv][e][0];
+                    dst[m0] = s0; dst[m1] = s1;
+                    if (row == 0) dst[8] = s2;
+                }
+            }
+            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += SLOTS;
         }
         __syncthreads();
         // combine the wave sums in a fixed order; 16 lanes per entry write its 48-byte record contiguously
@@ -453,6 +579,7 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, int T_pad, const uint2*
             }
         }
     }
+    }   // work-item loop
 }
 
 int env_int(const char* name, int dflt)
@@ -461,41 +588,63 @@ int env_int(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// resident workgroups of the persistent blend kernels: a fixed number per CU (dynamic balancing does the rest)
+int persistent_workgroups()
+{
+    static const int n = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        return cus * env_int("MOSS_BLEND_WGS_PER_CU", 3);
+    }();
+    return n;
+}
+
+int blend_slots()
+{
+    // measured on MI355X (profiles/r01_notes.md): 4 slots (4x4-pixel blocks, 4 waves per quadrant) is fastest; 8 and 16 do more
+    // total work per tile (every wave re-tests the whole batch) and lose despite their shorter per-wave trip counts
+    static const int s = env_int("MOSS_BLEND_SLOTS", 4);
+    return (s == 8 || s == 16) ? s : 4;
+}
+
 }  // anonymous namespace
 
-int blend_subgroups()      // workgroups per tile (1: 16 waves own a tile; 4: one 4-wave workgroup per 8x8 quadrant)
-{
-    static const int nw = env_int("MOSS_BLEND_WAVES", 4);
-    return nw == 4 ? 4 : 1;
-}
+unsigned long long* g_stamps = nullptr;      // diagnostics buffer registered by moss_raster_debug_set_stamps (NULL = off)
+
+int blend_subgroups() { return 4; }      // workgroups (8x8 quadrants) per tile = gradient-record slabs per instance
 
 void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
                           float* out_color, float* out_depth, float* out_alpha, hipStream_t s)
 {
-    static const int use_cull = env_int("MOSS_BLEND_CULL", 1);
-    const int T = fp.gx * fp.gy, T_pad = (T + 7) / 8 * 8;
-    if (blend_subgroups() == 4)
-        hipLaunchKernelGGL(blend_forward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
-                           fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
-    else
-        hipLaunchKernelGGL(blend_forward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
-                           fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, use_cull);
+    (void)g;
+    static const int flags = env_int("MOSS_BLEND_CULL", 1);
+    const int T = fp.gx * fp.gy;
+    const int wgs = min(4 * T, persistent_workgroups());
+#define LAUNCH_FWD(S)                                                                                                         \
+    hipLaunchKernelGGL(blend_forward_kernel<S>, dim3(wgs), dim3(S * 64), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order,           \
+                       im.header, im.header + 8, im.ranges, b.inst_rec, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T,         \
+                       im.n_contrib, flags, g_stamps)
+    switch (blend_slots()) { case 8: LAUNCH_FWD(8); break; case 16: LAUNCH_FWD(16); break; default: LAUNCH_FWD(4); }
+#undef LAUNCH_FWD
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
                            const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, hipStream_t s)
 {
-    static const int use_cull = env_int("MOSS_BLEND_CULL", 1);
-    const int T = fp.gx * fp.gy, T_pad = (T + 7) / 8 * 8;
+    (void)g;
+    static const int flags = env_int("MOSS_BLEND_CULL", 1);
+    const int T = fp.gx * fp.gy;
+    const int wgs = min(4 * T, persistent_workgroups());
     float* ig = reinterpret_cast<float*>(b.inst_grad);
-    if (blend_subgroups() == 4)
-        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(T_pad * 4), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
-                           fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
-                           ig, b.slab_stride_floats, use_cull);
-    else
-        hipLaunchKernelGGL(blend_backward_kernel<16>, dim3(T_pad), dim3(1024), 0, s, fp.W, fp.H, fp.gx, T, T_pad, im.ranges, b.inst_rec,
-                           fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, dL_dalpha,
-                           ig, b.slab_stride_floats, use_cull);
+    (void)hipMemsetAsync(im.header + 9, 0, sizeof(uint32_t), s);          // this launch's work-queue head
+#define LAUNCH_BWD(S)                                                                                                         \
+    hipLaunchKernelGGL(blend_backward_kernel<S>, dim3(wgs), dim3(S * 64), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order,          \
+                       im.header, im.header + 9, im.ranges, b.inst_rec, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth,        \
+                       dL_dalpha, ig, b.slab_stride_floats, flags)
+    switch (blend_slots()) { case 8: LAUNCH_BWD(8); break; case 16: LAUNCH_BWD(16); break; default: LAUNCH_BWD(4); }
+#undef LAUNCH_BWD
 }
 
 }  // namespace moss

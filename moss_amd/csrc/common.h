@@ -11,7 +11,7 @@
 //     tiles_touched u32, point_offsets u32 (exclusive scan), radius i32, clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
-//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [8]/[9]=work-queue heads of the forward/backward blend
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
 //     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id); inst_tile u32[R] tile of a slot
@@ -66,7 +66,7 @@ struct GeomView {
 
 struct ImageView {
     uint32_t* header;
-    uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base;
+    uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base; uint32_t* tile_order;
     float* final_T; uint32_t* n_contrib;
     static ImageView at(char* base, int W, int H)
     {
@@ -74,7 +74,7 @@ struct ImageView {
         size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
         v.header = carve<uint32_t>(p, 16);
         v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
-        v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T);
+        v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T); v.tile_order = carve<uint32_t>(p, T);
         v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
         return v;
     }
@@ -83,6 +83,7 @@ struct ImageView {
     size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
 };
 
+extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
 int blend_subgroups();       // workgroups per tile in the blend kernels (1 or 4), blend.hip
 
 struct BinView {

@@ -264,6 +264,8 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
     return 0;
 }
 
+void moss_raster_debug_set_stamps(unsigned long long* device_buffer) { moss::g_stamps = device_buffer; }
+
 void moss_raster_profile_enable(uint32_t stage_mask)
 {
     std::lock_guard<std::mutex> lk(g_prof.m);
