@@ -54,6 +54,12 @@ def main():
                          "compute_cov3D_python=False path, gaussian_renderer/__init__.py:92-93); precomp = cov3D computed by "
                          "torch ops and passed in (MOSS's shipped default, arguments/__init__.py:60)")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW instead of the flat fused HIP AdamW")
+    ap.add_argument("--forward", default="async", choices=["sync", "async"],
+                    help="sync = the reference's behaviour (the host reads num_rendered back in every forward); async = "
+                         "capacity-bounded forward with no host read-back (moss_raster_forward_async)")
+    ap.add_argument("--graph", type=int, default=1, choices=[0, 1],
+                    help="1 = capture the per-rank compute of a step (render, loss, backward[, AdamW]) in one hipGraph and replay "
+                         "it (needs --forward async); 0 = launch every kernel eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
@@ -92,16 +98,37 @@ def main():
         opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, fused=True)      # gaussian_model.py:226
     else:
         from moss_amd.optim import FlatAdamW
-        opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15)                          # same rule, one kernel over the bucket
+        opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)         # same rule, one kernel over the bucket
+    from moss_amd import diff_gaussian_rasterization as dgr
+    use_graph = bool(args.graph) and args.forward == "async" and not args.torch_adamw
+    dgr.set_async(args.forward == "async")
 
-    def step():
+    def compute():                      # everything of a step that is local to this rank
         bucket.attach()
         out = render(cam, pc, pipe, bg)
         loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
         loss.backward()
-        bucket.all_reduce_mean(loss, world)
-        opt.step()
+        bucket.loss_slot.copy_(loss.detach().reshape(1))
+        if world == 1:
+            opt.step()
+        # detached: holding an output with a grad_fn would keep this step's autograd graph (and its AccumulateGrad nodes,
+        # bound to the stream they were created on) alive into the next step / into graph capture
+        return {"radii": out["radii"]}
+
+    def eager_step():
+        out = compute()
+        if world > 1:
+            bucket.all_reduce_mean(None, world)          # ONE RCCL all-reduce of the flat gradient bucket (+ loss slot)
+            opt.step()
         return out
+
+    step = eager_step
+
+    t_start = time.perf_counter()
+
+    def note(msg):
+        if os.environ.get("MOSS_BENCH_VERBOSE") and rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
     def barrier():
         if world > 1:
@@ -110,7 +137,11 @@ def main():
     # ---- warmup (also finds the dominant kernel with all stages timed) -------------------------------------
     _lib.profile_enable(None)
     out = None
-    for _ in range(max(args.warmup, 1)):
+    n_warm = max(args.warmup, 1)
+    for i in range(n_warm):
+        if i == n_warm // 2 and i > 0:
+            torch.cuda.synchronize(dev)
+            _lib.profile_read()              # discard the first half: first launches include code-object loading
         out = step()
     torch.cuda.synchronize(dev)
     prof = _lib.profile_read()
@@ -118,6 +149,45 @@ def main():
     dominant = max(stage_ms, key=stage_ms.get)
     _lib.profile_enable([dominant])          # two events per step around the dominant kernel only
 
+    note(f"warmup done; stages {stage_ms}")
+    graph_note = "eager launches"
+    if use_graph:
+        # The first (synchronous) forward above sized the binning buffer; nothing in compute() talks to the host any more, so
+        # the whole per-rank step is captured once and replayed: ~50 launches become one hipGraphLaunch.
+        _lib.profile_enable([])              # hipEvent pairs cannot be read back from inside a captured graph
+        try:
+            out = None
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    compute()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                g_out = compute()
+            torch.cuda.synchronize(dev)
+
+            def graph_step():
+                graph.replay()
+                if world > 1:
+                    bucket.all_reduce_mean(None, world)
+                    opt.step()
+                return g_out
+
+            for _ in range(5):
+                graph_step()
+            torch.cuda.synchronize(dev)
+            step = graph_step
+            graph_note = "one hipGraph replay per step" + (" + eager RCCL all-reduce and AdamW" if world > 1 else "")
+        except Exception as e:                                   # keep measuring: same kernels, launched one by one
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize(dev)
+            use_graph = False
+            _lib.profile_enable([dominant])
+
+    note("entering timed region")
     # ---- timed region: EXACTLY K steps between barrier+sync pairs -------------------------------------------
     barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -125,6 +195,20 @@ def main():
         out = step()
     torch.cuda.synchronize(dev); barrier()
     elapsed = time.perf_counter() - t0
+    note(f"timed region done: {elapsed:.3f}s")
+    if args.forward == "async":
+        # the last frame of the timed region (graph mode: the graph's own buffers) rendered within its binning capacity, i.e. it
+        # really did the work; an overflowed frame would have produced a background image and is an error here
+        dgr.check_async_status()
+        assert dgr._C.ASYNC.last_needed > 0
+    if use_graph:
+        # the dominant kernel's launch duration: hipEvent pairs over the same number of eager launches of the same step,
+        # right after the timed region (events inside a replayed graph cannot be read back)
+        _lib.profile_enable([dominant])
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize(dev)
+    note("dominant pass done")
     dom_ms, dom_n = _lib.profile_read()[dominant]
     dom_ms = dom_ms / max(dom_n, 1)
     if world > 1:
@@ -136,12 +220,13 @@ def main():
     _lib.profile_enable(None)
     n_prof = min(args.steps, 50)
     for _ in range(n_prof):
-        out = step()
+        out = eager_step()
     torch.cuda.synchronize(dev)
     prof = _lib.profile_read()
     _lib.profile_enable([])
     stage_ms = {k: round(v[0] / v[1], 5) if v[1] else 0.0 for k, v in prof.items()}
 
+    note(f"stage pass done {stage_ms}")
     if rank != 0:
         return
 
@@ -169,11 +254,14 @@ def main():
                                f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
                    if args.config == "cfg3" else args.config,
                    "input_mode": args.mode, "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
-                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
+                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+                   "forward": args.forward, "launch": graph_note},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": _pmc_traffic(dominant),
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
-                     "timing": "hipEvent pairs on the launch stream inside the timed region"},
+                     "timing": ("hipEvent pairs on the launch stream over the same number of eager launches of the same step, "
+                                "taken right after the graph-replay timed region") if use_graph else
+                               "hipEvent pairs on the launch stream inside the timed region"},
         "stages_ms": stage_ms,
         "rasterizer_ms_per_step": round(raster_ms, 4),
         "step_algorithmic_bytes": int(total_bytes),

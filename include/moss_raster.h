@@ -83,6 +83,34 @@ int moss_raster_forward(
     void* stream);
 
 /*
+ * Asynchronous variant of moss_raster_forward for launch-bound training loops and hipGraph capture: NO host read-back.
+ * The caller states an upper bound `capacity` on the number of (Gaussian, tile) instances (e.g. 2x the value a previous,
+ * synchronous call returned); scratch buffers and launch grids are sized for it and every kernel bounds itself with the
+ * device-side count.  Returns `capacity` (>= 0) -- pass that as R to moss_raster_backward -- or a negative error code.
+ * If a frame needs more instances than `capacity`, nothing is rendered (outputs = background, gradients = 0) and the
+ * overflow bit is set in the status words; poll them with moss_raster_read_status once the stream has advanced.
+ * `debug` is not available in this mode (it synchronises by definition).
+ */
+int moss_raster_forward_async(
+    moss_alloc_fn geometry_alloc, void* geometry_user,
+    moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream);
+
+/* Enqueue (on `stream`) a copy of the forward's 8 status words from the image buffer to pinned host memory:
+ * [0] instances rendered  [1] longest tile list  [2] flags: bit0 prefiltered-point culled, bit1 capacity overflow
+ * [4] sort chunks  [5] non-empty tiles  [6] instances the frame needed. */
+#define MOSS_STATUS_PREFILTERED 1u
+#define MOSS_STATUS_OVERFLOW    2u
+int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out, void* stream);
+
+/*
  * Replaces CudaRasterizer::Rasterizer::backward (DGR/cuda_rasterizer/rasterizer.h:57-89,
  * DGR/cuda_rasterizer/rasterizer_impl.cu:345-447).  R is the value forward returned.
  *   dL_dpix (3,H,W), dL_ddepths (H,W), dL_dalphas (H,W): incoming gradients.
@@ -167,6 +195,12 @@ int moss_photometric_loss(int C, int H, int W, const float* image, const float* 
 int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     int num_segments, const long long* segment_end, const float* segment_lr,
                     float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* Same update with the step counter kept on the device: `step_state` is 16 zero-initialised device bytes ([0] = int step,
+ * advanced by one per call; [1], [2] = the bias corrections derived from it).  Nothing in the call depends on a host-side
+ * counter, so a captured hipGraph of a training step replays correctly. */
+int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                            int num_segments, const long long* segment_end, const float* segment_lr,
+                            float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
 
 /* ---- inspection entry points (used by the parity tests; not needed by a caller of the op) ---------------- */
 

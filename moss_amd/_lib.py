@@ -43,6 +43,10 @@ def _declare(lib):
         _p, _p, _p,                                        # viewmatrix, projmatrix, cam_pos
         _f, _f, _i,                                        # tan_fovx, tan_fovy, prefiltered
         _p, _p, _p, _p, _i, _p]                            # out_color, out_depth, out_alpha, radii, debug, stream
+    lib.moss_raster_forward_async.restype = _i
+    lib.moss_raster_forward_async.argtypes = list(lib.moss_raster_forward.argtypes)      # debug -> capacity (both int)
+    lib.moss_raster_read_status.restype = _i
+    lib.moss_raster_read_status.argtypes = [_p, _p, _p]
     lib.moss_raster_backward.restype = _i
     lib.moss_raster_backward.argtypes = [
         _i, _i, _i, _i,                                    # P, D, M, R
@@ -66,6 +70,8 @@ def _declare(lib):
     lib.moss_photometric_loss.argtypes = [_i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
     lib.moss_adamw_flat.restype = _i
     lib.moss_adamw_flat.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _i, _p]
+    lib.moss_adamw_flat_devstep.restype = _i
+    lib.moss_adamw_flat_devstep.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _p, _p]
     lib.moss_raster_profile_enable.restype = None
     lib.moss_raster_profile_enable.argtypes = [C.c_uint32]
     lib.moss_raster_profile_read.restype = _i

@@ -58,7 +58,7 @@ constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort
 // (The per-Gaussian offsets are produced by the preprocess kernel.)
 __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
-            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header)
+            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
@@ -73,25 +73,32 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
     uint32_t total, total_chunks;
     uint32_t off = block_scan_1024(sum, s_wave, total);
     uint32_t coff = block_scan_1024(nch, s_wave, total_chunks);
+    // Asynchronous mode (no host read-back): the binning buffer was sized for `capacity` instances before R was known.
+    // If this frame needs more, render NOTHING (all ranges empty, no queued work) and raise the overflow flag: the
+    // following kernels stay inside the buffer and the host reports the error at its next check.
+    const bool overflow = total > capacity;
     for (int i = b; i < e; i++) {
-        const uint32_t v = tile_count[i];
+        const uint32_t v = overflow ? 0u : tile_count[i];
         ranges[i] = make_uint2(off, off + v); off += v;
         chunk_base[i] = coff; coff += (v + CHUNK - 1) / CHUNK;
     }
+    if (overflow) { sum = 0; mx = 0; off = 0; coff = 0; }
     if (mx) atomicMax(&s_max, mx);
     // tile_order: tiles grouped by floor(log2(list length)), longest class first, empty tiles last.  The blend kernels
     // pull (tile, quadrant) work items in this order from an atomic queue (longest-processing-time-first balancing).
-    for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u); }
+    for (int i = b; i < e; i++) { const uint32_t v = overflow ? 0u : tile_count[i]; atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u); }
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
         for (int k = 0; k < 33; k++) { const uint32_t c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
-        header[0] = total; header[1] = s_max; header[4] = total_chunks;
+        header[0] = overflow ? 0u : total; header[1] = s_max; header[4] = overflow ? 0u : total_chunks;
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
+        header[6] = total;                             // instances this frame needs (for the host's capacity policy)
+        if (overflow) atomicOr(&header[2], ERRFLAG_OVERFLOW);
     }
     __syncthreads();
     for (int i = b; i < e; i++) {
-        const uint32_t v = tile_count[i];
+        const uint32_t v = overflow ? 0u : tile_count[i];
         tile_order[atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u)] = (uint32_t)i;
     }
 }
@@ -100,19 +107,19 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
 // with ONE returning global atomic (after counting its own instances in LDS) and hands the slots out with LDS atomics.
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ keys, uint32_t* __restrict__ inst_tile, int lds_hist)
+               uint64_t* __restrict__ keys, uint32_t* __restrict__ inst_tile, int lds_hist, const uint32_t* __restrict__ header)
 {
     extern __shared__ uint32_t s_mem[];
+    if (header[0] == 0u) return;                       // nothing rendered (or capacity overflow: see scan_kernel)
     uint32_t* s_cnt = s_mem;
     uint32_t* s_base = s_mem + T;
     if (lds_hist) {
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
-        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
-            const uint2 r = g.rect[idx];
-            const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
-            for (int ty = y0; ty < y1; ty++)
-                for (int tx = x0; tx < x1; tx++) atomicAdd(&s_cnt[ty * gx + tx], 1u);
+        for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {      // whole waves stay converged
+            const int idx = base + (int)threadIdx.x;
+            const uint2 r = idx < P ? g.rect[idx] : make_uint2(0u, 0u);
+            wave_for_each_tile(r, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
         }
         __syncthreads();
         for (int i = threadIdx.x; i < T; i += blockDim.x) {
@@ -121,20 +128,18 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
         }
         __syncthreads();
     }
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += gridDim.x * blockDim.x) {
-        const uint2 r = g.rect[idx];
-        const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
-        if (x1 <= x0 || y1 <= y0) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(g.geo_c[idx].w) << 32) | (uint32_t)idx;
-        for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++) {
-                const int t = ty * gx + tx;
-                uint32_t pos;
-                if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-                else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
-                keys[pos] = key;
-                inst_tile[pos] = (uint32_t)t;
-            }
+    for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {
+        const int idx = base + (int)threadIdx.x;
+        const uint2 r = idx < P ? g.rect[idx] : make_uint2(0u, 0u);
+        const bool any = idx < P && (r.y & 0xffffu) > (r.x & 0xffffu) && (r.y >> 16) > (r.x >> 16);
+        const uint64_t key = any ? (((uint64_t)__float_as_uint(g.geo_c[idx].w) << 32) | (uint32_t)idx) : 0ull;
+        wave_for_each_tile(r, gx, key, [&](int t, uint64_t k) {
+            uint32_t pos;
+            if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+            else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
+            keys[pos] = k;
+            inst_tile[pos] = (uint32_t)t;
+        });
     }
 }
 
@@ -174,11 +179,13 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, uint32_t n)
 // Stage A of the sort: one workgroup per CHUNK of a tile's bucket (a tile of n entries has ceil(n/CHUNK) chunks), keys
 // sorted in LDS and written back in place.  Every workgroup has at most 1024 keys, so there is no long-tile tail here.
 __global__ void __launch_bounds__(1024)
-chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys)
+chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
+                  const uint32_t* __restrict__ header)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[CHUNK];
     __shared__ int s_tile;
     const uint32_t c = blockIdx.x;
+    if (c >= header[4]) return;                        // the grid is an upper bound when R is not known on the host
     if (threadIdx.x == 0) {         // last tile whose chunk_base <= c (tiles without entries share their successor's base)
         int lo = 0, hi = T;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_base[mid] <= c) lo = mid; else hi = mid; }
@@ -201,12 +208,12 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
 // then emits everything that is per-instance: the sorted id, the 48-byte record the blend kernels stream, and the
 // Gaussian -> instance back-pointer used by the backward gather.
 __global__ void __launch_bounds__(256)
-merge_gather_kernel(int R, int gx, GeomView g, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
                     const uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
                     float4* __restrict__ inst_rec)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
+    if (i >= (int)header[0]) return;
     const uint32_t tile = inst_tile[i];
     const uint2 rg = ranges[tile];
     const uint64_t key = keys[i];
@@ -259,11 +266,28 @@ int env_int(const char* name, int dflt)
 
 }  // anonymous namespace
 
-void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s)
+__global__ void __launch_bounds__(256) clear_words_kernel(uint4* __restrict__ p, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// Zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel.  Used instead of hipMemsetAsync for the per-frame state: a memset
+// node inside a captured hipGraph did not re-execute on replay here (ROCm 7.2), which left stale histograms behind.
+void launch_clear(void* ptr, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 256);
+    hipLaunchKernelGGL(clear_words_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(ptr), n16);
+}
+
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s)
 {
     (void)P; (void)g;
+    const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header);
+                       im.header, cap);
 }
 
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
@@ -275,15 +299,17 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
-                       b.inst_tile, lds_hist);
+                       b.inst_tile, lds_hist, im.header);
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
+    // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
+    // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) return;
-    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(1024), 0, s, T, im.ranges, im.chunk_base, b.keys);
-    hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, fp.gx, g, im.ranges, b.keys, b.inst_tile,
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(1024), 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, im.header, fp.gx, g, im.ranges, b.keys, b.inst_tile,
                        b.point_list, b.inst_pos, b.inst_rec);
 }
 

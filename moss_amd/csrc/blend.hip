@@ -580,6 +580,12 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restr
         }
     }
     }   // work-item loop
+    // Self-cleaning queue: every workgroup has made its last pull by now, so the last one to leave rewinds the head for the
+    // next backward over the same forward state (no memset node -- see raster_api.hip on hipGraph capture).
+    if (tid == 0) {
+        uint32_t* leavers = queue_head + 1;                  // header[10]
+        if (atomicAdd(leavers, 1u) == gridDim.x - 1) { *queue_head = 0u; *leavers = 0u; }
+    }
 }
 
 int env_int(const char* name, int dflt)
@@ -638,7 +644,7 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());
     float* ig = reinterpret_cast<float*>(b.inst_grad);
-    (void)hipMemsetAsync(im.header + 9, 0, sizeof(uint32_t), s);          // this launch's work-queue head
+    // header[9] (queue head) and header[10] (leaver count) are zero here: cleared by the forward, rewound by each backward
 #define LAUNCH_BWD(S)                                                                                                         \
     hipLaunchKernelGGL(blend_backward_kernel<S>, dim3(wgs), dim3(S * 64), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order,          \
                        im.header, im.header + 9, im.ranges, b.inst_rec, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth,        \

@@ -11,7 +11,7 @@
 //     tiles_touched u32, point_offsets u32 (exclusive scan), radius i32, clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
-//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [8]/[9]=work-queue heads of the forward/backward blend
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [6]=instances needed [8]/[9]=work-queue heads of the forward/backward blend
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
 //     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id); inst_tile u32[R] tile of a slot
@@ -32,6 +32,7 @@ constexpr int TILE_PIX = TILE * TILE;
 constexpr size_t BUF_ALIGN = 256;
 constexpr int MAX_LDS_TILES = 8192;      // tile histograms are privatised in LDS up to this many tiles
 constexpr uint32_t ERRFLAG_PREFILTERED = 1u;
+constexpr uint32_t ERRFLAG_OVERFLOW = 2u;      // asynchronous forward: the frame needs more instances than the caller's capacity
 
 inline size_t align_up(size_t v, size_t a = BUF_ALIGN) { return (v + a - 1) / a * a; }
 
@@ -79,9 +80,41 @@ struct ImageView {
         return v;
     }
     static size_t bytes(int W, int H) { char* z = nullptr; ImageView v = at(z, W, H); return (size_t)((char*)v.n_contrib - z) + align_up((size_t)W * H * 4); }
-    // header + tile_count + tile_cursor are contiguous: one memset clears them
+    // header + tile_count + tile_cursor are contiguous (each carved at 16-byte granularity or coarser): one clear covers them
     size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
 };
+
+#if defined(__HIPCC__)
+// Visit every tile of every lane's tile rectangle (packed as in GeomView::rect).  Rectangles of up to COOP_TILES tiles are walked by
+// their own lane.  Larger ones -- a Gaussian that grew to cover much of the image owns up to gx*gy tiles, and a single lane walking
+// them is a millisecond-long tail -- are walked by the 64 lanes of the wave together, one rectangle at a time, the owner's
+// `payload` broadcast to all of them.  Must be called with the whole wave converged.
+constexpr int COOP_TILES = 32;
+template <typename F>
+__device__ __forceinline__ void wave_for_each_tile(uint2 rect, int gx, uint64_t payload, F&& f)
+{
+    const int x0 = (int)(rect.x & 0xffffu), y0 = (int)(rect.x >> 16), x1 = (int)(rect.y & 0xffffu), y1 = (int)(rect.y >> 16);
+    const int w = x1 - x0, h = y1 - y0;
+    const int n = (w > 0 && h > 0) ? w * h : 0;
+    if (n <= COOP_TILES) {
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) f(ty * gx + tx, payload);
+    }
+    unsigned long long big = __ballot(n > COOP_TILES);
+    const int lane = (int)(threadIdx.x & 63u);
+    while (big) {
+        const int src = __ffsll(big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bw = __shfl(w, src), bn = __shfl(n, src);
+        const uint32_t plo = __shfl((uint32_t)payload, src), phi = __shfl((uint32_t)(payload >> 32), src);
+        const uint64_t bp = ((uint64_t)phi << 32) | plo;
+        for (int j = lane; j < bn; j += 64) {
+            const int r = j / bw;
+            f((by0 + r) * gx + bx0 + (j - r * bw), bp);
+        }
+    }
+}
+#endif
 
 extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
 int blend_subgroups();       // workgroups per tile in the blend kernels (1 or 4), blend.hip
@@ -125,12 +158,13 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                                GeomView g, ImageView im, int* radii_out, hipStream_t s);
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
-                                GeomView g, BinView b,
+                                GeomView g, BinView b, const uint32_t* header,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
 
-void launch_scan(int P, GeomView g, ImageView im, int num_tiles, hipStream_t s);                 // offsets, ranges, header
+void launch_clear(void* ptr, size_t bytes, hipStream_t s);
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);  // duplicateWithKeys
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s);
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

@@ -13,8 +13,10 @@ struct Segs { int n; long long end[8]; float lr[8]; };
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-             Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt)
+             Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
+             const float* __restrict__ step_state)
 {
+    if (step_state) { bc1 = step_state[1]; bc2_sqrt = step_state[2]; }      // device-resident step counter (graph replay)
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
         const long long i = i4 * 4;
         float pv[4], gv[4], mv[4], vv[4];
@@ -49,6 +51,29 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     }
 }
 
+// One thread: advance the device-resident step counter and derive the two bias corrections from it.
+__global__ void adamw_tick_kernel(float* state, float beta1, float beta2)
+{
+    const int t = reinterpret_cast<int*>(state)[0] + 1;
+    reinterpret_cast<int*>(state)[0] = t;
+    state[1] = (float)(1.0 - pow((double)beta1, (double)t));
+    state[2] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+}
+
+int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
+                 const long long* segment_end, const float* segment_lr, float beta1, float beta2, float eps, float weight_decay,
+                 float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream)
+{
+    Segs segs; segs.n = num_segments;
+    for (int i = 0; i < 8; i++) { segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f; }
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
+                       segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state);
+    return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+}
+
 }  // namespace
 }  // namespace moss
 
@@ -59,13 +84,19 @@ extern "C" int moss_adamw_flat(long long n, float* params, const float* grads, f
     if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || step < 1)
         return MOSS_ERR_INVALID_ARG;
     if (n == 0) return 0;
-    moss::Segs segs; segs.n = num_segments;
-    for (int i = 0; i < 8; i++) { segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f; }
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(moss::adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq,
-                       segs, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
-    return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+    return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, beta1, beta2, eps,
+                              weight_decay, (float)bc1, (float)sqrt(bc2), nullptr, (hipStream_t)stream);
+}
+
+extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                       int num_segments, const long long* segment_end, const float* segment_lr,
+                                       float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream)
+{
+    if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || !step_state)
+        return MOSS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(moss::adamw_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (float*)step_state, beta1, beta2);
+    if (n == 0) return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+    return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, beta1, beta2, eps,
+                              weight_decay, 1.f, 1.f, (const float*)step_state, (hipStream_t)stream);
 }

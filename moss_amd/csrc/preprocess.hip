@@ -267,12 +267,12 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             out_tiles = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
             out_rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
 
-            for (int ty = y0; ty < y1; ty++)
-                for (int tx = x0; tx < x1; tx++) {
-                    if (lds_hist) atomicAdd(&s_hist[ty * gx + tx], 1u);
-                    else atomicAdd(&tile_count[ty * gx + tx], 1u);
-                }
         } while (0);
+        // per-tile histogram of the (Gaussian, tile) instances; large rectangles are walked by the whole wave
+        wave_for_each_tile(out_rect, gx, 0ull, [&](int t, uint64_t) {
+            if (lds_hist) atomicAdd(&s_hist[t], 1u);
+            else atomicAdd(&tile_count[t], 1u);
+        });
         // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos.  The runs only have to
         // be disjoint, not ordered by index, so a block-level prefix sum plus ONE returning atomic per block replaces the
         // device-wide scan of the reference (rasterizer_impl.cu:279).
@@ -331,20 +331,27 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                            const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                            GeomView g, const uint32_t* __restrict__ inst_pos, const float4* __restrict__ inst_grad,
-                           int slabs, size_t slab_stride_f4,
+                           int slabs, size_t slab_stride_f4, const uint32_t* __restrict__ header,
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const uint32_t n_inst = g.tiles_touched[idx];
+    const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
+    const uint32_t n_inst = in_range ? g.tiles_touched[idx] : 0u;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
-    const bool visible = n_inst > 0;            // <=> radii > 0 (backward.cu:156,367)
+    // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
+    // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
+    const bool visible = n_inst > 0 && !(header[2] & ERRFLAG_OVERFLOW);
 
-    if (visible) {
-        const uint32_t off = g.point_offsets[idx];
+    // Sum the per-instance partial records.  A Gaussian with few instances (the norm: 2-3) is summed by its own lane.  One that
+    // covers much of the image owns up to gx*gy instances x `slabs` records -- a serial sum of thousands of 48-byte gathers -- so
+    // those are summed by the 64 lanes of the wave together (lane-strided partial sums, then a fixed butterfly): still a fixed
+    // order, hence bitwise reproducible.
+    constexpr uint32_t COOP_INST = 16;
+    const uint32_t off = visible ? g.point_offsets[idx] : 0u;
+    if (visible && n_inst <= COOP_INST) {
         for (uint32_t k = 0; k < n_inst; k++) {
             const uint32_t pos = inst_pos[off + k];
             for (int sl = 0; sl < slabs; sl++) {
@@ -356,6 +363,36 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
         }
     }
+    {
+        unsigned long long big = __ballot(visible && n_inst > COOP_INST);
+        const int lane = (int)(threadIdx.x & 63u);
+        while (big) {
+            const int src = __ffsll(big) - 1;
+            big &= big - 1;
+            const uint32_t boff = __shfl(off, src), bn = __shfl(n_inst, src);
+            float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            const uint32_t items = bn * (uint32_t)slabs;
+            for (uint32_t j = (uint32_t)lane; j < items; j += 64u) {
+                const uint32_t k = j / (uint32_t)slabs, sl = j - k * (uint32_t)slabs;
+                const uint32_t pos = inst_pos[boff + k];
+                const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
+                acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
+                acc[8] += r2.x;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d);
+            }
+            if (lane == src) {
+                gcol.x = acc[0]; gcol.y = acc[1]; gcol.z = acc[2]; gmx = acc[3];
+                gmy = acc[4]; gca = acc[5]; gcb = acc[6]; gcc = acc[7]; gop = acc[8];
+            }
+        }
+    }
+    if (!in_range) return;
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
     dL_dopacity[idx] = gop;
@@ -615,7 +652,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
-                                GeomView g, BinView b,
+                                GeomView g, BinView b, const uint32_t* header,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s)
 {
@@ -624,7 +661,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, s,
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,
-                       g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                       g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, header, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
                        dL_dsh, dL_dscale, dL_drot);
 }
 

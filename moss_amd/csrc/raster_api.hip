@@ -97,16 +97,7 @@ FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float
 
 }  // namespace
 
-extern "C" {
-
-int moss_abi_version(void) { return MOSS_ABI_VERSION; }
-const char* moss_last_error(void) { return g_err; }
-
-size_t moss_raster_geometry_bytes(int P) { return GeomView::bytes(P > 0 ? P : 1); }
-size_t moss_raster_image_bytes(int width, int height) { return ImageView::bytes(width, height); }
-size_t moss_raster_binning_bytes(int R) { return BinView::bytes(R); }
-
-int moss_raster_forward(
+static int forward_impl(
     moss_alloc_fn geometry_alloc, void* geometry_user,
     moss_alloc_fn binning_alloc, void* binning_user,
     moss_alloc_fn image_alloc, void* image_user,
@@ -116,7 +107,7 @@ int moss_raster_forward(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream, long long capacity)
 {
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -149,21 +140,29 @@ int moss_raster_forward(
                                        viewmatrix, projmatrix, cam_pos, background);
     const int T = fp.gx * fp.gy;
 
-    HIP_TRY(hipMemsetAsync(im.header, 0, im.clear_bytes(), s));        // header + tile histogram + tile cursors
+    launch_clear(im.header, im.clear_bytes(), s);                        // header + tile histogram + tile cursors
     { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
       launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, im, radii, s); }
     STAGE_CHECK("preprocess");
-    { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, s); }
+    { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, capacity, s); }
     STAGE_CHECK("scan");
 
-    // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
-    if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const int R = (int)g_pinned.p[0];
-    const int total_chunks = (int)g_pinned.p[4];
-    if (g_pinned.p[2] & ERRFLAG_PREFILTERED)
-        return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    int R, total_chunks;
+    if (capacity < 0) {
+        // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
+        if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        R = (int)g_pinned.p[0];
+        total_chunks = (int)g_pinned.p[4];
+        if (g_pinned.p[2] & ERRFLAG_PREFILTERED)
+            return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    } else {
+        // Asynchronous: no read-back.  Buffers and grids are sized for the caller's capacity; kernels bound themselves with the
+        // device-side R; a frame that needs more renders nothing and sets the overflow flag (moss_raster_read_status).
+        R = (int)capacity;
+        total_chunks = (int)(capacity / 1024) + T;
+    }
 
     char* bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
     if (!bin_ptr) return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL");
@@ -179,6 +178,52 @@ int moss_raster_forward(
     STAGE_CHECK("blend_forward");
     return R;
 }
+
+extern "C" {
+
+int moss_raster_forward(
+    moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream)
+{
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
+                        debug, stream, -1);
+}
+
+int moss_raster_forward_async(
+    moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream)
+{
+    if (capacity < 0) return fail(MOSS_ERR_INVALID_ARG, "capacity must be >= 0");
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
+                        0, stream, capacity);
+}
+
+int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out /* 8 words */, void* stream)
+{
+    // enqueue a copy of {R rendered, longest list, error flags, -, chunks, non-empty tiles, instances needed, -} to host memory
+    if (!image_buffer || !host_pinned_out) return fail(MOSS_ERR_INVALID_ARG, "null pointer");
+    hipError_t e = hipMemcpyAsync(host_pinned_out, image_buffer, 32, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail(MOSS_ERR_HIP, "status copy failed: %s", hipGetErrorString(e));
+}
+
+int moss_abi_version(void) { return MOSS_ABI_VERSION; }
+const char* moss_last_error(void) { return g_err; }
+
+size_t moss_raster_geometry_bytes(int P) { return GeomView::bytes(P > 0 ? P : 1); }
+size_t moss_raster_image_bytes(int width, int height) { return ImageView::bytes(width, height); }
+size_t moss_raster_binning_bytes(int R) { return BinView::bytes(R); }
 
 int moss_raster_backward(
     int P, int D, int M, int R,
@@ -214,7 +259,7 @@ int moss_raster_backward(
         STAGE_CHECK("blend_backward");
     }
     { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
-      launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b,
+      launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b, im.header,
                                  dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s); }
     STAGE_CHECK("preprocess_backward");
     return 0;

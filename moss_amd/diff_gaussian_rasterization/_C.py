@@ -19,6 +19,72 @@ NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/conf
 _tls = threading.local()
 last_num_rendered = 0   # num_rendered of the most recent forward call (read by bench.py for its byte accounting)
 
+
+class _AsyncState:
+    """Opt-in asynchronous forward (C ABI moss_raster_forward_async): no host read-back of num_rendered.
+
+    The reference blocks in every forward to size its binning buffer (rasterizer_impl.cu:283).  In a training loop R
+    drifts slowly, so here the buffer is sized for ``margin x`` the last value seen; the true R stays on the device.  A
+    frame that needs more than the capacity renders nothing and sets a flag, which is read back (without blocking) and
+    raised by a later call or by :func:`check_async_status`.  With no synchronisation left in the step, a whole
+    training iteration can be captured in a hipGraph (``torch.cuda.graph``)."""
+    enabled = False
+    capacity = 0
+    margin = 2.0
+    pending = None          # (pinned status tensor, torch.cuda.Event)
+    last_needed = 0
+    status_buf = None       # one pinned 32-byte landing buffer, reused (only one status copy is pending at a time)
+    last_img_buffer = None  # image buffer (holds the status header) of the most recent asynchronous forward
+
+
+ASYNC = _AsyncState()
+
+
+def set_async(enabled: bool, capacity: int = 0, margin: float = 2.0):
+    ASYNC.enabled, ASYNC.capacity, ASYNC.margin, ASYNC.pending = bool(enabled), int(capacity), float(margin), None
+
+
+def _status_buffer():
+    if ASYNC.status_buf is None:
+        ASYNC.status_buf = torch.zeros(8, dtype=torch.int32).pin_memory()
+    return ASYNC.status_buf
+
+
+def _consume_status(block: bool):
+    """Look at the status words of the previous asynchronous forward, if they have arrived (or wait when block=True)."""
+    if ASYNC.pending is None:
+        return
+    status, ev = ASYNC.pending
+    if block:
+        ev.synchronize()
+    elif not ev.query():
+        return
+    ASYNC.pending = None
+    needed, flags = int(status[6]), int(status[2])
+    ASYNC.last_needed = needed
+    if needed * 1.25 > ASYNC.capacity:                       # drifting towards the limit: grow ahead of time
+        ASYNC.capacity = int(needed * ASYNC.margin) + 1024
+    if flags & 2:
+        raise RuntimeError(f"rasterize_gaussians (async): a frame needed {needed} (Gaussian, tile) instances but the binning "
+                           f"buffer was sized for fewer; that frame rendered nothing. Capacity is now {ASYNC.capacity}.")
+    if flags & 1:
+        raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+
+
+def check_async_status(img_buffer=None):
+    """Synchronously verify the most recent asynchronous forward (call outside graph capture, e.g. every N steps)."""
+    if img_buffer is None:
+        img_buffer = ASYNC.last_img_buffer
+    if img_buffer is not None:
+        status = _status_buffer()
+        dev = img_buffer.device
+        with torch.cuda.device(dev):
+            check(lib().moss_raster_read_status(img_buffer.data_ptr(), status.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "read_status")
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev))
+        ASYNC.pending = (status, ev)
+    _consume_status(block=True)
+
 lib()   # fail at import time if the HIP library is missing: there is no fallback
 
 
@@ -72,11 +138,16 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         ptr, c = _ptr(t, name)
         keep.append(c)
         return ptr
+    use_async = ASYNC.enabled and not debug and ASYNC.capacity > 0 and P > 0
+    capturing = torch.cuda.is_current_stream_capturing()
+    if use_async and not capturing:
+        _consume_status(block=False)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _tls.buffers = (geom, binning, img)
         try:
-            rc = L.moss_raster_forward(
+            fwd = L.moss_raster_forward_async if use_async else L.moss_raster_forward
+            rc = fwd(
                 _grow, 0, _grow, 1, _grow, 2,
                 P, int(degree), M,
                 p(background, "background"), W, H,
@@ -85,12 +156,22 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                 out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr() if P else None,
-                int(bool(debug)), stream)
+                int(ASYNC.capacity) if use_async else int(bool(debug)), stream)
         finally:
             _tls.buffers = None
-    rendered = check(rc, "rasterize_gaussians")
+        rendered = check(rc, "rasterize_gaussians")
+        if use_async:
+            ASYNC.last_img_buffer = img
+        if use_async and not capturing and ASYNC.pending is None:
+            status = _status_buffer()
+            check(L.moss_raster_read_status(img.data_ptr(), status.data_ptr(), stream), "read_status")
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev))
+            ASYNC.pending = (status, ev)
     global last_num_rendered
-    last_num_rendered = rendered
+    if ASYNC.enabled and not use_async and P > 0:          # first (synchronous) call of an async session: learn the size
+        ASYNC.capacity = max(ASYNC.capacity, int(rendered * ASYNC.margin) + 1024)
+        ASYNC.last_needed = rendered
+    last_num_rendered = ASYNC.last_needed if use_async else rendered
     return rendered, out_color, out_depth, out_alpha, radii, geom, binning, img
 
 

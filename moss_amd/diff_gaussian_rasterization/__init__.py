@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from ._C import set_async, check_async_status  # noqa: F401  (opt-in asynchronous forward / hipGraph capture)
 
 
 class GaussianRasterizationSettings(NamedTuple):

@@ -13,7 +13,9 @@ from ._lib import check, lib
 
 
 class FlatAdamW:
-    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.01):
+    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.01, capturable=False):
+        """capturable=True keeps the step counter on the device (``moss_adamw_flat_devstep``) so that a hipGraph capture of
+        the training step replays with the right bias correction (the analogue of torch.optim.AdamW(capturable=True))."""
         self.bucket = bucket
         params = bucket.params
         lr_of = {}
@@ -40,10 +42,20 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.t = 0
+        self.step_state = torch.zeros(4, dtype=torch.int32, device=dev) if capturable else None
 
     def step(self):
         self.t += 1
         dev = self.flat_params.device
+        if self.step_state is not None:
+            with torch.cuda.device(dev):
+                rc = lib().moss_adamw_flat_devstep(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(),
+                                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end,
+                                                   self.seg_lr, float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                   float(self.weight_decay), self.step_state.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream)
+            check(rc, "adamw_flat_devstep")
+            return
         with torch.cuda.device(dev):
             rc = lib().moss_adamw_flat(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,

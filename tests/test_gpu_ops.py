@@ -120,6 +120,29 @@ def test_long_tile_lists_and_depth_ties(gpu, hip_lib, P, ties):
     _check_backward(d, gpu, fw, t, e)
 
 
+def test_image_covering_gaussians(gpu, hip_lib):
+    """A few Gaussians grown to cover every tile of the image (what an optimiser does to a background splat) among ordinary ones:
+    their tile rectangles (up to gx*gy instances each) take the wave-cooperative paths of the histogram, the scatter and the
+    per-Gaussian gradient gather.  Results must still match the oracle."""
+    from tests.test_gpu_parity import _check_forward, _check_backward
+    W, H, P = 200, 136, 1500
+    g = torch.Generator().manual_seed(3)
+    s = scenes.config1(P=P, W=W, H=H)
+    s.means3D = torch.randn(P, 3, generator=g) * torch.tensor([0.9, 0.6, 0.3])
+    s.scales = torch.full((P, 3), 0.03) * torch.exp(0.3 * torch.randn(P, 3, generator=g))
+    big = torch.arange(0, P, 97)                                  # spread over many waves; 16 of them
+    s.scales[big] = torch.tensor([4.0, 3.0, 0.05]) * torch.exp(0.3 * torch.randn(len(big), 3, generator=g))
+    s.opacities = torch.sigmoid(torch.randn(P, 1, generator=g))
+    s.opacities[big] = 0.05
+    s.cov3D_precomp = scenes.covariance_precomp(s.scales, s.rotations)
+    s.camera = scenes.make_camera(W, H, 120.0, 120.0, W / 2, H / 2, np.eye(3), np.array([0.0, 0.0, 3.0]))
+    d = hp.inputs_of(s, "precomp")
+    fw, t, e = _check_forward(d, gpu, max_fragile=1e-2)
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    assert int((fw.tiles_touched == tiles).sum()) >= 8             # really image-covering
+    _check_backward(d, gpu, fw, t, e)
+
+
 def test_prefiltered_trap_is_reported(gpu, hip_lib):
     s = scenes.config1()
     s.means3D[0, 2] = -10.0
@@ -211,5 +234,149 @@ def test_flat_adamw_matches_torch_adamw(gpu, hip_lib):
         for p, q, g in zip(pa, pb, grads):
             p.grad.copy_(g); q.grad = g.clone()
         opt.step(); ref.step()
+    for p, q in zip(pa, pb):
+        assert hp.rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------- asynchronous forward / hipGraph capture
+def _train_like_step(pc, cam, pipe, bg, weights):
+    from moss_amd.gaussian_renderer import render
+    pc.zero_grad()
+    out = render(cam, pc, pipe, bg)
+    loss = (out["render"] * weights).sum() + 0.5 * out["render_alpha"].sum() + 0.1 * out["render_depth"].sum()
+    loss.backward()
+    grads = [p.grad.detach().clone() for p in pc.parameters()]
+    return out["render"].detach().clone(), out["render_alpha"].detach().clone(), out["radii"].clone(), grads
+
+
+@pytest.fixture
+def async_mode():
+    import moss_amd.diff_gaussian_rasterization as dgr
+    yield dgr
+    dgr.set_async(False)
+
+
+def test_async_forward_equals_sync_forward(gpu, hip_lib, async_mode):
+    """moss_raster_forward_async (no host read-back, capacity-bounded) runs the same kernels on the same data: image, alpha,
+    radii and every parameter gradient are BIT-IDENTICAL to the synchronous call."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import camera_view
+    s = scenes.config2()
+    pc = GaussianSet(s, device=gpu)
+    cam = camera_view(s.camera, gpu)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+    ref = _train_like_step(pc, cam, pipe, bg, w)
+    async_mode.set_async(True)
+    first = _train_like_step(pc, cam, pipe, bg, w)            # synchronous: learns the capacity
+    assert async_mode._C.ASYNC.capacity > 0
+    for _ in range(2):
+        got = _train_like_step(pc, cam, pipe, bg, w)          # asynchronous
+    async_mode.check_async_status()
+    for a, b, c in zip(ref[:3], first[:3], got[:3]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, c in zip(ref[3], got[3]):
+        assert torch.equal(a, c)
+
+
+def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode):
+    """A frame that needs more (Gaussian, tile) instances than the capacity: background image, zero alpha, zero gradients (never
+    an out-of-bounds write), the overflow flag raised at the next status check, and the capacity grown from the needed size."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import camera_view
+    s = scenes.config2()
+    pc = GaussianSet(s, device=gpu)
+    cam = camera_view(s.camera, gpu)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+    ref = _train_like_step(pc, cam, pipe, bg, w)
+    async_mode.set_async(True, capacity=2048)                  # far below what config2 needs
+    img, alpha, radii, grads = _train_like_step(pc, cam, pipe, bg, w)
+    assert torch.equal(img, bg[:, None, None].expand_as(img))
+    assert float(alpha.abs().max()) == 0.0
+    assert torch.equal(radii, ref[2])                          # preprocess still ran
+    for g in grads:
+        assert float(g.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="needed"):
+        async_mode.check_async_status()
+    assert async_mode._C.ASYNC.capacity > 2048
+    got = _train_like_step(pc, cam, pipe, bg, w)               # the grown capacity fits
+    async_mode.check_async_status()
+    assert torch.equal(got[0], ref[0])
+    for a, c in zip(ref[3], got[3]):
+        assert torch.equal(a, c)
+
+
+def test_step_captured_in_hipgraph_replays_with_new_parameters(gpu, hip_lib, async_mode):
+    """With the asynchronous forward nothing in render+backward talks to the host, so the step is capturable in a hipGraph.
+    Replays must track the CURRENT parameter values (not the captured ones) and agree bit-for-bit with eager launches."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    s = scenes.config2()
+    pc = GaussianSet(s, device=gpu)
+    cam = camera_view(s.camera, gpu)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    bg = torch.zeros(3, device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+    params = list(pc.parameters())
+    grads = [torch.zeros_like(p) for p in params]
+
+    def compute():
+        for p, g in zip(params, grads):
+            g.zero_(); p.grad = g
+        out = render(cam, pc, pipe, bg)
+        ((out["render"] * w).sum() + out["render_alpha"].sum()).backward()
+        return out["render"].detach()          # no grad_fn kept: the autograd graph (and its AccumulateGrad nodes) dies here
+
+    async_mode.set_async(True)
+    compute()                                                  # synchronous: learns the capacity
+    side = torch.cuda.Stream(gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        compute()
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize(gpu)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        g_img = compute()
+    for trial in range(2):
+        with torch.no_grad():
+            pc._xyz.add_(0.01 * (trial + 1))
+            pc._opacity.mul_(0.9)
+        graph.replay()
+        torch.cuda.synchronize(gpu)
+        img_g = g_img.clone(); grads_g = [g.clone() for g in grads]
+        img_e = compute().clone()
+        torch.cuda.synchronize(gpu)
+        assert torch.equal(img_g, img_e)
+        for a, b in zip(grads_g, grads):
+            assert torch.equal(a, b)
+    async_mode.check_async_status()
+
+
+def test_flat_adamw_device_step_counter(gpu, hip_lib):
+    """moss_adamw_flat_devstep keeps the step count (bias correction) on the device: five steps equal torch.optim.AdamW."""
+    from moss_amd.dist import GradBucket
+    from moss_amd.optim import FlatAdamW
+    torch.manual_seed(1)
+    shapes, lrs = [(513, 3), (513, 4)], [0.01, 0.002]
+    init = [torch.randn(*s) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(gpu)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(gpu)) for t in init]
+    ref = torch.optim.AdamW([{"params": [p], "lr": lr} for p, lr in zip(pb, lrs)], lr=0.0, eps=1e-15)
+    bucket = GradBucket(pa)
+    opt = FlatAdamW([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], bucket, eps=1e-15, capturable=True)
+    for it in range(5):
+        bucket.attach()
+        for p, q, s_ in zip(pa, pb, shapes):
+            g = torch.randn(*s_, device=gpu)
+            p.grad.copy_(g); q.grad = g.clone()
+        opt.step(); ref.step()
+    assert int(opt.step_state[0]) == 5
     for p, q in zip(pa, pb):
         assert hp.rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6
