@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--graph", type=int, default=1, choices=[0, 1],
                     help="1 = capture the per-rank compute of a step (render, loss, backward[, AdamW]) in one hipGraph and replay "
                          "it (needs --forward async); 0 = launch every kernel eagerly")
+    ap.add_argument("--torch-activations", action="store_true",
+                    help="compute the parameter activations (exp / sigmoid / normalize / cat) with torch ops and let autograd "
+                         "accumulate into the bucket, instead of the fused HIP activation kernels writing into it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
@@ -89,11 +92,13 @@ def main():
     cam = camera_view(scene.camera, dev)
     H, W = scene.camera.H, scene.camera.W
     pc = GaussianSet(scene, sh_degree=3, device=dev)
-    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode == "precomp"), debug=False)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode == "precomp"), debug=False,
+                           fused_activations=not args.torch_activations)
     bg = torch.zeros(3, device=dev)
     gt = scenes.synthetic_target(H, W).to(dev)
     gt_mask = (gt.mean(0, keepdim=True) > 0.5).float()
     bucket = mdist.GradBucket(list(pc.parameters()))
+    pipe.grad_bucket = bucket
     if args.torch_adamw:
         opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, fused=True)      # gaussian_model.py:226
     else:
@@ -104,10 +109,15 @@ def main():
     dgr.set_async(args.forward == "async")
 
     def compute():                      # everything of a step that is local to this rank
-        bucket.attach()
+        if pipe.fused_activations:
+            bucket.detach_grads()       # gradients are WRITTEN into the bucket by the activation backward kernel
+        else:
+            bucket.attach()             # zero the bucket; autograd accumulates into it
         out = render(cam, pc, pipe, bg)
         loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
         loss.backward()
+        if pipe.fused_activations:
+            bucket.collect()
         bucket.loss_slot.copy_(loss.detach().reshape(1))
         if world == 1:
             opt.step()

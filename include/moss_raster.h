@@ -113,7 +113,8 @@ int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out,
 /*
  * Replaces CudaRasterizer::Rasterizer::backward (DGR/cuda_rasterizer/rasterizer.h:57-89,
  * DGR/cuda_rasterizer/rasterizer_impl.cu:345-447).  R is the value forward returned.
- *   dL_dpix (3,H,W), dL_ddepths (H,W), dL_dalphas (H,W): incoming gradients.
+ *   dL_dpix (3,H,W), dL_ddepths (H,W), dL_dalphas (H,W): incoming gradients; any (not all) of them may be NULL, meaning
+ *   zeros (an output that did not take part in the loss), which saves the caller a zero-filled image.
  *   Gradient outputs: dL_dmean2D (P,3), dL_dconic (P,4 = 2x2), dL_dopacity (P), dL_dcolor (P,3),
  *   dL_dmean3D (P,3), dL_dcov3D (P,6), dL_dsh (P,M,3) (may be NULL if M==0), dL_dscale (P,3), dL_drot (P,4).
  *   Every element of every output is written (zeros for culled Gaussians, for dL_dscale/dL_drot when
@@ -201,6 +202,24 @@ int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_a
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
                             float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
+
+/*
+ * Gaussian parameter activations, forward and backward, one launch each (the rasterizer-facing getters of MOSS's GaussianModel,
+ * scene/gaussian_model.py:46-53 and :134-166: get_xyz identity, get_features = cat(_features_dc, _features_rest, dim=1),
+ * get_opacity = sigmoid, get_scaling = exp, get_rotation = F.normalize (eps 1e-12)).  K = SH coefficients per channel
+ * ((max_sh_degree+1)^2); features_dc is (P,1,3), features_rest (P,K-1,3), out_features (P,K,3); all fp32, contiguous.
+ * Backward: a NULL incoming gradient means that output was unused (its parameter gets zeros); every element of every d_*
+ * array is written exactly once, so destinations (e.g. slices of a flat gradient bucket) need no zero fill.
+ */
+int moss_gaussian_activate_forward(int P, int K, const float* xyz, const float* features_dc, const float* features_rest,
+                                   const float* opacity, const float* scaling, const float* rotation,
+                                   float* out_xyz, float* out_features, float* out_opacity, float* out_scaling,
+                                   float* out_rotation, void* stream);
+int moss_gaussian_activate_backward(int P, int K, const float* rotation, const float* out_opacity, const float* out_scaling,
+                                    const float* g_xyz, const float* g_features, const float* g_opacity,
+                                    const float* g_scaling, const float* g_rotation,
+                                    float* d_xyz, float* d_features_dc, float* d_features_rest, float* d_opacity,
+                                    float* d_scaling, float* d_rotation, void* stream);
 
 /* ---- inspection entry points (used by the parity tests; not needed by a caller of the op) ---------------- */
 

@@ -72,6 +72,10 @@ def _declare(lib):
     lib.moss_adamw_flat.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _i, _p]
     lib.moss_adamw_flat_devstep.restype = _i
     lib.moss_adamw_flat_devstep.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _p, _p]
+    lib.moss_gaussian_activate_forward.restype = _i
+    lib.moss_gaussian_activate_forward.argtypes = [_i, _i] + [_p] * 12
+    lib.moss_gaussian_activate_backward.restype = _i
+    lib.moss_gaussian_activate_backward.argtypes = [_i, _i] + [_p] * 15
     lib.moss_raster_profile_enable.restype = None
     lib.moss_raster_profile_enable.argtypes = [C.c_uint32]
     lib.moss_raster_profile_read.restype = _i

@@ -28,6 +28,7 @@ SOURCES = {
     "blend.hip": [],
     "loss.hip": [],
     "optim.hip": [],
+    "activations.hip": [],
     "raster_api.hip": [],
 }
 

@@ -425,8 +425,10 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restr
     const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
     float gpr = 0.f, gpg = 0.f, gpb = 0.f, gpd = 0.f, gpa = 0.f;
     if (inside) {
-        gpr = dL_dpixels[pix_id]; gpg = dL_dpixels[plane + pix_id]; gpb = dL_dpixels[2 * plane + pix_id];
-        gpd = dL_ddepths[pix_id]; gpa = dL_dalphas[pix_id];
+        // a null incoming gradient = that output did not take part in the loss (zeros, without a zero-filled image)
+        if (dL_dpixels) { gpr = dL_dpixels[pix_id]; gpg = dL_dpixels[plane + pix_id]; gpb = dL_dpixels[2 * plane + pix_id]; }
+        if (dL_ddepths) gpd = dL_ddepths[pix_id];
+        if (dL_dalphas) gpa = dL_dalphas[pix_id];
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;

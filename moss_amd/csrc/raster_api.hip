@@ -243,7 +243,7 @@ int moss_raster_backward(
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(MOSS_ERR_INVALID_ARG, "bad sizes");
     if (P == 0) return 0;                                                 // rasterize_points.cu:168
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(MOSS_ERR_INVALID_ARG, "null scratch buffer");
-    if (!dL_dpix || !dL_ddepths || !dL_dalphas) return fail(MOSS_ERR_INVALID_ARG, "null incoming gradient");
+    if (!dL_dpix && !dL_ddepths && !dL_dalphas) return fail(MOSS_ERR_INVALID_ARG, "all three incoming gradients are NULL");
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
         return fail(MOSS_ERR_INVALID_ARG, "null gradient output");
     if (shs && !dL_dsh) return fail(MOSS_ERR_INVALID_ARG, "dL_dsh is NULL although shs is given");

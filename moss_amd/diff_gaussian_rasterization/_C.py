@@ -184,7 +184,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     L = lib()
     dev = means3D.device
     P = int(means3D.size(0))
-    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    H, W = int(alphas.size(-2)), int(alphas.size(-1))      # incoming gradients may be None (= zeros): sizes come from alphas
     M = int(sh.size(1)) if sh.numel() != 0 else 0
     fopts = dict(dtype=torch.float32, device=dev)
     # The reference zero-fills nine tensors here (300 B per Gaussian, rasterize_points.cu:158-166); the HIP backward

@@ -73,6 +73,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # an output that takes no part in the loss reaches backward as None (NULL at the C ABI = zeros) instead of as a
+        # zero-filled image; the values computed are the same as with the reference's materialised zeros
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, alpha)
         return color, radii, depth, alpha
@@ -82,6 +85,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, alpha) = ctx.saved_tensors
+        if grad_out_color is None and grad_depth is None and grad_alpha is None:
+            return (None,) * 9
         native_args = (
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,

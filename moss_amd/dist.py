@@ -50,11 +50,41 @@ class GradBucket:
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
         self.loss_slot = self.flat[off:off + 1]
+        self._offset = {}
+        o = 0
+        for p, n in zip(self.params, self.sizes):
+            self._offset[id(p)] = o
+            o += n
 
     def attach(self):
-        """Make every parameter's .grad a view into the bucket, so backward writes straight into it (no pack copy)."""
+        """Make every parameter's .grad a view into the bucket, so backward ACCUMULATES straight into it (no pack copy)."""
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    # -- direct mode: the op that produces a parameter's gradient WRITES it into the bucket (no zero fill, no accumulate) ----
+    def detach_grads(self):
+        """Start of a step in direct mode: parameters carry no .grad, so autograd adopts whatever tensor backward returns."""
+        for p in self.params:
+            p.grad = None
+
+    def sink_for(self, param):
+        """A NEW view object of `param`'s slice of the bucket (or None if it is not in the bucket).  A gradient-producing op
+        writes its result there and returns the view; autograd's AccumulateGrad adopts a fresh, exclusively-owned tensor as
+        .grad without copying it."""
+        off = self._offset.get(id(param))
+        if off is None:
+            return None
+        return self.flat[off:off + param.numel()].view_as(param)
+
+    def collect(self):
+        """End of backward in direct mode: make sure every parameter's gradient is where the bucket says it is.  Costs nothing
+        when every gradient was written through a sink; otherwise copies (or zero-fills a parameter that got no gradient)."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
             p.grad = v
 
     def all_reduce_mean(self, loss=None, world=None):

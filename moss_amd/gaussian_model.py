@@ -5,6 +5,8 @@ rasterizer exactly the way ``gaussian_renderer.render`` does.
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
+
 import torch
 import torch.nn as nn
 
@@ -49,6 +51,19 @@ class GaussianSet(nn.Module):
     @property
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def activate(self, bucket=None):
+        """All five getters above from ONE fused HIP kernel (moss_amd/activations.py); same values and gradients.  Returns a
+        namespace with get_xyz / get_features / get_opacity / get_scaling / get_rotation / get_covariance, i.e. it can stand in
+        for ``self`` wherever the render binding reads the activated parameters."""
+        from .activations import activate_gaussians
+        xyz, feat, opa, scl, rot = activate_gaussians(self._xyz, self._features_dc, self._features_rest, self._opacity,
+                                                      self._scaling, self._rotation, bucket)
+        raw_rotation = self._rotation
+        return SimpleNamespace(
+            get_xyz=xyz, get_features=feat, get_opacity=opa, get_scaling=scl, get_rotation=rot,
+            get_covariance=lambda scaling_modifier=1, transform=None: scenes.covariance_precomp(scl, raw_rotation, scaling_modifier, transform),
+            max_sh_degree=self.max_sh_degree, active_sh_degree=self.active_sh_degree)
 
     def get_covariance(self, scaling_modifier=1, transform=None):
         return scenes.covariance_precomp(self.get_scaling, self._rotation, scaling_modifier, transform)

@@ -42,13 +42,16 @@ def eval_sh_rgb(deg, sh, dirs):
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, return_smpl_rot=False,
            transforms=None, translation=None):
-    """Render one view.  ``bg_color`` must be on the GPU."""
+    """Render one view.  ``bg_color`` must be on the GPU.
+
+    ``pipe.fused_activations`` (an addition, default off): read the activated parameters from ``pc.activate(pipe.grad_bucket)``
+    -- one HIP kernel instead of the five torch getters (moss_amd/activations.py); values and gradients are the same."""
+    if getattr(pipe, "fused_activations", False):
+        pc = pc.activate(getattr(pipe, "grad_bucket", None))
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # the zero "means2D" whose .grad receives the screen-space gradient (reference :29-33 builds it as zeros + 0 and retains its
+    # grad; a leaf needs neither the add kernel nor retain_grad and exposes the same .grad)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

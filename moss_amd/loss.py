@@ -74,8 +74,9 @@ class _FusedPhotometricLoss(torch.autograd.Function):
         image_c, gt_c = image.contiguous(), gt_image.contiguous()
         alpha_c, mask_c = alpha.contiguous(), gt_mask.contiguous()
         out = torch.empty(4, dtype=torch.float32, device=image.device)
-        d_img = torch.empty_like(image_c)
-        d_alpha = torch.empty_like(alpha_c)
+        # both gradient images in one buffer: backward scales them by the incoming gradient with ONE kernel
+        d_both = torch.empty((C + 1, H, W), dtype=torch.float32, device=image.device)
+        d_img, d_alpha = d_both[:C], d_both[C:]
         nbytes = int(L.moss_loss_workspace_bytes(C, H, W))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
         with torch.cuda.device(image.device):
@@ -84,14 +85,16 @@ class _FusedPhotometricLoss(torch.autograd.Function):
                                          d_alpha.data_ptr(), ws.data_ptr(), nbytes,
                                          torch.cuda.current_stream(image.device).cuda_stream)
         check(rc, "photometric_loss")
-        ctx.save_for_backward(d_img, d_alpha)
+        ctx.save_for_backward(d_both)
+        ctx.C, ctx.alpha_shape = C, alpha.shape
         ctx.terms = out
         return out[0]
 
     @staticmethod
     def backward(ctx, grad_out):
-        d_img, d_alpha = ctx.saved_tensors
-        return grad_out * d_img, grad_out * d_alpha, None, None, None, None
+        (d_both,) = ctx.saved_tensors
+        scaled = grad_out * d_both
+        return scaled[:ctx.C], scaled[ctx.C:].reshape(ctx.alpha_shape), None, None, None, None
 
 
 def training_loss_fused(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5):

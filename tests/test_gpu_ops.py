@@ -380,3 +380,85 @@ def test_flat_adamw_device_step_counter(gpu, hip_lib):
     assert int(opt.step_state[0]) == 5
     for p, q in zip(pa, pb):
         assert hp.rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------- fused parameter activations
+def _raw_params(P, K, gpu, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g).to(gpu))
+    return dict(xyz=mk(P, 3), dc=mk(P, 1, 3), rest=mk(P, K - 1, 3), opa=mk(P, 1), scl=mk(P, 3), rot=mk(P, 4))
+
+
+@pytest.mark.parametrize("P,K", [(1, 16), (5, 16), (1000, 16), (6890, 4), (4097, 1)])
+def test_fused_activations_match_torch_getters(gpu, hip_lib, P, K):
+    """moss_gaussian_activate_forward/backward vs the torch ops of scene/gaussian_model.py:46-53,134-166 (exp, sigmoid,
+    F.normalize, cat): values to 1e-6 relative, gradients to 1e-5."""
+    from moss_amd.activations import activate_gaussians
+    a = _raw_params(P, K, gpu)
+    b = {k: torch.nn.Parameter(v.detach().clone()) for k, v in a.items()}
+    outs = activate_gaussians(a["xyz"], a["dc"], a["rest"], a["opa"], a["scl"], a["rot"])
+    refs = (b["xyz"] * 1.0, torch.cat((b["dc"], b["rest"]), dim=1), torch.sigmoid(b["opa"]), torch.exp(b["scl"]),
+            torch.nn.functional.normalize(b["rot"]))
+    g = torch.Generator().manual_seed(9)
+    ws = [torch.randn(*o.shape, generator=g).to(gpu) for o in outs]
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape
+        assert hp.rel_err(o.detach().cpu().numpy(), r.detach().cpu().numpy()) < 1e-6
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    sum((r * w).sum() for r, w in zip(refs, ws)).backward()
+    for k in a:
+        if a[k].numel():
+            assert hp.rel_err(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy()) < 1e-5, k
+
+
+def test_fused_activations_write_into_the_bucket_without_copies(gpu, hip_lib):
+    """With a GradBucket as sink the backward kernel writes the raw-parameter gradients into the flat bucket and autograd adopts
+    those views as .grad (same storage, no accumulate kernel); an unused output (NULL incoming gradient) yields zeros even
+    though the bucket is never zero-filled."""
+    from moss_amd.activations import activate_gaussians
+    from moss_amd.dist import GradBucket
+    P, K = 777, 16
+    a = _raw_params(P, K, gpu, seed=4)
+    params = [a[k] for k in ("xyz", "dc", "rest", "opa", "scl", "rot")]
+    bucket = GradBucket(params)
+    bucket.flat.fill_(float("nan"))                          # stale contents must be overwritten, never accumulated into
+    bucket.detach_grads()
+    xyz, feat, opa, scl, rot = activate_gaussians(*params, bucket=bucket)
+    w = torch.randn(P, K, 3, device=gpu)
+    ((feat * w).sum() + (opa * 2.0).sum() + xyz.sum()).backward()       # scaling and rotation outputs unused
+    for p, v in zip(params, bucket.views):
+        assert p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+    bucket.collect()
+    assert not torch.isnan(bucket.flat[:-1]).any()
+    assert torch.equal(a["rest"].grad, w[:, 1:, :]) and torch.equal(a["dc"].grad, w[:, :1, :])
+    assert float(a["scl"].grad.abs().max()) == 0.0 and float(a["rot"].grad.abs().max()) == 0.0
+    s = torch.sigmoid(a["opa"].detach())
+    assert hp.rel_err(a["opa"].grad.cpu().numpy(), (2.0 * s * (1 - s)).cpu().numpy()) < 1e-6
+    assert torch.equal(a["xyz"].grad, torch.ones_like(a["xyz"]))
+
+
+def test_render_with_fused_activations_equals_torch_getters(gpu, hip_lib):
+    """render() with pipe.fused_activations: same image, same raw-parameter gradients as the five torch getters."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    s = scenes.config2()
+    pc = GaussianSet(s, device=gpu)
+    cam = camera_view(s.camera, gpu)
+    bg = torch.tensor([0.2, 0.1, 0.0], device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+    res = {}
+    for fused in (False, True):
+        for cov_py in (False, True):
+            pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=cov_py, debug=False, fused_activations=fused)
+            pc.zero_grad()
+            out = render(cam, pc, pipe, bg)
+            ((out["render"] * w).sum() + out["render_alpha"].sum()).backward()      # render_depth unused: None gradient path
+            res[(fused, cov_py)] = (out["render"].detach().clone(), [p.grad.detach().clone() for p in pc.parameters()],
+                                    out["viewspace_points"].grad.detach().clone())
+    for cov_py in (False, True):
+        a, b = res[(False, cov_py)], res[(True, cov_py)]
+        assert hp.rel_err(a[0].cpu().numpy(), b[0].cpu().numpy()) < 1e-5
+        assert hp.rel_err(a[2].cpu().numpy(), b[2].cpu().numpy()) < 1e-4
+        for ga, gb in zip(a[1], b[1]):
+            assert hp.rel_err(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-4
