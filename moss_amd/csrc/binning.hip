@@ -58,7 +58,7 @@ constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort
 // (The per-Gaussian offsets are produced by the preprocess kernel.)
 __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
-            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity)
+            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
@@ -94,6 +94,7 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
         header[0] = overflow ? 0u : total; header[1] = s_max; header[4] = overflow ? 0u : total_chunks;
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
         header[6] = total;                             // instances this frame needs (for the host's capacity policy)
+        header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
         if (overflow) atomicOr(&header[2], ERRFLAG_OVERFLOW);
     }
     __syncthreads();
@@ -210,10 +211,11 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
 __global__ void __launch_bounds__(256)
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
                     const uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
-                    float4* __restrict__ inst_rec)
+                    float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int)header[0]) return;
+    inst_mask[i] = 0u;                                        // no gradient record yet (set by the backward blend)
     const uint32_t tile = inst_tile[i];
     const uint2 rg = ranges[tile];
     const uint64_t key = keys[i];
@@ -286,8 +288,9 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 {
     (void)P; (void)g;
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
+    static const int light_log2 = std::max(0, std::min(31, env_int("MOSS_LIGHT_LOG2", LIGHT_TILE_LOG2)));
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header, cap);
+                       im.header, cap, light_log2);
 }
 
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
@@ -310,7 +313,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     if (R <= 0 || total_chunks <= 0) return;
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(1024), 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
     hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, im.header, fp.gx, g, im.ranges, b.keys, b.inst_tile,
-                       b.point_list, b.inst_pos, b.inst_rec);
+                       b.point_list, b.inst_pos, b.inst_rec, b.inst_mask);
 }
 
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

@@ -65,6 +65,12 @@ struct GeomView {
     static size_t bytes(int P) { char* z = nullptr; GeomView g = at(z, P); return (size_t)((char*)g.cov3D - z) + align_up(6 * (size_t)P * 4); }
 };
 
+// header words: [0] R, [1] longest tile list, [2] error flags, [3] inst_pos slot allocator, [4] sort chunks, [5] tiles that own
+// instances, [6] instances needed, [7] heavy tiles (list length >= 2^LIGHT_TILE_LOG2; they come first in tile_order), [8]/[9] queue heads of the workgroup blend kernels, [10] backward leaver count,
+// [16..23] / [24..31] per-XCD queue heads of the wave blend kernels (forward / backward)
+constexpr int HEADER_WORDS = 32;
+constexpr int LIGHT_TILE_LOG2 = 7;     // tiles with fewer than 2^7 entries are "light": blended one pixel per lane ([7] = heavy tiles)
+constexpr int HDR_FWD_HEADS = 16, HDR_BWD_HEADS = 24, HDR_LEAVERS = 10, NUM_XCD_QUEUES = 8;
 struct ImageView {
     uint32_t* header;
     uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base; uint32_t* tile_order;
@@ -73,7 +79,7 @@ struct ImageView {
     {
         ImageView v; char* p = base;
         size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
-        v.header = carve<uint32_t>(p, 16);
+        v.header = carve<uint32_t>(p, HEADER_WORDS);
         v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
         v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T); v.tile_order = carve<uint32_t>(p, T);
         v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
@@ -117,10 +123,12 @@ __device__ __forceinline__ void wave_for_each_tile(uint2 rect, int gx, uint64_t 
 #endif
 
 extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
-int blend_subgroups();       // workgroups per tile in the blend kernels (1 or 4), blend.hip
+int blend_subgroups();       // gradient-record slabs per instance (16: wave kernels, 4: workgroup kernels), blend.hip
+int blend_impl();            // 1 = wave-autonomous blend kernels (sparse records + inst_mask), 0 = workgroup kernels
 
 struct BinView {
     uint32_t* point_list; uint32_t* inst_pos; uint32_t* inst_tile;
+    uint32_t* inst_mask;     // per instance (sorted order): bit b set <=> slab b holds a record for it (wave kernels)
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
     float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
     float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per blend workgroup of a tile)
@@ -131,6 +139,7 @@ struct BinView {
         b.slabs = blend_subgroups();
         b.slab_stride_floats = align_up(3 * n * 16) / 4;
         b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n); b.inst_tile = carve<uint32_t>(p, n);
+        b.inst_mask = carve<uint32_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);
         b.inst_grad = reinterpret_cast<float4*>(p);
         b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);

@@ -324,6 +324,13 @@ __device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv)   // auxiliary.h
     return r;
 }
 
+// STAGE_SH (requires M == 16, shs and dL_dsh given): the block's SH records are read from HBM with coalesced loads into LDS and
+// the dL_dsh records leave the same way.  Per thread a record is 48 floats at a 192-byte stride, i.e. every one of the 48 loads
+// and 48 stores of a wave would touch 64 different cache lines; through LDS (row stride 49 words: conflict-free) the global side
+// is 12 fully coalesced 16-byte accesses per lane.  SLABS > 0 fixes the number of gradient slabs at compile time so that the 3 x
+// SLABS record loads of one instance are issued together.
+constexpr int SH_ROW = 49;
+template <bool STAGE_SH, int SLABS>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float scale_modifier,
                            const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -331,14 +338,29 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                            const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                            GeomView g, const uint32_t* __restrict__ inst_pos, const float4* __restrict__ inst_grad,
-                           int slabs, size_t slab_stride_f4, const uint32_t* __restrict__ header,
+                           int slabs, size_t slab_stride_f4, const uint32_t* __restrict__ inst_mask, const uint32_t* __restrict__ header,
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
+    extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then the same for dL_dsh out
+    float* const s_dsh = s_sh + blockDim.x * SH_ROW;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
     const uint32_t n_inst = in_range ? g.tiles_touched[idx] : 0u;
+    if (STAGE_SH) {
+        const size_t base4 = (size_t)blockIdx.x * blockDim.x * 12, total4 = (size_t)P * 12;     // in float4 units (48 floats = 12)
+        const float4* src = reinterpret_cast<const float4*>(shs);
+        for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
+            if (base4 + f < total4) {
+                const float4 v = src[base4 + f];
+                float* d = &s_sh[(f / 12) * SH_ROW + (f % 12) * 4];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        // no barrier needed before the gather below; one is placed before the first SH use
+    }
+    const int n_slabs = SLABS > 0 ? SLABS : slabs;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
@@ -354,7 +376,20 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     if (visible && n_inst <= COOP_INST) {
         for (uint32_t k = 0; k < n_inst; k++) {
             const uint32_t pos = inst_pos[off + k];
-            for (int sl = 0; sl < slabs; sl++) {
+            if (SLABS < 0) {
+                // sparse records of the wave blend kernels: only the slabs flagged in the instance's mask, ascending
+                for (uint32_t mbits = inst_mask[pos]; mbits != 0u; mbits &= mbits - 1u) {
+                    const int sl = __ffs((int)mbits) - 1;
+                    const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
+                    gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
+                    gop += r2.x;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int sl = 0; sl < n_slabs; sl++) {
                 const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
                 const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
@@ -371,15 +406,83 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             big &= big - 1;
             const uint32_t boff = __shfl(off, src), bn = __shfl(n_inst, src);
             float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            const uint32_t items = bn * (uint32_t)slabs;
+            if (SLABS < 0) {
+                // Sparse records.  A Gaussian that covers the image owns ~1000 instances with up to 4 (light tiles) or 16 (heavy
+                // tiles) flagged records each, found through two levels of indirection (inst_pos -> inst_mask -> record): walked
+                // naively that is thousands of DEPENDENT loads for one wave (measured: +90 us per frame with ~50 such Gaussians).
+                // So: 16 instances per lane at a time, their positions and masks fetched together, then the first four flagged
+                // records of every instance with unconditional loads in straight-line code (the next instance's loads are
+                // issued before this one's are summed); further records (only heavy tiles have them) in a clean-up loop.
+                constexpr int IPL = 16;                                          // instances per lane per round
+                for (uint32_t c0 = 0; c0 < bn; c0 += 64u * IPL) {
+                    uint32_t p[IPL], mk[IPL];
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
+                        p[i] = inst_pos[boff + min(k, bn - 1u)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
+                        const uint32_t m = inst_mask[p[i]];
+                        mk[i] = k < bn ? m : 0u;
+                    }
+                    struct Quad { float4 r[4][3]; float w[4]; };
+                    auto fetch = [&](int i) {
+                        Quad qd;
+                        uint32_t m = mk[i];
+                        int sl = m ? __ffs((int)m) - 1 : 0;                      // no flagged record: slab 0 is read and ignored
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            qd.w[j] = m ? 1.0f : 0.0f;
+                            if (m) { sl = __ffs((int)m) - 1; m &= m - 1u; }
+                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)p[i];
+                            qd.r[j][0] = rec[0]; qd.r[j][1] = rec[1]; qd.r[j][2] = rec[2];
+                        }
+                        mk[i] = m;                                               // what is left for the clean-up loop
+                        return qd;
+                    };
+                    auto add = [&](const Quad& qd) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            // unflagged slots may hold anything (never written): select, do not multiply
+                            const bool on = qd.w[j] != 0.0f;
+                            acc[0] += on ? qd.r[j][0].x : 0.f; acc[1] += on ? qd.r[j][0].y : 0.f; acc[2] += on ? qd.r[j][0].z : 0.f;
+                            acc[3] += on ? qd.r[j][0].w : 0.f; acc[4] += on ? qd.r[j][1].x : 0.f; acc[5] += on ? qd.r[j][1].y : 0.f;
+                            acc[6] += on ? qd.r[j][1].z : 0.f; acc[7] += on ? qd.r[j][1].w : 0.f; acc[8] += on ? qd.r[j][2].x : 0.f;
+                        }
+                    };
+                    Quad cur = fetch(0);
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        Quad nxt;
+                        if (i + 1 < IPL) nxt = fetch(i + 1);
+                        add(cur);
+                        if (i + 1 < IPL) cur = nxt;
+                    }
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        for (uint32_t mbits = mk[i]; mbits != 0u; mbits &= mbits - 1u) {
+                            const int sl = __ffs((int)mbits) - 1;
+                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)p[i];
+                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                            acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
+                            acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
+                            acc[8] += r2.x;
+                        }
+                    }
+                }
+            } else {
+            const uint32_t items = bn * (uint32_t)n_slabs;
             for (uint32_t j = (uint32_t)lane; j < items; j += 64u) {
-                const uint32_t k = j / (uint32_t)slabs, sl = j - k * (uint32_t)slabs;
+                const uint32_t k = j / (uint32_t)n_slabs, sl = j - k * (uint32_t)n_slabs;
                 const uint32_t pos = inst_pos[boff + k];
                 const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
                 const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
                 acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
                 acc[8] += r2.x;
+            }
             }
 #pragma unroll
             for (int q = 0; q < 9; q++) {
@@ -392,13 +495,15 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
         }
     }
-    if (!in_range) return;
+    if (STAGE_SH) __syncthreads();                           // SH records are in LDS
+    if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
     dL_dopacity[idx] = gop;
     dL_dcolor[3 * (size_t)idx] = gcol.x; dL_dcolor[3 * (size_t)idx + 1] = gcol.y; dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
 
-    float* dsh = (M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr;
+    float* dsh = STAGE_SH ? &s_dsh[threadIdx.x * SH_ROW]
+                          : ((M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr);
 
     if (visible) {
         float view[16], proj[16];
@@ -470,7 +575,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 
         // ---- SH backward, backward.cu:20-139
         if (shs != nullptr) {
-            const float* sh = shs + (size_t)idx * M * 3;
+            const float* sh = STAGE_SH ? &s_sh[threadIdx.x * SH_ROW] : shs + (size_t)idx * M * 3;
             const float3 dir_orig = make_float3(mean.x - cam_pos[0], mean.y - cam_pos[1], mean.z - cam_pos[2]);
             const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
             const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
@@ -589,6 +694,18 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
     for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
     reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }   // in_range
+    if (STAGE_SH) {
+        __syncthreads();                                     // every row now holds dL_dsh
+        const size_t base4 = (size_t)blockIdx.x * blockDim.x * 12, total4 = (size_t)P * 12;
+        float4* dst = reinterpret_cast<float4*>(dL_dsh);
+        for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
+            if (base4 + f < total4) {
+                const float* r = &s_dsh[(f / 12) * SH_ROW + (f % 12) * 4];
+                dst[base4 + f] = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -657,12 +774,22 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s)
 {
     (void)colors_precomp;
-    const int blocks = (fp.P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(blocks), dim3(256), 0, s,
-                       fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,
-                       means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,
-                       g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, header, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
-                       dL_dsh, dL_dscale, dL_drot);
+    static const int threads = env_int("MOSS_PREBWD_THREADS", 128);
+    const int blocks = (fp.P + threads - 1) / threads;
+    const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
+                       (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
+#define LAUNCH_PB(STAGE, SL)                                                                                                    \
+    hipLaunchKernelGGL((preprocess_backward_kernel<STAGE, SL>), dim3(blocks), dim3(threads),                                    \
+                       (STAGE) ? 2 * (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
+                       fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
+                       means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
+                       g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot)
+    // SLABS: -1 = sparse records selected by inst_mask (wave blend kernels), 4 = four dense slabs, 0 = run-time count
+    const int sl = blend_impl() ? -1 : (b.slabs == 4 ? 4 : 0);
+    if (stage) { if (sl < 0) LAUNCH_PB(true, -1); else if (sl == 4) LAUNCH_PB(true, 4); else LAUNCH_PB(true, 0); }
+    else { if (sl < 0) LAUNCH_PB(false, -1); else if (sl == 4) LAUNCH_PB(false, 4); else LAUNCH_PB(false, 0); }
+#undef LAUNCH_PB
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s)

@@ -23,3 +23,13 @@ for i in order:
 tot = s[s[:, 6] > 0]
 print("all WGs with work:", len(tot), "sum total cycles", tot[:, 0].sum(), "max", tot[:, 0].max(), "mean", int(tot[:, 0].mean()))
 print("phase shares of the top-12:", (s[order, 1:6].sum(0) / s[order, 0].sum()).round(3))
+# load-balance view: every queued item (tile, quadrant) with work, in queue (LPT) order
+items = s[: 4 * T_pad]
+work = items[items[:, 6] > 0]
+tot_cycles = work[:, 0].astype(np.float64)
+print("items with work:", len(work), " sum of item cycles:", int(tot_cycles.sum()), " longest item:", int(tot_cycles.max()),
+      " sum/768 workgroups:", int(tot_cycles.sum() / 768), " (span lower bounds: longest item vs. perfectly balanced)")
+print("item cycles percentiles 50/90/99/100:", np.percentile(tot_cycles, [50, 90, 99, 100]).astype(int))
+print("trips per item percentiles 50/90/99/100:", np.percentile(work[:, 7], [50, 90, 99, 100]).astype(int), " total trips", int(work[:, 7].sum()),
+      " batches total", int(work[:, 6].sum()))
+print("phase shares over all items:", (work[:, 1:6].sum(0) / work[:, 0].sum()).round(3), "(top, stage, barrier, cull, trips)")
