@@ -197,6 +197,10 @@ def main():
             use_graph = False
             _lib.profile_enable([dominant])
 
+    # The step trains (AdamW moves the Gaussians), so the workload drifts from iteration to iteration.  The measurement passes after
+    # the timed region restore this snapshot and REPLAY THE SAME K ITERATIONS (the kernels are deterministic), so the per-kernel
+    # durations they report belong to exactly the frames the timed region rendered.
+    snap = opt.snapshot() if hasattr(opt, "snapshot") else None
     note("entering timed region")
     # ---- timed region: EXACTLY K steps between barrier+sync pairs -------------------------------------------
     barrier(); torch.cuda.synchronize(dev)
@@ -211,35 +215,36 @@ def main():
         # really did the work; an overflowed frame would have produced a background image and is an error here
         dgr.check_async_status()
         assert dgr._C.ASYNC.last_needed > 0
-    if use_graph:
-        # the dominant kernel's launch duration: hipEvent pairs over the same number of eager launches of the same step,
-        # right after the timed region (events inside a replayed graph cannot be read back)
-        _lib.profile_enable([dominant])
-        for _ in range(args.steps):
-            eager_step()
-        torch.cuda.synchronize(dev)
-    note("dominant pass done")
-    dom_ms, dom_n = _lib.profile_read()[dominant]
-    dom_ms = dom_ms / max(dom_n, 1)
+    dom_in_region = None
+    if not use_graph:
+        dom_in_region = _lib.profile_read()[dominant]          # hipEvent pairs recorded inside the timed region
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- per-stage device times of the same step (separate pass, all stages timed; not part of `value`) ----
+    # ---- per-kernel device times: eager replay of the same K iterations with a hipEvent pair around every kernel of the op -------
+    # (graph mode: events inside a replayed graph cannot be read back, so this replay is also where the dominant kernel's launch
+    # duration comes from; it is not part of `value`)
+    if snap is not None:
+        opt.restore(snap)
     _lib.profile_enable(None)
-    n_prof = min(args.steps, 50)
-    for _ in range(n_prof):
+    for _ in range(args.steps):
         out = eager_step()
     torch.cuda.synchronize(dev)
     prof = _lib.profile_read()
     _lib.profile_enable([])
     stage_ms = {k: round(v[0] / v[1], 5) if v[1] else 0.0 for k, v in prof.items()}
+    dominant = max(stage_ms, key=stage_ms.get) if use_graph else dominant
+    dom_ms, dom_n = dom_in_region if dom_in_region is not None else prof[dominant]
+    dom_ms = dom_ms / max(dom_n, 1)
 
     note(f"stage pass done {stage_ms}")
     if rank != 0:
         return
 
+    if args.forward == "async":
+        dgr.check_async_status()                 # also brings num_rendered of the last replayed frame to the host
     # ---- measured problem statistics and the roofline -------------------------------------------------------
     radii = out["radii"]
     P = int(radii.numel()); Pv = int((radii > 0).sum().item())
@@ -269,8 +274,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": _pmc_traffic(dominant),
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
-                     "timing": ("hipEvent pairs on the launch stream over the same number of eager launches of the same step, "
-                                "taken right after the graph-replay timed region") if use_graph else
+                     "timing": ("hipEvent pairs on the launch stream over an eager replay of the SAME K iterations (parameters and "
+                                "optimizer state restored to the start of the graph-replay timed region)") if use_graph else
                                "hipEvent pairs on the launch stream inside the timed region"},
         "stages_ms": stage_ms,
         "rasterizer_ms_per_step": round(raster_ms, 4),

@@ -452,13 +452,16 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                             acc[6] += on ? qd.r[j][1].z : 0.f; acc[7] += on ? qd.r[j][1].w : 0.f; acc[8] += on ? qd.r[j][2].x : 0.f;
                         }
                     };
+                    const int rounds = (int)min((uint32_t)IPL, (bn - c0 + 63u) / 64u);     // wave-uniform: rounds with any instance
                     Quad cur = fetch(0);
 #pragma unroll
                     for (int i = 0; i < IPL; i++) {
-                        Quad nxt;
-                        if (i + 1 < IPL) nxt = fetch(i + 1);
-                        add(cur);
-                        if (i + 1 < IPL) cur = nxt;
+                        if (i < rounds) {
+                            Quad nxt = cur;
+                            if (i + 1 < rounds) nxt = fetch(i + 1);
+                            add(cur);
+                            cur = nxt;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < IPL; i++) {

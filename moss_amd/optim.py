@@ -44,6 +44,16 @@ class FlatAdamW:
         self.t = 0
         self.step_state = torch.zeros(4, dtype=torch.int32, device=dev) if capturable else None
 
+    def snapshot(self):
+        """Copies of everything a step changes (parameters, both moments, step counters)."""
+        return (self.flat_params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.t,
+                None if self.step_state is None else self.step_state.clone())
+
+    def restore(self, snap):
+        self.flat_params.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2]); self.t = snap[3]
+        if self.step_state is not None:
+            self.step_state.copy_(snap[4])
+
     def step(self):
         self.t += 1
         dev = self.flat_params.device

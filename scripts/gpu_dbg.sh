@@ -1,8 +1,6 @@
-timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
-timeout 600 python scripts/stage_times.py --mode scale_rot 2>&1 | tail -1 | cut -c1-300
-timeout 900 python bench.py --steps 300 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "
+for i in 1 2; do timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stages_ms'])"
-timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python3 -c "
+d = json.loads(sys.stdin.read()); print('default', d['value'], d['ms_per_step'], d['stages_ms'], d['roofline'], d['config']['num_rendered'])"; done
+timeout 900 python bench.py --no-cpu-baseline --graph 0 2>&1 | tail -1 | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('default', d['value'], d['ms_per_step'], d['stages_ms'])"
+d = json.loads(sys.stdin.read()); print('eager', d['value'], d['ms_per_step'], d['stages_ms'], d['roofline']['kernel'], d['roofline']['avg_launch_ms'])"

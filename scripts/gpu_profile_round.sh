@@ -1,0 +1,27 @@
+# Round profile set: (1) rocprofv3 kernel trace + stats of the default bench command, (2) PMC passes (separate runs, counters only)
+# over the eager-launch form of the same bench step.  Outputs under gpurun_out/r01_final/ ; copy the summaries into profiles/.
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/r01_final; rm -rf $OUT; mkdir -p $OUT/pmc; cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_stdout.log 2>&1
+grep "^{\"metric\"" $OUT/bench_stdout.log > $OUT/bench_line.json
+pmc() { n=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc -o $n -- python3 $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 30 --warmup 10 --no-cpu-baseline > $OUT/pmc/$n.log 2>&1
+}
+pmc p1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
+pmc p2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
+pmc p3 FETCH_SIZE
+pmc p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+cd $GRAFT_REPO_ROOT
+python3 scripts/summarize_pmc.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_hbm_bytes.txt 2>&1
+python3 - <<PY
+import csv
+rows=list(csv.DictReader(open("$OUT/bench_kernel_stats.csv")))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms:", tot/1e6, "calls", sum(int(r["Calls"]) for r in rows))
+for r in rows[:24]:
+    print(r["Name"][:90].ljust(90), r["Calls"].rjust(6), "avg_us=%8.1f"%(float(r["AverageNs"])/1e3), "tot_ms=%7.2f"%(float(r["TotalDurationNs"])/1e6), r["Percentage"])
+PY
+cat $OUT/pmc_hbm_bytes.txt | tail -20
+cut -c1-400 $OUT/bench_line.json
+rm -f $OUT/bench_kernel_trace.csv $OUT/pmc/*counter_collection.csv.bak
+ls -la $OUT $OUT/pmc | head -40

@@ -1,19 +1,50 @@
-"""Aggregate rocprofv3 --pmc counter_collection CSVs (one per pass) into a small per-kernel JSON + markdown table."""
-import collections, csv, glob, json, sys
+"""Aggregate rocprofv3 --pmc counter_collection CSVs (one per pass) into per-kernel and per-stage JSON.
+
+usage: summarize_pmc.py <dir with *counter_collection.csv> <out.json> [<stage_out.json>]
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (section on FETCH_SIZE / WRITE_SIZE): both counters are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of wide (16 B per lane) coalesced reads, so it is doubled -- every read stream of the kernels
+of interest here (record streams, float4 gathers, float4 parameter streams) is of that class.  `hbm_bytes_raw` keeps the undoubled sum.
+"""
+import collections, csv, glob, json, re, sys
 src, out = sys.argv[1], sys.argv[2]
+stage_out = sys.argv[3] if len(sys.argv) > 3 else None
+KERNELS = ["preprocess_forward_kernel", "preprocess_backward_kernel", "scan_kernel", "scatter_kernel", "chunk_sort_kernel",
+           "merge_gather_kernel", "blend_forward_wave_kernel", "blend_backward_wave_kernel", "blend_forward_kernel",
+           "blend_backward_kernel", "clear_words_kernel", "ssim_pass1_kernel", "ssim_pass2_kernel", "loss_finish_kernel",
+           "adamw_kernel", "adamw_tick_kernel", "activate_forward_kernel", "activate_backward_kernel", "mark_visible_kernel"]
+STAGES = {"preprocess_fwd": ["preprocess_forward_kernel"], "scan": ["scan_kernel"], "scatter": ["scatter_kernel"],
+          "tile_sort": ["chunk_sort_kernel", "merge_gather_kernel"], "blend_fwd": ["blend_forward_wave_kernel", "blend_forward_kernel"],
+          "blend_bwd": ["blend_backward_wave_kernel", "blend_backward_kernel"], "preprocess_bwd": ["preprocess_backward_kernel"]}
+
+
+def short(name):
+    for k in KERNELS:
+        if re.search(r"\b" + k + r"\b", name):
+            return k
+    return None
+
+
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(src + "/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if "moss" not in k:
-            continue
-        short = k.split("(anonymous namespace)::")[-1].split("(")[0]
-        agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
 for k, c in res.items():
+    c["launches_sampled"] = max(len(v) for v in agg[k].values())
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide
-        # (16 B/lane) reads -> doubled.  Our reads are 16-byte record gathers and dwordx4 streams, i.e. that access class.
         c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        c["hbm_bytes_raw"] = int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in res.items()}, indent=1))
+if stage_out:
+    st = {}
+    for s, ks in STAGES.items():
+        present = [res[k] for k in ks if k in res and "hbm_bytes_per_launch" in res[k]]
+        if present:
+            st[s] = {"hbm_bytes_per_launch": sum(p["hbm_bytes_per_launch"] for p in present),
+                     "hbm_bytes_raw": sum(p["hbm_bytes_raw"] for p in present), "kernels": [k for k in ks if k in res],
+                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), eager-launch bench.py --graph 0 --steps 30 --warmup 10"}
+    json.dump(st, open(stage_out, "w"), indent=1, sort_keys=True)
+for k, c in sorted(res.items()):
+    print(k.ljust(30), {n: (round(v) if isinstance(v, float) else v) for n, v in c.items()})
