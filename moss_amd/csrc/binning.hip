@@ -211,7 +211,7 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
 __global__ void __launch_bounds__(256)
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
                     const uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
-                    float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask)
+                    float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int)header[0]) return;
@@ -233,10 +233,27 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
     const uint32_t id = (uint32_t)key;
     point_list[pos] = id;
     float4* rec = inst_rec + 3 * (size_t)pos;
-    rec[0] = g.geo_a[id]; rec[1] = g.geo_b[id]; rec[2] = g.geo_c[id];
+    const float4 ga = g.geo_a[id];
+    rec[0] = ga; rec[1] = g.geo_b[id]; rec[2] = g.geo_c[id];
     const uint2 r = g.rect[id];
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
     const int tx = (int)tile % gx, ty = (int)tile / gx;
+    {
+        // which 4x4 pixel blocks of this tile the entry's alpha >= 1/255 bounding box {x, y, hx, hy} touches (pixel centres are
+        // integers; block b spans [bx0, bx0+3] x [by0, by0+3]); NaN extents give no bit, infinite ones every bit.  The blend
+        // kernels scan these 2-byte masks instead of the 48-byte records.
+        uint32_t xm = 0u, ym = 0u;
+#pragma unroll
+        for (int bq = 0; bq < 4; bq++) {
+            const float bx0 = (float)(tx * TILE + 4 * bq), by0 = (float)(ty * TILE + 4 * bq);
+            if (ga.x + ga.z >= bx0 && ga.x - ga.z <= bx0 + 3.0f) xm |= 1u << bq;
+            if (ga.y + ga.w >= by0 && ga.y - ga.w <= by0 + 3.0f) ym |= 1u << bq;
+        }
+        uint32_t bmask = 0u;
+#pragma unroll
+        for (int by = 0; by < 4; by++) if (ym & (1u << by)) bmask |= xm << (4 * by);
+        inst_bmask[pos] = (uint16_t)bmask;
+    }
     const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     inst_pos[g.point_offsets[id] + k] = pos;
 }
@@ -313,7 +330,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     if (R <= 0 || total_chunks <= 0) return;
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(1024), 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
     hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, im.header, fp.gx, g, im.ranges, b.keys, b.inst_tile,
-                       b.point_list, b.inst_pos, b.inst_rec, b.inst_mask);
+                       b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask);
 }
 
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

@@ -608,8 +608,7 @@ blend_backward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restr
 // and sets the block's bit in the instance's mask; the per-Gaussian gather reads only flagged records (a fixed order ->
 // still bitwise reproducible), ~10x fewer than the one-record-per-instance-per-quadrant scheme of the workgroup kernels.
 // =========================================================================================================
-constexpr int RING = 128;                 // per-wave LDS ring of compacted hits (entries): <= 3 carried over + 64 new
-constexpr int RING_MASK = RING - 1;
+
 constexpr int WAVE_BLOCKS = 16;           // 4x4-pixel blocks per tile = items per tile = gradient slabs
 
 struct Rec { float4 a, b, c; };
@@ -636,7 +635,7 @@ __device__ __forceinline__ Rec load_rec(const float4* __restrict__ inst_rec, int
 // tiles with thousands of entries, spent most of the frame on those short lists.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
-                                                   const float4* __restrict__ inst_rec, float4* ra, float4* rb, float4* rc,
+                                                   const float4* __restrict__ inst_rec, float4 (*ring)[3],
                                                    const float* __restrict__ bg_color, float* __restrict__ out_color,
                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags)
@@ -655,12 +654,12 @@ __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int til
         bool hit = base + lane < n;
         if (hit && (flags & 1)) hit = block_hit(cur.a, bx0, by0, 7.0f, 7.0f);
         unsigned long long m = __ballot(hit);
-        ra[lane] = cur.a; rb[lane] = cur.b; rc[lane] = cur.c;
+        ring[lane][0] = cur.a; ring[lane][1] = cur.b; ring[lane][2] = cur.c;
         __builtin_amdgcn_wave_barrier();
         while (m != 0ull) {
             const int e = __ffsll((long long)m) - 1;         // wave-uniform: the records are LDS broadcasts
             m &= m - 1ull;
-            const float4 a = ra[e], b = rb[e], c = rc[e];
+            const float4 a = ring[e][0], b = ring[e][1], c = ring[e][2];
             const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.x, b.y, b.z, b.w);
             const float al = live ? pe.alpha : 0.0f;
             const float test_T = T * (1.0f - al);
@@ -700,7 +699,7 @@ __device__ __forceinline__ float row_sum16(float v)
 }
 
 __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
-                                                    const float4* __restrict__ inst_rec, float4* ra, float4* rb, float4* rc,
+                                                    const float4* __restrict__ inst_rec, float4 (*ring)[3],
                                                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
                                                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                                                     const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
@@ -739,7 +738,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
         bool hit = base + lane < n_eff;
         if (hit && (flags & 1)) hit = block_hit(cur.a, bx0, by0, 7.0f, 7.0f);
         unsigned long long m = __ballot(hit);
-        ra[lane] = cur.a; rb[lane] = cur.b; rc[lane] = cur.c;
+        ring[lane][0] = cur.a; ring[lane][1] = cur.b; ring[lane][2] = cur.c;
         __builtin_amdgcn_wave_barrier();
         while (m != 0ull) {
             // up to four entries per round; the 4 x 9 partial gradients are summed over the 64 pixels by ONE reduce-scatter:
@@ -753,7 +752,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 const int e = valid ? __ffsll((long long)m) - 1 : 0;
                 if (valid) m &= m - 1ull;
                 const int pos = n_eff - 1 - (base + e);
-                const float4 a = ra[e], b = rb[e], c = rc[e];
+                const float4 a = ring[e][0], b = ring[e][1], c = ring[e][2];
                 const float dx = a.x - pixx, dy = a.y - pixy;
                 const PairEval pe = eval_pair(dx, dy, b.x, b.y, b.z, b.w);
                 const float al = (valid && pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514
@@ -801,366 +800,445 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// HEAVY tiles: one wave per 4x4 block, lane = (pixel, slot).
+//
+// Scan: the wave does not read the tile's 48-byte records to find its hits -- stamps showed that scan costing as many cycles as
+// the blending (1000-1400 cycles per 64 entries: per-CU load-path throughput, 24 cache lines per step whether 16 or 48 bytes of a
+// record are used).  It reads the 2-byte BLOCK MASK merge_gather_kernel wrote for every instance (bit b set <=> the bounding
+// box of the entry's alpha >= 1/255 region touches 4x4 block b of its tile): 64 entries = ONE cache line.  Hit positions go to a
+// private LDS list.
+// Fetch: the records of the hits (only) are copied global -> LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source address,
+// lane-linear destination, no VGPRs held), one round AHEAD of their use: a round scans until it has found >= 64 new hits (16+
+// trips = 8k+ cycles of blending, which covers the DMA latency), issues their DMAs, then blends the previous round's records.  Fetching them into registers
+// inside the trip loop (first version of this scheme) made every trip wait on L2: 640 instead of 520 cycles per trip.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LCAP = 1024, LMASK = LCAP - 1;     // per-wave list of hit positions
+constexpr int CHAPTER = 8;                       // 64-entry groups of block masks staged in LDS at a time (512 entries)
+constexpr int ROUND_HITS = 64;                   // a scan round ends once it has found this many new hits (<= 127 with its last group)
+constexpr int RCAP = 512, RMASK = RCAP - 1;      // per-wave record ring (slots; a multiple of the 64-slot DMA batch): the hits of
+                                                 // two rounds (<= 2 x 128 + 3 carried) plus one batch of slack
+struct HeavyLds { float4 a[RCAP], b[RCAP], c[RCAP]; uint32_t lst[LCAP]; uint16_t mbuf[64 * CHAPTER]; };
+
+// Issue the DMA batches that cover list entries [from, to): batch q = entries 64q .. 64q+63 -> ring slots (64q & RMASK) + lane.
+// Lanes whose entry is not in the list yet copy the tile's first record (overwritten when the batch is re-issued with that
+// entry; never read before); lanes whose entry was fetched before re-copy the same record.
+__device__ __forceinline__ void dma_records(HeavyLds* L, const float4* __restrict__ recs, int from, int to, int nlist, int lane)
+{
+    for (int q = from >> 6; q <= (to - 1) >> 6; q++) {
+        const int li = 64 * q + lane;
+        const uint32_t p = li < nlist ? L->lst[li & LMASK] : 0u;
+        const float4* r = recs + 3 * (size_t)p;
+        const int base = (64 * q) & RMASK;
+        __builtin_amdgcn_global_load_lds(r, &L->a[base], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(r + 1, &L->b[base], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(r + 2, &L->c[base], 16, 0, 0);
+    }
+}
+
+struct Fetched { float4 a, b, c; float pos1, valid; };   // pos1 = 1-based list position; valid = 0 for a padding slot
+
+__device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
+                                                   const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
+                                                   HeavyLds* L, const float* __restrict__ bg_color, float* __restrict__ out_color,
+                                                   float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
+                                                   unsigned long long* stamp_out)
+{
+    const int slot = lane & 3, pl = lane >> 2, gbase = lane & ~3;
+    const uint32_t below_mask = (1u << slot) - 1u;
+    const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
+    const int px = ox + (pl & 3), py = oy + (pl >> 2);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px, pixy = (float)py;
+    const int n = (int)(rg.y - rg.x);
+    const uint16_t* const bm = inst_bmask + rg.x;
+    const float4* const recs = inst_rec + 3 * (size_t)rg.x;
+    const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;     // culling switched off (diagnostics): every entry is a hit
+#define STAMP() (stamp_out ? __builtin_amdgcn_s_memtime() : 0ull)
+    const unsigned long long t_begin = STAMP();
+    unsigned long long d_trip = 0, n_rounds = 0, n_trips = 0;
+
+    float T = 1.0f, T_stop = -1.0f;
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
+    float last_contributor = 0.0f;                                       // list positions < 2^24: exact in fp32
+    float live = inside ? 1.0f : 0.0f;
+    bool finished = __ballot(live > 0.0f) == 0ull;
+
+    // one trip: 4 consecutive hits x 16 pixels; returns true when every pixel of the block is finished
+    auto trip = [&](const Fetched& f) -> bool {
+        const PairEval pe = eval_pair(f.a.x - pixx, f.a.y - pixy, f.b.x, f.b.y, f.b.z, f.b.w);
+        const float al = pe.alpha * live * f.valid;                    // 0 for finished / outside pixels and padding slots
+        const float fm = 1.0f - al;
+        // multiplied in list order: bit-identical to the serial loop
+        float X = T * fm, Y;
+        Y = DPP_MOV(X, 0x90); X = slot >= 1 ? Y * fm : X;              // quad_perm:[0,0,1,2]
+        Y = DPP_MOV(X, 0x90); X = slot >= 2 ? Y * fm : X;
+        Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y * fm : X;
+        Y = DPP_MOV(X, 0x90);
+        const float Tb = slot == 0 ? T : Y;                            // T in front of this slot's entry
+        const float st = (X < 0.0001f) ? al : 0.0f;                    // > 0: this entry ends the pixel (forward.cu:351-356)
+        const unsigned long long sb = __ballot(st > 0.0f);
+        const uint32_t q = (uint32_t)(sb >> gbase) & 15u;              // stop flags of this pixel's slots
+        const uint32_t below = q & below_mask;                         // an earlier slot already stopped the pixel
+        float wgt = al * Tb;
+        wgt = (st > 0.0f) ? 0.0f : wgt;
+        wgt = (below != 0u) ? 0.0f : wgt;
+        const float ts = (st > 0.0f) ? Tb : T_stop;
+        T_stop = (below != 0u) ? T_stop : ts;                          // the first stopping slot records the final T
+        Cr = __fmaf_rn(f.c.x, wgt, Cr); Cg = __fmaf_rn(f.c.y, wgt, Cg); Cb = __fmaf_rn(f.c.z, wgt, Cb);
+        weight += wgt;
+        Dacc = __fmaf_rn(f.c.w, wgt, Dacc);
+        last_contributor = (wgt > 0.0f) ? f.pos1 : last_contributor;
+        T = DPP_MOV(X, 0xFF);
+        live = (q != 0u) ? 0.0f : live;
+        return __ballot(live > 0.0f) == 0ull;
+    };
+
+    // list entries: [0, C) blended, [C, F) records requested by DMA, [F, nlist) found by the scan but not requested yet
+    int scan_pos = 0, nlist = 0, C = 0, F = 0, grp = CHAPTER;
+    bool scan_done = false;
+    uint32_t nx[CHAPTER];                                    // the next chapter of masks, in flight
+#pragma unroll
+    for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(64 * k + lane, n - 1)];
+    while (!finished) {
+        __builtin_amdgcn_s_waitcnt(0);                       // every DMA issued so far has landed (they had a round of blending to do so)
+        __builtin_amdgcn_wave_barrier();
+        const int ready = F;                                 // records of [C, ready) are in the ring
+        const bool final_round = scan_done;                  // nothing new can come: blend everything that is left
+        n_rounds++;
+        // ---- scan 64-entry groups until this round has found ROUND_HITS new hits (or the list ends)
+        int new_hits = 0;
+        while (!scan_done && new_hits < ROUND_HITS) {
+            if (grp == CHAPTER) {                            // stage the chapter that was in flight, request the one after it
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) L->mbuf[64 * k + lane] = (uint16_t)nx[k];
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(scan_pos + 64 * (CHAPTER + k) + lane, n - 1)];
+                grp = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t mkv = L->mbuf[64 * grp + lane];
+            grp++;
+            const int idx = scan_pos + lane;
+            const bool hit = idx < n && (((mkv | all_hit) >> blk) & 1u) != 0u;
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ull) {
+                const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit) L->lst[r & LMASK] = (uint32_t)idx;
+                const int c = __popcll(m);
+                nlist += c; new_hits += c;
+            }
+            scan_pos += 64;
+            scan_done = scan_pos >= n;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- request the new hits' records; they land while the previous round's are blended below
+        if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
+        // ---- blend the complete groups of 4 among [C, ready) (in the final round: all of it)
+        const int avail = ready - C;
+        const int ntrip = (avail >> 2) + ((final_round && (avail & 3) != 0) ? 1 : 0);
+        if (ntrip > 0 && !(flags & 2)) {
+            const unsigned long long t4 = STAMP();
+            n_trips += ntrip;
+            auto get = [&](int t) -> Fetched {
+                const int li = C + 4 * t + slot;
+                Fetched f;
+                f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];      // (stale past `ready`: masked)
+                f.pos1 = (float)(L->lst[li & LMASK] + 1u); f.valid = li < ready ? 1.0f : 0.0f;
+                return f;
+            };
+            Fetched f0 = get(0);
+            for (int t = 0; t < ntrip; t += 2) {
+                const Fetched f1 = get(t + 1);                                             // next trip's LDS reads under this trip
+                if (trip(f0)) { finished = true; break; }
+                if (t + 1 >= ntrip) break;
+                f0 = get(t + 2);
+                if (trip(f1)) { finished = true; break; }
+            }
+            C += 4 * ntrip;
+            d_trip += STAMP() - t4;
+        }
+        if (final_round) break;
+    }
+    __builtin_amdgcn_s_waitcnt(0);                           // no DMA may still be writing this wave's LDS when the next item starts
+    if (stamp_out && lane == 0) {
+        stamp_out[0] = STAMP() - t_begin; stamp_out[1] = (unsigned long long)n; stamp_out[2] = 0; stamp_out[3] = 0; stamp_out[4] = 0;
+        stamp_out[5] = d_trip; stamp_out[6] = n_rounds; stamp_out[7] = n_trips;
+    }
+#undef STAMP
+
+    // combine the slots of each pixel
+    GROUP_ALLREDUCE(4, Cr, OP_ADD) GROUP_ALLREDUCE(4, Cg, OP_ADD) GROUP_ALLREDUCE(4, Cb, OP_ADD)
+    GROUP_ALLREDUCE(4, weight, OP_ADD) GROUP_ALLREDUCE(4, Dacc, OP_ADD)
+    GROUP_ALLREDUCE(4, T_stop, OP_MAX) GROUP_ALLREDUCE(4, last_contributor, OP_MAX)
+    const float Tf = T_stop >= 0.0f ? T_stop : T;
+    if (inside && slot == 0) {
+        const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
+        final_T[pix_id] = Tf;
+        n_contrib[pix_id] = (uint32_t)last_contributor;
+        out_color[pix_id] = __fmaf_rn(Tf, bg_color[0], Cr);
+        out_color[plane + pix_id] = __fmaf_rn(Tf, bg_color[1], Cg);
+        out_color[2 * plane + pix_id] = __fmaf_rn(Tf, bg_color[2], Cb);
+        out_alpha[pix_id] = weight;
+        out_depth[pix_id] = Dacc;
+    }
+}
+
+__device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
+                                                    const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
+                                                    HeavyLds* L, const float* __restrict__ bg_color,
+                                                    const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                                                    const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths,
+                                                    const float* __restrict__ dL_dalphas, float* __restrict__ inst_grad,
+                                                    size_t slab_stride, uint32_t* __restrict__ inst_mask, int flags)
+{
+    const int slot = lane & 3, pl = lane >> 2;
+    // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
+    const int row = lane >> 4, rh = row >> 1, rp = row & 1;
+    const int m0 = 2 * rp + rh, m1 = 4 + m0;
+    const bool writer = (lane & 15) < 4;                     // one lane per (row, slot)
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
+    const int px = ox + (pl & 3), py = oy + (pl >> 2);
+    const bool inside = px < W && py < H;
+    const float pixx = (float)px, pixy = (float)py;
+    const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
+
+    const float T_final = inside ? final_Ts[pix_id] : 0.0f;
+    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
+    // entries at list positions >= n_eff are behind every pixel's last contributor: nobody visits them
+    int n_eff = last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d));
+    if (n_eff == 0) return;                                  // nothing was blended into this block: no record, no mask bit
+
+    float gpr = 0.f, gpg = 0.f, gpb = 0.f, gpd = 0.f, gpa = 0.f;
+    if (inside) {
+        // a null incoming gradient = that output did not take part in the loss (zeros, without a zero-filled image)
+        if (dL_dpixels) { gpr = dL_dpixels[pix_id]; gpg = dL_dpixels[plane + pix_id]; gpb = dL_dpixels[2 * plane + pix_id]; }
+        if (dL_ddepths) gpd = dL_ddepths[pix_id];
+        if (dL_dalphas) gpa = dL_dalphas[pix_id];
+    }
+    const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
+    float* const my_grad = inst_grad + (size_t)blk * slab_stride + (size_t)rg.x * NPART;   // this block's slab of the tile's records
+    uint32_t* const my_mask = inst_mask + rg.x;
+    const uint32_t blk_bit = 1u << blk;
+    const uint16_t* const bm = inst_bmask + rg.x;
+    const float4* const recs = inst_rec + 3 * (size_t)rg.x;
+    const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;
+
+    // Pixel state, replicated in the pixel's lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
+    // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
+    float T = T_final, Q = 0.0f;
+
+    auto trip = [&](const Fetched& f) {
+        const int pos = (int)f.pos1 - 1;
+        const float dx = f.a.x - pixx, dy = f.a.y - pixy;
+        const PairEval pe = eval_pair(dx, dy, f.b.x, f.b.y, f.b.z, f.b.w);
+        const float al = (f.valid != 0.0f && pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = pair skipped
+        const float G = (al > 0.0f) ? pe.G : 0.0f;
+        // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
+        const float mm = 1.0f - al;
+        const float rinv = __builtin_amdgcn_rcpf(mm);
+        const float u = __fmaf_rn(f.c.x, gpr, __fmaf_rn(f.c.y, gpg, __fmaf_rn(f.c.z, gpb, __fmaf_rn(f.c.w, gpd, gpa))));
+        const float kq = al * u;
+        // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
+        float Ti = T, Qi = Q;
+        float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);
+#pragma unroll
+        for (int k = 1; k <= 3; k++) {
+            const float yT = DPP_MOV(To, 0x90), yQ = DPP_MOV(Qo, 0x90);
+            Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
+            To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
+        }
+        T = DPP_MOV(To, 0xFF); Q = DPP_MOV(Qo, 0xFF);               // the pixel's state after these four entries
+
+        // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
+        float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
+        dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
+        const float dchannel_dcolor = al * To;
+        const float dL_dG = f.b.w * dL_dopa;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * f.b.x - gdy * f.b.y;
+        const float dG_ddely = -gdy * f.b.z - gdx * f.b.y;
+        const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
+        const float v3 = dL_dG * dG_ddelx * ddelx_dx;
+        const float v4 = dL_dG * dG_ddely * ddely_dy;
+        const float hdG = -0.5f * dL_dG;
+        const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
+        const float v8 = G * dL_dopa;
+
+        const unsigned long long contrib = __ballot(al > 0.0f);
+        if (contrib != 0ull) {
+            // reduce-scatter over the wave's pixels, separately per slot: after fold32 the lower/upper half-waves hold
+            // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
+            const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
+            const float s0 = row_slot_sum<4>(fold16(r0, r1)), s1 = row_slot_sum<4>(fold16(r2, r3)),
+                        s2 = row_slot_sum<4>(fold16(r4, 0.0f));
+            // an entry leaves a record (and its block bit) only if one of the block's pixels blended it
+            const bool slot_any = ((contrib >> slot) & 0x1111111111111111ull) != 0ull;
+            if (writer && slot_any) {
+                float* dst = my_grad + (size_t)pos * NPART;
+                dst[m0] = s0; dst[m1] = s1;
+                if (row == 0) { dst[8] = s2; atomicOr(&my_mask[pos], blk_bit); }
+            }
+        }
+    };
+
+    // back to front: scan offset o <-> list position n_eff-1-o.  Same pipeline as the forward kernel.
+    int scan_off = 0, nlist = 0, C = 0, F = 0, grp = CHAPTER;
+    bool scan_done = false;
+    uint32_t nx[CHAPTER];
+#pragma unroll
+    for (int k = 0; k < CHAPTER; k++) nx[k] = bm[max(n_eff - 1 - (64 * k + lane), 0)];
+    for (;;) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int ready = F;
+        const bool final_round = scan_done;
+        int new_hits = 0;
+        while (!scan_done && new_hits < ROUND_HITS) {
+            if (grp == CHAPTER) {
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) L->mbuf[64 * k + lane] = (uint16_t)nx[k];
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) nx[k] = bm[max(n_eff - 1 - (scan_off + 64 * (CHAPTER + k) + lane), 0)];
+                grp = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t mkv = L->mbuf[64 * grp + lane];
+            grp++;
+            const int idx = n_eff - 1 - (scan_off + lane);
+            const bool hit = idx >= 0 && (((mkv | all_hit) >> blk) & 1u) != 0u;
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ull) {
+                const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit) L->lst[r & LMASK] = (uint32_t)idx;
+                const int c = __popcll(m);
+                nlist += c; new_hits += c;
+            }
+            scan_off += 64;
+            scan_done = scan_off >= n_eff;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
+        const int avail = ready - C;
+        const int ntrip = (avail >> 2) + ((final_round && (avail & 3) != 0) ? 1 : 0);
+        if (ntrip > 0 && !(flags & 2)) {
+            auto get = [&](int t) -> Fetched {
+                const int li = C + 4 * t + slot;
+                Fetched f;
+                f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];
+                f.pos1 = (float)(L->lst[li & LMASK] + 1u); f.valid = li < ready ? 1.0f : 0.0f;
+                return f;
+            };
+            Fetched f0 = get(0);
+            for (int t = 0; t < ntrip; t += 2) {
+                const Fetched f1 = get(t + 1);
+                trip(f0);
+                if (t + 1 >= ntrip) break;
+                f0 = get(t + 2);
+                trip(f1);
+            }
+            C += 4 * ntrip;
+        }
+        if (final_round) break;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+}
+
+// Work-item decode shared by both kernels.  One queue per XCD (workgroups are dealt round-robin to the 8 XCDs, so blockIdx % 8
+// names the XCD): the 16 blocks of a tile are pulled by waves that share an L2 (PMC: the forward kernel's HBM traffic equals its
+// algorithmic bytes).  Tiles are dealt to the queues in LPT order, rank r -> queue r % nq; of a queue's tiles the first hx are
+// heavy (16 block items each), the rest light (4 quadrant items each).
+struct WaveItem { int tile, sub, rank; bool heavy, valid; };
+__device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int nq, int qx, int hx, int n_work,
+                                              const uint32_t* __restrict__ tile_order)
+{
+    int qi = 0;
+    if (lane == 0) qi = (int)atomicAdd(my_head, 1u);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+    WaveItem it;
+    it.heavy = qi < WAVE_BLOCKS * hx;
+    const int k = it.heavy ? (qi >> 4) : hx + ((qi - WAVE_BLOCKS * hx) >> 2);
+    it.sub = it.heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
+    it.rank = k * nq + qx;
+    it.valid = it.rank < n_work;
+    it.tile = it.valid ? (int)tile_order[it.rank] : 0;
+    return it;
+}
+
 __global__ void __launch_bounds__(256)
 blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
                           uint32_t* __restrict__ queue_head, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
+                          const uint16_t* __restrict__ inst_bmask,
                           const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                           float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
                           unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */)
 {
-    __shared__ float4 s_ra[4][RING];
-    __shared__ float4 s_rb[4][RING];
-    __shared__ float4 s_rc[4][RING];
+    __shared__ float4 s_ring[4][64][3];                     // light path: the current 64 records of a wave
+    __shared__ HeavyLds s_heavy[4];                         // heavy path: per-wave hit list and record ring (28 KB each)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4* const ra = s_ra[wv]; float4* const rb = s_rb[wv]; float4* const rc = s_rc[wv];
-    const int slot = lane & 3, pl = lane >> 2, gbase = lane & ~3;
-#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
-    const uint32_t below_mask = (1u << slot) - 1u;
     const int n_work = (int)header[5];                       // tile_order lists the tiles that own instances first
-    const int n_items = WAVE_BLOCKS * n_work;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // One queue per XCD (workgroups are dealt round-robin to the 8 XCDs, so blockIdx % 8 names the XCD): the 16 blocks of a tile
-    // are pulled by waves that share an L2, which turns 16 HBM/fabric reads of the tile's record stream into one plus 15 L2 hits
-    // (measured: with a single queue the scan alone ran at the ~3 TB/s the fabric delivers).  Tiles are dealt to the queues in
-    // LPT order, rank r -> queue r % nq.
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
-    uint32_t* const my_head = queue_head + qx;
-
-    // this queue's tiles are the ranks qx, qx+nq, ...: the first hx of them are heavy (16 block items each), the rest light (4)
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
     for (;;) {
-        int qi = 0;
-        if (lane == 0) qi = (int)atomicAdd(my_head, 1u);
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        const bool heavy = qi < WAVE_BLOCKS * hx;
-        const int k = heavy ? (qi >> 4) : hx + ((qi - WAVE_BLOCKS * hx) >> 2);
-        const int blk = heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
-        const int rank = k * nq + qx;
-        if (rank >= n_work) break;
-        const int item = rank * WAVE_BLOCKS + blk;           // (diagnostics index)
-        const int tile = (int)tile_order[rank];
-        if (!heavy) {
-            light_forward_item(W, H, gx, tile, blk, lane, ranges[tile], inst_rec, ra, rb, rc, bg_color, out_color, out_depth,
+        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order);
+        if (!it.valid) break;
+        if (it.heavy)
+            heavy_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, out_color,
+                               out_depth, out_alpha, final_T, n_contrib, flags,
+                               stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr);
+        else
+            light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, s_ring[wv], bg_color, out_color, out_depth,
                                out_alpha, final_T, n_contrib, flags);
-            continue;
-        }
-        const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
-        const int px = ox + (pl & 3), py = oy + (pl >> 2);
-        const bool inside = px < W && py < H;
-        const float pixx = (float)px, pixy = (float)py, bx0 = (float)ox, by0 = (float)oy;
-        const uint2 rg = ranges[tile];
-        const int n = (int)(rg.y - rg.x);
-
-        float T = 1.0f, T_stop = -1.0f;
-        float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
-        float last_contributor = 0.0f;                                       // list positions < 2^24: exact in fp32
-        float live = inside ? 1.0f : 0.0f;
-        int head = 0, tail = 0;                                              // ring: [head, tail) are compacted hits not blended yet
-        bool finished = __ballot(live > 0.0f) == 0ull;
-        const unsigned long long t_begin = STAMP();
-        unsigned long long d_trip = 0, n_steps = 0, n_trips = 0;
-
-        // rolling window of WIN steps of records in flight: a step's loads were issued WIN steps (and their blending) earlier
-        // One step: cull 64 entries (one per lane), compact the hits into the ring, blend every complete group of 4.
-        auto step = [&](const Rec& cur, const int base) {
-            if (finished || base >= n) return;               // (no loads in here: see load_rec)
-            n_steps++;
-            const int j = base + lane;
-            bool hit = j < n;
-            if (hit && (flags & 1)) hit = block_hit(cur.a, bx0, by0, 3.0f, 3.0f);
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull) {
-                const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) {
-                    const int idx = pos & RING_MASK;
-                    float4 a = cur.a; a.z = (float)(j + 1);                  // the cull extents are spent: keep the 1-based list position
-                    ra[idx] = a; rb[idx] = cur.b; rc[idx] = cur.c;
-                }
-                tail += __popcll(m);
-            }
-            const bool last = base + 64 >= n;
-            const int avail = tail - head;
-            int ntrip = avail >> 2;                                          // whole groups of 4; the remainder waits for more hits
-            if (last && (avail & 3) != 0) {
-                if (lane < 3) { const int idx = (tail + lane) & RING_MASK; ra[idx] = z4; rb[idx] = z4; rc[idx] = z4; }   // opacity 0
-                ntrip++;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (ntrip > 0 && !(flags & 2)) {
-                const unsigned long long t4 = STAMP();
-                n_trips += ntrip;
-                int lp = head + slot;
-                float4 a = ra[lp & RING_MASK], b = rb[lp & RING_MASK], c = rc[lp & RING_MASK];
-                for (int it = 0; it < ntrip; it++) {
-                    const int ln = lp + 4;
-                    const float4 an = ra[ln & RING_MASK], bn = rb[ln & RING_MASK], cn = rc[ln & RING_MASK];   // next trip (stale past tail: unused)
-
-                    const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.x, b.y, b.z, b.w);
-                    const float al = pe.alpha * live;                              // 0 for finished / outside pixels
-                    const float f = 1.0f - al;
-                    // multiplied in list order: bit-identical to the serial loop
-                    float X = T * f, Y;
-                    Y = DPP_MOV(X, 0x90); X = slot >= 1 ? Y * f : X;               // quad_perm:[0,0,1,2]
-                    Y = DPP_MOV(X, 0x90); X = slot >= 2 ? Y * f : X;
-                    Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y * f : X;
-                    Y = DPP_MOV(X, 0x90);
-                    const float Tb = slot == 0 ? T : Y;                            // T in front of this slot's entry
-                    const float st = (X < 0.0001f) ? al : 0.0f;                    // > 0: this entry ends the pixel (forward.cu:351-356)
-                    const unsigned long long sb = __ballot(st > 0.0f);
-                    const uint32_t q = (uint32_t)(sb >> gbase) & 15u;              // stop flags of this pixel's slots
-                    const uint32_t below = q & below_mask;                         // an earlier slot already stopped the pixel
-                    float wgt = al * Tb;
-                    wgt = (st > 0.0f) ? 0.0f : wgt;
-                    wgt = (below != 0u) ? 0.0f : wgt;
-                    const float ts = (st > 0.0f) ? Tb : T_stop;
-                    T_stop = (below != 0u) ? T_stop : ts;                          // the first stopping slot records the final T
-                    Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);
-                    weight += wgt;
-                    Dacc = __fmaf_rn(c.w, wgt, Dacc);
-                    last_contributor = (wgt > 0.0f) ? a.z : last_contributor;
-                    T = DPP_MOV(X, 0xFF);
-                    live = (q != 0u) ? 0.0f : live;
-                    if (__ballot(live > 0.0f) == 0ull) { finished = true; break; }
-                    a = an; b = bn; c = cn; lp = ln;
-                }
-                head += 4 * ntrip;
-                d_trip += STAMP() - t4;
-            }
-            __builtin_amdgcn_wave_barrier();
-        };
-        // Rolling window: WIN steps of records are in flight; a step's loads were issued WIN steps (and their blending) earlier.
-        // Written out per window slot so that every slot is its own set of registers (a rotating array would force a wait on
-        // the newest load at every step).
-        const int first = (int)rg.x;
-#define WLOAD(e0) load_rec(inst_rec, first + min((e0), n - 1), n - (e0), lane, 1)          /* steps past the end: the last entry */
-        // issue order matters (the compiler sizes the loop's waits for the worst predecessor): oldest window slot first
-        Rec w0 = WLOAD(0);   __builtin_amdgcn_sched_barrier(0);
-        Rec w1 = WLOAD(64);  __builtin_amdgcn_sched_barrier(0);
-        Rec w2 = WLOAD(128); __builtin_amdgcn_sched_barrier(0);
-        Rec w3 = WLOAD(192); __builtin_amdgcn_sched_barrier(0);
-        for (int base = 0; base < n && !finished; base += 256) {
-#define WSTEP(wk, k)                                                                                                          \
-            { const Rec cur = wk; wk = WLOAD(base + 64 * (k) + 256); step(cur, base + 64 * (k)); }
-            WSTEP(w0, 0) WSTEP(w1, 1) WSTEP(w2, 2) WSTEP(w3, 3)
-#undef WSTEP
-        }
-#undef WLOAD
-        if (stamps && lane == 0) {
-            unsigned long long* o = stamps + (size_t)item * 8;
-            o[0] = STAMP() - t_begin; o[1] = (unsigned long long)n; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = d_trip; o[6] = n_steps; o[7] = n_trips;
-        }
-
-        // combine the slots of each pixel
-        GROUP_ALLREDUCE(4, Cr, OP_ADD) GROUP_ALLREDUCE(4, Cg, OP_ADD) GROUP_ALLREDUCE(4, Cb, OP_ADD)
-        GROUP_ALLREDUCE(4, weight, OP_ADD) GROUP_ALLREDUCE(4, Dacc, OP_ADD)
-        GROUP_ALLREDUCE(4, T_stop, OP_MAX) GROUP_ALLREDUCE(4, last_contributor, OP_MAX)
-        const float Tf = T_stop >= 0.0f ? T_stop : T;
-        if (inside && slot == 0) {
-            const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
-            final_T[pix_id] = Tf;
-            n_contrib[pix_id] = (uint32_t)last_contributor;
-            out_color[pix_id] = __fmaf_rn(Tf, bg_color[0], Cr);
-            out_color[plane + pix_id] = __fmaf_rn(Tf, bg_color[1], Cg);
-            out_color[2 * plane + pix_id] = __fmaf_rn(Tf, bg_color[2], Cb);
-            out_alpha[pix_id] = weight;
-            out_depth[pix_id] = Dacc;
-        }
     }
 
     // Tiles without instances get the background only (forward.cu:374-382 with an empty range); done after the queue so that
     // the heavy items start immediately.
+    const int pl = lane >> 2;
     const int wave_id = (int)blockIdx.x * 4 + wv, n_waves = (int)gridDim.x * 4;
-    for (int i = n_items + wave_id; i < WAVE_BLOCKS * T_tiles; i += n_waves) {
+    for (int i = WAVE_BLOCKS * n_work + wave_id; i < WAVE_BLOCKS * T_tiles; i += n_waves) {
         const int tile = (int)tile_order[i >> 4], blk = i & 15;
         const int px = (tile % gx) * TILE + (blk & 3) * 4 + (pl & 3), py = (tile / gx) * TILE + (blk >> 2) * 4 + (pl >> 2);
-        if (px < W && py < H && slot == 0) {
+        if (px < W && py < H && (lane & 3) == 0) {
             const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
             final_T[pix_id] = 1.0f; n_contrib[pix_id] = 0u;
             out_color[pix_id] = bg_color[0]; out_color[plane + pix_id] = bg_color[1]; out_color[2 * plane + pix_id] = bg_color[2];
             out_alpha[pix_id] = 0.0f; out_depth[pix_id] = 0.0f;
         }
     }
-#undef STAMP
 }
 
 __global__ void __launch_bounds__(256)
 blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
                            uint32_t* __restrict__ queue_head, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
+                           const uint16_t* __restrict__ inst_bmask,
                            const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                            const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
                            float* __restrict__ inst_grad /* [16][R][12] */, size_t slab_stride, uint32_t* __restrict__ inst_mask,
                            uint32_t* __restrict__ leavers, int flags)
 {
-    __shared__ float4 s_ra[4][RING];
-    __shared__ float4 s_rb[4][RING];
-    __shared__ float4 s_rc[4][RING];
+    __shared__ float4 s_ring[4][64][3];
+    __shared__ HeavyLds s_heavy[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4* const ra = s_ra[wv]; float4* const rb = s_rb[wv]; float4* const rc = s_rc[wv];
-    const int slot = lane & 3, pl = lane >> 2;
     const int n_work = (int)header[5];
-    const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;      // per-XCD queues: see the forward kernel
-    uint32_t* const my_head = queue_head + qx;
-    // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
-    const int row = lane >> 4, rh = row >> 1, rp = row & 1;
-    const int m0 = 2 * rp + rh, m1 = 4 + m0;
-    const bool writer = (lane & 15) < 4;                     // one lane per (row, slot)
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-
+    const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
     for (;;) {
-        int qi = 0;
-        if (lane == 0) qi = (int)atomicAdd(my_head, 1u);
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        const bool heavy = qi < WAVE_BLOCKS * hx;
-        const int k = heavy ? (qi >> 4) : hx + ((qi - WAVE_BLOCKS * hx) >> 2);
-        const int blk = heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
-        const int rank = k * nq + qx;
-        if (rank >= n_work) break;
-        const int tile = (int)tile_order[rank];
-        if (!heavy) {
-            light_backward_item(W, H, gx, tile, blk, lane, ranges[tile], inst_rec, ra, rb, rc, bg_color, final_Ts, n_contrib,
+        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order);
+        if (!it.valid) break;
+        if (it.heavy)
+            heavy_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
+                                n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
+        else
+            light_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, s_ring[wv], bg_color, final_Ts, n_contrib,
                                 dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
-            continue;
-        }
-        const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
-        const int px = ox + (pl & 3), py = oy + (pl >> 2);
-        const bool inside = px < W && py < H;
-        const float pixx = (float)px, pixy = (float)py, bx0 = (float)ox, by0 = (float)oy;
-        const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
-        const uint2 rg = ranges[tile];
-
-        const float T_final = inside ? final_Ts[pix_id] : 0.0f;
-        const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
-        // entries at list positions >= n_eff are behind every pixel's last contributor: nobody visits them
-        int n_eff = last_contributor;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d));
-        if (n_eff == 0) continue;                            // nothing was blended into this block: no record, no mask bit
-
-        float gpr = 0.f, gpg = 0.f, gpb = 0.f, gpd = 0.f, gpa = 0.f;
-        if (inside) {
-            // a null incoming gradient = that output did not take part in the loss (zeros, without a zero-filled image)
-            if (dL_dpixels) { gpr = dL_dpixels[pix_id]; gpg = dL_dpixels[plane + pix_id]; gpb = dL_dpixels[2 * plane + pix_id]; }
-            if (dL_ddepths) gpd = dL_ddepths[pix_id];
-            if (dL_dalphas) gpa = dL_dalphas[pix_id];
-        }
-        const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
-        float* const my_grad = inst_grad + (size_t)blk * slab_stride + (size_t)rg.x * NPART;   // this block's slab of the tile's records
-        uint32_t* const my_mask = inst_mask + rg.x;
-        const uint32_t blk_bit = 1u << blk;
-
-        // Pixel state, replicated in the pixel's lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
-        // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
-        float T = T_final, Q = 0.0f;
-        int head = 0, tail = 0;
-
-        auto step = [&](const Rec& cur, const int base) {
-            if (base >= n_eff) return;
-            const int j = base + lane;                       // back to front: list position n_eff-1-j
-            bool hit = j < n_eff;
-            if (hit && (flags & 1)) hit = block_hit(cur.a, bx0, by0, 3.0f, 3.0f);
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull) {
-                const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) {
-                    const int idx = pos & RING_MASK;
-                    float4 a = cur.a; a.z = (float)(n_eff - 1 - j);          // 0-based list position
-                    ra[idx] = a; rb[idx] = cur.b; rc[idx] = cur.c;
-                }
-                tail += __popcll(m);
-            }
-            const bool last = base + 64 >= n_eff;
-            const int avail = tail - head;
-            int ntrip = avail >> 2;
-            if (last && (avail & 3) != 0) {
-                if (lane < 3) {
-                    const int idx = (tail + lane) & RING_MASK;
-                    ra[idx] = make_float4(0.f, 0.f, -1.0f, 0.f); rb[idx] = make_float4(0.f, 0.f, 0.f, 0.f); rc[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                ntrip++;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (ntrip > 0 && !(flags & 2)) {
-                int lp = head + slot;
-                float4 a = ra[lp & RING_MASK], b = rb[lp & RING_MASK], c = rc[lp & RING_MASK];
-                for (int it = 0; it < ntrip; it++) {
-                    const int ln = lp + 4;
-                    const float4 an = ra[ln & RING_MASK], bn = rb[ln & RING_MASK], cn = rc[ln & RING_MASK];
-
-                    const int pos = (int)a.z;                                      // -1 for the padding of the last group
-                    const float dx = a.x - pixx, dy = a.y - pixy;
-                    const PairEval pe = eval_pair(dx, dy, b.x, b.y, b.z, b.w);
-                    const float al = (pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = this pair is skipped
-                    const float G = (al > 0.0f) ? pe.G : 0.0f;
-                    // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
-                    const float mm = 1.0f - al;
-                    const float rinv = __builtin_amdgcn_rcpf(mm);
-                    const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));
-                    const float kq = al * u;
-                    // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
-                    float Ti = T, Qi = Q;
-                    float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);
-#pragma unroll
-                    for (int k = 1; k <= 3; k++) {
-                        const float yT = DPP_MOV(To, 0x90), yQ = DPP_MOV(Qo, 0x90);
-                        Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
-                        To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
-                    }
-                    T = DPP_MOV(To, 0xFF); Q = DPP_MOV(Qo, 0xFF);               // the pixel's state after these four entries
-
-                    // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
-                    float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
-                    dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
-                    const float dchannel_dcolor = al * To;
-                    const float dL_dG = b.w * dL_dopa;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * b.x - gdy * b.y;
-                    const float dG_ddely = -gdy * b.z - gdx * b.y;
-                    const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
-                    const float v3 = dL_dG * dG_ddelx * ddelx_dx;
-                    const float v4 = dL_dG * dG_ddely * ddely_dy;
-                    const float hdG = -0.5f * dL_dG;
-                    const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
-                    const float v8 = G * dL_dopa;
-
-                    const unsigned long long contrib = __ballot(al > 0.0f);
-                    if (contrib != 0ull) {
-                        // reduce-scatter over the wave's pixels, separately per slot: after fold32 the lower/upper half-waves hold
-                        // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
-                        const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
-                        const float s0 = row_slot_sum<4>(fold16(r0, r1)), s1 = row_slot_sum<4>(fold16(r2, r3)),
-                                    s2 = row_slot_sum<4>(fold16(r4, 0.0f));
-                        // an entry leaves a record (and its block bit) only if one of the block's pixels blended it
-                        const bool slot_any = ((contrib >> slot) & 0x1111111111111111ull) != 0ull;
-                        if (writer && slot_any) {
-                            float* dst = my_grad + (size_t)pos * NPART;
-                            dst[m0] = s0; dst[m1] = s1;
-                            if (row == 0) { dst[8] = s2; atomicOr(&my_mask[pos], blk_bit); }
-                        }
-                    }
-                    a = an; b = bn; c = cn; lp = ln;
-                }
-                head += 4 * ntrip;
-            }
-            __builtin_amdgcn_wave_barrier();
-        };
-        const int first = (int)rg.x + n_eff - 1;             // back to front
-#define WLOAD(e0) load_rec(inst_rec, first - min((e0), n_eff - 1), n_eff - (e0), lane, -1)
-        Rec w0 = WLOAD(0);   __builtin_amdgcn_sched_barrier(0);
-        Rec w1 = WLOAD(64);  __builtin_amdgcn_sched_barrier(0);
-        Rec w2 = WLOAD(128); __builtin_amdgcn_sched_barrier(0);
-        Rec w3 = WLOAD(192); __builtin_amdgcn_sched_barrier(0);
-        for (int base = 0; base < n_eff; base += 256) {
-#define WSTEP(wk, k)                                                                                                          \
-            { const Rec cur = wk; wk = WLOAD(base + 64 * (k) + 256); step(cur, base + 64 * (k)); }
-            WSTEP(w0, 0) WSTEP(w1, 1) WSTEP(w2, 2) WSTEP(w3, 3)
-#undef WSTEP
-        }
-#undef WLOAD
     }
-    // Self-cleaning queue: every wave has made its last pull by now, so the last one to leave rewinds the head for the next
+    // Self-cleaning queue: every wave has made its last pull by now, so the last one to leave rewinds the heads for the next
     // backward over the same forward state (no memset node -- see raster_api.hip on hipGraph capture).
     if (lane == 0) {
         if (atomicAdd(leavers, 1u) == gridDim.x * 4u - 1u) {
@@ -1219,8 +1297,8 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     if (blend_impl()) {
         const int wgs = min(4 * T, persistent_workgroups());           // 4 independent waves per workgroup, 16 items per tile
         hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
-                           im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, flags,
-                           g_stamps);
+                           im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                           im.final_T, im.n_contrib, flags, g_stamps);
         return;
     }
     const int wgs = min(4 * T, persistent_workgroups());
@@ -1243,7 +1321,7 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     // header[9] (queue head) and header[10] (leaver count) are zero here: cleared by the forward, rewound by each backward
     if (blend_impl()) {
         hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
-                           im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth,
+                           im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth,
                            dL_dalpha, ig, b.slab_stride_floats, b.inst_mask, im.header + HDR_LEAVERS, flags);
         return;
     }

@@ -129,6 +129,7 @@ int blend_impl();            // 1 = wave-autonomous blend kernels (sparse record
 struct BinView {
     uint32_t* point_list; uint32_t* inst_pos; uint32_t* inst_tile;
     uint32_t* inst_mask;     // per instance (sorted order): bit b set <=> slab b holds a record for it (wave kernels)
+    uint16_t* inst_bmask;    // per instance (sorted order): bit b set <=> its alpha >= 1/255 bounding box touches 4x4 block b of its tile
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
     float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
     float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per blend workgroup of a tile)
@@ -140,6 +141,7 @@ struct BinView {
         b.slab_stride_floats = align_up(3 * n * 16) / 4;
         b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n); b.inst_tile = carve<uint32_t>(p, n);
         b.inst_mask = carve<uint32_t>(p, n);
+        b.inst_bmask = carve<uint16_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);
         b.inst_grad = reinterpret_cast<float4*>(p);
         b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);
