@@ -341,40 +341,117 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            int slabs, size_t slab_stride_f4, const uint32_t* __restrict__ inst_mask, const uint32_t* __restrict__ header,
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
-                           float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+                           float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                           unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */)
 {
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then the same for dL_dsh out
+#define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
+    PSTAMP(0);
     float* const s_dsh = s_sh + blockDim.x * SH_ROW;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
-    const uint32_t n_inst = in_range ? g.tiles_touched[idx] : 0u;
+    // All first-level loads are issued together and unconditionally (clamped indices): the 12 SH float4 of this thread's share of
+    // the block's records, tiles_touched, point_offsets, the header flags.  Stamps showed this phase -- 12 SH loads each waited
+    // for in turn, then a five-deep chain tiles_touched -> point_offsets -> inst_pos -> inst_mask -> record -- taking 48k of a
+    // block's 62k cycles.
+    const int idc = min(idx, P - 1);
+    float4 shv[12];
     if (STAGE_SH) {
         const size_t base4 = (size_t)blockIdx.x * blockDim.x * 12, total4 = (size_t)P * 12;     // in float4 units (48 floats = 12)
         const float4* src = reinterpret_cast<const float4*>(shs);
-        for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
-            if (base4 + f < total4) {
-                const float4 v = src[base4 + f];
-                float* d = &s_sh[(f / 12) * SH_ROW + (f % 12) * 4];
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        }
-        // no barrier needed before the gather below; one is placed before the first SH use
+#pragma unroll
+        for (int j = 0; j < 12; j++) shv[j] = src[min(base4 + threadIdx.x + (size_t)j * blockDim.x, total4 - 1)];
     }
+    const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc], hdr_flags = header[2];
+    const uint32_t n_inst = in_range ? tt_raw : 0u;
     const int n_slabs = SLABS > 0 ? SLABS : slabs;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
     // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
-    const bool visible = n_inst > 0 && !(header[2] & ERRFLAG_OVERFLOW);
+    const bool visible = n_inst > 0 && !(hdr_flags & ERRFLAG_OVERFLOW);
 
     // Sum the per-instance partial records.  A Gaussian with few instances (the norm: 2-3) is summed by its own lane.  One that
     // covers much of the image owns up to gx*gy instances x `slabs` records -- a serial sum of thousands of 48-byte gathers -- so
     // those are summed by the 64 lanes of the wave together (lane-strided partial sums, then a fixed butterfly): still a fixed
     // order, hence bitwise reproducible.
     constexpr uint32_t COOP_INST = 16;
-    const uint32_t off = visible ? g.point_offsets[idx] : 0u;
+    const uint32_t off = visible ? off_raw : 0u;
+    uint32_t k_first = 0;                                    // first instance the serial loop below still has to visit
+    // (buffer loads address with 32-bit byte offsets: beyond 4 GB of record slabs -- R > 5.5M instances -- the serial loop does it all)
+    if (SLABS < 0 && (unsigned long long)slabs * slab_stride_f4 * 16ull < 0xffffff00ull) {
+        // Sparse records, the common case (a Gaussian owns 2-3 instances, at most 16 here, with 1-2 flagged records each): walked one
+        // after the other, every record costs three DEPENDENT loads (inst_pos -> inst_mask -> record) and the wave waits for its
+        // lane with the most instances: stamps showed this phase taking 48k of a block's 62k cycles.  Here all positions, then all
+        // masks, then -- four instances at a time -- the first two flagged records of each instance are fetched as batches of
+        // independent loads.  The summation order is fixed (batch of 4 instances, round of 2 records, instance, slab), so gradients
+        // stay bitwise reproducible.
+        const bool mine = visible && n_inst <= COOP_INST;
+        PSTAMP(8);
+        uint32_t wmax = mine ? n_inst : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
+        // Loads are PREDICATED per lane (a lane without a k-th instance issues no request): the random 4- and 48-byte reads are
+        // bound by request count (stamps: 16 + 16 + 72 unconditional loads per lane cost 51k cycles per wave).  Each batch is waited
+        // for as a whole, so the compiler's vmcnt(0) after predicated loads costs nothing here.
+        // BUFFER loads: a lane without a k-th instance / j-th record passes an out-of-range offset, which returns 0 WITHOUT a memory
+        // request.  That keeps every load unconditional (no branch, so the compiler counts its waits exactly and a batch is in
+        // flight together) and free for absent lanes -- these random 4- and 48-byte reads are bound by request count (stamps:
+        // 104 unconditional global loads per lane cost 51k cycles per wave; predicated ones were each waited for at their join).
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr uint32_t OOB = 0xffffffffu, RSRC3 = 0x00020000u;
+        const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc((void*)inst_pos, 0, 0xffffff00u, RSRC3);
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)inst_mask, 0, 0xffffff00u, RSRC3);
+        const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)inst_grad, 0, 0xffffff00u, RSRC3);
+        const uint32_t slab_bytes = (uint32_t)(slab_stride_f4 * 16);
+        uint32_t pp[COOP_INST], mm[COOP_INST];
+#pragma unroll
+        for (int k = 0; k < (int)COOP_INST; k++)
+            pp[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pos, (mine && (uint32_t)k < n_inst) ? (off + k) * 4u : OOB, 0, 0);
+        PSTAMP(9);
+#pragma unroll
+        for (int k = 0; k < (int)COOP_INST; k++)
+            mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_inst) ? pp[k] * 4u : OOB, 0, 0);
+        PSTAMP(10);
+#pragma unroll
+        for (int kb = 0; kb < (int)COOP_INST; kb += 4) {
+            if ((uint32_t)kb < wmax) {                       // wave-uniform
+                uint32_t bits[4] = { mm[kb], mm[kb + 1], mm[kb + 2], mm[kb + 3] };
+                // rounds of (4 instances x their next 2 flagged records); almost always one round, an instance whose box covers
+                // a whole heavy tile has up to 16 records = 8 rounds.  The order (round, instance, slab) is fixed.
+                do {
+                    v4f rr[4][2][3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const bool any = bits[k] != 0u;
+                            const uint32_t sl = any ? (uint32_t)(__ffs((int)bits[k]) - 1) : 0u;
+                            bits[k] &= bits[k] - 1u;                               // (0 stays 0)
+                            const uint32_t o = any ? sl * slab_bytes + pp[kb + k] * 48u : OOB;
+                            rr[k][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
+                            rr[k][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 16u : OOB, 0, 0);
+                            rr[k][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 32u : OOB, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            // (slots not loaded are exact zeros: adding them changes nothing)
+                            gcol.x += rr[k][j][0].x; gcol.y += rr[k][j][0].y; gcol.z += rr[k][j][0].z; gmx += rr[k][j][0].w;
+                            gmy += rr[k][j][1].x; gca += rr[k][j][1].y; gcb += rr[k][j][1].z; gcc += rr[k][j][1].w;
+                            gop += rr[k][j][2].x;
+                        }
+                    }
+                } while (__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u) != 0ull);
+            }
+        }
+        k_first = COOP_INST;                                 // nothing left for the serial loop
+        PSTAMP(11);
+    }
     if (visible && n_inst <= COOP_INST) {
-        for (uint32_t k = 0; k < n_inst; k++) {
+        for (uint32_t k = k_first; k < n_inst; k++) {
             const uint32_t pos = inst_pos[off + k];
             if (SLABS < 0) {
                 // sparse records of the wave blend kernels: only the slabs flagged in the instance's mask, ascending
@@ -498,7 +575,18 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
         }
     }
+    PSTAMP(12);
+    if (STAGE_SH) {                                          // the SH loads have long landed: into LDS (row stride 49: conflict-free rows)
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int f = threadIdx.x + j * blockDim.x;
+            float* d = &s_sh[(f / 12) * SH_ROW + (f % 12) * 4];
+            d[0] = shv[j].x; d[1] = shv[j].y; d[2] = shv[j].z; d[3] = shv[j].w;
+        }
+    }
+    PSTAMP(1);
     if (STAGE_SH) __syncthreads();                           // SH records are in LDS
+    PSTAMP(2);
     if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
@@ -576,6 +664,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gmx + (proj[5] * m_w - proj[7] * mul2) * gmy;
         dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gmx + (proj[9] * m_w - proj[11] * mul2) * gmy;
 
+        PSTAMP(3);
         // ---- SH backward, backward.cu:20-139
         if (shs != nullptr) {
             const float* sh = STAGE_SH ? &s_sh[threadIdx.x * SH_ROW] : shs + (size_t)idx * M * 3;
@@ -650,6 +739,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
         }
 
+        PSTAMP(4);
         // ---- scale / rotation backward, backward.cu:278-341
         if (scales != nullptr) {
             const float r = rotations[4 * (size_t)idx], x = rotations[4 * (size_t)idx + 1], y = rotations[4 * (size_t)idx + 2], z = rotations[4 * (size_t)idx + 3];
@@ -698,6 +788,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
     reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
     }   // in_range
+    PSTAMP(5);
     if (STAGE_SH) {
         __syncthreads();                                     // every row now holds dL_dsh
         const size_t base4 = (size_t)blockIdx.x * blockDim.x * 12, total4 = (size_t)P * 12;
@@ -709,6 +800,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
         }
     }
+    PSTAMP(6);
+#undef PSTAMP
 }
 
 __global__ void __launch_bounds__(256)
@@ -787,7 +880,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, g_stamps)
     // SLABS: -1 = sparse records selected by inst_mask (wave blend kernels), 4 = four dense slabs, 0 = run-time count
     const int sl = blend_impl() ? -1 : (b.slabs == 4 ? 4 : 0);
     if (stage) { if (sl < 0) LAUNCH_PB(true, -1); else if (sl == 4) LAUNCH_PB(true, 4); else LAUNCH_PB(true, 0); }
