@@ -72,7 +72,7 @@ def main():
     from moss_amd import scenes, _lib
     from moss_amd.gaussian_model import GaussianSet
     from moss_amd.gaussian_renderer import render, camera_view
-    from moss_amd.loss import training_loss_fused as training_loss     # HIP-fused L1 + SSIM + mask loss (same value/grads)
+    from moss_amd.loss import training_loss_fused as training_loss, backward_from_loss     # HIP-fused L1 + SSIM + mask loss
     from types import SimpleNamespace
 
     rank, world, local_rank = mdist.init_from_env()
@@ -115,7 +115,7 @@ def main():
             bucket.attach()             # zero the bucket; autograd accumulates into it
         out = render(cam, pc, pipe, bg)
         loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
-        loss.backward()
+        backward_from_loss(loss)
         if pipe.fused_activations:
             bucket.collect()
         bucket.loss_slot.copy_(loss.detach().reshape(1))

@@ -16,7 +16,24 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
              Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
              const float* __restrict__ step_state)
 {
-    if (step_state) { bc1 = step_state[1]; bc2_sqrt = step_state[2]; }      // device-resident step counter (graph replay)
+    __shared__ float s_bc[2];
+    int t_dev = 0;
+    if (step_state) {
+        // Device-resident step counter (graph replay): the LAST block of a step to finish stores t back and caches the bias
+        // corrections of step t + 1 (double precision like the host path), which is after every block has read the old values.
+        // No separate "tick" launch (a minimal launch costs 4-5 us here).
+        if (threadIdx.x == 0) {
+            t_dev = reinterpret_cast<const int*>(step_state)[0] + 1;
+            if (t_dev == 1) {                                // first step ever: nothing cached yet
+                s_bc[0] = (float)(1.0 - pow((double)beta1, 1.0));
+                s_bc[1] = (float)sqrt(1.0 - pow((double)beta2, 1.0));
+            } else {                                         // cached by the previous step's last block (two double pow() per
+                s_bc[0] = step_state[1]; s_bc[1] = step_state[2];     // block on the critical path cost ~25 us per step)
+            }
+        }
+        __syncthreads();
+        bc1 = s_bc[0]; bc2_sqrt = s_bc[1];
+    }
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
         const long long i = i4 * 4;
         float pv[4], gv[4], mv[4], vv[4];
@@ -49,15 +66,15 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             for (int k = 0; k < 4; k++) if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
         }
     }
-}
-
-// One thread: advance the device-resident step counter and derive the two bias corrections from it.
-__global__ void adamw_tick_kernel(float* state, float beta1, float beta2)
-{
-    const int t = reinterpret_cast<int*>(state)[0] + 1;
-    reinterpret_cast<int*>(state)[0] = t;
-    state[1] = (float)(1.0 - pow((double)beta1, (double)t));
-    state[2] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    if (step_state && threadIdx.x == 0) {
+        int* st = reinterpret_cast<int*>(const_cast<float*>(step_state));
+        if (atomicAdd(&st[3], 1) == (int)gridDim.x - 1) {
+            float* sf = const_cast<float*>(step_state);
+            sf[1] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));      // bias corrections of the NEXT step
+            sf[2] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
+            st[0] = t_dev; st[3] = 0;
+        }
+    }
 }
 
 int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
@@ -67,7 +84,9 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
     Segs segs; segs.n = num_segments;
     for (int i = 0; i < 8; i++) { segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f; }
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    // (grid-stride kernel) few enough blocks that the one same-address atomic each of them issues at its end does not serialise
+    // into tens of microseconds (4096 blocks: +34 us), enough threads to keep HBM busy (128k threads x 64 B in flight)
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
                        segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state);
@@ -95,8 +114,7 @@ extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* 
 {
     if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || !step_state)
         return MOSS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(moss::adamw_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (float*)step_state, beta1, beta2);
-    if (n == 0) return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+    if (n == 0) return MOSS_ERR_INVALID_ARG;                 // the counter advances inside the update kernel: nothing to launch
     return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, beta1, beta2, eps,
                               weight_decay, 1.f, 1.f, (const float*)step_state, (hipStream_t)stream);
 }

@@ -93,8 +93,23 @@ class _FusedPhotometricLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (d_both,) = ctx.saved_tensors
-        scaled = grad_out * d_both
+        # the loss is normally the root of the graph: its incoming gradient is then the constant 1 handed to backward() by
+        # `backward_from_loss` below, recognised by identity -- multiplying by exactly 1.0 would be a no-op kernel
+        unit = _UNIT.get(d_both.device)
+        scaled = d_both if (unit is not None and grad_out.data_ptr() == unit.data_ptr()) else grad_out * d_both
         return scaled[:ctx.C], scaled[ctx.C:].reshape(ctx.alpha_shape), None, None, None, None
+
+
+_UNIT = {}
+
+
+def backward_from_loss(loss):
+    """``loss.backward()`` without the two minimal kernels autograd would launch for a root loss (ones_like fill + scaling of the
+    loss gradients by 1.0): the unit gradient is a cached constant that the fused loss recognises."""
+    one = _UNIT.get(loss.device)
+    if one is None:
+        one = _UNIT[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    torch.autograd.backward(loss, grad_tensors=one)
 
 
 def training_loss_fused(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5):

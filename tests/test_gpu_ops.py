@@ -462,3 +462,18 @@ def test_render_with_fused_activations_equals_torch_getters(gpu, hip_lib):
         assert hp.rel_err(a[2].cpu().numpy(), b[2].cpu().numpy()) < 1e-4
         for ga, gb in zip(a[1], b[1]):
             assert hp.rel_err(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-4
+
+
+def test_backward_from_loss_equals_loss_backward(gpu, hip_lib):
+    """backward_from_loss() (cached unit gradient, no ones_like fill, no multiply-by-one kernel) gives bit-identical gradients."""
+    from moss_amd.loss import training_loss_fused, backward_from_loss
+    torch.manual_seed(2)
+    img = torch.rand(3, 96, 80, device=gpu); alpha = torch.rand(1, 96, 80, device=gpu)
+    gt = torch.rand(3, 96, 80, device=gpu); mask = (torch.rand(1, 96, 80, device=gpu) > 0.5).float()
+    res = []
+    for fn in (lambda l: l.backward(), backward_from_loss, lambda l: (2.0 * l).backward()):
+        a = img.clone().requires_grad_(True); b = alpha.clone().requires_grad_(True)
+        fn(training_loss_fused(a, b, gt, mask))
+        res.append((a.grad.clone(), b.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.allclose(res[2][0], 2.0 * res[0][0], rtol=1e-6, atol=0) and torch.allclose(res[2][1], 2.0 * res[0][1], rtol=1e-6, atol=0)
