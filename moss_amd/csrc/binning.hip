@@ -252,6 +252,36 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
         uint32_t bmask = 0u;
 #pragma unroll
         for (int by = 0; by < 4; by++) if (ym & (1u << by)) bmask |= xm << (4 * by);
+        // Refinement: the box is loose for elongated, rotated Gaussians.  A pixel can only pass the alpha >= 1/255 test if
+        // q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy <= tau = ln(255 opacity) (forward.cu:336-350), so a block whose MINIMUM of the convex
+        // form q over its pixel rectangle exceeds tau (plus a margin for fp32 rounding: 1e-4 relative + 1e-3 absolute, against
+        // |q| <= 5.6 at the threshold) cannot contribute and loses its bit.  Only done for finite extents (otherwise the box
+        // decision stands).  Every wasted (entry, block) pair costs a quarter of a blend trip, forward and backward.
+        const float4 gb = g.geo_b[id];
+        const float A = gb.x, B = gb.y, C = gb.z, opa = gb.w;
+        if (bmask != 0u && ga.z < 3.0e38f && ga.w < 3.0e38f && A > 0.0f && C > 0.0f && opa > 0.0f) {
+            const float tau = logf(255.0f * opa);
+            const float invA = 1.0f / A, invC = 1.0f / C;
+            uint32_t keep = 0u;
+#pragma unroll
+            for (int by = 0; by < 4; by++) {
+#pragma unroll
+                for (int bx = 0; bx < 4; bx++) {
+                    const float x0 = (float)(tx * TILE + 4 * bx) - ga.x, x1 = x0 + 3.0f;       // rectangle in d = pixel - mean
+                    const float y0 = (float)(ty * TILE + 4 * by) - ga.y, y1 = y0 + 3.0f;
+                    float qmin = 0.0f;
+                    if (!(x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f)) {
+                        // the minimum lies on the boundary: each edge is a 1-D quadratic, minimised at its clamped vertex
+                        auto qf = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
+                        const float ya = fminf(fmaxf(-B * x0 * invC, y0), y1), yb = fminf(fmaxf(-B * x1 * invC, y0), y1);
+                        const float xa = fminf(fmaxf(-B * y0 * invA, x0), x1), xb = fminf(fmaxf(-B * y1 * invA, x0), x1);
+                        qmin = fminf(fminf(qf(x0, ya), qf(x1, yb)), fminf(qf(xa, y0), qf(xb, y1)));
+                    }
+                    if (!(qmin * 0.9999f - 1.0e-3f > tau)) keep |= 1u << (4 * by + bx);    // (NaN keeps the bit)
+                }
+            }
+            bmask &= keep;
+        }
         inst_bmask[pos] = (uint16_t)bmask;
     }
     const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
@@ -328,7 +358,8 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
     // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) return;
-    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(1024), 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
+    static const int sort_threads = std::max(64, std::min(1024, env_int("MOSS_SORT_THREADS", 1024)));
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(sort_threads), 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
     hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, im.header, fp.gx, g, im.ranges, b.keys, b.inst_tile,
                        b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask);
 }

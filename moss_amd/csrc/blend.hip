@@ -635,25 +635,31 @@ __device__ __forceinline__ Rec load_rec(const float4* __restrict__ inst_rec, int
 // tiles with thousands of entries, spent most of the frame on those short lists.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
-                                                   const float4* __restrict__ inst_rec, float4 (*ring)[3],
-                                                   const float* __restrict__ bg_color, float* __restrict__ out_color,
+                                                   const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
+                                                   float4 (*ring)[3], const float* __restrict__ bg_color, float* __restrict__ out_color,
                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags)
 {
     const int ox = (tile % gx) * TILE + (q & 1) * 8, oy = (tile / gx) * TILE + (q >> 1) * 8;
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float pixx = (float)px, pixy = (float)py, bx0 = (float)ox, by0 = (float)oy;
+    const float pixx = (float)px, pixy = (float)py;
     const int n = (int)(rg.y - rg.x);
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;
     uint32_t last_contributor = 0;
     bool live = inside;
+    // the quadrant's blocks in the per-instance block mask: q = (qy, qx) covers blocks (2qy..2qy+1, 2qx..2qx+1)
+    const uint32_t qmask = 0x0033u << (2 * (q & 1) + 8 * (q >> 1));
+    const uint16_t* const bm = inst_bmask + rg.x;
     Rec cur = load_rec(inst_rec, (int)rg.x, n, lane, 1);
+    uint32_t bmk = bm[min(lane, n - 1)];
     for (int base = 0; base < n; base += 64) {
         const Rec nxt = load_rec(inst_rec, (int)rg.x + min(base + 64, n - 1), n - base - 64, lane, 1);
+        const uint32_t bmk_nxt = bm[min(base + 64 + lane, n - 1)];
         bool hit = base + lane < n;
-        if (hit && (flags & 1)) hit = block_hit(cur.a, bx0, by0, 7.0f, 7.0f);
+        if (hit && (flags & 1)) hit = (bmk & qmask) != 0u;                   // one of the quadrant's four 4x4 blocks can be reached
         unsigned long long m = __ballot(hit);
+        bmk = bmk_nxt;
         ring[lane][0] = cur.a; ring[lane][1] = cur.b; ring[lane][2] = cur.c;
         __builtin_amdgcn_wave_barrier();
         while (m != 0ull) {
@@ -699,8 +705,8 @@ __device__ __forceinline__ float row_sum16(float v)
 }
 
 __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
-                                                    const float4* __restrict__ inst_rec, float4 (*ring)[3],
-                                                    const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
+                                                    const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
+                                                    float4 (*ring)[3], const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
                                                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                                                     const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
                                                     float* __restrict__ inst_grad, size_t slab_stride, uint32_t* __restrict__ inst_mask,
@@ -709,7 +715,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
     const int ox = (tile % gx) * TILE + (q & 1) * 8, oy = (tile / gx) * TILE + (q >> 1) * 8;
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float pixx = (float)px, pixy = (float)py, bx0 = (float)ox, by0 = (float)oy;
+    const float pixx = (float)px, pixy = (float)py;
     const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
     const float T_final = inside ? final_Ts[pix_id] : 0.0f;
     const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
@@ -732,12 +738,17 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
     float T = T_final, Q = 0.0f;
 
     const int first = (int)rg.x + n_eff - 1;                 // back to front
+    const uint32_t qmask = 0x0033u << (2 * (q & 1) + 8 * (q >> 1));
+    const uint16_t* const bm = inst_bmask + rg.x;
     Rec cur = load_rec(inst_rec, first, n_eff, lane, -1);
+    uint32_t bmk = bm[max(n_eff - 1 - lane, 0)];
     for (int base = 0; base < n_eff; base += 64) {
         const Rec nxt = load_rec(inst_rec, first - min(base + 64, n_eff - 1), n_eff - base - 64, lane, -1);
+        const uint32_t bmk_nxt = bm[max(n_eff - 1 - (base + 64 + lane), 0)];
         bool hit = base + lane < n_eff;
-        if (hit && (flags & 1)) hit = block_hit(cur.a, bx0, by0, 7.0f, 7.0f);
+        if (hit && (flags & 1)) hit = (bmk & qmask) != 0u;
         unsigned long long m = __ballot(hit);
+        bmk = bmk_nxt;
         ring[lane][0] = cur.a; ring[lane][1] = cur.b; ring[lane][2] = cur.c;
         __builtin_amdgcn_wave_barrier();
         while (m != 0ull) {
@@ -1192,7 +1203,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
                                out_depth, out_alpha, final_T, n_contrib, flags,
                                stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr);
         else
-            light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, s_ring[wv], bg_color, out_color, out_depth,
+            light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, s_ring[wv], bg_color, out_color, out_depth,
                                out_alpha, final_T, n_contrib, flags);
     }
 
@@ -1235,7 +1246,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
             heavy_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
                                 n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
         else
-            light_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, s_ring[wv], bg_color, final_Ts, n_contrib,
+            light_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, s_ring[wv], bg_color, final_Ts, n_contrib,
                                 dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
     }
     // Self-cleaning queue: every wave has made its last pull by now, so the last one to leave rewinds the heads for the next
