@@ -91,7 +91,9 @@ def main():
         scene.camera = scenes.make_camera(c0.W, c0.H, float(c0.K[0, 0]), float(c0.K[1, 1]), float(c0.K[0, 2]), float(c0.K[1, 2]), R_, t_)
     cam = camera_view(scene.camera, dev)
     H, W = scene.camera.H, scene.camera.W
-    pc = GaussianSet(scene, sh_degree=3, device=dev)
+    # SH coefficients as one (P,16,3) parameter (no per-step concat) whenever the flat optimizer can give dc / rest their two rates
+    unified = not args.torch_adamw and not args.torch_activations
+    pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode == "precomp"), debug=False,
                            fused_activations=not args.torch_activations)
     bg = torch.zeros(3, device=dev)
@@ -107,6 +109,8 @@ def main():
     from moss_amd import diff_gaussian_rasterization as dgr
     use_graph = bool(args.graph) and args.forward == "async" and not args.torch_adamw
     dgr.set_async(args.forward == "async")
+    if unified:
+        dgr.set_grad_sink(sh=lambda: bucket.sink_for(pc._features))       # dL_dsh is written straight into the gradient bucket
 
     def compute():                      # everything of a step that is local to this rank
         if pipe.fused_activations:

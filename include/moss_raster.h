@@ -192,9 +192,14 @@ int moss_photometric_loss(int C, int H, int W, const float* image, const float* 
  * Flat fused AdamW (torch.optim.AdamW semantics, amsgrad off) over `n` contiguous fp32 parameters with their gradients and
  * moments; up to 8 learning-rate segments: parameter i belongs to the first segment s with i < segment_end[s] (host arrays).
  * Replaces the per-group optimizer step of scene/gaussian_model.py:215-226 for the Gaussian parameters.  `step` counts from 1.
+ * Optional periodic pattern per segment (all three arrays NULL = none): where segment_period[s] > 0, element j of segment s uses
+ * segment_lr[s] if j % segment_period[s] < segment_split[s], else segment_lr2[s] -- e.g. the SH coefficients stored as ONE
+ * (P,16,3) tensor with the DC term's learning rate on the first 3 of every 48 floats and lr/20 on the rest (the reference's
+ * separate f_dc / f_rest groups, without the per-step torch.cat of get_features).
  */
 int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     int num_segments, const long long* segment_end, const float* segment_lr,
+                    const int* segment_period, const int* segment_split, const float* segment_lr2,
                     float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 /* Same update with the step counter kept on the device: `step_state` is 16 zero-initialised device bytes ([0] = int step,
  * advanced by one per call by the update kernel itself; [1], [2] = cached bias corrections of the next step; [3] = its
@@ -202,6 +207,7 @@ int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_a
  * counter, so a captured hipGraph of a training step replays correctly. */
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
+                            const int* segment_period, const int* segment_split, const float* segment_lr2,
                             float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
 
 /*
@@ -209,6 +215,7 @@ int moss_adamw_flat_devstep(long long n, float* params, const float* grads, floa
  * scene/gaussian_model.py:46-53 and :134-166: get_xyz identity, get_features = cat(_features_dc, _features_rest, dim=1),
  * get_opacity = sigmoid, get_scaling = exp, get_rotation = F.normalize (eps 1e-12)).  K = SH coefficients per channel
  * ((max_sh_degree+1)^2); features_dc is (P,1,3), features_rest (P,K-1,3), out_features (P,K,3); all fp32, contiguous.
+ * K = 0: the features are not touched (callers that keep them as one (P,K,3) tensor need no concatenation).
  * Backward: a NULL incoming gradient means that output was unused (its parameter gets zeros); every element of every d_*
  * array is written exactly once, so destinations (e.g. slices of a flat gradient bucket) need no zero fill.
  */

@@ -160,9 +160,9 @@ extern "C" int moss_gaussian_activate_forward(int P, int K, const float* xyz, co
                                               float* out_xyz, float* out_features, float* out_opacity, float* out_scaling,
                                               float* out_rotation, void* stream)
 {
-    if (P < 0 || K < 1) return MOSS_ERR_INVALID_ARG;
+    if (P < 0 || K < 0) return MOSS_ERR_INVALID_ARG;
     if (P == 0) return 0;
-    if (!xyz || !features_dc || (K > 1 && !features_rest) || !opacity || !scaling || !rotation || !out_xyz || !out_features ||
+    if (!xyz || (K > 0 && !features_dc) || (K > 1 && !features_rest) || !opacity || !scaling || !rotation || !out_xyz || (K > 0 && !out_features) ||
         !out_opacity || !out_scaling || !out_rotation)
         return MOSS_ERR_INVALID_ARG;
     const moss::Sections sec = moss::make_sections(P, K);
@@ -178,9 +178,9 @@ extern "C" int moss_gaussian_activate_backward(int P, int K, const float* rotati
                                                float* d_xyz, float* d_features_dc, float* d_features_rest, float* d_opacity,
                                                float* d_scaling, float* d_rotation, void* stream)
 {
-    if (P < 0 || K < 1) return MOSS_ERR_INVALID_ARG;
+    if (P < 0 || K < 0) return MOSS_ERR_INVALID_ARG;
     if (P == 0) return 0;
-    if (!rotation || !out_opacity || !out_scaling || !d_xyz || !d_features_dc || (K > 1 && !d_features_rest) || !d_opacity ||
+    if (!rotation || !out_opacity || !out_scaling || !d_xyz || (K > 0 && !d_features_dc) || (K > 1 && !d_features_rest) || !d_opacity ||
         !d_scaling || !d_rotation)
         return MOSS_ERR_INVALID_ARG;
     const moss::Sections sec = moss::make_sections(P, K);

@@ -9,7 +9,7 @@
 namespace moss {
 namespace {
 
-struct Segs { int n; long long end[8]; float lr[8]; };
+struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; float lr2[8]; };
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -51,7 +51,13 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             float lr = 0.f;
             const long long idx = i + k;
 #pragma unroll
-            for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) lr = segs.lr[s];
+            for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) {
+                lr = segs.lr[s];
+                if (segs.period[s] > 0) {                    // periodic pattern: the first `split` of every `period` elements use lr, the rest lr2
+                    const long long local = idx - (s > 0 ? segs.end[s - 1] : 0);
+                    if ((int)(local % segs.period[s]) >= segs.split[s]) lr = segs.lr2[s];
+                }
+            }
             pv[k] *= 1.0f - lr * weight_decay;
             mv[k] = beta1 * mv[k] + (1.0f - beta1) * gv[k];
             vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
@@ -78,11 +84,16 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
 }
 
 int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
-                 const long long* segment_end, const float* segment_lr, float beta1, float beta2, float eps, float weight_decay,
+                 const long long* segment_end, const float* segment_lr, const int* segment_period, const int* segment_split,
+                 const float* segment_lr2, float beta1, float beta2, float eps, float weight_decay,
                  float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream)
 {
     Segs segs; segs.n = num_segments;
-    for (int i = 0; i < 8; i++) { segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f; }
+    for (int i = 0; i < 8; i++) {
+        segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f;
+        const bool pat = i < num_segments && segment_period && segment_split && segment_lr2 && segment_period[i] > 0;
+        segs.period[i] = pat ? segment_period[i] : 0; segs.split[i] = pat ? segment_split[i] : 0; segs.lr2[i] = pat ? segment_lr2[i] : 0.f;
+    }
     long long blocks = (n / 4 + 255) / 256;
     // (grid-stride kernel) few enough blocks that the one same-address atomic each of them issues at its end does not serialise
     // into tens of microseconds (4096 blocks: +34 us), enough threads to keep HBM busy (128k threads x 64 B in flight)
@@ -98,23 +109,27 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
 
 extern "C" int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                int num_segments, const long long* segment_end, const float* segment_lr,
+                               const int* segment_period, const int* segment_split, const float* segment_lr2,
                                float beta1, float beta2, float eps, float weight_decay, int step, void* stream)
 {
     if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || step < 1)
         return MOSS_ERR_INVALID_ARG;
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, beta1, beta2, eps,
-                              weight_decay, (float)bc1, (float)sqrt(bc2), nullptr, (hipStream_t)stream);
+    return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
+                              segment_split, segment_lr2, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), nullptr,
+                              (hipStream_t)stream);
 }
 
 extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                        int num_segments, const long long* segment_end, const float* segment_lr,
+                                       const int* segment_period, const int* segment_split, const float* segment_lr2,
                                        float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream)
 {
     if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || !step_state)
         return MOSS_ERR_INVALID_ARG;
     if (n == 0) return MOSS_ERR_INVALID_ARG;                 // the counter advances inside the update kernel: nothing to launch
-    return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, beta1, beta2, eps,
-                              weight_decay, 1.f, 1.f, (const float*)step_state, (hipStream_t)stream);
+    return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
+                              segment_split, segment_lr2, beta1, beta2, eps, weight_decay, 1.f, 1.f, (const float*)step_state,
+                              (hipStream_t)stream);
 }

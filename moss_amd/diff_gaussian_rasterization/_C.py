@@ -39,6 +39,14 @@ class _AsyncState:
 
 ASYNC = _AsyncState()
 
+# Optional destination for dL_dsh: a callable returning a fresh (P, M, 3) float32 tensor (e.g. a view into a flat gradient
+# bucket) that the backward kernel fills instead of a newly allocated one; autograd then adopts it as .grad without a copy.
+GRAD_SINK = {"sh": None}
+
+
+def set_grad_sink(sh=None):
+    GRAD_SINK["sh"] = sh
+
 
 def set_async(enabled: bool, capacity: int = 0, margin: float = 2.0):
     ASYNC.enabled, ASYNC.capacity, ASYNC.margin, ASYNC.pending = bool(enabled), int(capacity), float(margin), None
@@ -196,7 +204,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dconic = alloc((P, 2, 2), **fopts)
     dL_dopacity = alloc((P, 1), **fopts)
     dL_dcov3D = alloc((P, 6), **fopts)
-    dL_dsh = alloc((P, M, 3), **fopts)
+    dL_dsh = None
+    if GRAD_SINK["sh"] is not None and P != 0 and M != 0:
+        cand = GRAD_SINK["sh"]()
+        if cand is not None and tuple(cand.shape) == (P, M, 3) and cand.dtype == torch.float32 and cand.device == dev and cand.is_contiguous():
+            dL_dsh = cand
+    if dL_dsh is None:
+        dL_dsh = alloc((P, M, 3), **fopts)
     dL_dscales = alloc((P, 3), **fopts)
     dL_drotations = alloc((P, 4), **fopts)
     if P != 0:

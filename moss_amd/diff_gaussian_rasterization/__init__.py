@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from ._C import set_async, check_async_status  # noqa: F401  (opt-in asynchronous forward / hipGraph capture)
+from ._C import set_async, check_async_status, set_grad_sink  # noqa: F401  (opt-in: asynchronous forward / graph capture, dL_dsh sink)
 
 
 class GaussianRasterizationSettings(NamedTuple):

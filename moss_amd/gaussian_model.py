@@ -18,15 +18,23 @@ def inverse_sigmoid(x):
 
 
 class GaussianSet(nn.Module):
-    def __init__(self, scene, sh_degree=3, device="cpu"):
+    def __init__(self, scene, sh_degree=3, device="cpu", unified_features=False):
+        """unified_features: keep the SH coefficients as ONE (P,16,3) parameter ``_features`` -- ``_features_dc`` / ``_features_rest``
+        are then views of it and ``get_features`` needs no torch.cat (47 MB of copies per step and direction at 100k Gaussians).
+        The reference's two learning rates (f_dc, f_rest = f_dc / 20) become a periodic pattern of one optimizer segment
+        (``param_groups()`` -> FlatAdamW); torch.optim cannot express that, so this mode needs moss_amd.optim.FlatAdamW."""
         super().__init__()
+        self.unified_features = bool(unified_features)
         self.max_sh_degree = 3
         self.active_sh_degree = sh_degree
         self.motion_offset_flag = True
         dev = torch.device(device)
         self._xyz = nn.Parameter(scene.means3D.clone().to(dev))
-        self._features_dc = nn.Parameter(scene.shs[:, :1, :].clone().to(dev))
-        self._features_rest = nn.Parameter(scene.shs[:, 1:, :].clone().to(dev))
+        if self.unified_features:
+            self._features = nn.Parameter(scene.shs.clone().contiguous().to(dev))
+        else:
+            self._features_dc = nn.Parameter(scene.shs[:, :1, :].clone().to(dev))
+            self._features_rest = nn.Parameter(scene.shs[:, 1:, :].clone().to(dev))
         self._scaling = nn.Parameter(torch.log(scene.scales).to(dev))
         self._rotation = nn.Parameter(scene.rotations.clone().to(dev))
         self._opacity = nn.Parameter(inverse_sigmoid(scene.opacities.clamp(1e-4, 1 - 1e-4)).to(dev))
@@ -48,8 +56,19 @@ class GaussianSet(nn.Module):
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
+    def __getattr__(self, name):
+        # unified mode: the reference's two tensors as views of the single parameter
+        if name in ("_features_dc", "_features_rest"):
+            params = self.__dict__.get("_parameters", {})
+            if "_features" in params:
+                f = params["_features"]
+                return f[:, :1, :] if name == "_features_dc" else f[:, 1:, :]
+        return super().__getattr__(name)
+
     @property
     def get_features(self):
+        if self.unified_features:
+            return self._features
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
     def activate(self, bucket=None):
@@ -57,8 +76,12 @@ class GaussianSet(nn.Module):
         namespace with get_xyz / get_features / get_opacity / get_scaling / get_rotation / get_covariance, i.e. it can stand in
         for ``self`` wherever the render binding reads the activated parameters."""
         from .activations import activate_gaussians
-        xyz, feat, opa, scl, rot = activate_gaussians(self._xyz, self._features_dc, self._features_rest, self._opacity,
-                                                      self._scaling, self._rotation, bucket)
+        if self.unified_features:
+            xyz, _, opa, scl, rot = activate_gaussians(self._xyz, None, None, self._opacity, self._scaling, self._rotation, bucket)
+            feat = self._features                          # handed to the rasterizer as it is
+        else:
+            xyz, feat, opa, scl, rot = activate_gaussians(self._xyz, self._features_dc, self._features_rest, self._opacity,
+                                                          self._scaling, self._rotation, bucket)
         raw_rotation = self._rotation
         return SimpleNamespace(
             get_xyz=xyz, get_features=feat, get_opacity=opa, get_scaling=scl, get_rotation=rot,
@@ -70,10 +93,15 @@ class GaussianSet(nn.Module):
 
     def param_groups(self):
         """AdamW groups with the reference's learning rates (arguments/__init__.py:66-79, gaussian_model.py:215-226)."""
+        if self.unified_features:
+            k3 = 3 * int(self._features.shape[1])
+            feats = [{"params": [self._features], "lr": 0.0025, "lr_pattern": (k3, 3, 0.0025 / 20.0), "name": "features"}]
+        else:
+            feats = [{"params": [self._features_dc], "lr": 0.0025, "name": "f_dc"},
+                     {"params": [self._features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"}]
         return [
             {"params": [self._xyz], "lr": 0.00016, "name": "xyz"},
-            {"params": [self._features_dc], "lr": 0.0025, "name": "f_dc"},
-            {"params": [self._features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+            *feats,
             {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
             {"params": [self._scaling], "lr": 0.005, "name": "scaling"},
             {"params": [self._rotation], "lr": 0.001, "name": "rotation"},

@@ -18,25 +18,32 @@ class FlatAdamW:
         the training step replays with the right bias correction (the analogue of torch.optim.AdamW(capturable=True))."""
         self.bucket = bucket
         params = bucket.params
-        lr_of = {}
+        lr_of, pat_of = {}, {}
         for gidx, grp in enumerate(param_groups):
             for p in grp["params"]:
                 lr_of[id(p)] = float(grp["lr"])
+                # optional periodic pattern (period, split, lr_rest): first `split` of every `period` elements use lr, the rest lr_rest
+                pat_of[id(p)] = grp.get("lr_pattern")
         total = sum(bucket.sizes)
         dev = params[0].device
         self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)
         off = 0
-        ends, lrs = [], []
+        ends, lrs, periods, splits, lr2s = [], [], [], [], []
         for p, n in zip(params, bucket.sizes):
             self.flat_params[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_params[off:off + n].view_as(p)              # the parameter now lives in the flat buffer
             off += n
             ends.append(off); lrs.append(lr_of[id(p)])
+            pat = pat_of[id(p)]
+            periods.append(int(pat[0]) if pat else 0); splits.append(int(pat[1]) if pat else 0); lr2s.append(float(pat[2]) if pat else 0.0)
         if len(ends) > 8:
             raise ValueError("FlatAdamW supports at most 8 learning-rate segments")
         self.n = total
         self.seg_end = (C.c_longlong * len(ends))(*ends)
         self.seg_lr = (C.c_float * len(lrs))(*lrs)
+        self.seg_period = (C.c_int * len(ends))(*periods)
+        self.seg_split = (C.c_int * len(ends))(*splits)
+        self.seg_lr2 = (C.c_float * len(ends))(*lr2s)
         self.nseg = len(ends)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -61,7 +68,7 @@ class FlatAdamW:
             with torch.cuda.device(dev):
                 rc = lib().moss_adamw_flat_devstep(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(),
                                                    self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end,
-                                                   self.seg_lr, float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                   self.seg_lr, self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                                    float(self.weight_decay), self.step_state.data_ptr(),
                                                    torch.cuda.current_stream(dev).cuda_stream)
             check(rc, "adamw_flat_devstep")
@@ -69,6 +76,6 @@ class FlatAdamW:
         with torch.cuda.device(dev):
             rc = lib().moss_adamw_flat(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
-                                       float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                       self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                        self.t, torch.cuda.current_stream(dev).cuda_stream)
         check(rc, "adamw_flat")

@@ -477,3 +477,66 @@ def test_backward_from_loss_equals_loss_backward(gpu, hip_lib):
         res.append((a.grad.clone(), b.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.allclose(res[2][0], 2.0 * res[0][0], rtol=1e-6, atol=0) and torch.allclose(res[2][1], 2.0 * res[0][1], rtol=1e-6, atol=0)
+
+
+def test_flat_adamw_periodic_learning_rates(gpu, hip_lib):
+    """One (P,16,3) SH parameter with the dc rate on the first 3 of every 48 floats and the rest rate elsewhere == torch.optim.AdamW
+    over separate f_dc / f_rest tensors (the reference's two parameter groups, scene/gaussian_model.py:215-226)."""
+    from moss_amd.dist import GradBucket
+    from moss_amd.optim import FlatAdamW
+    torch.manual_seed(5)
+    P = 333
+    init = torch.randn(P, 16, 3)
+    xyz0 = torch.randn(P, 3)
+    uni = torch.nn.Parameter(init.clone().to(gpu)); xa = torch.nn.Parameter(xyz0.clone().to(gpu))
+    dc = torch.nn.Parameter(init[:, :1].clone().to(gpu)); rest = torch.nn.Parameter(init[:, 1:].clone().to(gpu)); xb = torch.nn.Parameter(xyz0.clone().to(gpu))
+    ref = torch.optim.AdamW([{"params": [xb], "lr": 0.01}, {"params": [dc], "lr": 0.0025}, {"params": [rest], "lr": 0.0025 / 20}], lr=0.0, eps=1e-15)
+    bucket = GradBucket([xa, uni])
+    opt = FlatAdamW([{"params": [xa], "lr": 0.01}, {"params": [uni], "lr": 0.0025, "lr_pattern": (48, 3, 0.0025 / 20)}], bucket, eps=1e-15,
+                    capturable=True)
+    for it in range(4):
+        bucket.attach()
+        g = torch.randn(P, 16, 3, device=gpu); gx = torch.randn(P, 3, device=gpu)
+        uni.grad.copy_(g); xa.grad.copy_(gx)
+        dc.grad = g[:, :1].clone(); rest.grad = g[:, 1:].clone(); xb.grad = gx.clone()
+        opt.step(); ref.step()
+    assert hp.rel_err(uni[:, :1].detach().cpu().numpy(), dc.detach().cpu().numpy()) < 1e-6
+    assert hp.rel_err(uni[:, 1:].detach().cpu().numpy(), rest.detach().cpu().numpy()) < 1e-6
+    assert hp.rel_err(xa.detach().cpu().numpy(), xb.detach().cpu().numpy()) < 1e-6
+
+
+def test_unified_features_step_equals_separate_features(gpu, hip_lib):
+    """GaussianSet(unified_features=True): render() + backward with the dL_dsh sink gives the same image and the same gradients as
+    the reference's separate _features_dc / _features_rest parameters (and writes them into the bucket without a copy)."""
+    from types import SimpleNamespace
+    from moss_amd.dist import GradBucket
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    import moss_amd.diff_gaussian_rasterization as dgr
+    s = scenes.config2()
+    cam = camera_view(s.camera, gpu)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+    out = {}
+    try:
+        for uni in (False, True):
+            pc = GaussianSet(s, device=gpu, unified_features=uni)
+            bucket = GradBucket(list(pc.parameters()))
+            pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, fused_activations=True,
+                                   grad_bucket=bucket)
+            dgr.set_grad_sink(sh=(lambda: bucket.sink_for(pc._features)) if uni else None)
+            bucket.flat.fill_(float("nan"))
+            bucket.detach_grads()
+            r = render(cam, pc, pipe, bg)
+            ((r["render"] * w).sum() + r["render_alpha"].sum()).backward()
+            if uni:
+                assert pc._features.grad.data_ptr() == bucket.sink_for(pc._features).data_ptr()      # adopted, not copied
+            bucket.collect()
+            assert not torch.isnan(bucket.flat[:-1]).any()
+            feat_grad = pc._features.grad if uni else torch.cat((pc._features_dc.grad, pc._features_rest.grad), dim=1)
+            out[uni] = (r["render"].detach().clone(), feat_grad.clone(), pc._xyz.grad.clone(), pc._opacity.grad.clone(),
+                        pc._scaling.grad.clone(), pc._rotation.grad.clone())
+    finally:
+        dgr.set_grad_sink(sh=None)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
