@@ -46,18 +46,38 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
         } else {
             for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
         }
+        // learning rate of each of the 4 elements: segment lookup, then the segment's optional periodic pattern (ONE 32-bit modulo
+        // per thread for the first element, stepped for the others: a 64-bit modulo per element cost 12 us per step)
+        float lr4[4];
+        {
+            int s0 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float lr = 0.f;
-            const long long idx = i + k;
+            for (int s = 7; s >= 0; s--) if (s < segs.n && i < segs.end[s]) s0 = s;
+            const long long start0 = s0 > 0 ? segs.end[s0 - 1] : 0;
+            unsigned ph = segs.period[s0] > 0 ? (unsigned)((unsigned long long)(i - start0) % (unsigned)segs.period[s0]) : 0u;
 #pragma unroll
-            for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) {
-                lr = segs.lr[s];
-                if (segs.period[s] > 0) {                    // periodic pattern: the first `split` of every `period` elements use lr, the rest lr2
-                    const long long local = idx - (s > 0 ? segs.end[s - 1] : 0);
-                    if ((int)(local % segs.period[s]) >= segs.split[s]) lr = segs.lr2[s];
+            for (int k = 0; k < 4; k++) {
+                const long long idx = i + k;
+                if (idx < segs.end[s0] || s0 + 1 >= segs.n) {          // still in the first element's segment (the common case)
+                    lr4[k] = (segs.period[s0] > 0 && (int)ph >= segs.split[s0]) ? segs.lr2[s0] : segs.lr[s0];
+                    if (++ph == (unsigned)segs.period[s0]) ph = 0u;
+                } else {                                               // crossed into a later segment: general lookup
+                    float lr = 0.f;
+#pragma unroll
+                    for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) {
+                        lr = segs.lr[s];
+                        if (segs.period[s] > 0) {
+                            const long long local = idx - (s > 0 ? segs.end[s - 1] : 0);
+                            if ((int)(local % segs.period[s]) >= segs.split[s]) lr = segs.lr2[s];
+                        }
+                    }
+                    lr4[k] = lr;
                 }
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float lr = lr4[k];
             pv[k] *= 1.0f - lr * weight_decay;
             mv[k] = beta1 * mv[k] + (1.0f - beta1) * gv[k];
             vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
