@@ -121,6 +121,7 @@ __constant__ const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, 
 // K1: forward preprocess, one thread per Gaussian (grid-stride).  Also counts instances per tile: lanes add into
 // an LDS-private histogram and the block flushes its non-zero bins with one global atomic each.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int SH_ROW_F = 49;           // LDS row stride (floats) of a staged 48-float SH record
 __global__ void __launch_bounds__(256)
 preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           float tan_fovx, float tan_fovy, float focal_x, float focal_y, float scale_modifier, int prefiltered,
@@ -129,7 +130,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                           GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header,
-                          int* __restrict__ radii_out, int lds_hist)
+                          int* __restrict__ radii_out, int lds_hist, int stage_sh)
 {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
@@ -146,8 +147,27 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 
     // every thread runs the same number of iterations (the slot reservation below uses block barriers)
     const int iters = (P + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    // SH staging (M == 16 only): per thread a record is 48 floats at a 192-byte stride, i.e. each of the 48 scalar loads of a wave
+    // touches 64 cache lines.  The block's 256 records of this iteration are instead read with coalesced 16-byte loads into LDS
+    // (row stride 49 words: conflict-free) and evaluated from there -- same values, same arithmetic, so still bit-exact.
+    float* const s_shf = reinterpret_cast<float*>(s_hist + (lds_hist ? ((T + 3) & ~3) : 0));
     for (int it = 0; it < iters; it++) {
         const int idx = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        if (stage_sh) {
+            const size_t base4 = (size_t)(it * gridDim.x + blockIdx.x) * blockDim.x * 12, total4 = (size_t)P * 12;
+            const float4* src = reinterpret_cast<const float4*>(shs);
+            float4 v[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) v[j] = src[min(base4 + threadIdx.x + (size_t)j * blockDim.x, total4 - 1)];
+            __syncthreads();                                 // the previous iteration's readers are done
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const int f = threadIdx.x + j * blockDim.x;
+                float* d = &s_shf[(f / 12) * SH_ROW_F + (f % 12) * 4];
+                d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+            }
+            __syncthreads();
+        }
         int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
         if (idx < P) do {
             const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -198,7 +218,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             float3 rgb;
             uint8_t clamp_bits = 0;
             if (colors_precomp == nullptr) {
-                const float* sh = shs + (size_t)idx * M * 3;
+                const float* sh = stage_sh ? &s_shf[threadIdx.x * SH_ROW_F] : shs + (size_t)idx * M * 3;
                 float3 dir = make_float3(p_orig.x - campos.x, p_orig.y - campos.y, p_orig.z - campos.z);
                 const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                 dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
@@ -856,11 +876,14 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     static const int per_thread = env_int("MOSS_PREPROCESS_ITEMS", 2);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
-    const size_t lds = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
+    const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
+    const int stage_sh = (fp.M == 16 && shs != nullptr && colors_precomp == nullptr && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 &&
+                          lds_h + lds_s <= 65536 /* default dynamic-LDS limit of a launch */ && env_int("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
+    const size_t lds = lds_h + (stage_sh ? lds_s : 0);
     hipLaunchKernelGGL(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
-                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist);
+                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh);
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
