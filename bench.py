@@ -276,7 +276,9 @@ def main():
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                    "forward": args.forward, "launch": graph_note},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": _pmc_traffic(dominant),
+                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     # PMC bytes were collected on the headline workload (profiles/pmc_latest.json): null for any other
+                     "traffic": _pmc_traffic(dominant) if (args.config == "cfg3" and args.mode == "scale_rot") else None,
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
                      "timing": ("hipEvent pairs on the launch stream over an eager replay of the SAME K iterations (parameters and "
                                 "optimizer state restored to the start of the graph-replay timed region)") if use_graph else
