@@ -49,10 +49,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--mode", default="scale_rot", choices=["precomp", "scale_rot"],
+    ap.add_argument("--mode", default="scale_rot", choices=["precomp", "scale_rot", "lbs", "lbs_python"],
                     help="scale_rot = cov3D computed inside the rasterizer from scales+rotations (the reference's "
                          "compute_cov3D_python=False path, gaussian_renderer/__init__.py:92-93); precomp = cov3D computed by "
-                         "torch ops and passed in (MOSS's shipped default, arguments/__init__.py:60)")
+                         "torch ops and passed in (MOSS's shipped default, arguments/__init__.py:60); lbs = per-Gaussian 3x3 LBS-like "
+                         "transforms applied to the covariance INSIDE the op (extension row n2) vs lbs_python = the same transforms "
+                         "through MOSS's Python get_covariance (scene/gaussian_model.py:37-44)")
     ap.add_argument("--torch-adamw", action="store_true", help="use torch.optim.AdamW instead of the flat fused HIP AdamW")
     ap.add_argument("--forward", default="async", choices=["sync", "async"],
                     help="sync = the reference's behaviour (the host reads num_rendered back in every forward); async = "
@@ -78,6 +80,8 @@ def main():
     rank, world, local_rank = mdist.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if os.environ.get("MOSS_FORCE_DEVICE"):             # testing aid: several ranks on one GPU (with MOSS_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["MOSS_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -94,8 +98,12 @@ def main():
     # SH coefficients as one (P,16,3) parameter (no per-step concat) whenever the flat optimizer can give dc / rest their two rates
     unified = not args.torch_adamw and not args.torch_activations
     pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
-    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode == "precomp"), debug=False,
-                           fused_activations=not args.torch_activations)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode in ("precomp", "lbs_python")), debug=False,
+                           fused_activations=not args.torch_activations, transforms_in_op=(args.mode == "lbs"))
+    lbs_T = None
+    if args.mode in ("lbs", "lbs_python"):
+        gT = torch.Generator().manual_seed(1234)
+        lbs_T = (torch.eye(3) + 0.05 * torch.randn(scene.means3D.shape[0], 3, 3, generator=gT)).to(dev)
     bg = torch.zeros(3, device=dev)
     gt = scenes.synthetic_target(H, W).to(dev)
     gt_mask = (gt.mean(0, keepdim=True) > 0.5).float()
@@ -117,7 +125,7 @@ def main():
             bucket.detach_grads()       # gradients are WRITTEN into the bucket by the activation backward kernel
         else:
             bucket.attach()             # zero the bucket; autograd accumulates into it
-        out = render(cam, pc, pipe, bg)
+        out = render(cam, pc, pipe, bg, transforms=lbs_T)
         loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
         backward_from_loss(loss)
         if pipe.fused_activations:
@@ -256,7 +264,7 @@ def main():
     R = int(_C.last_num_rendered)
     N = H * W
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode == "scale_rot")
+    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"))
     all_b = dict(fwd_b); all_b.update(bwd_b)
     dom_bytes = all_b[dominant]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -312,7 +320,7 @@ def cpu_baseline(scene, args, gt, gt_mask):
     from moss_amd.loss import training_loss
     from tests import helpers as hp
     torch.set_num_threads(1)
-    d = hp.inputs_of(scene, args.mode)
+    d = hp.inputs_of(scene, "precomp" if args.mode == "lbs_python" else ("scale_rot" if args.mode == "lbs" else args.mode))
     gt_c, mask_c = gt.cpu(), gt_mask.cpu()
     n = max(1, args.cpu_iters)
     t0 = time.perf_counter()

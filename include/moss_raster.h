@@ -211,6 +211,35 @@ int moss_adamw_flat_devstep(long long n, float* params, const float* grads, floa
                             float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
 
 /*
+ * Extension: covariance with a per-Gaussian 3x3 transform INSIDE the op.
+ * MOSS feeds cov3D_precomp = strip_symmetric(T (R S S^T R^T) T^T) built by torch ops (scene/gaussian_model.py:37-44,168-169;
+ * gaussian_renderer/__init__.py:88-91) because the LBS transform T of each Gaussian changes every frame; on MI355X that Python
+ * path costs more than the whole rasterizer.  These two entry points take (scales, rotations, transforms (P,3,3) row-major)
+ * instead and return gradients for all three.  Same semantics otherwise as moss_raster_forward[_async] (capacity < 0:
+ * synchronous sizing of the binning buffer, >= 0: asynchronous with that capacity) and moss_raster_backward.
+ *   dL_dcov3D (P,6): gradient w.r.t. the transformed covariance (what the op stores); dL_dscale / dL_drot include the transform;
+ *   dL_dtransforms (P,9): written for every Gaussian (zeros for culled ones).
+ */
+int moss_raster_forward_tf(
+    moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream);
+int moss_raster_backward_tf(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, void* stream);
+
+/*
  * Gaussian parameter activations, forward and backward, one launch each (the rasterizer-facing getters of MOSS's GaussianModel,
  * scene/gaussian_model.py:46-53 and :134-166: get_xyz identity, get_features = cat(_features_dc, _features_rest, dim=1),
  * get_opacity = sigmoid, get_scaling = exp, get_rotation = F.normalize (eps 1e-12)).  K = SH coefficients per channel

@@ -45,6 +45,19 @@ def _declare(lib):
         _p, _p, _p, _p, _i, _p]                            # out_color, out_depth, out_alpha, radii, debug, stream
     lib.moss_raster_forward_async.restype = _i
     lib.moss_raster_forward_async.argtypes = list(lib.moss_raster_forward.argtypes)      # debug -> capacity (both int)
+    lib.moss_raster_forward_tf.restype = _i
+    lib.moss_raster_forward_tf.argtypes = list(lib.moss_raster_forward.argtypes)          # cov3D_precomp -> transforms, debug -> capacity
+    lib.moss_raster_backward_tf.restype = _i
+    lib.moss_raster_backward_tf.argtypes = [
+        _i, _i, _i, _i,                                    # P, D, M, R
+        _p, _i, _i,                                        # background, width, height
+        _p, _p, _p,                                        # means3D, shs, colors_precomp
+        _p, _f, _p, _p,                                    # scales, scale_modifier, rotations, transforms
+        _p, _p, _p, _f, _f,                                # viewmatrix, projmatrix, campos, tan_fovx, tan_fovy
+        _p, _p, _p,                                        # geom, binning, image buffers
+        _p, _p, _p,                                        # dL_dpix, dL_ddepths, dL_dalphas
+        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,            # dL_dmean2D .. dL_drot, dL_dtransforms
+        _p]                                                # stream
     lib.moss_raster_read_status.restype = _i
     lib.moss_raster_read_status.argtypes = [_p, _p, _p]
     lib.moss_raster_backward.restype = _i

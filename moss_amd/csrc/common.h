@@ -166,12 +166,13 @@ struct FrameParams {
 // ---- launchers (each defined in exactly one .hip file; all enqueue on `s`, none synchronises) -------------
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                               GeomView g, ImageView im, int* radii_out, hipStream_t s);
+                               const float* transforms, GeomView g, ImageView im, int* radii_out, hipStream_t s);
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 GeomView g, BinView b, const uint32_t* header,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                                const float* transforms, float* dL_dtransforms, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
 
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);

@@ -89,6 +89,60 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* sc, float mod,
     cov[3] = Sigma.m[1][1]; cov[4] = Sigma.m[1][2]; cov[5] = Sigma.m[2][2];
 }
 
+// n2 extension: covariance with a per-Gaussian 3x3 transform INSIDE the op, Sigma' = T Sigma T^T, as
+// scene/gaussian_model.py:37-44 builds it in Python.  T row-major, Sigma = 6-float upper triangle.  Same summation order as the
+// oracle's transformCov3D / transformCov3D_bw (this file is compiled with -ffp-contract=off: bit-identical).
+__device__ __forceinline__ void sym6_to_full(const float* c, float S[3][3])
+{
+    S[0][0] = c[0]; S[0][1] = c[1]; S[0][2] = c[2];
+    S[1][0] = c[1]; S[1][1] = c[3]; S[1][2] = c[4];
+    S[2][0] = c[2]; S[2][1] = c[4]; S[2][2] = c[5];
+}
+
+__device__ __forceinline__ void transform_cov3d(const float* T, const float* cov6, float* out6)
+{
+    float S[3][3], tmp[3][3];
+    sym6_to_full(cov6, S);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            tmp[a][j] = T[3 * a + 0] * S[0][j] + T[3 * a + 1] * S[1][j] + T[3 * a + 2] * S[2][j];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = a; b < 3; b++)
+            out6[k++] = tmp[a][0] * T[3 * b + 0] + tmp[a][1] * T[3 * b + 1] + tmp[a][2] * T[3 * b + 2];
+}
+
+__device__ __forceinline__ void transform_cov3d_bw(const float* T, const float* cov6_pre, const float* d6, float* d6_pre, float* dT)
+{
+    float S[3][3], G[3][3], U[3][3];
+    sym6_to_full(cov6_pre, S);
+    G[0][0] = d6[0];        G[0][1] = 0.5f * d6[1]; G[0][2] = 0.5f * d6[2];
+    G[1][0] = 0.5f * d6[1]; G[1][1] = d6[3];        G[1][2] = 0.5f * d6[4];
+    G[2][0] = 0.5f * d6[2]; G[2][1] = 0.5f * d6[4]; G[2][2] = d6[5];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            U[a][j] = G[a][0] * T[0 + j] + G[a][1] * T[3 + j] + G[a][2] * T[6 + j];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+            dT[3 * a + b] = 2.0f * (U[a][0] * S[0][b] + U[a][1] * S[1][b] + U[a][2] * S[2][b]);
+    float Gp[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int jj = i; jj < 3; jj++)
+            Gp[i][jj] = T[0 + i] * U[0][jj] + T[3 + i] * U[1][jj] + T[6 + i] * U[2][jj];
+    d6_pre[0] = Gp[0][0]; d6_pre[1] = 2.0f * Gp[0][1]; d6_pre[2] = 2.0f * Gp[0][2];
+    d6_pre[3] = Gp[1][1]; d6_pre[4] = 2.0f * Gp[1][2]; d6_pre[5] = Gp[2][2];
+}
+
 struct Cov2DSetup { float3 t; float txtz, tytz; M3 W, T, Vrk; };
 
 __device__ __forceinline__ Cov2DSetup cov2d_setup(float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
@@ -130,7 +184,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                           GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header,
-                          int* __restrict__ radii_out, int lds_hist, int stage_sh)
+                          int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms)
 {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
@@ -188,6 +242,14 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                 float sc[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
                 float q[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
                 cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
+                if (transforms != nullptr) {
+                    float Tm[9], pre[6];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) pre[i] = cov3D[i];
+                    transform_cov3d(Tm, pre, cov3D);
+                }
 #pragma unroll
                 for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = cov3D[i];
             }
@@ -362,6 +424,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                           const float* __restrict__ transforms, float* __restrict__ dL_dtransforms,
                            unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */)
 {
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then the same for dL_dsh out
@@ -387,6 +450,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     const int n_slabs = SLABS > 0 ? SLABS : slabs;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
+    float dtf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
     // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
     const bool visible = n_inst > 0 && !(hdr_flags & ERRFLAG_OVERFLOW);
@@ -768,9 +832,22 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
             S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
             const M3 Mm = m3_mul(S, R);
-            const M3 dSigma = m3_cols(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2],
-                                      0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
-                                      0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+            // with a transform the stored covariance is T Sigma T^T: pull dL_dcov3D back to the untransformed Sigma (and emit dL_dT)
+            float dc6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
+            if (transforms != nullptr) {
+                float Tm[9], pre[6], d6_pre[6];
+#pragma unroll
+                for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+                const float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
+                const float qr[4] = { r, x, y, z };
+                cov3d_from_scale_rot(scr, scale_modifier, qr, pre);
+                transform_cov3d_bw(Tm, pre, dc6, d6_pre, dtf);
+#pragma unroll
+                for (int i = 0; i < 6; i++) dc6[i] = d6_pre[i];
+            }
+            const M3 dSigma = m3_cols(dc6[0], 0.5f * dc6[1], 0.5f * dc6[2],
+                                      0.5f * dc6[1], dc6[3], 0.5f * dc6[4],
+                                      0.5f * dc6[2], 0.5f * dc6[4], dc6[5]);
             M3 M2;
 #pragma unroll
             for (int cc = 0; cc < 3; cc++)
@@ -807,6 +884,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
     for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
     reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    if (dL_dtransforms != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) dL_dtransforms[9 * (size_t)idx + i] = dtf[i];
+    }
     }   // in_range
     PSTAMP(5);
     if (STAGE_SH) {
@@ -868,7 +949,7 @@ static int env_int(const char* name, int dflt)
 
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                               GeomView g, ImageView im, int* radii_out, hipStream_t s)
+                               const float* transforms, GeomView g, ImageView im, int* radii_out, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
@@ -883,14 +964,16 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     hipLaunchKernelGGL(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
-                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh);
+                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh,
+                       transforms);
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 GeomView g, BinView b, const uint32_t* header,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s)
+                                float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                                const float* transforms, float* dL_dtransforms, hipStream_t s)
 {
     (void)colors_precomp;
     static const int threads = env_int("MOSS_PREBWD_THREADS", 128);
@@ -903,7 +986,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, g_stamps)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, g_stamps)
     // SLABS: -1 = sparse records selected by inst_mask (wave blend kernels), 4 = four dense slabs, 0 = run-time count
     const int sl = blend_impl() ? -1 : (b.slabs == 4 ? 4 : 0);
     if (stage) { if (sl < 0) LAUNCH_PB(true, -1); else if (sl == 4) LAUNCH_PB(true, 4); else LAUNCH_PB(true, 0); }

@@ -107,7 +107,8 @@ static int forward_impl(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream, long long capacity)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream, long long capacity,
+    const float* transforms)
 {
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -142,7 +143,7 @@ static int forward_impl(
 
     launch_clear(im.header, im.clear_bytes(), s);                        // header + tile histogram + tile cursors
     { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
-      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, im, radii, s); }
+      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, g, im, radii, s); }
     STAGE_CHECK("preprocess");
     { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, capacity, s); }
     STAGE_CHECK("scan");
@@ -192,7 +193,7 @@ int moss_raster_forward(
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        debug, stream, -1);
+                        debug, stream, -1, nullptr);
 }
 
 int moss_raster_forward_async(
@@ -207,7 +208,24 @@ int moss_raster_forward_async(
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity);
+                        0, stream, capacity, nullptr);
+}
+
+// n2 extension: like moss_raster_forward / _async (capacity < 0: synchronous, debug off) with a per-Gaussian 3x3
+// transform applied to the scale/rotation covariance inside the op.
+int moss_raster_forward_tf(
+    moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream)
+{
+    if (P > 0 && (!scales || !rotations || !transforms)) return fail(MOSS_ERR_INVALID_ARG, "scales, rotations and transforms are required");
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
+                        0, stream, capacity < 0 ? -1 : capacity, transforms);
 }
 
 int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out /* 8 words */, void* stream)
@@ -225,7 +243,7 @@ size_t moss_raster_geometry_bytes(int P) { return GeomView::bytes(P > 0 ? P : 1)
 size_t moss_raster_image_bytes(int width, int height) { return ImageView::bytes(width, height); }
 size_t moss_raster_binning_bytes(int R) { return BinView::bytes(R); }
 
-int moss_raster_backward(
+static int backward_impl(
     int P, int D, int M, int R,
     const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
@@ -235,7 +253,8 @@ int moss_raster_backward(
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream,
+    const float* transforms, float* dL_dtransforms)
 {
     (void)alphas; (void)radii;
     g_err[0] = 0;
@@ -260,9 +279,50 @@ int moss_raster_backward(
     }
     { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
       launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b, im.header,
-                                 dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s); }
+                                 dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                                 transforms, dL_dtransforms, s); }
     STAGE_CHECK("preprocess_backward");
     return 0;
+}
+
+int moss_raster_backward(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales, scale_modifier, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, nullptr, nullptr);
+}
+
+// n2 extension: backward of moss_raster_forward_tf; dL_dtransforms (P,9) is written for every Gaussian (zeros if culled).
+// dL_dcov3D is the gradient w.r.t. the TRANSFORMED covariance (as stored), dL_dscale / dL_drot already include the transform.
+int moss_raster_backward_tf(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, void* stream)
+{
+    if (P > 0 && (!scales || !rotations || !transforms || !dL_dtransforms))
+        return fail(MOSS_ERR_INVALID_ARG, "scales, rotations, transforms and dL_dtransforms are required");
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,
+                         nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0, stream, transforms, dL_dtransforms);
 }
 
 int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -119,8 +119,10 @@ def _ptr(t: torch.Tensor, name: str, dtype=torch.float32):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, transforms=None):
     """RasterizeGaussiansCUDA, rasterize_points.cu:35-119.
+    ``transforms`` (an addition): (P,3,3) per-Gaussian matrices applied to the scale/rotation covariance
+    inside the op (Sigma' = T Sigma T^T, what MOSS's Python get_covariance builds); needs scales and rotations, no cov3D_precomp.
     Returns (num_rendered, out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P,), geomBuffer,
     binningBuffer, imgBuffer)."""
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -146,6 +148,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         ptr, c = _ptr(t, name)
         keep.append(c)
         return ptr
+    if transforms is not None:
+        if transforms.numel() != 9 * P or scales.numel() == 0 or rotations.numel() == 0 or cov3D_precomp.numel() != 0:
+            raise RuntimeError("transforms must be (P,3,3) and comes with scales and rotations (no cov3D_precomp)")
+        if debug:
+            raise RuntimeError("debug mode is not available together with transforms")
     use_async = ASYNC.enabled and not debug and ASYNC.capacity > 0 and P > 0
     capturing = torch.cuda.is_current_stream_capturing()
     if use_async and not capturing:
@@ -155,16 +162,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _tls.buffers = (geom, binning, img)
         try:
             fwd = L.moss_raster_forward_async if use_async else L.moss_raster_forward
+            if transforms is not None:
+                fwd = L.moss_raster_forward_tf                # cov3D_precomp slot carries the transforms, last int the capacity (-1 = sync)
             rc = fwd(
                 _grow, 0, _grow, 1, _grow, 2,
                 P, int(degree), M,
                 p(background, "background"), W, H,
                 p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"), p(opacity, "opacity"),
-                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"),
+                p(cov3D_precomp, "cov3D_precomp") if transforms is None else p(transforms, "transforms"),
                 p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                 out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr() if P else None,
-                int(ASYNC.capacity) if use_async else int(bool(debug)), stream)
+                (int(ASYNC.capacity) if use_async else (-1 if transforms is not None else int(bool(debug)))), stream)
         finally:
             _tls.buffers = None
         rendered = check(rc, "rasterize_gaussians")
@@ -185,10 +195,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
-                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug):
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, transforms=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:121-206.
     Returns (dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P,1), dL_dmeans3D (P,3), dL_dcov3D (P,6),
-    dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4))."""
+    dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4)) -- plus dL_dtransforms (P,3,3) when ``transforms`` was given."""
     L = lib()
     dev = means3D.device
     P = int(means3D.size(0))
@@ -213,6 +223,30 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dsh = alloc((P, M, 3), **fopts)
     dL_dscales = alloc((P, 3), **fopts)
     dL_drotations = alloc((P, 4), **fopts)
+    dL_dtransforms = alloc((P, 3, 3), **fopts) if transforms is not None else None
+    if P != 0 and transforms is not None:
+        keep = []
+        def p(t, name, dtype=torch.float32):
+            ptr, c = _ptr(t, name, dtype)
+            keep.append(c)
+            return ptr
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.moss_raster_backward_tf(
+                P, int(degree), M, int(R),
+                p(background, "background"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"),
+                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(transforms, "transforms"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tan_fovx), float(tan_fovy),
+                p(geomBuffer, "geomBuffer", torch.uint8), p(binningBuffer, "binningBuffer", torch.uint8),
+                p(imageBuffer, "imageBuffer", torch.uint8),
+                p(dL_dout_color, "dL_dout_color"), p(dL_dout_depth, "dL_dout_depth"), p(dL_dout_alpha, "dL_dout_alpha"),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None,
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), dL_dtransforms.data_ptr(), stream)
+        check(rc, "rasterize_gaussians_backward")
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtransforms
     if P != 0:
         keep = []
         def p(t, name, dtype=torch.float32):
@@ -235,6 +269,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None,
                 dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)), stream)
         check(rc, "rasterize_gaussians_backward")
+    if transforms is not None:
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtransforms
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -63,12 +63,14 @@ def _call_native(fn, args, debug, dump_name, what):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                transforms=None):
+        # (the tenth input is an addition: per-Gaussian 3x3 transforms applied to the covariance inside the op)
         rs = raster_settings
         native_args = (
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
-            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug) + (() if transforms is None else (transforms,))
         (num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_native(
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
@@ -76,32 +78,38 @@ class _RasterizeGaussians(torch.autograd.Function):
         # an output that takes no part in the loss reaches backward as None (NULL at the C ABI = zeros) instead of as a
         # zero-filled image; the values computed are the same as with the reference's materialised zeros
         ctx.set_materialize_grads(False)
+        ctx.has_transforms = transforms is not None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
-                              geomBuffer, binningBuffer, imgBuffer, alpha)
+                              geomBuffer, binningBuffer, imgBuffer, alpha, *(() if transforms is None else (transforms,)))
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha):
         rs = ctx.raster_settings
+        saved = ctx.saved_tensors
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
-         geomBuffer, binningBuffer, imgBuffer, alpha) = ctx.saved_tensors
+         geomBuffer, binningBuffer, imgBuffer, alpha) = saved[:11]
+        transforms = saved[11] if ctx.has_transforms else None
         if grad_out_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 9
+            return (None,) * 10
         native_args = (
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,
-            sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug)
+            sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug) + \
+            (() if transforms is None else (transforms,))
+        grads = _call_native(_C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-         grad_scales, grad_rotations) = _call_native(
-            _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
+         grad_scales, grad_rotations) = grads[:8]
+        grad_transforms = grads[8] if transforms is not None else None
         # one gradient per forward() input, in forward()'s order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, None)
+                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        transforms=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, transforms)
 
 
 class GaussianRasterizer(nn.Module):
@@ -116,7 +124,9 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, transforms=None):
+        """``transforms`` (an addition): (P,3,3) per-Gaussian matrices; with scales and rotations the op then builds
+        T (R S S^T R^T) T^T itself -- MOSS's Python get_covariance -- and returns a gradient for the transforms too."""
         rs = self.raster_settings
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -130,4 +140,6 @@ class GaussianRasterizer(nn.Module):
         scales = absent if scales is None else scales
         rotations = absent if rotations is None else rotations
         cov3D_precomp = absent if cov3D_precomp is None else cov3D_precomp
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+        if transforms is not None and (scales.numel() == 0 or cov3D_precomp.numel() != 0):
+            raise Exception('transforms need the scale/rotation pair (and no precomputed 3D covariance)!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, transforms)

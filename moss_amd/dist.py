@@ -23,7 +23,9 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MOSS_DIST_BACKEND=gloo: lets the N > 1 code path be exercised with several processes on ONE GPU (RCCL refuses two
+            # ranks on the same device); the production backend on MI355X is "nccl" (= RCCL over xGMI)
+            backend = os.environ.get("MOSS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -66,7 +66,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     means3D = xyz
     bweights = correct_Rs = pose_out = None
     if transforms is not None:
-        means3D = torch.matmul(transforms, means3D[..., None]).squeeze(-1) + (0 if translation is None else translation)
+        # = torch.matmul(transforms, means3D[..., None]).squeeze(-1) (reference :74-75), written as an elementwise product + row sum:
+        # a batched GEMM over 100k 3x3 matrices goes through hipBLASLt on MI355X and costs ~0.9 ms per call (and twice more backward)
+        means3D = (transforms * means3D[..., None, :]).sum(-1) + (0 if translation is None else translation)
     elif hasattr(pc, "coarse_deform_c2source"):
         _, means3D, bweights, transforms, translation = pc.coarse_deform_c2source(
             means3D[None], viewpoint_camera.smpl_param, viewpoint_camera.big_pose_smpl_param,
@@ -75,11 +77,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     means2D = screenspace_points
     opacity = pc.get_opacity
 
-    scales = rotations = cov3D_precomp = None
+    scales = rotations = cov3D_precomp = op_transforms = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier, None if transforms is None else transforms.squeeze())
     else:
         scales, rotations = pc.get_scaling, pc.get_rotation
+        # an addition (pipe.transforms_in_op): the per-Gaussian LBS transform of the covariance is applied INSIDE the op instead of
+        # by the torch ops of get_covariance (the reference ignores `transforms` in this branch, gaussian_renderer/__init__.py:92-93)
+        if transforms is not None and getattr(pipe, "transforms_in_op", False):
+            op_transforms = transforms.squeeze()
 
     shs = colors_precomp = None
     if override_color is None:
@@ -95,7 +101,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     rendered_image, radii, depth, alpha = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+        **({} if op_transforms is None else {"transforms": op_transforms}))
 
     return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,

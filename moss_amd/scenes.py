@@ -112,7 +112,8 @@ def covariance_precomp(scales, rots, scale_modifier=1.0, transforms=None) -> tor
     R = quat_to_rot(rots)
     L = R * (scale_modifier * scales)[:, None, :]
     if transforms is not None:
-        L = transforms @ L                      # T (R S) ; cov = L L^T = T R S S^T R^T T^T
+        # T (R S) ; cov = L L^T = T R S S^T R^T T^T.  (= transforms @ L without the batched 3x3 GEMM, see below)
+        L = (transforms[:, :, :, None] * L[:, None, :, :]).sum(2)
     # six unique entries of L L^T as row dot products: elementwise kernels only (a batched 3x3 GEMM over 100k tiny
     # matrices costs ~0.9 ms per call through hipBLASLt on MI355X)
     r0, r1, r2 = L[:, 0, :], L[:, 1, :], L[:, 2, :]

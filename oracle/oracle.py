@@ -96,7 +96,7 @@ def dist2(points):
 
 def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
             viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered=False,
-            want_margin=True):
+            want_margin=True, transforms=None):
     """Returns a namespace with the reference's outputs (color (3,H,W), depth (1,H,W), alpha (1,H,W),
     radii (P,), num_rendered) and every intermediate."""
     L = lib()
@@ -104,6 +104,7 @@ def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_mod
     viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
     colors_precomp = _opt(colors_precomp); scales = _opt(scales); rotations = _opt(rotations)
     cov3D_precomp = _opt(cov3D_precomp); sh = _opt(sh)
+    transforms = None if transforms is None else np.ascontiguousarray(_f32(transforms).reshape(-1, 9))   # n2 extension: (P,3,3)
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise ValueError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:57-59
     P = means3D.shape[0]
@@ -130,7 +131,7 @@ def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_mod
         _p(opacities), _p(sh), _p(cov3D_precomp), _p(colors_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
         C.c_int(W), C.c_int(H), C.c_float(tan_fovx), C.c_float(tan_fovy), C.c_int(int(prefiltered)),
         _p(o.radii), _p(o.means2D), _p(o.depths), _p(o.cov3D), _p(o.rgb), _p(o.conic_opacity),
-        _p(o.tiles_touched), _p(o.clamped))
+        _p(o.tiles_touched), _p(o.clamped), _p(transforms))
     if err:
         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
     o.point_offsets = np.zeros(P, np.uint32)
@@ -158,7 +159,7 @@ def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_mod
 
 
 def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-             projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos):
+             projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None):
     """``fw`` is the namespace returned by :func:`forward`.  Returns the reference's 8 gradient arrays
     (rasterize_points.cu:205) plus dL_dconic as a namespace."""
     L = lib()
@@ -166,6 +167,7 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
     colors_precomp = _opt(colors_precomp); scales = _opt(scales); rotations = _opt(rotations)
     cov3D_precomp = _opt(cov3D_precomp); sh = _opt(sh)
+    transforms = None if transforms is None else np.ascontiguousarray(_f32(transforms).reshape(-1, 9))
     P = means3D.shape[0]
     M = 0 if sh is None else sh.shape[1]
     H, W = fw.H, fw.W
@@ -179,6 +181,7 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     g.dL_dsh = np.zeros((P, M, 3), np.float32)
     g.dL_dscales = np.zeros((P, 3), np.float32)
     g.dL_drotations = np.zeros((P, 4), np.float32)
+    g.dL_dtransforms = np.zeros((P, 3, 3), np.float32)
     if P == 0:
         return g
     dpix = _f32(dL_dout_color).reshape(3, H, W)
@@ -198,5 +201,5 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     L.oracle_preprocess_backward(C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D), _p(fw.radii), _p(sh),
                                  _p(fw.clamped), _p(scales), _p(rotations), C.c_float(scale_modifier), _p(projmatrix),
                                  _p(campos), _p(g.dL_dmeans2D), _p(g.dL_dmeans3D), _p(g.dL_dcolors), _p(g.dL_dcov3D),
-                                 _p(g.dL_dsh), _p(g.dL_dscales), _p(g.dL_drotations))
+                                 _p(g.dL_dsh), _p(g.dL_dscales), _p(g.dL_drotations), _p(transforms), _p(g.dL_dtransforms))
     return g

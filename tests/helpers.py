@@ -12,13 +12,18 @@ from oracle import oracle
 
 def inputs_of(scene, mode="scale_rot", degree=None, colors=False, bg=None):
     """Select the op's input mode like gaussian_renderer/__init__.py:85-109 does.
-    mode: 'scale_rot' (scales+rotations) or 'precomp' (cov3D_precomp).  colors=True feeds colours instead of SHs."""
+    mode: 'scale_rot' (scales+rotations), 'precomp' (cov3D_precomp) or 'lbs' (scales+rotations+per-Gaussian 3x3 transforms applied
+    inside the op: the n2 extension).  colors=True feeds colours instead of SHs."""
     d = SimpleNamespace()
     d.P = scene.means3D.shape[0]
     d.means3D = scene.means3D.float().contiguous()
     d.opacities = scene.opacities.float().contiguous()
     d.scale_modifier = 1.0
-    if mode == "scale_rot":
+    d.transforms = None
+    if mode == "lbs":
+        d.scales, d.rotations, d.cov3D_precomp = scene.scales.float().contiguous(), scene.rotations.float().contiguous(), None
+        d.transforms = scene.transforms.float().contiguous()
+    elif mode == "scale_rot":
         d.scales, d.rotations, d.cov3D_precomp = scene.scales.float().contiguous(), scene.rotations.float().contiguous(), None
     else:
         d.scales, d.rotations, d.cov3D_precomp = None, None, scene.cov3D_precomp.float().contiguous()
@@ -39,14 +44,14 @@ def oracle_forward(d):
     c = d.cam
     return oracle.forward(d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), d.opacities.numpy(), _np(d.scales),
                           _np(d.rotations), d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(),
-                          c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy())
+                          c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
 
 
 def oracle_backward(d, fw, dc, dd, da):
     c = d.cam
     return oracle.backward(fw, d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), _np(d.scales), _np(d.rotations),
                            d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(), c.tanfovx,
-                           c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy())
+                           c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
 
 
 def _np(t):
@@ -65,11 +70,13 @@ def hip_forward(d, device, debug=False, prefiltered=False):
     t.args = dict(bg=d.bg.to(device), means3D=d.means3D.to(device), colors=_dev(d.colors_precomp, device),
                   opacity=d.opacities.to(device), scales=_dev(d.scales, device), rotations=_dev(d.rotations, device),
                   cov3D=_dev(d.cov3D_precomp, device), view=c.viewmatrix.to(device), proj=c.projmatrix.to(device),
-                  sh=_dev(d.shs, device), campos=c.campos.to(device))
+                  sh=_dev(d.shs, device), campos=c.campos.to(device),
+                  transforms=None if getattr(d, "transforms", None) is None else d.transforms.to(device))
     a = t.args
     (t.R, t.color, t.depth, t.alpha, t.radii, t.geom, t.binning, t.img) = _C.rasterize_gaussians(
         a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"], a["rotations"], d.scale_modifier, a["cov3D"],
-        a["view"], a["proj"], c.tanfovx, c.tanfovy, c.H, c.W, a["sh"], d.degree, a["campos"], prefiltered, debug)
+        a["view"], a["proj"], c.tanfovx, c.tanfovy, c.H, c.W, a["sh"], d.degree, a["campos"], prefiltered, debug,
+        **({} if a["transforms"] is None else {"transforms": a["transforms"]}))
     return t
 
 
@@ -113,8 +120,9 @@ def hip_backward(d, t, dc, dd, da, device, debug=False):
     out = _C.rasterize_gaussians_backward(
         a["bg"], a["means3D"], t.radii, a["colors"], a["scales"], a["rotations"], d.scale_modifier, a["cov3D"], a["view"],
         a["proj"], c.tanfovx, c.tanfovy, dc.to(device), dd.to(device), da.to(device), a["sh"], d.degree, a["campos"],
-        t.geom, t.R, t.binning, t.img, t.alpha, debug)
-    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+        t.geom, t.R, t.binning, t.img, t.alpha, debug, **({} if a["transforms"] is None else {"transforms": a["transforms"]}))
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations",
+             "dL_dtransforms"]
     return SimpleNamespace(**{n: o for n, o in zip(names, out)})
 
 

@@ -143,6 +143,18 @@ def test_image_covering_gaussians(gpu, hip_lib):
     _check_backward(d, gpu, fw, t, e)
 
 
+def test_heavy_tiles_on_a_ragged_image(gpu, hip_lib):
+    """Heavy tiles (>= 128 entries: block-mask scan + LDS-DMA path, 16 wave items per tile) on an image whose size is not a multiple
+    of the tile: partial tiles on the right and bottom edge, pixels outside the image inside 4x4 blocks."""
+    from tests.test_gpu_parity import _check_forward, _check_backward
+    s = _stacked_scene(2500, W=70, H=50, spread=0.25, scale=0.12, seed=7)
+    d = hp.inputs_of(s, "precomp")
+    fw, t, e = _check_forward(d, gpu, max_fragile=3e-2)
+    n = fw.ranges[:, 1] - fw.ranges[:, 0]
+    assert (n >= 128).sum() >= 6 and n.max() < 2500            # several heavy tiles, including edge ones
+    _check_backward(d, gpu, fw, t, e)
+
+
 def test_prefiltered_trap_is_reported(gpu, hip_lib):
     s = scenes.config1()
     s.means3D[0, 2] = -10.0
@@ -540,3 +552,52 @@ def test_unified_features_step_equals_separate_features(gpu, hip_lib):
         dgr.set_grad_sink(sh=None)
     for a, b in zip(out[False], out[True]):
         assert torch.equal(a, b)
+
+
+def test_transforms_inside_the_op_equal_python_covariance(gpu, hip_lib):
+    """n2 extension: rasterizer(scales, rotations, transforms=T) == rasterizer(cov3D_precomp = get_covariance(.., T)) -- MOSS's shipped
+    path (gaussian_renderer/__init__.py:88-91, scene/gaussian_model.py:37-44) -- in image and in the gradients of scales, rotations
+    and T; asynchronous mode included."""
+    import moss_amd.diff_gaussian_rasterization as dgr
+    from moss_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    s = scenes.config1(P=400, W=96, H=80)
+    c = s.camera
+    rs = GaussianRasterizationSettings(image_height=c.H, image_width=c.W, tanfovx=c.tanfovx, tanfovy=c.tanfovy,
+                                       bg=torch.tensor([0.1, 0.2, 0.3], device=gpu), scale_modifier=1.0, viewmatrix=c.viewmatrix.to(gpu),
+                                       projmatrix=c.projmatrix.to(gpu), sh_degree=3, campos=c.campos.to(gpu), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(rs)
+    w = torch.rand(3, c.H, c.W, device=gpu)
+    leaf = lambda t: t.clone().to(gpu).requires_grad_(True)
+    res = []
+    try:
+        for variant in ("python", "in_op", "in_op_async"):
+            dgr.set_async(variant == "in_op_async")
+            reps = 2 if variant == "in_op_async" else 1           # first call of an async session is synchronous
+            for _ in range(reps):
+                means, opa, shs = leaf(s.means3D), leaf(s.opacities), leaf(s.shs)
+                scl, rot, T = leaf(s.scales), leaf(s.rotations), leaf(s.transforms)
+                m2d = torch.zeros_like(means, requires_grad=True)
+                if variant == "python":
+                    cov = scenes.covariance_precomp(scl, rot, 1.0, T)
+                    img, radii, depth, alpha = rast(means3D=means, means2D=m2d, opacities=opa, shs=shs, cov3D_precomp=cov)
+                else:
+                    img, radii, depth, alpha = rast(means3D=means, means2D=m2d, opacities=opa, shs=shs, scales=scl, rotations=rot,
+                                                    transforms=T)
+                ((img * w).sum() + alpha.sum() + 0.1 * depth.sum()).backward()
+            res.append((img.detach(), radii, scl.grad, rot.grad, T.grad, means.grad, opa.grad, shs.grad))
+    finally:
+        dgr.set_async(False)
+    py, op, op_async = res
+    assert torch.equal(py[1], op[1])
+    assert hp.rel_err(py[0].cpu().numpy(), op[0].cpu().numpy()) < 1e-5
+    # scene.rotations are unit quaternions; covariance_precomp normalises, the kernel uses them as given: the rotation gradients
+    # differ by the normalisation's projection, so compare its tangential part
+    q = s.rotations.to(gpu)
+    tang = lambda g: g - q * (g * q).sum(1, keepdim=True)
+    for k in (2, 4, 5, 6, 7):
+        assert hp.rel_err(py[k].cpu().numpy(), op[k].cpu().numpy()) < 2e-4, k
+    assert hp.rel_err(tang(py[3]).cpu().numpy(), tang(op[3]).cpu().numpy()) < 2e-4
+    for a, b in zip(op, op_async):
+        assert torch.equal(a, b)                                  # asynchronous == synchronous, bit for bit
+    with pytest.raises(Exception):
+        rast(means3D=means, means2D=m2d, opacities=opa, shs=shs, cov3D_precomp=cov, transforms=T)

@@ -67,6 +67,8 @@ def _check_backward(d, gpu, fw, t, e, zero_depth=False, tol=GRAD_TOL):
     pairs = [("dL_dmeans2D", ref.dL_dmeans2D), ("dL_dcolors", ref.dL_dcolors), ("dL_dopacity", ref.dL_dopacity),
              ("dL_dmeans3D", ref.dL_dmeans3D), ("dL_dcov3D", ref.dL_dcov3D), ("dL_dsh", ref.dL_dsh),
              ("dL_dscales", ref.dL_dscales), ("dL_drotations", ref.dL_drotations)]
+    if getattr(d, "transforms", None) is not None:            # n2 extension: transform applied inside the op
+        pairs.append(("dL_dtransforms", ref.dL_dtransforms))
     errs = {}
     for name, r in pairs:
         got = getattr(g, name).cpu().numpy()
@@ -83,7 +85,7 @@ def _check_backward(d, gpu, fw, t, e, zero_depth=False, tol=GRAD_TOL):
     return g
 
 
-@pytest.mark.parametrize("mode", ["scale_rot", "precomp"])
+@pytest.mark.parametrize("mode", ["scale_rot", "precomp", "lbs"])
 @pytest.mark.parametrize("zero_depth", [True, False])
 def test_cfg1_forward_backward(gpu, hip_lib, mode, zero_depth):
     d = hp.inputs_of(scenes.config1(), mode)

@@ -19,7 +19,8 @@ def _gold(name):
     return np.load(os.path.join(GOLD, name))
 
 
-def _preprocess_only(means, shs, degree, campos, scales=None, rots=None, cov=None, W=64, H=64, tan=2.0, t=(0, 0, 10.0), op=None):
+def _preprocess_only(means, shs, degree, campos, scales=None, rots=None, cov=None, W=64, H=64, tan=2.0, t=(0, 0, 10.0), op=None,
+                     transforms=None):
     """Run just the oracle's preprocess stage on a wide camera so that nothing is culled."""
     L = oracle.lib()
     P = means.shape[0]
@@ -27,6 +28,7 @@ def _preprocess_only(means, shs, degree, campos, scales=None, rots=None, cov=Non
     f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     means, shs, scales, rots, cov = f(means), f(shs), f(scales), f(rots), f(cov)
+    transforms = None if transforms is None else f(np.asarray(transforms).reshape(-1, 9))
     op = np.full(P, 0.5, np.float32) if op is None else f(op)
     view, proj, cp = f(cam.viewmatrix.numpy()), f(cam.projmatrix.numpy()), f(campos)
     radii = np.zeros(P, np.int32); xy = np.zeros((P, 2), np.float32); depths = np.zeros(P, np.float32)
@@ -36,7 +38,7 @@ def _preprocess_only(means, shs, degree, campos, scales=None, rots=None, cov=Non
     err = L.oracle_preprocess(C.c_int(P), C.c_int(degree), C.c_int(M), p(means), p(scales), C.c_float(1.0), p(rots), p(op), p(shs),
                               p(cov), None, p(view), p(proj), p(cp), C.c_int(W), C.c_int(H), C.c_float(cam.tanfovx),
                               C.c_float(cam.tanfovy), C.c_int(0), p(radii), p(xy), p(depths), p(cov3D), p(rgb), p(conic), p(tiles),
-                              p(clamped))
+                              p(clamped), p(transforms))
     assert err == 0
     return dict(radii=radii, xy=xy, depths=depths, cov3D=cov3D, rgb=rgb, conic=conic, tiles=tiles, clamped=clamped, cam=cam)
 
@@ -73,6 +75,18 @@ def test_cov3d_from_scale_rotation_matches_reference():
     shs = np.zeros((len(scales), 1, 3), np.float32)
     r = _preprocess_only(means, shs, 0, np.array([0, 0, -5.0], np.float32), scales=scales, rots=qn)
     np.testing.assert_allclose(r["cov3D"], g["cov_plain"], rtol=2e-5, atol=1e-9)
+
+
+def test_cov3d_with_transform_inside_the_op_matches_reference():
+    """n2 extension: oracle Sigma' = T Sigma T^T == the reference's build_covariance_from_scaling_rotation(..., transform)
+    (scene/gaussian_model.py:37-44; fixture generated from the reference's own function)."""
+    g = _gold("cov3d.npz")
+    scales, rots, T = g["scales"], g["rots"], g["transforms"]
+    qn = rots / np.linalg.norm(rots, axis=1, keepdims=True)
+    means = np.zeros((len(scales), 3), np.float32)
+    shs = np.zeros((len(scales), 1, 3), np.float32)
+    r = _preprocess_only(means, shs, 0, np.array([0, 0, -5.0], np.float32), scales=scales, rots=qn, transforms=T)
+    np.testing.assert_allclose(r["cov3D"], g["cov_T"], rtol=5e-5, atol=1e-9)
 
 
 def test_covariance_precomp_helper_matches_reference():
@@ -204,7 +218,7 @@ def test_dist2_known_answers():
 
 
 # ------------------------------------------------------------------------------------------------ backward vs autograd
-@pytest.mark.parametrize("mode", ["scale_rot", "precomp"])
+@pytest.mark.parametrize("mode", ["scale_rot", "precomp", "lbs"])
 def test_explicit_backward_matches_independent_autograd(mode):
     """The C oracle's explicit backward (restated backward.cu) against autograd of an independent float64 forward.
     Tolerance 2e-3 of each gradient's max: fp32 vs fp64 plus semantic (vii) above."""
@@ -220,9 +234,22 @@ def test_explicit_backward_matches_independent_autograd(mode):
     leaf = lambda t: None if t is None else t.double().clone().requires_grad_(True)
     means, opa, shs = leaf(d.means3D), leaf(d.opacities), leaf(d.shs)
     scales, rots, cov = leaf(d.scales), leaf(d.rotations), leaf(d.cov3D_precomp)
+    tfm = None
+    if mode == "lbs":
+        # n2 extension: the op applies a per-Gaussian transform to the scale/rotation covariance.  The independent forward gets the
+        # covariance the way MOSS's Python builds it (scene/gaussian_model.py:37-44) as a differentiable function of all three.
+        tfm = leaf(d.transforms)
+        r, x, y, z = rots.unbind(1)                         # quaternion used AS GIVEN, like the kernel (Q5): no normalisation here
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        Lm = tfm @ (R * scales[:, None, :])
+        full = Lm @ Lm.transpose(1, 2)
+        cov = torch.stack([full[:, 0, 0], full[:, 0, 1], full[:, 0, 2], full[:, 1, 1], full[:, 1, 2], full[:, 2, 2]], dim=1)
     ndc = torch.zeros(d.P, 2, dtype=torch.float64, requires_grad=True)
     col, dep, alp = ag.render(fw, means, opa, f64(c.viewmatrix), f64(c.projmatrix), f64(c.campos), c.tanfovx, c.tanfovy,
-                              f64(d.bg), d.degree, shs=shs, scales=scales, rotations=rots, cov3D_precomp=cov, ndc_offset=ndc)
+                              f64(d.bg), d.degree, shs=shs, scales=None if mode == "lbs" else scales,
+                              rotations=None if mode == "lbs" else rots, cov3D_precomp=cov, ndc_offset=ndc)
     # forward agreement first (fp32 oracle vs fp64 autograd forward)
     assert hp.rel_err(fw.color, col.detach().numpy()) < 5e-5
     assert hp.rel_err(fw.alpha, alp.detach().numpy()) < 5e-5
@@ -232,6 +259,8 @@ def test_explicit_backward_matches_independent_autograd(mode):
     checks = [("dL_dmeans3D", means.grad), ("dL_dopacity", opa.grad), ("dL_dsh", shs.grad), ("dL_dmeans2D", ndc.grad)]
     if mode == "scale_rot":
         checks += [("dL_dscales", scales.grad), ("dL_drotations", rots.grad)]
+    elif mode == "lbs":
+        checks += [("dL_dscales", scales.grad), ("dL_drotations", rots.grad), ("dL_dtransforms", tfm.grad)]
     else:
         checks += [("dL_dcov3D", cov.grad)]
     for name, gref in checks:
