@@ -211,6 +211,15 @@ int moss_adamw_flat_devstep(long long n, float* params, const float* grads, floa
                             float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
 
 /*
+ * k nearest reference points of every query point, 3-D, exact, k = 1..4: replaces the third-party
+ * `knn_cuda.KNN(k, transpose_mode=True)(ref, query)` MOSS calls at scene/gaussian_model.py:85-86,586,657,759,827 (a CUDA-only
+ * binary wheel, not in the repository; parity unpinned by the reference).
+ *   ref (Nr,3), query (Nq,3) fp32 device arrays; dist_out (Nq,k) Euclidean distances ascending; idx_out (Nq,k) int64 reference
+ *   indices.  Nr >= k.  Ties: the lower reference index first.  Asynchronous on `stream`.
+ */
+int moss_knn_query(int Nr, int Nq, int k, const float* ref, const float* query, float* dist_out, long long* idx_out, void* stream);
+
+/*
  * Extension: covariance with a per-Gaussian 3x3 transform INSIDE the op.
  * MOSS feeds cov3D_precomp = strip_symmetric(T (R S S^T R^T) T^T) built by torch ops (scene/gaussian_model.py:37-44,168-169;
  * gaussian_renderer/__init__.py:88-91) because the LBS transform T of each Gaussian changes every frame; on MI355X that Python

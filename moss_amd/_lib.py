@@ -77,6 +77,8 @@ def _declare(lib):
     lib.moss_knn_workspace_bytes.argtypes = [_i]
     lib.moss_knn_dist2.restype = _i
     lib.moss_knn_dist2.argtypes = [_i, _p, _p, _p, C.c_size_t, _p]
+    lib.moss_knn_query.restype = _i
+    lib.moss_knn_query.argtypes = [_i, _i, _i, _p, _p, _p, _p, _p]
     lib.moss_loss_workspace_bytes.restype = C.c_size_t
     lib.moss_loss_workspace_bytes.argtypes = [_i, _i, _i]
     lib.moss_photometric_loss.restype = _i

@@ -24,6 +24,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],
+    "knn_query.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "blend.hip": [],
     "loss.hip": [],

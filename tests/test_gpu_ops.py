@@ -601,3 +601,34 @@ def test_transforms_inside_the_op_equal_python_covariance(gpu, hip_lib):
         assert torch.equal(a, b)                                  # asynchronous == synchronous, bit for bit
     with pytest.raises(Exception):
         rast(means3D=means, means2D=m2d, opacities=opa, shs=shs, cov3D_precomp=cov, transforms=T)
+
+
+# ---------------------------------------------------------------- k-NN query (replacement for the knn_cuda wheel, row n3)
+@pytest.mark.parametrize("Nr,Nq,k", [(6890, 20000, 1), (3000, 3000, 2), (5, 17, 4), (1025, 300, 3)])
+def test_knn_query_matches_exhaustive_search(gpu, hip_lib, Nr, Nq, k):
+    """KNN(k, transpose_mode=True)(ref, query) as MOSS calls it (scene/gaussian_model.py:85-86,586,657,827): indices and Euclidean
+    distances equal an exhaustive float64 search (random points: no ties)."""
+    from knn_cuda import KNN
+    g = torch.Generator().manual_seed(Nr + k)
+    ref = torch.randn(1, Nr, 3, generator=g)
+    query = ref.clone() if Nr == Nq else torch.randn(1, Nq, 3, generator=g)
+    dist, idx = KNN(k=k, transpose_mode=True)(ref.to(gpu), query.to(gpu))
+    assert dist.shape == (1, Nq, k) and idx.shape == (1, Nq, k) and idx.dtype == torch.int64
+    d_ref = torch.cdist(query.double(), ref.double())[0]
+    want_d, want_i = d_ref.topk(k, dim=1, largest=False)
+    assert torch.equal(idx[0].cpu(), want_i)
+    assert hp.rel_err(dist[0].cpu().numpy(), want_d.float().numpy()) < 1e-5 or float((dist[0].cpu() - want_d.float()).abs().max()) < 1e-6
+    if Nr == Nq:                                                  # self query: the point itself comes first at distance 0
+        assert torch.equal(idx[0, :, 0].cpu(), torch.arange(Nq)) and float(dist[0, :, 0].abs().max()) == 0.0
+
+
+def test_knn_dimension_major_mode_and_ties(gpu, hip_lib):
+    from knn_cuda import KNN
+    ref = torch.tensor([[[0.0, 0, 0], [1.0, 0, 0], [1.0, 0, 0], [5.0, 0, 0]]], device=gpu)        # two identical references
+    query = torch.tensor([[[0.9, 0, 0]]], device=gpu)
+    d, i = KNN(k=3, transpose_mode=True)(ref, query)
+    assert i[0, 0].tolist() == [1, 2, 0]                           # equal distances: the lower index first
+    d2, i2 = KNN(k=3, transpose_mode=False)(ref.transpose(1, 2).contiguous(), query.transpose(1, 2).contiguous())
+    assert d2.shape == (1, 3, 1) and torch.equal(i2[0, :, 0], i[0, 0]) and torch.equal(d2[0, :, 0], d[0, 0])
+    with pytest.raises(RuntimeError):
+        KNN(k=1, transpose_mode=True)(ref.cpu(), query.cpu())
