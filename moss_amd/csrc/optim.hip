@@ -94,11 +94,19 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     }
     if (step_state && threadIdx.x == 0) {
         int* st = reinterpret_cast<int*>(const_cast<float*>(step_state));
-        if (atomicAdd(&st[3], 1) == (int)gridDim.x - 1) {
-            float* sf = const_cast<float*>(step_state);
-            sf[1] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));      // bias corrections of the NEXT step
-            sf[2] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
-            st[0] = t_dev; st[3] = 0;
+        // two-level completion count: 64 group counters (words 4..67), then one global counter (word 3), so that no address sees
+        // more than gridDim/64 + 64 atomics (4096 same-address atomics cost +34 us, see profiles/r01_notes.md)
+        const int grp = (int)(blockIdx.x & 63u);
+        const int grp_size = ((int)gridDim.x - grp + 63) / 64;                    // blocks with this group id
+        const int n_groups = min((int)gridDim.x, 64);
+        if (atomicAdd(&st[4 + grp], 1) == grp_size - 1) {
+            st[4 + grp] = 0;
+            if (atomicAdd(&st[3], 1) == n_groups - 1) {
+                float* sf = const_cast<float*>(step_state);
+                sf[1] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));      // bias corrections of the NEXT step
+                sf[2] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
+                st[0] = t_dev; st[3] = 0;
+            }
         }
     }
 }
@@ -115,9 +123,7 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
         segs.period[i] = pat ? segment_period[i] : 0; segs.split[i] = pat ? segment_split[i] : 0; segs.lr2[i] = pat ? segment_lr2[i] : 0.f;
     }
     long long blocks = (n / 4 + 255) / 256;
-    // (grid-stride kernel) few enough blocks that the one same-address atomic each of them issues at its end does not serialise
-    // into tens of microseconds (4096 blocks: +34 us), enough threads to keep HBM busy (128k threads x 64 B in flight)
-    if (blocks > 512) blocks = 512;
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
                        segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state);
