@@ -954,7 +954,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
     // Gaussians per thread: more -> better aggregation of the tile-histogram atomics, fewer -> more waves in flight.
-    static const int per_thread = env_int("MOSS_PREPROCESS_ITEMS", 2);
+    static const int per_thread = env_int("MOSS_PREPROCESS_ITEMS", 1);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
