@@ -825,11 +825,11 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
 // inside the trip loop (first version of this scheme) made every trip wait on L2: 640 instead of 520 cycles per trip.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LCAP = 1024, LMASK = LCAP - 1;     // per-wave list of hit positions
-constexpr int CHAPTER = 8;                       // 64-entry groups of block masks staged in LDS at a time (512 entries)
+constexpr int CHAPTER = 8;                       // 64-entry groups of block masks turned into hit masks at a time (512 entries)
 constexpr int ROUND_HITS = 64;                   // a scan round ends once it has found this many new hits (<= 127 with its last group)
 constexpr int RCAP = 512, RMASK = RCAP - 1;      // per-wave record ring (slots; a multiple of the 64-slot DMA batch): the hits of
                                                  // two rounds (<= 2 x 128 + 3 carried) plus one batch of slack
-struct HeavyLds { float4 a[RCAP], b[RCAP], c[RCAP]; uint32_t lst[LCAP]; uint16_t mbuf[64 * CHAPTER]; };
+struct HeavyLds { float4 a[RCAP], b[RCAP], c[RCAP]; uint32_t lst[LCAP]; };
 
 // Issue the DMA batches that cover list entries [from, to): batch q = entries 64q .. 64q+63 -> ring slots (64q & RMASK) + lane.
 // Lanes whose entry is not in the list yet copy the tile's first record (overwritten when the batch is re-issued with that
@@ -910,6 +910,7 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
     int scan_pos = 0, nlist = 0, C = 0, F = 0, grp = CHAPTER;
     bool scan_done = false;
     uint32_t nx[CHAPTER];                                    // the next chapter of masks, in flight
+    uint32_t vb_lo = 0u, vb_hi = 0u;                         // lane k: the hit mask of the current chapter's group k
 #pragma unroll
     for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(64 * k + lane, n - 1)];
     while (!finished) {
@@ -921,22 +922,28 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
         // ---- scan 64-entry groups until this round has found ROUND_HITS new hits (or the list ends)
         int new_hits = 0;
         while (!scan_done && new_hits < ROUND_HITS) {
-            if (grp == CHAPTER) {                            // stage the chapter that was in flight, request the one after it
+            if (grp == CHAPTER) {
+                // A new chapter: the 8 hit masks of its 64-entry groups are formed at once from the masks that were in flight (8
+                // independent ballots, no per-group LDS read -> ballot -> branch chain) and parked in lane k of a VGPR pair;
+                // the chapter after it is requested.
+                unsigned long long bl = 0ull;
 #pragma unroll
-                for (int k = 0; k < CHAPTER; k++) L->mbuf[64 * k + lane] = (uint16_t)nx[k];
+                for (int k = 0; k < CHAPTER; k++) {
+                    const int idx = scan_pos + 64 * k + lane;
+                    const unsigned long long b = __ballot(idx < n && (((nx[k] | all_hit) >> blk) & 1u) != 0u);
+                    bl = lane == k ? b : bl;
+                }
+                vb_lo = (uint32_t)bl; vb_hi = (uint32_t)(bl >> 32);
 #pragma unroll
                 for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(scan_pos + 64 * (CHAPTER + k) + lane, n - 1)];
                 grp = 0;
-                __builtin_amdgcn_wave_barrier();
             }
-            const uint32_t mkv = L->mbuf[64 * grp + lane];
+            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vb_hi, grp) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)vb_lo, grp);
             grp++;
-            const int idx = scan_pos + lane;
-            const bool hit = idx < n && (((mkv | all_hit) >> blk) & 1u) != 0u;
-            const unsigned long long m = __ballot(hit);
             if (m != 0ull) {
                 const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) L->lst[r & LMASK] = (uint32_t)idx;
+                if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(scan_pos + lane);
                 const int c = __popcll(m);
                 nlist += c; new_hits += c;
             }
@@ -1101,6 +1108,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     int scan_off = 0, nlist = 0, C = 0, F = 0, grp = CHAPTER;
     bool scan_done = false;
     uint32_t nx[CHAPTER];
+    uint32_t vb_lo = 0u, vb_hi = 0u;
 #pragma unroll
     for (int k = 0; k < CHAPTER; k++) nx[k] = bm[max(n_eff - 1 - (64 * k + lane), 0)];
     for (;;) {
@@ -1110,22 +1118,25 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         const bool final_round = scan_done;
         int new_hits = 0;
         while (!scan_done && new_hits < ROUND_HITS) {
-            if (grp == CHAPTER) {
+            if (grp == CHAPTER) {                            // (see the forward kernel)
+                unsigned long long bl = 0ull;
 #pragma unroll
-                for (int k = 0; k < CHAPTER; k++) L->mbuf[64 * k + lane] = (uint16_t)nx[k];
+                for (int k = 0; k < CHAPTER; k++) {
+                    const int idx = n_eff - 1 - (scan_off + 64 * k + lane);
+                    const unsigned long long b = __ballot(idx >= 0 && (((nx[k] | all_hit) >> blk) & 1u) != 0u);
+                    bl = lane == k ? b : bl;
+                }
+                vb_lo = (uint32_t)bl; vb_hi = (uint32_t)(bl >> 32);
 #pragma unroll
                 for (int k = 0; k < CHAPTER; k++) nx[k] = bm[max(n_eff - 1 - (scan_off + 64 * (CHAPTER + k) + lane), 0)];
                 grp = 0;
-                __builtin_amdgcn_wave_barrier();
             }
-            const uint32_t mkv = L->mbuf[64 * grp + lane];
+            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vb_hi, grp) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)vb_lo, grp);
             grp++;
-            const int idx = n_eff - 1 - (scan_off + lane);
-            const bool hit = idx >= 0 && (((mkv | all_hit) >> blk) & 1u) != 0u;
-            const unsigned long long m = __ballot(hit);
             if (m != 0ull) {
                 const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (hit) L->lst[r & LMASK] = (uint32_t)idx;
+                if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(n_eff - 1 - (scan_off + lane));
                 const int c = __popcll(m);
                 nlist += c; new_hits += c;
             }

@@ -1,2 +1,3 @@
 timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -2
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 600 python scripts/stage_times.py --mode scale_rot 2>&1 | tail -1 | cut -c1-300
+timeout 300 python scripts/wave_stamps.py 2>&1 | tail -8
