@@ -1,3 +1,1 @@
-timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -2
-timeout 600 python scripts/stage_times.py --mode scale_rot 2>&1 | tail -1 | cut -c1-300
-timeout 300 python scripts/wave_stamps.py 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "more_tiles or ragged" 2>&1 | tail -3

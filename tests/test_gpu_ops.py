@@ -155,6 +155,23 @@ def test_heavy_tiles_on_a_ragged_image(gpu, hip_lib):
     _check_backward(d, gpu, fw, t, e)
 
 
+def test_more_tiles_than_the_lds_histogram_holds(gpu, hip_lib):
+    """2200 x 1504 pixels = 138 x 94 = 12 972 tiles > 8192: the tile histogram and the scatter's slot reservation fall back from LDS
+    to global atomics, the scan / tile order / empty-tile fill run over a long tile table."""
+    from tests.test_gpu_parity import _check_forward, _check_backward
+    W, H, P = 2200, 1504, 3000
+    g = torch.Generator().manual_seed(21)
+    s = scenes.config1(P=P, W=W, H=H)
+    s.means3D = (torch.rand(P, 3, generator=g) - 0.5) * torch.tensor([4.0, 2.7, 0.6])
+    s.scales = torch.full((P, 3), 0.02) * torch.exp(0.4 * torch.randn(P, 3, generator=g))
+    s.cov3D_precomp = scenes.covariance_precomp(s.scales, s.rotations)
+    s.camera = scenes.make_camera(W, H, 1500.0, 1500.0, W / 2, H / 2, np.eye(3), np.array([0.0, 0.0, 3.0]))
+    d = hp.inputs_of(s, "scale_rot")
+    fw, t, e = _check_forward(d, gpu)
+    assert fw.ranges.shape[0] == 138 * 94 and int((fw.ranges[:, 1] > fw.ranges[:, 0]).sum()) > 2000
+    _check_backward(d, gpu, fw, t, e)
+
+
 def test_prefiltered_trap_is_reported(gpu, hip_lib):
     s = scenes.config1()
     s.means3D[0, 2] = -10.0
