@@ -201,9 +201,9 @@ int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_a
                     int num_segments, const long long* segment_end, const float* segment_lr,
                     const int* segment_period, const int* segment_split, const float* segment_lr2,
                     float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
-/* Same update with the step counter kept on the device: `step_state` is 272 zero-initialised device bytes ([0] = int step,
- * advanced by one per call by the update kernel itself; [1], [2] = cached bias corrections of the next step; [3] and
- * [4..67] = its two-level block-completion counters).  n must be > 0.  Nothing in the call depends on a host-side
+/* Same update with the step counter kept on the device: `step_state` is 288 zero-initialised device bytes ([0] = int step,
+ * advanced by one per call by the update kernel itself; [3] and [4..67] = its two-level block-completion counters; [68..71] =
+ * the bias corrections of the current / next step, double-buffered by step parity).  n must be > 0.  Nothing in the call depends on a host-side
  * counter, so a captured hipGraph of a training step replays correctly. */
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,

@@ -16,23 +16,25 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
              Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
              const float* __restrict__ step_state)
 {
-    __shared__ float s_bc[2];
     int t_dev = 0;
     if (step_state) {
         // Device-resident step counter (graph replay): the LAST block of a step to finish stores t back and caches the bias
         // corrections of step t + 1 (double precision like the host path), which is after every block has read the old values.
-        // No separate "tick" launch (a minimal launch costs 4-5 us here).
-        if (threadIdx.x == 0) {
-            t_dev = reinterpret_cast<const int*>(step_state)[0] + 1;
-            if (t_dev == 1) {                                // first step ever: nothing cached yet
-                s_bc[0] = (float)(1.0 - pow((double)beta1, 1.0));
-                s_bc[1] = (float)sqrt(1.0 - pow((double)beta2, 1.0));
-            } else {                                         // cached by the previous step's last block (two double pow() per
-                s_bc[0] = step_state[1]; s_bc[1] = step_state[2];     // block on the critical path cost ~25 us per step)
-            }
+        // No separate "tick" launch (a minimal launch costs 4-5 us here).  The reads are wave-uniform (scalar loads): no barrier.
+        t_dev = reinterpret_cast<const int*>(step_state)[0] + 1;
+        if (t_dev == 1) {                                    // first step ever: nothing cached yet
+            bc1 = (float)(1.0 - pow((double)beta1, 1.0));
+            bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, 1.0));
+        } else {                                             // cached by the previous step (slot = parity of the step)
+            bc1 = step_state[68 + 2 * (t_dev & 1)]; bc2_sqrt = step_state[69 + 2 * (t_dev & 1)];
         }
-        __syncthreads();
-        bc1 = s_bc[0]; bc2_sqrt = s_bc[1];
+        // the NEXT step's corrections go to the other slot, computed by one thread at the START of this launch (two double pow()
+        // at the end of the last block were a 3-5 us serial tail); nobody reads that slot during this launch
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            float* sf = const_cast<float*>(step_state);
+            sf[68 + 2 * ((t_dev + 1) & 1)] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));
+            sf[69 + 2 * ((t_dev + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
+        }
     }
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
         const long long i = i4 * 4;
@@ -46,29 +48,35 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
         } else {
             for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
         }
-        // learning rate of each of the 4 elements: segment lookup, then the segment's optional periodic pattern (ONE 32-bit modulo
-        // per thread for the first element, stepped for the others: a 64-bit modulo per element cost 12 us per step)
+        // Learning rate of each of the 4 elements: the segment of the first element (static indices only: a run-time index into the
+        // kernel-argument tables would spill them to scratch), then its optional periodic pattern with ONE 32-bit modulo per
+        // thread, stepped for the other elements.  A thread whose 4 elements straddle a segment end takes the general lookup.
         float lr4[4];
         {
-            int s0 = 0;
+            long long seg_start = 0, seg_end = n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0;
 #pragma unroll
-            for (int s = 7; s >= 0; s--) if (s < segs.n && i < segs.end[s]) s0 = s;
-            const long long start0 = s0 > 0 ? segs.end[s0 - 1] : 0;
-            unsigned ph = segs.period[s0] > 0 ? (unsigned)((unsigned long long)(i - start0) % (unsigned)segs.period[s0]) : 0u;
+            for (int s = 7; s >= 0; s--) if (s < segs.n && i < segs.end[s]) {
+                seg_end = segs.end[s]; seg_start = s > 0 ? segs.end[s - 1] : 0;
+                lr_a = segs.lr[s]; lr_b = segs.lr2[s]; period = segs.period[s]; split = segs.split[s];
+            }
+            if (i + 3 < seg_end) {
+                unsigned ph = period > 0 ? (unsigned)(i - seg_start) % (unsigned)period : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const long long idx = i + k;
-                if (idx < segs.end[s0] || s0 + 1 >= segs.n) {          // still in the first element's segment (the common case)
-                    lr4[k] = (segs.period[s0] > 0 && (int)ph >= segs.split[s0]) ? segs.lr2[s0] : segs.lr[s0];
-                    if (++ph == (unsigned)segs.period[s0]) ph = 0u;
-                } else {                                               // crossed into a later segment: general lookup
+                for (int k = 0; k < 4; k++) {
+                    lr4[k] = (period > 0 && (int)ph >= split) ? lr_b : lr_a;
+                    if (++ph == (unsigned)period) ph = 0u;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long long idx = i + k;
                     float lr = 0.f;
 #pragma unroll
                     for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) {
                         lr = segs.lr[s];
                         if (segs.period[s] > 0) {
-                            const long long local = idx - (s > 0 ? segs.end[s - 1] : 0);
-                            if ((int)(local % segs.period[s]) >= segs.split[s]) lr = segs.lr2[s];
+                            const unsigned local = (unsigned)(idx - (s > 0 ? segs.end[s - 1] : 0));
+                            if ((int)(local % (unsigned)segs.period[s]) >= segs.split[s]) lr = segs.lr2[s];
                         }
                     }
                     lr4[k] = lr;
@@ -102,9 +110,6 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
         if (atomicAdd(&st[4 + grp], 1) == grp_size - 1) {
             st[4 + grp] = 0;
             if (atomicAdd(&st[3], 1) == n_groups - 1) {
-                float* sf = const_cast<float*>(step_state);
-                sf[1] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));      // bias corrections of the NEXT step
-                sf[2] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
                 st[0] = t_dev; st[3] = 0;
             }
         }
