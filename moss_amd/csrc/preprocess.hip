@@ -446,6 +446,16 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         for (int j = 0; j < 12; j++) shv[j] = src[min(base4 + threadIdx.x + (size_t)j * blockDim.x, total4 - 1)];
     }
     const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc], hdr_flags = header[2];
+    if (STAGE_SH) {
+        // into LDS right away (row stride 49: conflict-free rows): the SH loads are the oldest outstanding ones, so this waits for
+        // them only, and their 48 registers are free during the gather (holding them across it spilled to scratch)
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int f = threadIdx.x + j * blockDim.x;
+            float* d = &s_sh[(f / 12) * SH_ROW + (f % 12) * 4];
+            d[0] = shv[j].x; d[1] = shv[j].y; d[2] = shv[j].z; d[3] = shv[j].w;
+        }
+    }
     const uint32_t n_inst = in_range ? tt_raw : 0u;
     const int n_slabs = SLABS > 0 ? SLABS : slabs;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
@@ -660,14 +670,6 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     PSTAMP(12);
-    if (STAGE_SH) {                                          // the SH loads have long landed: into LDS (row stride 49: conflict-free rows)
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const int f = threadIdx.x + j * blockDim.x;
-            float* d = &s_sh[(f / 12) * SH_ROW + (f % 12) * 4];
-            d[0] = shv[j].x; d[1] = shv[j].y; d[2] = shv[j].z; d[3] = shv[j].w;
-        }
-    }
     PSTAMP(1);
     if (STAGE_SH) __syncthreads();                           // SH records are in LDS
     PSTAMP(2);
