@@ -144,41 +144,12 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
     }
 }
 
-// Bitonic sorting network ("flip" form: every comparator leaves the minimum at the lower index, so elements past n
-// behave as +infinity without being stored and comparators touching them are skipped).
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr a, uint32_t n)
-{
-    uint32_t lpad = 0;
-    while ((1u << lpad) < n) lpad++;
-    const uint32_t half = (1u << lpad) >> 1;
-    for (uint32_t lk = 1; lk <= lpad; lk++) {                              // k = 2^lk
-        const uint32_t lhk = lk - 1, hkm = (1u << lhk) - 1u;
-        for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {        // flip step
-            const uint32_t blk = t >> lhk, off = t & hkm;
-            const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + ((1u << lk) - 1u) - off;
-            if (hi < n) {
-                const uint64_t x = a[lo], y = a[hi];
-                if (x > y) { a[lo] = y; a[hi] = x; }
-            }
-        }
-        __syncthreads();
-        for (int lj = (int)lhk - 1; lj >= 0; lj--) {                        // half-cleaners, j = 2^lj
-            const uint32_t j = 1u << lj;
-            for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-                const uint32_t lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u)), hi = lo + j;
-                if (hi < n) {
-                    const uint64_t x = a[lo], y = a[hi];
-                    if (x > y) { a[lo] = y; a[hi] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// Stage A of the sort: one workgroup per CHUNK of a tile's bucket (a tile of n entries has ceil(n/CHUNK) chunks), keys
-// sorted in LDS and written back in place.  Every workgroup has at most 1024 keys, so there is no long-tile tail here.
+// Stage A of the sort: one workgroup per CHUNK of a tile's bucket (a tile of n entries has ceil(n/CHUNK) chunks), sorted and
+// written back in place.  Every workgroup has at most 1024 keys, so there is no long-tile tail here.
+// One key per thread, in REGISTERS: a bitonic network whose compare-exchange partner is tid ^ j.  For j < 64 the partner is in the
+// same wave (two ds_bpermute, no barrier): 45 of the 55 stages of a full chunk; only j >= 64 goes through LDS with barriers
+// (the all-LDS version spent ~800 cycles per stage on barriers with 16 waves).  Threads past n hold the maximum key, and the
+// network stops at the padded size, so short chunks run few stages.
 __global__ void __launch_bounds__(1024)
 chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
                   const uint32_t* __restrict__ header)
@@ -187,7 +158,8 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
     __shared__ int s_tile;
     const uint32_t c = blockIdx.x;
     if (c >= header[4]) return;                        // the grid is an upper bound when R is not known on the host
-    if (threadIdx.x == 0) {         // last tile whose chunk_base <= c (tiles without entries share their successor's base)
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {                 // last tile whose chunk_base <= c (tiles without entries share their successor's base)
         int lo = 0, hi = T;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_base[mid] <= c) lo = mid; else hi = mid; }
         s_tile = lo;
@@ -198,10 +170,31 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
     const uint32_t first = rg.x + (c - chunk_base[tile]) * CHUNK;
     const uint32_t n = min((uint32_t)CHUNK, rg.y - first);
     uint64_t* gk = keys + first;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = gk[i];
-    __syncthreads();
-    bitonic_sort(s_keys, n);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gk[i] = s_keys[i];
+    uint32_t npad = 64;                                // at least one wave's worth: the intra-wave stages need no branches
+    while (npad < n) npad <<= 1;
+    if (tid >= npad) return;                           // whole waves only (npad is a multiple of 64); the barriers below count the
+                                                       // waves that are still alive
+    uint64_t key = tid < n ? gk[tid] : ~0ull;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        const bool up = (tid & k) == 0u;
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            uint64_t other;
+            if (j >= 64u) {                            // cross-wave partner through LDS
+                s_keys[tid] = key;
+                __syncthreads();
+                other = s_keys[tid ^ j];
+                __syncthreads();
+            } else {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j);
+                other = ((uint64_t)hi << 32) | lo;
+            }
+            const bool lower = (tid & j) == 0u;
+            const bool take_min = lower == up;
+            const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+            key = take_min ? mn : mx;
+        }
+    }
+    if (tid < n) gk[tid] = key;
 }
 
 // Stage B: one thread per instance.  Its final rank inside the tile = its rank inside its own (sorted) chunk + the number
@@ -358,8 +351,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
     // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) return;
-    static const int sort_threads = std::max(64, std::min(1024, env_int("MOSS_SORT_THREADS", 1024)));
-    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(sort_threads), 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
     hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, im.header, fp.gx, g, im.ranges, b.keys, b.inst_tile,
                        b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask);
 }
