@@ -119,7 +119,8 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
         __syncthreads();
         for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {      // whole waves stay converged
             const int idx = base + (int)threadIdx.x;
-            const uint2 r = idx < P ? g.rect[idx] : make_uint2(0u, 0u);
+            const float4 gd = g.geo[4 * (size_t)min(idx, P - 1) + 3];
+            const uint2 r = idx < P ? make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y)) : make_uint2(0u, 0u);
             wave_for_each_tile(r, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
         }
         __syncthreads();
@@ -131,9 +132,10 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
     }
     for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {
         const int idx = base + (int)threadIdx.x;
-        const uint2 r = idx < P ? g.rect[idx] : make_uint2(0u, 0u);
+        const float4 gd = g.geo[4 * (size_t)min(idx, P - 1) + 3];
+        const uint2 r = idx < P ? make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y)) : make_uint2(0u, 0u);
         const bool any = idx < P && (r.y & 0xffffu) > (r.x & 0xffffu) && (r.y >> 16) > (r.x >> 16);
-        const uint64_t key = any ? (((uint64_t)__float_as_uint(g.geo_c[idx].w) << 32) | (uint32_t)idx) : 0ull;
+        const uint64_t key = any ? (((uint64_t)__float_as_uint(g.geo[4 * (size_t)idx + 2].w) << 32) | (uint32_t)idx) : 0ull;
         wave_for_each_tile(r, gx, key, [&](int t, uint64_t k) {
             uint32_t pos;
             if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
@@ -226,9 +228,10 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
     const uint32_t id = (uint32_t)key;
     point_list[pos] = id;
     float4* rec = inst_rec + 3 * (size_t)pos;
-    const float4 ga = g.geo_a[id];
-    rec[0] = ga; rec[1] = g.geo_b[id]; rec[2] = g.geo_c[id];
-    const uint2 r = g.rect[id];
+    const float4* gsrc = g.geo + 4 * (size_t)id;                  // the Gaussian's one 64-byte record
+    const float4 ga = gsrc[0], gb = gsrc[1], gd = gsrc[3];
+    rec[0] = ga; rec[1] = gb; rec[2] = gsrc[2];
+    const uint2 r = make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y));
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
     const int tx = (int)tile % gx, ty = (int)tile / gx;
     {
@@ -250,7 +253,6 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
         // form q over its pixel rectangle exceeds tau (plus a margin for fp32 rounding: 1e-4 relative + 1e-3 absolute, against
         // |q| <= 5.6 at the threshold) cannot contribute and loses its bit.  Only done for finite extents (otherwise the box
         // decision stands).  Every wasted (entry, block) pair costs a quarter of a blend trip, forward and backward.
-        const float4 gb = g.geo_b[id];
         const float A = gb.x, B = gb.y, C = gb.z, opa = gb.w;
         if (bmask != 0u && ga.z < 3.0e38f && ga.w < 3.0e38f && A > 0.0f && C > 0.0f && opa > 0.0f) {
             const float tau = logf(255.0f * opa);
@@ -278,7 +280,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
         inst_bmask[pos] = (uint16_t)bmask;
     }
     const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-    inst_pos[g.point_offsets[id] + k] = pos;
+    inst_pos[__float_as_uint(gd.z) + k] = pos;
 }
 
 __global__ void __launch_bounds__(256)
@@ -296,7 +298,7 @@ export_binning_kernel(int T, GeomView g, const uint2* __restrict__ ranges, const
     for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x) {
         const uint32_t id = point_list[i];
         if (list_out) list_out[i] = id;
-        if (keys_out) keys_out[i] = ((uint64_t)(uint32_t)tile << 32) | (uint64_t)__float_as_uint(g.geo_c[id].w);
+        if (keys_out) keys_out[i] = ((uint64_t)(uint32_t)tile << 32) | (uint64_t)__float_as_uint(g.geo[4 * (size_t)id + 2].w);
     }
 }
 

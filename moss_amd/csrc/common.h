@@ -4,11 +4,13 @@
 // reference's layout is rasterizer_impl.cu:155-194, ours differs on purpose -- see DESIGN.md "Data layout"):
 //
 //   geometry buffer (per Gaussian, P entries)
-//     geo_a  float4 {pix.x, pix.y, cull_hx, cull_hy}        16 B  } three 16-byte records; geo_a alone is the cull record.
-//     geo_b  float4 {conic.A, conic.B, conic.C, opacity}    16 B  } The tile sort copies them, in sorted order, into the
-//     geo_c  float4 {r, g, b, depth}                        16 B  } per-instance stream the blend kernels read (inst_rec)
-//     rect   uint2  {min.x | min.y<<16, max.x | max.y<<16}   8 B    tile rectangle (getRect result)
-//     tiles_touched u32, point_offsets u32 (exclusive scan), radius i32, clamped u8 (bit c = channel c),
+//     geo    4 x float4 = ONE 64-byte record per Gaussian (a per-instance gather in the sort touches one cache line, not five):
+//       [0] {pix.x, pix.y, cull_hx, cull_hy}      position + half-extents of the alpha >= 1/255 box
+//       [1] {conic.A, conic.B, conic.C, opacity}  } [0..2] are copied, in sorted order, into the per-instance stream the
+//       [2] {r, g, b, depth}                      } blend kernels read (inst_rec)
+//       [3] bits {rect.min (x | y<<16), rect.max, point_offsets, tiles_touched}   tile rectangle (getRect result) + slot run
+//     tiles_touched u32, point_offsets u32 (also kept as plain arrays: the backward reads them coalesced), radius i32,
+//     clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
 //     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [6]=instances needed [8]/[9]=work-queue heads of the forward/backward blend
@@ -45,8 +47,7 @@ inline T* carve(char*& p, size_t count)
 }
 
 struct GeomView {
-    float4* geo_a; float4* geo_b; float4* geo_c;
-    uint2* rect;
+    float4* geo;             // 4 float4 per Gaussian, see the layout comment at the top of this file
     uint32_t* tiles_touched; uint32_t* point_offsets;
     int* radius;
     uint8_t* clamped;
@@ -54,8 +55,7 @@ struct GeomView {
     static GeomView at(char* base, int P)
     {
         GeomView g; char* p = base; size_t n = (size_t)P;
-        g.geo_a = carve<float4>(p, n); g.geo_b = carve<float4>(p, n); g.geo_c = carve<float4>(p, n);
-        g.rect = carve<uint2>(p, n);
+        g.geo = carve<float4>(p, 4 * n);
         g.tiles_touched = carve<uint32_t>(p, n); g.point_offsets = carve<uint32_t>(p, n);
         g.radius = carve<int>(p, n);
         g.clamped = carve<uint8_t>(p, n);

@@ -341,9 +341,9 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                 }
             }
 
-            g.geo_a[idx] = make_float4(pix.x, pix.y, hx, hy);                 // position + cull extents (the cull record)
-            g.geo_b[idx] = make_float4(conic.x, conic.y, conic.z, opa);
-            g.geo_c[idx] = make_float4(rgb.x, rgb.y, rgb.z, p_view.z);
+            g.geo[4 * (size_t)idx + 0] = make_float4(pix.x, pix.y, hx, hy);  // position + cull extents (the cull record)
+            g.geo[4 * (size_t)idx + 1] = make_float4(conic.x, conic.y, conic.z, opa);
+            g.geo[4 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, p_view.z);
             g.clamped[idx] = clamp_bits;
             out_radius = rad;
             out_tiles = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
@@ -375,7 +375,8 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             g.radius[idx] = out_radius;
             g.tiles_touched[idx] = out_tiles;
             g.point_offsets[idx] = wbase + incl - out_tiles;
-            g.rect[idx] = out_rect;
+            g.geo[4 * (size_t)idx + 3] = make_float4(__uint_as_float(out_rect.x), __uint_as_float(out_rect.y),
+                                                     __uint_as_float(wbase + incl - out_tiles), __uint_as_float(out_tiles));
             if (radii_out) radii_out[idx] = out_radius;
         }
         __syncthreads();
@@ -928,7 +929,7 @@ export_geometry_kernel(int P, GeomView g, float* depths, float* means2D, float* 
     if (idx >= P) return;
     const bool vis = g.tiles_touched[idx] > 0;
     const float4 z4 = make_float4(0, 0, 0, 0);
-    const float4 a = vis ? g.geo_a[idx] : z4, b = vis ? g.geo_b[idx] : z4, c = vis ? g.geo_c[idx] : z4;
+    const float4 a = vis ? g.geo[4 * (size_t)idx] : z4, b = vis ? g.geo[4 * (size_t)idx + 1] : z4, c = vis ? g.geo[4 * (size_t)idx + 2] : z4;
     if (depths) depths[idx] = c.w;
     if (means2D) { means2D[2 * (size_t)idx] = a.x; means2D[2 * (size_t)idx + 1] = a.y; }
     if (conic_opacity) reinterpret_cast<float4*>(conic_opacity)[idx] = b;
