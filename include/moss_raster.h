@@ -220,6 +220,38 @@ int moss_adamw_flat_devstep(long long n, float* params, const float* grads, floa
 int moss_knn_query(int Nr, int Nq, int k, const float* ref, const float* query, float* dist_out, long long* idx_out, void* stream);
 
 /*
+ * The same query through a uniform cell grid over the references (exact; results identical to moss_knn_query bit for bit, ties
+ * included).  Built once per reference set (8 small launches), queried any number of times: MOSS queries the SAME template
+ * vertices every step (scene/gaussian_model.py:827) and the Gaussians themselves when densifying (:586,759; 100k x 100k is 7.7 ms
+ * by brute force).  workspace: moss_knn_grid_workspace_bytes(Nr) device bytes, owned by the caller, read-only for queries.
+ * Cost grows with the distance between a query and its k-th neighbour measured in cells (about two cells per reference): meant
+ * for queries that lie among the references; far outliers stay exact but approach brute-force cost.  Asynchronous on `stream`.
+ */
+size_t moss_knn_grid_workspace_bytes(int Nr);
+int moss_knn_grid_build(int Nr, const float* ref, char* workspace, size_t workspace_bytes, void* stream);
+int moss_knn_grid_query(int Nr, int Nq, int k, const char* workspace, size_t workspace_bytes, const float* query,
+                        float* dist_out, long long* idx_out, void* stream);
+
+/*
+ * Densification bookkeeping, one launch, no host synchronisation.  Replaces, for vis = radii > 0,
+ *   gaussians.max_radii2D[vis] = max(max_radii2D[vis], radii[vis])                          (train_ZJU.py:173)
+ *   xyz_gradient_accum[vis] += norm(viewspace_points.grad[vis,:2], dim=-1); denom[vis] += 1  (scene/gaussian_model.py:815-817)
+ * radii (P) int32 from the forward; viewspace_grad (P, grad_stride >= 2) = dL_dmeans2D of the backward;
+ * xyz_gradient_accum (P), denom (P), max_radii2D (P, may be NULL) fp32, updated in place.
+ */
+int moss_densify_stats(int P, const int* radii, const float* viewspace_grad, int grad_stride,
+                       float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
+/*
+ * KL divergence between pairs of Gaussians, with the gather fused in: replaces GaussianModel.kl_div
+ * (scene/gaussian_model.py:773-813) applied to the pairs picked by the k = 2 self-query (:586-597, :759-770).
+ *   xyz (Nsrc,3), rotation (Nsrc,4) raw quaternions (normalised inside like build_rotation, utils/general_utils.py:79-100),
+ *   scaling (Nsrc,3) ACTIVATED scales; pair_idx (P,2) int64 = the kNN result (column 0: Gaussian "0", column 1: Gaussian "1");
+ *   kl_out (P) = 0.5 (tr(S1^-1 S0) + (mu1-mu0)^T S1^-1 (mu1-mu0) + ln prod((s1/s0)^2) - 3).  An out-of-range index gives NaN.
+ */
+int moss_neighbour_kl(int P, int Nsrc, const float* xyz, const float* rotation, const float* scaling,
+                      const long long* pair_idx, float* kl_out, void* stream);
+
+/*
  * Extension: covariance with a per-Gaussian 3x3 transform INSIDE the op.
  * MOSS feeds cov3D_precomp = strip_symmetric(T (R S S^T R^T) T^T) built by torch ops (scene/gaussian_model.py:37-44,168-169;
  * gaussian_renderer/__init__.py:88-91) because the LBS transform T of each Gaussian changes every frame; on MI355X that Python

@@ -79,6 +79,16 @@ def _declare(lib):
     lib.moss_knn_dist2.argtypes = [_i, _p, _p, _p, C.c_size_t, _p]
     lib.moss_knn_query.restype = _i
     lib.moss_knn_query.argtypes = [_i, _i, _i, _p, _p, _p, _p, _p]
+    lib.moss_knn_grid_workspace_bytes.restype = C.c_size_t
+    lib.moss_knn_grid_workspace_bytes.argtypes = [_i]
+    lib.moss_knn_grid_build.restype = _i
+    lib.moss_knn_grid_build.argtypes = [_i, _p, _p, C.c_size_t, _p]
+    lib.moss_knn_grid_query.restype = _i
+    lib.moss_knn_grid_query.argtypes = [_i, _i, _i, _p, C.c_size_t, _p, _p, _p, _p]
+    lib.moss_densify_stats.restype = _i
+    lib.moss_densify_stats.argtypes = [_i, _p, _p, _i, _p, _p, _p, _p]
+    lib.moss_neighbour_kl.restype = _i
+    lib.moss_neighbour_kl.argtypes = [_i, _i, _p, _p, _p, _p, _p, _p]
     lib.moss_loss_workspace_bytes.restype = C.c_size_t
     lib.moss_loss_workspace_bytes.argtypes = [_i, _i, _i]
     lib.moss_photometric_loss.restype = _i

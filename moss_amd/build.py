@@ -30,6 +30,7 @@ SOURCES = {
     "loss.hip": [],
     "optim.hip": [],
     "activations.hip": [],
+    "densify.hip": [],
     "raster_api.hip": [],
 }
 

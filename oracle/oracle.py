@@ -203,3 +203,66 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
                                  _p(campos), _p(g.dL_dmeans2D), _p(g.dL_dmeans3D), _p(g.dL_dcolors), _p(g.dL_dcov3D),
                                  _p(g.dL_dsh), _p(g.dL_dscales), _p(g.dL_drotations), _p(transforms), _p(g.dL_dtransforms))
     return g
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Densification bookkeeping and the KL test of the KL-guided densify: numpy restatements.
+# Parity unpinned by the reference for kl_div: GaussianModel.kl_div allocates with .to('cuda') (scene/gaussian_model.py:796)
+# and cannot run in a container without CUDA; it is restated here step by step in float64 and pinned by known answers
+# (tests/test_oracle_cpu.py: identical Gaussians -> 0, isotropic closed form, scipy-free direct matrix evaluation).
+
+def densify_stats(radii, viewspace_grad, xyz_gradient_accum, denom, max_radii2D):
+    """train_ZJU.py:171-174 + GaussianModel.add_densification_stats (scene/gaussian_model.py:815-817), out of place, fp32."""
+    vis = np.asarray(radii) > 0
+    acc = np.array(xyz_gradient_accum, dtype=np.float32, copy=True).reshape(-1)
+    den = np.array(denom, dtype=np.float32, copy=True).reshape(-1)
+    mr = np.array(max_radii2D, dtype=np.float32, copy=True)
+    g = np.asarray(viewspace_grad, dtype=np.float32)
+    mr[vis] = np.maximum(mr[vis], np.asarray(radii)[vis].astype(np.float32))                     # train_ZJU.py:173
+    acc[vis] += np.sqrt(g[vis, 0] * g[vis, 0] + g[vis, 1] * g[vis, 1]).astype(np.float32)      # gaussian_model.py:816
+    den[vis] += 1.0                                                                             # :817
+    return acc, den, mr
+
+
+def build_rotation(q):
+    """utils/general_utils.py:79-100 (float64)."""
+    q = np.asarray(q, dtype=np.float64)
+    q = q / np.sqrt((q * q).sum(-1, keepdims=True))
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.zeros((q.shape[0], 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - r * z); R[:, 0, 2] = 2 * (x * z + r * y)
+    R[:, 1, 0] = 2 * (x * y + r * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - r * x)
+    R[:, 2, 0] = 2 * (x * z - r * y); R[:, 2, 1] = 2 * (y * z + r * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def kl_div(mu_0, rotation_0_q, scaling_0_diag, mu_1, rotation_1_q, scaling_1_diag):
+    """GaussianModel.kl_div, scene/gaussian_model.py:773-813, in float64; returns (kl, magnitude) where magnitude is the sum
+    of the absolute values of the four terms (the scale the fp32 kernel's rounding error is measured against)."""
+    s0 = np.asarray(scaling_0_diag, dtype=np.float64); s1 = np.asarray(scaling_1_diag, dtype=np.float64)
+    R0 = build_rotation(rotation_0_q)                                   # :776
+    L0 = R0 * s0[:, None, :]                                            # rotation_0 @ build_scaling(s0)   :779
+    cov0 = L0 @ L0.transpose(0, 2, 1)                                   # :780
+    R1 = build_rotation(rotation_1_q)                                   # :783
+    L1i = R1 * (1.0 / s1)[:, None, :]                                   # rotation_1 @ build_scaling(1/s1) :786
+    cov1_inv = L1i @ L1i.transpose(0, 2, 1)                             # :787
+    d = np.asarray(mu_1, dtype=np.float64) - np.asarray(mu_0, dtype=np.float64)    # :790
+    kl0 = np.trace(cov1_inv @ cov0, axis1=1, axis2=2)                   # :796-804 (trace of each product)
+    kl1 = np.einsum("pi,pij,pj->p", d, cov1_inv, d)                     # :806
+    kl2 = np.log(np.prod((s1 / s0) ** 2, axis=1))                       # :807
+    return 0.5 * (kl0 + kl1 + kl2 - 3), np.abs(kl0) + np.abs(kl1) + np.abs(kl2) + 3   # :808
+
+
+def knn_exhaustive(ref, query, k):
+    """Exhaustive k nearest references per query (float32 arithmetic of moss_knn_query: dx*dx + dy*dy + dz*dz, no fused
+    multiply-add; ties -> lower index).  O(Nq Nr) memory in chunks; for small cases."""
+    ref = np.asarray(ref, dtype=np.float32); query = np.asarray(query, dtype=np.float32)
+    dist = np.empty((query.shape[0], k), dtype=np.float32); idx = np.empty((query.shape[0], k), dtype=np.int64)
+    for s in range(0, query.shape[0], 2048):
+        q = query[s:s + 2048]
+        dx = ref[None, :, 0] - q[:, None, 0]; dy = ref[None, :, 1] - q[:, None, 1]; dz = ref[None, :, 2] - q[:, None, 2]
+        d = (dx * dx + dy * dy) + dz * dz
+        order = np.argsort(d, axis=1, kind="stable")[:, :k]
+        idx[s:s + 2048] = order
+        dist[s:s + 2048] = np.sqrt(np.take_along_axis(d, order, axis=1))
+    return dist, idx

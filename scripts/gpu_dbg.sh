@@ -1,2 +1,4 @@
-timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -2
-timeout 600 python scripts/stage_times.py --mode scale_rot 2>&1 | tail -1 | cut -c1-300
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -5 gpurun_out/t.log
+timeout 600 python scripts/bench_densify.py 2>&1 | tail -3

@@ -649,3 +649,110 @@ def test_knn_dimension_major_mode_and_ties(gpu, hip_lib):
     assert d2.shape == (1, 3, 1) and torch.equal(i2[0, :, 0], i[0, 0]) and torch.equal(d2[0, :, 0], d[0, 0])
     with pytest.raises(RuntimeError):
         KNN(k=1, transpose_mode=True)(ref.cpu(), query.cpu())
+
+
+# ---------------------------------------------------------------- cell-grid k-NN, densification statistics, neighbour KL (rows n3/n4)
+def _body_points(n, seed, spread=0.02):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.rand(n, generator=g) * 1.7
+    ang = torch.rand(n, generator=g) * 6.2831853
+    rad = 0.1 + 0.1 * torch.rand(n, generator=g)
+    pts = torch.stack([rad * torch.cos(ang), t, rad * torch.sin(ang)], 1) + spread * torch.randn(n, 3, generator=g)
+    return pts.float()
+
+
+@pytest.mark.parametrize("Nr,Nq,k", [(1, 5, 1), (7, 100, 4), (3000, 2500, 1), (6890, 20000, 1), (20000, 20000, 2), (50000, 3000, 3)])
+def test_knn_grid_is_identical_to_brute_force(gpu, hip_lib, Nr, Nq, k):
+    from knn_cuda import knn
+    ref = _body_points(Nr, 1).cuda()
+    query = (ref if Nr == Nq else _body_points(Nq, 2)).cuda()
+    d0, i0 = knn(ref[None], query[None], k, "brute")
+    d1, i1 = knn(ref[None], query[None], k, "grid")
+    torch.cuda.synchronize()
+    assert torch.equal(i0, i1)
+    assert torch.equal(d0, d1)
+
+
+def test_knn_grid_ties_outliers_and_degenerate_boxes(gpu, hip_lib):
+    from knn_cuda import knn, KnnGrid
+    # duplicates (ties broken by index), coplanar references (a degenerate bounding box), queries far outside the box
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(1500, 3, generator=g)
+    base[:, 2] = 0.25
+    ref = torch.cat([base, base[:700]]).cuda()
+    query = torch.cat([base[:900], torch.tensor([[5.0, -3.0, 2.0], [-40.0, 0.5, 0.25], [0.5, 0.5, 1e4]])]).cuda()
+    d0, i0 = knn(ref[None], query[None], 4, "brute")
+    d1, i1 = knn(ref[None], query[None], 4, "grid")
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    # all references identical: one cell
+    same = torch.full((3000, 3), 0.5).cuda()
+    d0, i0 = knn(same[None], query[None], 3, "brute")
+    d1, i1 = knn(same[None], query[None], 3, "grid")
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    # a kept grid answers several queries and ignores later changes of the reference tensor
+    grid = KnnGrid(ref)
+    ref.zero_()
+    d2, i2 = grid.query(query, 2)
+    d3, i3 = knn(torch.cat([base, base[:700]]).cuda()[None], query[None], 2, "brute")
+    assert torch.equal(i2, i3[0]) and torch.equal(d2, d3[0])
+
+
+def test_knn_grid_matches_the_exhaustive_oracle(gpu, hip_lib):
+    from knn_cuda import KNN
+    from oracle import oracle
+    ref = _body_points(5000, 3)
+    query = _body_points(4000, 4)
+    d, i = KNN(2, transpose_mode=True, impl="grid")(ref.cuda()[None], query.cuda()[None])
+    d_ref, i_ref = oracle.knn_exhaustive(ref.numpy(), query.numpy(), 2)
+    assert np.array_equal(i[0].cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d[0].cpu().numpy(), d_ref)
+
+
+def test_densify_stats_match_the_reference_expressions(gpu, hip_lib):
+    from moss_amd.densify import DensifyStats
+    from oracle import oracle
+    P = 5000
+    g = torch.Generator().manual_seed(11)
+    stats = DensifyStats(P)
+    acc, den, mr = np.zeros(P, np.float32), np.zeros(P, np.float32), np.zeros(P, np.float32)
+    for it in range(3):
+        radii = (torch.randint(-2, 40, (P,), generator=g) * (torch.rand(P, generator=g) > 0.3)).int()
+        grad = torch.randn(P, 3, generator=g)
+        stats.add(radii.cuda(), grad.cuda())
+        acc, den, mr = oracle.densify_stats(radii.numpy(), grad.numpy(), acc, den, mr)
+    np.testing.assert_array_equal(stats.denom.cpu().numpy().ravel(), den)
+    np.testing.assert_array_equal(stats.max_radii2D.cpu().numpy(), mr)
+    np.testing.assert_allclose(stats.xyz_gradient_accum.cpu().numpy().ravel(), acc, rtol=3e-7, atol=0)   # sqrt rounding only
+    # the reference's own torch expressions on the GPU
+    t_acc = torch.zeros(P, 1).cuda(); t_den = torch.zeros(P, 1).cuda(); t_mr = torch.zeros(P).cuda()
+    s2 = DensifyStats(P)
+    radii = torch.randint(0, 30, (P,), generator=g).int().cuda(); grad = torch.randn(P, 3, generator=g).cuda()
+    vis = radii > 0
+    t_mr[vis] = torch.max(t_mr[vis], radii[vis].float())
+    t_acc[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True); t_den[vis] += 1
+    s2.add(radii, grad)
+    assert torch.equal(s2.denom, t_den) and torch.equal(s2.max_radii2D, t_mr)
+    torch.testing.assert_close(s2.xyz_gradient_accum, t_acc, rtol=1e-6, atol=0)
+    g_mean = s2.mean_grads()
+    assert not g_mean.isnan().any() and (g_mean[~vis] == 0).all()
+
+
+def test_neighbour_kl_matches_the_float64_oracle(gpu, hip_lib):
+    from moss_amd.densify import neighbour_kl, cal_kl
+    from oracle import oracle
+    P = 20000
+    g = torch.Generator().manual_seed(12)
+    xyz = _body_points(P, 6)
+    rot = torch.randn(P, 4, generator=g)
+    scaling = torch.exp(torch.randn(P, 3, generator=g) * 0.5 + np.log(0.01)).float()
+    kl, ids = cal_kl(xyz.cuda(), rot.cuda(), scaling.cuda())
+    ids_np = ids.cpu().numpy()
+    assert (ids_np[:, 0] == np.arange(P)).all()                      # distinct points: the nearest is the point itself
+    want, mag = oracle.kl_div(xyz.numpy()[ids_np[:, 0]], rot.numpy()[ids_np[:, 0]], scaling.numpy()[ids_np[:, 0]],
+                              xyz.numpy()[ids_np[:, 1]], rot.numpy()[ids_np[:, 1]], scaling.numpy()[ids_np[:, 1]])
+    err = np.abs(kl.cpu().numpy().astype(np.float64) - want)
+    assert (err <= 2e-5 * mag).all(), float((err / mag).max())       # fp32 evaluation vs float64, relative to the terms' magnitude
+    # explicit pairs, including a Gaussian against itself (KL = 0 up to rounding) and an invalid index (NaN, no fault)
+    pairs = torch.tensor([[0, 0], [5, 9], [9, 5], [3, P]], dtype=torch.int64).cuda()
+    out = neighbour_kl(xyz.cuda(), rot.cuda(), scaling.cuda(), pairs).cpu().numpy()
+    assert abs(out[0]) < 1e-5 and np.isnan(out[3]) and out[1] != out[2]

@@ -145,3 +145,55 @@ def test_frame_parallel_gradient_bucket_gloo_world2():
         assert torch.allclose(g0, torch.full((5, 3), 1.5))                  # mean of 1 and 2
         assert torch.allclose(g1, torch.full((7,), 15.0))                   # mean of 10 and 20
         assert torch.allclose(loss, torch.tensor([(15.0 + 30.0) / 2]))      # mean of the two ranks' losses
+
+
+def _stats_rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from moss_amd import dist as mdist
+    from moss_amd.densify import DensifyStats
+    mdist.init_from_env(backend="gloo")
+    stats = DensifyStats(6, device="cpu")
+    # what two steps of moss_densify_stats would have left on this rank (the kernel itself needs a GPU)
+    stats.xyz_gradient_accum[:, 0] = torch.tensor([1.0, 0.0, 2.0, 0.0, 0.5, 0.0]) * (rank + 1)
+    stats.denom[:, 0] = torch.tensor([2.0, 0.0, 1.0, 0.0, 1.0, 0.0]) + rank
+    stats.max_radii2D[:] = torch.tensor([3.0, 0.0, 9.0, 0.0, 1.0, 0.0]) if rank == 0 else torch.tensor([4.0, 7.0, 2.0, 0.0, 1.0, 0.0])
+    stats.sync()
+    q.put((rank, stats.xyz_gradient_accum.clone(), stats.denom.clone(), stats.max_radii2D.clone(), stats.mean_grads().clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_densification_statistics_sync_gloo_world2():
+    """Frame-parallel replicas must take the same densification decision: sum / sum / max of the per-rank statistics."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_stats_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, acc, den, mr, mean in res:
+        assert torch.equal(acc[:, 0], torch.tensor([3.0, 0.0, 6.0, 0.0, 1.5, 0.0]))
+        assert torch.equal(den[:, 0], torch.tensor([5.0, 1.0, 3.0, 1.0, 3.0, 1.0]))
+        assert torch.equal(mr, torch.tensor([4.0, 7.0, 9.0, 0.0, 1.0, 0.0]))
+        assert torch.equal(mean[:, 0], torch.tensor([0.6, 0.0, 2.0, 0.0, 0.5, 0.0]))
+
+
+def test_densify_ops_refuse_cpu_tensors(hip_lib):
+    from moss_amd.densify import DensifyStats, neighbour_kl
+    from knn_cuda import KnnGrid
+    s = DensifyStats(4, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        s.add(torch.ones(4, dtype=torch.int32), torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        neighbour_kl(torch.zeros(4, 3), torch.ones(4, 4), torch.ones(4, 3), torch.zeros(4, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        KnnGrid(torch.zeros(4, 3))
+    assert hip_lib.moss_knn_grid_workspace_bytes(100000) > 100000 * 24
+    assert hip_lib.moss_knn_grid_build(0, None, None, 0, None) != 0          # argument validation happens before any launch
+    assert hip_lib.moss_neighbour_kl(-1, 0, None, None, None, None, None, None) != 0

@@ -269,3 +269,37 @@ def test_explicit_backward_matches_independent_autograd(mode):
             got = got[:, :2]
         err = hp.rel_err(got.reshape(gref.shape), gref.numpy())
         assert err < 2e-3, (name, err)
+
+
+# ---------------------------------------------------------------- densification restatements: known answers
+def test_kl_div_known_answers():
+    rng = np.random.default_rng(7)
+    P = 64
+    mu0 = rng.normal(size=(P, 3)); q0 = rng.normal(size=(P, 4)); s0 = np.exp(rng.normal(size=(P, 3)) * 0.4)
+    mu1 = mu0 + 0.3 * rng.normal(size=(P, 3)); q1 = rng.normal(size=(P, 4)); s1 = np.exp(rng.normal(size=(P, 3)) * 0.4)
+    kl, mag = oracle.kl_div(mu0, q0, s0, mu0, q0, s0)
+    assert np.abs(kl).max() < 1e-12                                         # a Gaussian against itself
+    iso = np.full((P, 3), 0.7)
+    kl, _ = oracle.kl_div(mu0, q0, iso, mu1, q1, iso)                        # equal isotropic covariances: |d|^2 / (2 s^2)
+    np.testing.assert_allclose(kl, 0.5 * ((mu1 - mu0) ** 2).sum(1) / 0.49, rtol=1e-12)
+    # the textbook formula evaluated with explicit covariance matrices, inverse and determinants
+    kl, _ = oracle.kl_div(mu0, q0, s0, mu1, q1, s1)
+    R0, R1 = oracle.build_rotation(q0), oracle.build_rotation(q1)
+    for i in range(P):
+        S0 = R0[i] @ np.diag(s0[i] ** 2) @ R0[i].T
+        S1 = R1[i] @ np.diag(s1[i] ** 2) @ R1[i].T
+        d = mu1[i] - mu0[i]
+        want = 0.5 * (np.trace(np.linalg.inv(S1) @ S0) + d @ np.linalg.inv(S1) @ d - 3 + np.log(np.linalg.det(S1) / np.linalg.det(S0)))
+        assert abs(kl[i] - want) < 1e-9 * max(1.0, abs(want))
+    assert (kl > -1e-12).all()                                               # a KL divergence is non-negative
+
+
+def test_densify_stats_and_exhaustive_knn_restatements():
+    radii = np.array([3, 0, -1, 7, 2], dtype=np.int32)
+    grad = np.array([[3, 4, 9], [1, 1, 1], [5, 12, 0], [0, 0, 5], [6, 8, 1]], dtype=np.float32)
+    acc, den, mr = oracle.densify_stats(radii, grad, np.zeros(5), np.ones(5), np.array([1, 1, 1, 9, 1], dtype=np.float32))
+    assert acc.tolist() == [5.0, 0.0, 0.0, 0.0, 10.0] and den.tolist() == [2.0, 1.0, 1.0, 2.0, 2.0] and mr.tolist() == [3.0, 1.0, 1.0, 9.0, 2.0]
+    ref = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [1, 0, 0]], dtype=np.float32)
+    d, i = oracle.knn_exhaustive(ref, np.array([[0.9, 0, 0], [0, 1.5, 0]], dtype=np.float32), 3)
+    assert i.tolist() == [[1, 3, 0], [2, 0, 1]]                              # the duplicate keeps the lower index in front
+    np.testing.assert_allclose(d[0], [0.1, 0.1, 0.9], rtol=1e-6)
