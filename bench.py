@@ -65,6 +65,11 @@ def main():
     ap.add_argument("--torch-activations", action="store_true",
                     help="compute the parameter activations (exp / sigmoid / normalize / cat) with torch ops and let autograd "
                          "accumulate into the bucket, instead of the fused HIP activation kernels writing into it")
+    ap.add_argument("--target", default="body", choices=["body", "smooth"],
+                    help="ground truth of the photometric loss: body = a render of a DIFFERENT random Gaussian body (other points, "
+                         "other colours) through the same camera, mask = its alpha > 0.5 -- a masked person on black, like MOSS's "
+                         "ZJU-MoCap frames; smooth = a full-frame smooth colour field (drives a few dozen Gaussians to cover the "
+                         "whole image within ~250 steps, a regime real captures do not have)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
@@ -105,8 +110,17 @@ def main():
         gT = torch.Generator().manual_seed(1234)
         lbs_T = (torch.eye(3) + 0.05 * torch.randn(scene.means3D.shape[0], 3, 3, generator=gT)).to(dev)
     bg = torch.zeros(3, device=dev)
-    gt = scenes.synthetic_target(H, W).to(dev)
-    gt_mask = (gt.mean(0, keepdim=True) > 0.5).float()
+    if args.target == "smooth":
+        gt = scenes.synthetic_target(H, W).to(dev)
+        gt_mask = (gt.mean(0, keepdim=True) > 0.5).float()
+    else:
+        gt_scene = maker(seed=scenes.SEED + 7)
+        gt_pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+        with torch.no_grad():
+            gt_out = render(cam, GaussianSet(gt_scene, sh_degree=3, device=dev), gt_pipe, bg)
+        gt = gt_out["render"].detach().clamp(0, 1).contiguous()
+        gt_mask = (gt_out["render_alpha"].detach() > 0.5).float().contiguous()
+        del gt_out, gt_scene
     bucket = mdist.GradBucket(list(pc.parameters()))
     pipe.grad_bucket = bucket
     if args.torch_adamw:
@@ -280,7 +294,7 @@ def main():
         "config": {"workload": f"BASELINE configs[2]: {P} Gaussians on a synthetic capsule body, {W}x{H}, SH degree 3, "
                                f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
                    if args.config == "cfg3" else args.config,
-                   "input_mode": args.mode, "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
+                   "target": args.target, "input_mode": args.mode, "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                    "forward": args.forward, "launch": graph_note},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -297,9 +311,33 @@ def main():
         "step_hbm_frac": round(total_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
     }
 
+    if world == 1:
+        result["densify_side_ms"] = densify_side(pc, out)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
     print(json.dumps(result))
+
+
+def densify_side(pc, out):
+    """the KL-guided densify test (k = 2 self query + kl_div, every 100 steps in MOSS) and the per-step densification
+    statistics are reported BESIDE the step metric, never inside it."""
+    import torch
+    from moss_amd.densify import DensifyStats, cal_kl
+    with torch.no_grad():
+        xyz, rot, scl = pc.get_xyz.detach(), pc._rotation.detach(), pc.get_scaling.detach()
+        radii = out["radii"]
+        stats = DensifyStats(xyz.shape[0], device=xyz.device)
+        grad = torch.randn(xyz.shape[0], 3, device=xyz.device)
+        res = {}
+        for name, fn in (("cal_kl_every_100_steps", lambda: cal_kl(xyz, rot, scl)), ("statistics_per_step", lambda: stats.add(radii, grad))):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            res[name] = round(a.elapsed_time(b) / 10, 4)
+    return res
 
 
 def _pmc_traffic(kernel):
