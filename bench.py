@@ -140,11 +140,11 @@ def main():
         else:
             bucket.attach()             # zero the bucket; autograd accumulates into it
         out = render(cam, pc, pipe, bg, transforms=lbs_T)
-        loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
+        # the loss kernels write [loss, L1, SSIM, mask] into the bucket's tail: it travels with the gradients, no copy
+        loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
         backward_from_loss(loss)
         if pipe.fused_activations:
             bucket.collect()
-        bucket.loss_slot.copy_(loss.detach().reshape(1))
         if world == 1:
             opt.step()
         # detached: holding an output with a grad_fn would keep this step's autograd graph (and its AccumulateGrad nodes,

@@ -27,6 +27,7 @@ __device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u &
 __global__ void __launch_bounds__(256)
 bounds_kernel(int P, const float* __restrict__ pts, uint32_t* __restrict__ mm /* [0..2]=min, [3..5]=max, ordered ints */)
 {
+    __shared__ float s_mn[4][3], s_mx[4][3];
     float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x)
 #pragma unroll
@@ -35,7 +36,13 @@ bounds_kernel(int P, const float* __restrict__ pts, uint32_t* __restrict__ mm /*
     for (int k = 0; k < 3; k++) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], d)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[k], f2ord(mn[k])); atomicMax(&mm[3 + k], f2ord(mx[k])); }
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][k] = mn[k]; s_mx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {                          // one set of atomics per workgroup: same-address atomics serialise
+        const int k = threadIdx.x;
+        atomicMin(&mm[k], f2ord(fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]))));
+        atomicMax(&mm[3 + k], f2ord(fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]))));
     }
 }
 
@@ -218,7 +225,7 @@ extern "C" int moss_knn_dist2(int P, const float* points, float* mean_dists, cha
     const int num_boxes = (P + BOX - 1) / BOX;
     if (hipMemsetAsync(v.mm, 0xff, 3 * sizeof(uint32_t), s) != hipSuccess) return MOSS_ERR_HIP;
     if (hipMemsetAsync(v.mm + 3, 0x00, 3 * sizeof(uint32_t), s) != hipSuccess) return MOSS_ERR_HIP;
-    hipLaunchKernelGGL(bounds_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, P, points, v.mm);
+    hipLaunchKernelGGL(bounds_kernel, dim3(blocks < 128 ? blocks : 128), dim3(256), 0, s, P, points, v.mm);
     hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, s, P, points, v.mm, v.keys);
     hipLaunchKernelGGL(sort_keys_kernel, dim3(1), dim3(1024), 0, s, v.keys, (uint32_t)P);
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, P, points, v.keys, v.sorted);

@@ -114,6 +114,7 @@ grid_init_kernel(uint32_t* __restrict__ hdr, uint32_t* __restrict__ start, int w
 __global__ void __launch_bounds__(256)
 grid_bounds_kernel(int Nr, const float* __restrict__ pts, uint32_t* __restrict__ hdr)
 {
+    __shared__ float s_mn[4][3], s_mx[4][3];
     float mn[3] = { __builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf() };
     float mx[3] = { -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf() };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Nr; i += gridDim.x * blockDim.x)
@@ -123,7 +124,15 @@ grid_bounds_kernel(int Nr, const float* __restrict__ pts, uint32_t* __restrict__
     for (int k = 0; k < 3; k++) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], d)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&hdr[k], f2ord(mn[k])); atomicMax(&hdr[3 + k], f2ord(mx[k])); }
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][k] = mn[k]; s_mx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    // one set of atomics per workgroup (and few workgroups): thousands of ordered atomics on the same six words serialise
+    // (24k of them took 108 us at 100k points)
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        atomicMin(&hdr[k], f2ord(fminf(fminf(s_mn[0][k], s_mn[1][k]), fminf(s_mn[2][k], s_mn[3][k]))));
+        atomicMax(&hdr[3 + k], f2ord(fmaxf(fmaxf(s_mx[0][k], s_mx[1][k]), fmaxf(s_mx[2][k], s_mx[3][k]))));
     }
 }
 
@@ -355,7 +364,7 @@ extern "C" int moss_knn_grid_build(int Nr, const float* ref, char* workspace, si
     const int blocks = (Nr + 255) / 256;
     const int words = v.nblocks * SCAN_BLOCK;
     hipLaunchKernelGGL(grid_init_kernel, dim3(min((words + 255) / 256, 2048)), dim3(256), 0, s, v.hdr, v.start, words, Nr);
-    hipLaunchKernelGGL(grid_bounds_kernel, dim3(min(blocks, 1024)), dim3(256), 0, s, Nr, ref, v.hdr);
+    hipLaunchKernelGGL(grid_bounds_kernel, dim3(min(blocks, 128)), dim3(256), 0, s, Nr, ref, v.hdr);
     hipLaunchKernelGGL(grid_dims_kernel, dim3(1), dim3(64), 0, s, v.hdr, v.ncells_max);
     hipLaunchKernelGGL(grid_count_kernel, dim3(blocks), dim3(256), 0, s, Nr, ref, v.hdr, v.start, v.cell, v.rank);
     hipLaunchKernelGGL(grid_scan_blocks_kernel, dim3(v.nblocks), dim3(256), 0, s, v.start, v.bsum);

@@ -33,12 +33,14 @@ __device__ __forceinline__ float ld0(const float* __restrict__ p, int x, int y, 
 
 __global__ void __launch_bounds__(256)
 ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Win win,
-                  float* __restrict__ dmap /* [3][C][H][W] */, float* __restrict__ partials /* [blocks][2] */)
+                  float* __restrict__ dmap /* [3][C][H][W] */, float* __restrict__ partials /* [blocks][2] */,
+                  const float* __restrict__ alpha, const float* __restrict__ mask, float lambda_mask,
+                  float* __restrict__ dL_dalpha, float* __restrict__ mask_partials /* [tiles] */)
 {
     __shared__ float s_x[LP][LP + 1];
     __shared__ float s_y[LP][LP + 1];
     __shared__ float s_h[5][LP][LT + 1];
-    __shared__ float s_red[2][4];
+    __shared__ float s_red[3][4];
 
     const int c = blockIdx.z;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -66,7 +68,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
     const int px = x0 + lx, py = y0 + ly;
-    float ssim_v = 0.f, l1_v = 0.f;
+    float ssim_v = 0.f, l1_v = 0.f, mask_v = 0.f;
     if (px < W && py < H) {
         float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
 #pragma unroll
@@ -91,15 +93,24 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         dmap[o] = dS_dmu1; dmap[plane3 + o] = dS_ds1; dmap[2 * plane3 + o] = dS_ds12;
         ssim_v = S;
         l1_v = fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
+        // the alpha-vs-mask L2 term rides on channel 0's tiles; it is computed HERE (not in pass 2, where its gradient would
+        // fit just as well) so that everything pass 2's closing fold reads was written by an earlier kernel
+        if (c == 0 && alpha != nullptr) {
+            const size_t oa = (size_t)py * W + px;
+            const float da = alpha[oa] - mask[oa];
+            mask_v = da * da;
+            dL_dalpha[oa] = lambda_mask * 2.f * da / ((float)H * (float)W);
+        }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { ssim_v += __shfl_xor(ssim_v, d); l1_v += __shfl_xor(l1_v, d); }
-    if ((tid & 63) == 0) { s_red[0][tid >> 6] = ssim_v; s_red[1][tid >> 6] = l1_v; }
+    for (int d = 32; d >= 1; d >>= 1) { ssim_v += __shfl_xor(ssim_v, d); l1_v += __shfl_xor(l1_v, d); mask_v += __shfl_xor(mask_v, d); }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = ssim_v; s_red[1][tid >> 6] = l1_v; s_red[2][tid >> 6] = mask_v; }
     __syncthreads();
     if (tid == 0) {
         const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         partials[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
         partials[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+        if (c == 0 && alpha != nullptr) mask_partials[blockIdx.y * gridDim.x + blockIdx.x] = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
     }
 }
 
@@ -108,7 +119,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
                   const float* __restrict__ alpha, const float* __restrict__ mask, Win win,
                   const float* __restrict__ dmap, const float* __restrict__ partials, int nblocks,
                   float lambda_dssim, float lambda_mask, float* __restrict__ dL_dimg, float* __restrict__ dL_dalpha,
-                  float* __restrict__ mask_partials, float* __restrict__ loss_out)
+                  const float* __restrict__ mask_partials, float* __restrict__ loss_out)
 {
     __shared__ float s_d[3][LP][LP + 1];
     __shared__ float s_h[3][LP][LT + 1];
@@ -137,7 +148,6 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
     const int px = x0 + lx, py = y0 + ly;
-    float mask_v = 0.f;
     if (px < W && py < H) {
         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
 #pragma unroll
@@ -151,52 +161,27 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         dL_dimg[o] = sgn / N - lambda_dssim * dssim / N;
-        if (c == 0 && alpha != nullptr) {
-            const size_t oa = (size_t)py * W + px;
-            const float da = alpha[oa] - mask[oa];
-            mask_v = da * da;
-            dL_dalpha[oa] = lambda_mask * 2.f * da / ((float)H * (float)W);
-        }
     }
-    if (c == 0 && alpha != nullptr) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mask_v += __shfl_xor(mask_v, d);
-        if ((tid & 63) == 0) s_red[0][tid >> 6] = mask_v;
-        __syncthreads();
-        if (tid == 0) mask_partials[blockIdx.y * gridDim.x + blockIdx.x] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-    }
-    // block (0,0,0) folds pass 1's partials; the mask term is folded by the caller-visible finish kernel below
+    // Block (0,0,0) folds pass 1's partials into the four loss terms (no separate "finish" launch: a minimal launch costs 4-5 us).
+    // Everything it reads was written by pass 1, an earlier kernel -- which is why the mask term is computed there.
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        float a = 0.f, b = 0.f;
+        const int nmask = alpha != nullptr ? (int)(gridDim.x * gridDim.y) : 0;
+        float a = 0.f, b = 0.f, m = 0.f;
         for (int i = tid; i < nblocks; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+        for (int i = tid; i < nmask; i += 256) m += mask_partials[i];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); m += __shfl_xor(m, d); }
         __syncthreads();
-        if ((tid & 63) == 0) { s_red[1][tid >> 6] = a; s_red[2][tid >> 6] = b; }
+        if ((tid & 63) == 0) { s_red[0][tid >> 6] = m; s_red[1][tid >> 6] = a; s_red[2][tid >> 6] = b; }
         __syncthreads();
         if (tid == 0) {
             const float ssim_mean = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) / N;
             const float l1_mean = ((s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3])) / N;
-            loss_out[1] = l1_mean; loss_out[2] = ssim_mean;
+            const float mask_mean = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) / ((float)H * (float)W);
+            const float lm = alpha != nullptr ? lambda_mask : 0.0f;
+            loss_out[1] = l1_mean; loss_out[2] = ssim_mean; loss_out[3] = mask_mean;
+            loss_out[0] = l1_mean + lm * mask_mean + lambda_dssim * (1.0f - ssim_mean);
         }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-loss_finish_kernel(int nmask, const float* __restrict__ mask_partials, float inv_hw, float lambda_dssim, float lambda_mask,
-                   float* __restrict__ loss_out)
-{
-    __shared__ float s_red[4];
-    float m = 0.f;
-    for (int i = threadIdx.x; i < nmask; i += 256) m += mask_partials[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m += __shfl_xor(m, d);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float mask_mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_hw;
-        loss_out[3] = mask_mean;
-        loss_out[0] = loss_out[1] + lambda_mask * mask_mean + lambda_dssim * (1.0f - loss_out[2]);
     }
 }
 
@@ -235,10 +220,8 @@ extern "C" int moss_photometric_loss(int C, int H, int W, const float* image, co
     float* mask_partials = carve<float>(p, (size_t)gx * gy);
     static const Win win = make_window();
     const dim3 grid(gx, gy, C);
-    hipLaunchKernelGGL(ssim_pass1_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials);
+    hipLaunchKernelGGL(ssim_pass1_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials);
     hipLaunchKernelGGL(ssim_pass2_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
                        lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, alpha ? gx * gy : 0, mask_partials, 1.0f / ((float)H * (float)W),
-                       lambda_dssim, alpha ? lambda_mask : 0.0f, loss_out);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }

@@ -38,12 +38,13 @@ def shard_views(num_views: int, rank: int, world: int):
 
 
 class GradBucket:
-    """One flat fp32 buffer for all parameter gradients (+1 slot for the loss); a single all-reduce averages it."""
+    """One flat fp32 buffer for all parameter gradients (+4 slots for the loss and its three terms); a single all-reduce
+    averages it."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
-        total = sum(self.sizes) + 1
+        total = sum(self.sizes) + 4
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views = []
@@ -52,6 +53,7 @@ class GradBucket:
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
         self.loss_slot = self.flat[off:off + 1]
+        self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {}
         o = 0
         for p, n in zip(self.params, self.sizes):
@@ -90,7 +92,7 @@ class GradBucket:
             p.grad = v
 
     def all_reduce_mean(self, loss=None, world=None):
-        if loss is not None:
+        if loss is not None and loss.data_ptr() != self.loss_slot.data_ptr():
             self.loss_slot.copy_(loss.detach().reshape(1))
         world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
         if world > 1:

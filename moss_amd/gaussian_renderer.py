@@ -40,6 +40,19 @@ def eval_sh_rgb(deg, sh, dirs):
     return res
 
 
+_ZERO_POINTS = {}
+
+
+def _zero_points(like: torch.Tensor) -> torch.Tensor:
+    key = (like.device, tuple(like.shape), like.dtype)
+    z = _ZERO_POINTS.get(key)
+    if z is None:
+        if len(_ZERO_POINTS) > 8:
+            _ZERO_POINTS.clear()
+        z = _ZERO_POINTS[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return z
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, return_smpl_rot=False,
            transforms=None, translation=None):
     """Render one view.  ``bg_color`` must be on the GPU.
@@ -51,7 +64,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     xyz = pc.get_xyz
     # the zero "means2D" whose .grad receives the screen-space gradient (reference :29-33 builds it as zeros + 0 and retains its
     # grad; a leaf needs neither the add kernel nor retain_grad and exposes the same .grad)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    # The VALUES are never read by anything (the rasterizer takes means2D only to hang the gradient on it), so every call shares
+    # one cached block of zeros per (device, shape) -- a fresh leaf over the same storage, with its own .grad -- instead of
+    # launching a fill kernel per render.
+    screenspace_points = _zero_points(xyz).detach().requires_grad_(True)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

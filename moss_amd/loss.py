@@ -65,7 +65,7 @@ class _FusedPhotometricLoss(torch.autograd.Function):
     gradient w.r.t. image and alpha come out of two fused kernels; backward only scales them by the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask):
+    def forward(ctx, image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask, terms_out=None):
         from ._lib import check, lib
         L = lib()
         if not image.is_cuda:
@@ -73,7 +73,12 @@ class _FusedPhotometricLoss(torch.autograd.Function):
         C, H, W = image.shape
         image_c, gt_c = image.contiguous(), gt_image.contiguous()
         alpha_c, mask_c = alpha.contiguous(), gt_mask.contiguous()
-        out = torch.empty(4, dtype=torch.float32, device=image.device)
+        if terms_out is not None:
+            if terms_out.shape != (4,) or terms_out.dtype != torch.float32 or terms_out.device != image.device or not terms_out.is_contiguous():
+                raise RuntimeError("fused loss: terms_out must be 4 contiguous float32 values on the image's device")
+            out = terms_out
+        else:
+            out = torch.empty(4, dtype=torch.float32, device=image.device)
         # both gradient images in one buffer: backward scales them by the incoming gradient with ONE kernel
         d_both = torch.empty((C + 1, H, W), dtype=torch.float32, device=image.device)
         d_img, d_alpha = d_both[:C], d_both[C:]
@@ -97,7 +102,7 @@ class _FusedPhotometricLoss(torch.autograd.Function):
         # `backward_from_loss` below, recognised by identity -- multiplying by exactly 1.0 would be a no-op kernel
         unit = _UNIT.get(d_both.device)
         scaled = d_both if (unit is not None and grad_out.data_ptr() == unit.data_ptr()) else grad_out * d_both
-        return scaled[:ctx.C], scaled[ctx.C:].reshape(ctx.alpha_shape), None, None, None, None
+        return scaled[:ctx.C], scaled[ctx.C:].reshape(ctx.alpha_shape), None, None, None, None, None
 
 
 _UNIT = {}
@@ -112,6 +117,8 @@ def backward_from_loss(loss):
     torch.autograd.backward(loss, grad_tensors=one)
 
 
-def training_loss_fused(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5):
-    """Same value and gradients as :func:`training_loss`, computed by the fused HIP kernels."""
-    return _FusedPhotometricLoss.apply(image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask)
+def training_loss_fused(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5, terms_out=None):
+    """Same value and gradients as :func:`training_loss`, computed by the fused HIP kernels.  ``terms_out`` (optional, 4 floats):
+    where the kernels write [loss, L1, SSIM, mask L2] -- e.g. ``GradBucket.loss_terms``, so that the loss travels with the
+    gradients in the one all-reduce without a copy; the returned loss is then ``terms_out[0]``."""
+    return _FusedPhotometricLoss.apply(image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask, terms_out)
