@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 5924.0           # measured: scripts/hbm_bandwidth.py (triad, 1 GiB buffers), profiles/r01_hbm_bandwidth.json      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
 def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
@@ -299,6 +300,8 @@ def main():
                    "forward": args.forward, "launch": graph_note},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     # the best a plain streaming kernel reaches on this part (profiles/r01_hbm_bandwidth.json: triad over 1 GiB buffers)
+                     "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),
                      # PMC bytes were collected on the headline workload (profiles/pmc_latest.json): null for any other
                      "traffic": _pmc_traffic(dominant) if (args.config == "cfg3" and args.mode == "scale_rot") else None,
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),

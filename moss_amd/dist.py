@@ -55,6 +55,7 @@ class GradBucket:
         self.loss_slot = self.flat[off:off + 1]
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {}
+        self._avg_ok = None
         o = 0
         for p, n in zip(self.params, self.sizes):
             self._offset[id(p)] = o
@@ -96,6 +97,16 @@ class GradBucket:
             self.loss_slot.copy_(loss.detach().reshape(1))
         world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
         if world > 1:
+            # RCCL averages inside the collective (ncclAvg): no separate pass over the bucket to divide by the world size.
+            # gloo (CPU tests) has no AVG: sum, then divide.
+            if self._avg_ok is None:
+                self._avg_ok = dist.get_backend() == "nccl" and os.environ.get("MOSS_ALLREDUCE_AVG", "1") != "0"
+            if self._avg_ok:
+                try:
+                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+                    return self.loss_slot
+                except (RuntimeError, ValueError):             # a build without ncclAvg refuses before launching anything
+                    self._avg_ok = False
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(world)
         return self.loss_slot

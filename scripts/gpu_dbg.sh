@@ -1,6 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -5 gpurun_out/t.log
-timeout 600 python scripts/bench_densify.py 2>&1 | tail -1
-timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1800
-timeout 300 python scripts/dbg_determinism.py 2>&1 | tail -2
+timeout 300 python scripts/hbm_bandwidth.py 2>&1 | tail -1
