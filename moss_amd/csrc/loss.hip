@@ -55,7 +55,10 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     }
     __syncthreads();
     for (int i = tid; i < LP * LT; i += 256) {          // horizontal 11-tap for the 5 moments
-        const int r = i / LT, q = i % LT;
+        // lanes run down a column (r fastest): consecutive lanes are LP + 1 = 27 words apart, an odd stride, so the 11-tap reads
+        // below hit distinct LDS banks (row-major lanes put rows r and r + 1 of a half-wave on the same banks: PMC showed
+        // 30% of this kernel's wave-cycles waiting on LDS with 2.6M bank-conflict cycles)
+        const int r = i % LP, q = i / LP;
         float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
@@ -139,7 +142,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __syncthreads();
     for (int i = tid; i < 3 * LP * LT; i += 256) {
         const int m = i / (LP * LT), j = i % (LP * LT);
-        const int r = j / LT, q = j % LT;
+        const int r = j % LP, q = j / LP;                    // column-major lanes: conflict-free LDS reads (see pass 1)
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) acc = __fmaf_rn(win.g[k], s_d[m][r][q + k], acc);

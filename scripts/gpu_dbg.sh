@@ -1,2 +1,4 @@
 #!/bin/bash
-timeout 300 python scripts/hbm_bandwidth.py 2>&1 | tail -1
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -2 gpurun_out/t.log
+timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
