@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--torch-activations", action="store_true",
                     help="compute the parameter activations (exp / sigmoid / normalize / cat) with torch ops and let autograd "
                          "accumulate into the bucket, instead of the fused HIP activation kernels writing into it")
+    ap.add_argument("--activations", default="in_op", choices=["in_op", "fused"],
+                    help="in_op = the rasterizer takes the raw _opacity / _scaling / _rotation and runs sigmoid / exp / normalize inside "
+                         "its preprocess kernels (moss_raster_forward_raw: no activation launches); fused = one activation kernel "
+                         "each way (moss_gaussian_activate_*).  --torch-activations overrides both")
     ap.add_argument("--target", default="body", choices=["body", "smooth"],
                     help="ground truth of the photometric loss: body = a render of a DIFFERENT random Gaussian body (other points, "
                          "other colours) through the same camera, mask = its alpha > 0.5 -- a masked person on black, like MOSS's "
@@ -105,7 +109,9 @@ def main():
     unified = not args.torch_adamw and not args.torch_activations
     pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode in ("precomp", "lbs_python")), debug=False,
-                           fused_activations=not args.torch_activations, transforms_in_op=(args.mode == "lbs"))
+                           fused_activations=not args.torch_activations, transforms_in_op=(args.mode == "lbs"),
+                           raw_parameters_in_op=(not args.torch_activations and args.activations == "in_op" and unified
+                                                 and args.mode in ("scale_rot", "lbs")))
     lbs_T = None
     if args.mode in ("lbs", "lbs_python"):
         gT = torch.Generator().manual_seed(1234)
@@ -133,7 +139,13 @@ def main():
     use_graph = bool(args.graph) and args.forward == "async" and not args.torch_adamw
     dgr.set_async(args.forward == "async")
     if unified:
-        dgr.set_grad_sink(sh=lambda: bucket.sink_for(pc._features))       # dL_dsh is written straight into the gradient bucket
+        sinks = {"sh": lambda: bucket.sink_for(pc._features)}             # dL_dsh is written straight into the gradient bucket
+        if pipe.raw_parameters_in_op:                                     # ... and so are the raw-parameter gradients
+            sinks.update(opacity=lambda: bucket.sink_for(pc._opacity), scales=lambda: bucket.sink_for(pc._scaling),
+                         rotations=lambda: bucket.sink_for(pc._rotation))
+            if lbs_T is None:                                             # (with a transform the means are not the parameter)
+                sinks["means3D"] = lambda: bucket.sink_for(pc._xyz)
+        dgr.set_grad_sink(**sinks)
 
     def compute():                      # everything of a step that is local to this rank
         if pipe.fused_activations:
@@ -295,7 +307,8 @@ def main():
         "config": {"workload": f"BASELINE configs[2]: {P} Gaussians on a synthetic capsule body, {W}x{H}, SH degree 3, "
                                f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
                    if args.config == "cfg3" else args.config,
-                   "target": args.target, "input_mode": args.mode, "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
+                   "target": args.target, "input_mode": args.mode,
+                   "activations": "torch" if args.torch_activations else ("in_op" if pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                    "forward": args.forward, "launch": graph_note},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

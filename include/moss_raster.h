@@ -281,6 +281,38 @@ int moss_raster_backward_tf(
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, void* stream);
 
 /*
+ * Extension (caller side of the boundary): the GaussianModel getters applied INSIDE the op.
+ * MOSS hands the rasterizer get_opacity = sigmoid(_opacity), get_scaling = exp(_scaling), get_rotation = normalize(_rotation)
+ * (scene/gaussian_model.py:142-161, gaussian_renderer/__init__.py:77-93): five torch ops forward and a dozen backward per step.
+ * These entry points take the RAW parameters for the inputs named in raw_flags and return the gradients w.r.t. the raw
+ * parameters; otherwise they are moss_raster_forward_tf / moss_raster_backward_tf (transforms may be NULL here = none).
+ *   raw_flags: MOSS_RAW_OPACITY (opacities are logits) | MOSS_RAW_SCALE (scales are logarithms) | MOSS_RAW_ROTATION
+ *   (rotations are not normalised; normalised as x / max(|x|, 1e-12) like torch.nn.functional.normalize).
+ *   The backward needs the raw opacities again (the reference backward does not take opacities at all).
+ */
+#define MOSS_RAW_OPACITY 1
+#define MOSS_RAW_SCALE 2
+#define MOSS_RAW_ROTATION 4
+int moss_raster_forward_raw(
+    moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, void* stream);
+int moss_raster_backward_raw(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, void* stream);
+
+/*
  * Gaussian parameter activations, forward and backward, one launch each (the rasterizer-facing getters of MOSS's GaussianModel,
  * scene/gaussian_model.py:46-53 and :134-166: get_xyz identity, get_features = cat(_features_dc, _features_rest, dim=1),
  * get_opacity = sigmoid, get_scaling = exp, get_rotation = F.normalize (eps 1e-12)).  K = SH coefficients per channel

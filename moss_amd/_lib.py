@@ -71,6 +71,18 @@ def _declare(lib):
         _p, _p, _p,                                        # dL_dpix, dL_ddepths, dL_dalphas
         _p, _p, _p, _p, _p, _p, _p, _p, _p,                # dL_dmean2D .. dL_drot
         _i, _p]                                            # debug, stream
+    lib.moss_raster_forward_raw.restype = _i
+    lib.moss_raster_forward_raw.argtypes = [
+        ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _p, _i, _i,
+        _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _i,
+        _p, _p, _p, _p, _i, _i, _p]                         # ..., radii, raw_flags, capacity, stream
+    lib.moss_raster_backward_raw.restype = _i
+    lib.moss_raster_backward_raw.argtypes = [
+        _i, _i, _i, _i, _p, _i, _i,
+        _p, _p, _p, _p, _p, _f, _p, _p,                     # means3D, shs, colors, opacities, scales, mod, rotations, transforms
+        _p, _p, _p, _f, _f,
+        _p, _p, _p, _p, _p, _p,
+        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]     # 10 gradient outputs, raw_flags, stream
     lib.moss_raster_mark_visible.restype = _i
     lib.moss_raster_mark_visible.argtypes = [_i, _p, _p, _p, _p, _p]
     lib.moss_knn_workspace_bytes.restype = C.c_size_t

@@ -156,10 +156,15 @@ struct BinView {
 
 // Per-call constants.  The camera matrices stay on the device (the boundary hands over device pointers, exactly
 // like the reference); kernels read them through wave-uniform (scalar) loads, so no host copy / sync is needed.
+// `raw` bits of FrameParams (moss_raster_forward_raw / _backward_raw): the GaussianModel getters applied inside preprocess
+constexpr int RAW_OPACITY = 1;      // opacities are logits:            get_opacity  = sigmoid(_opacity)          (scene/gaussian_model.py:160-161)
+constexpr int RAW_SCALE = 2;        // scales are logarithms:           get_scaling  = exp(_scaling)              (:142-143)
+constexpr int RAW_ROTATION = 4;     // rotations are not normalised:    get_rotation = normalize(_rotation)       (:146-147)
 struct FrameParams {
     int P, D, M, W, H, gx, gy;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int prefiltered;
+    int raw;                 // RAW_* bits: which of opacity / scales / rotations arrive as MOSS's raw parameters (activated inside the op)
     const float* view_dev; const float* proj_dev; const float* campos_dev; const float* bg_dev;
 };
 
@@ -168,6 +173,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                                const float* transforms, GeomView g, ImageView im, int* radii_out, hipStream_t s);
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* opacities /* only read in raw mode */,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 GeomView g, BinView b, const uint32_t* header,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,

@@ -17,6 +17,27 @@ namespace {
 
 struct M3 { float m[3][3]; };   // m[c][r], the column-major convention of the reference's glm matrices
 
+// ---- the GaussianModel getters, for the raw-parameter mode (FrameParams::raw; same expressions as csrc/activations.hip) ----
+__device__ __forceinline__ float sigmoid_act(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ void activate_scale_rot(int raw, float* sc, float* q)
+{
+    if (raw & RAW_SCALE) { sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]); }
+    if (raw & RAW_ROTATION) {                                // torch.nn.functional.normalize: x / max(|x|, 1e-12)
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const float inv = 1.0f / fmaxf(n, 1e-12f);
+        q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+    }
+}
+// y = q / d, d = max(|q|, eps):  |q| >= eps: dq = (g - y (y.g)) / d;  |q| < eps: d is a constant, dq = g / d.  In place on g.
+__device__ __forceinline__ void normalize_backward(const float* q, const float* y, float* g)
+{
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    const float yg = n >= 1e-12f ? (y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3]) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) g[k] = (g[k] - y[k] * yg) * inv;
+}
+
 __device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B)
 {
     M3 R;
@@ -184,7 +205,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                           GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header,
-                          int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms)
+                          int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms, int raw)
 {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
@@ -241,6 +262,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             } else {
                 float sc[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
                 float q[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
+                activate_scale_rot(raw, sc, q);
                 cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
                 if (transforms != nullptr) {
                     float Tm[9], pre[6];
@@ -326,7 +348,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             // Conservative extent of the region where this Gaussian can reach alpha >= 1/255 (power >= -tau,
             // tau = ln(255*opacity)): half-widths sqrt(2*tau*cov_xx), sqrt(2*tau*cov_yy) of the ellipse's bounding box,
             // widened by 1e-4 relative + 0.01 px against rounding.  Used only to SKIP work in the blend kernels.
-            const float opa = opacities[idx];
+            const float opa = (raw & RAW_OPACITY) ? sigmoid_act(opacities[idx]) : opacities[idx];
             float hx = __builtin_huge_valf(), hy = __builtin_huge_valf();
             if (opa == opa) {
                 if (!(opa > 0.0f)) { hx = -1.0f; hy = -1.0f; }
@@ -426,6 +448,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                            const float* __restrict__ transforms, float* __restrict__ dL_dtransforms,
+                           const float* __restrict__ opacities /* raw mode only */, int raw,
                            unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */)
 {
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then the same for dL_dsh out
@@ -677,6 +700,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
+    if (raw & RAW_OPACITY) {                                 // d sigmoid(v) = y (1 - y)
+        const float sg = sigmoid_act(opacities[idx]);
+        gop = gop * ((1.0f - sg) * sg);
+    }
     dL_dopacity[idx] = gop;
     dL_dcolor[3 * (size_t)idx] = gcol.x; dL_dcolor[3 * (size_t)idx + 1] = gcol.y; dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
 
@@ -829,9 +856,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         PSTAMP(4);
         // ---- scale / rotation backward, backward.cu:278-341
         if (scales != nullptr) {
-            const float r = rotations[4 * (size_t)idx], x = rotations[4 * (size_t)idx + 1], y = rotations[4 * (size_t)idx + 2], z = rotations[4 * (size_t)idx + 3];
+            float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
+            float qr[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
+            const float q_raw[4] = { qr[0], qr[1], qr[2], qr[3] };
+            activate_scale_rot(raw, scr, qr);                    // raw mode: exp / normalize as in the forward
+            const float r = qr[0], x = qr[1], y = qr[2], z = qr[3];
             const M3 R = quat_to_R(r, x, y, z);
-            const float s[3] = { scale_modifier * scales[3 * (size_t)idx], scale_modifier * scales[3 * (size_t)idx + 1], scale_modifier * scales[3 * (size_t)idx + 2] };
+            const float s[3] = { scale_modifier * scr[0], scale_modifier * scr[1], scale_modifier * scr[2] };
             M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
             S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
             const M3 Mm = m3_mul(S, R);
@@ -841,8 +872,6 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                 float Tm[9], pre[6], d6_pre[6];
 #pragma unroll
                 for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
-                const float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
-                const float qr[4] = { r, x, y, z };
                 cov3d_from_scale_rot(scr, scale_modifier, qr, pre);
                 transform_cov3d_bw(Tm, pre, dc6, d6_pre, dtf);
 #pragma unroll
@@ -872,6 +901,12 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             drot[2] = 2 * x * (DM(1,0) + DM(0,1)) + 2 * r * (DM(2,0) - DM(0,2)) + 2 * z * (DM(1,2) + DM(2,1)) - 4 * y * (DM(2,2) + DM(0,0));
             drot[3] = 2 * r * (DM(0,1) - DM(1,0)) + 2 * x * (DM(2,0) + DM(0,2)) + 2 * y * (DM(1,2) + DM(2,1)) - 4 * z * (DM(1,1) + DM(0,0));
 #undef DM
+            // raw mode: chain through the getters (same expressions as csrc/activations.hip)
+            if (raw & RAW_SCALE) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) dscale[k] *= scr[k];                                  // d exp(v) = exp(v)
+            }
+            if (raw & RAW_ROTATION) normalize_backward(q_raw, qr, drot);
         }
     } else if (dsh != nullptr) {
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
@@ -968,11 +1003,11 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh,
-                       transforms);
+                       transforms, fp.raw);
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
-                                const float* scales, const float* rotations, const float* cov3D_precomp,
+                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                                 GeomView g, BinView b, const uint32_t* header,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
@@ -989,7 +1024,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, g_stamps)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw, g_stamps)
     // SLABS: -1 = sparse records selected by inst_mask (wave blend kernels), 4 = four dense slabs, 0 = run-time count
     const int sl = blend_impl() ? -1 : (b.slabs == 4 ? 4 : 0);
     if (stage) { if (sl < 0) LAUNCH_PB(true, -1); else if (sl == 4) LAUNCH_PB(true, 4); else LAUNCH_PB(true, 0); }

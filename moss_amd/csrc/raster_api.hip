@@ -90,7 +90,7 @@ FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
     fp.focal_y = H / (2.0f * tan_fovy);         // rasterizer_impl.cu:224-225
     fp.focal_x = W / (2.0f * tan_fovx);
-    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered;
+    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0;
     fp.view_dev = view; fp.proj_dev = proj; fp.campos_dev = campos; fp.bg_dev = bg;
     return fp;
 }
@@ -108,7 +108,7 @@ static int forward_impl(
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
     float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream, long long capacity,
-    const float* transforms)
+    const float* transforms, int raw_flags = 0)
 {
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -137,8 +137,9 @@ static int forward_impl(
     if (!img_ptr) return fail(MOSS_ERR_ALLOC, "image allocator returned NULL");
     GeomView g = GeomView::at(geom_ptr, P);
     ImageView im = ImageView::at(img_ptr, width, height);
-    const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, prefiltered,
-                                       viewmatrix, projmatrix, cam_pos, background);
+    FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, prefiltered,
+                                 viewmatrix, projmatrix, cam_pos, background);
+    fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;     // scales / rotations are not read with a precomputed covariance
     const int T = fp.gx * fp.gy;
 
     launch_clear(im.header, im.clear_bytes(), s);                        // header + tile histogram + tile cursors
@@ -254,7 +255,7 @@ static int backward_impl(
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream,
-    const float* transforms, float* dL_dtransforms)
+    const float* transforms, float* dL_dtransforms, const float* opacities = nullptr, int raw_flags = 0)
 {
     (void)alphas; (void)radii;
     g_err[0] = 0;
@@ -271,14 +272,16 @@ static int backward_impl(
     GeomView g = GeomView::at(geom_buffer, P);
     ImageView im = ImageView::at(image_buffer, width, height);
     BinView b = BinView::at(binning_buffer, R);
-    const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, 0,
-                                       viewmatrix, projmatrix, campos, background);
+    FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, 0,
+                                 viewmatrix, projmatrix, campos, background);
+    fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;
+    if ((fp.raw & RAW_OPACITY) && !opacities) return fail(MOSS_ERR_INVALID_ARG, "raw opacities are required to chain through the sigmoid");
     if (R > 0) {
         { StageTimer tm(MOSS_STAGE_BLEND_BWD, s); launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s); }
         STAGE_CHECK("blend_backward");
     }
     { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
-      launch_preprocess_backward(fp, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, g, b, im.header,
+      launch_preprocess_backward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, im.header,
                                  dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                                  transforms, dL_dtransforms, s); }
     STAGE_CHECK("preprocess_backward");
@@ -323,6 +326,45 @@ int moss_raster_backward_tf(
                          nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
                          image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
                          dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0, stream, transforms, dL_dtransforms);
+}
+
+// Raw-parameter variant (the getters of GaussianModel applied inside preprocess, see include/moss_raster.h).
+int moss_raster_forward_raw(
+    moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
+    moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, void* stream)
+{
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (P > 0 && (!scales || !rotations)) return fail(MOSS_ERR_INVALID_ARG, "scales and rotations are required");
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
+                        0, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags);
+}
+
+int moss_raster_backward_raw(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, void* stream)
+{
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))
+        return fail(MOSS_ERR_INVALID_ARG, "scales and rotations (and dL_dtransforms with transforms) are required");
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,
+                         nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0, stream, transforms, transforms ? dL_dtransforms : nullptr, opacities,
+                         raw_flags);
 }
 
 int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -41,11 +41,25 @@ ASYNC = _AsyncState()
 
 # Optional destination for dL_dsh: a callable returning a fresh (P, M, 3) float32 tensor (e.g. a view into a flat gradient
 # bucket) that the backward kernel fills instead of a newly allocated one; autograd then adopts it as .grad without a copy.
-GRAD_SINK = {"sh": None}
+# The same for dL_dmeans3D / dL_dopacity / dL_dscales / dL_drotations -- meaningful when those inputs ARE the parameters (raw mode,
+# no transform on the means): then no activation kernel and no copy stands between the backward kernel and the bucket.
+GRAD_SINK = {"sh": None, "means3D": None, "opacity": None, "scales": None, "rotations": None}
+
+RAW_OPACITY, RAW_SCALE, RAW_ROTATION = 1, 2, 4       # include/moss_raster.h MOSS_RAW_*
 
 
-def set_grad_sink(sh=None):
-    GRAD_SINK["sh"] = sh
+def set_grad_sink(sh=None, means3D=None, opacity=None, scales=None, rotations=None):
+    GRAD_SINK.update(sh=sh, means3D=means3D, opacity=opacity, scales=scales, rotations=rotations)
+
+
+def _sink(name, shape, dev):
+    fn = GRAD_SINK.get(name)
+    if fn is None or shape[0] == 0:
+        return None
+    cand = fn()
+    if cand is not None and tuple(cand.shape) == tuple(shape) and cand.dtype == torch.float32 and cand.device == dev and cand.is_contiguous():
+        return cand
+    return None
 
 
 def set_async(enabled: bool, capacity: int = 0, margin: float = 2.0):
@@ -119,8 +133,10 @@ def _ptr(t: torch.Tensor, name: str, dtype=torch.float32):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, transforms=None):
+                        prefiltered, debug, transforms=None, raw_flags=0):
     """RasterizeGaussiansCUDA, rasterize_points.cu:35-119.
+    ``raw_flags`` (an addition): RAW_OPACITY | RAW_SCALE | RAW_ROTATION -- those inputs are MOSS's raw parameters and the getters
+    (sigmoid / exp / normalize) run inside the op (C ABI moss_raster_forward_raw); needs scales and rotations, no cov3D_precomp.
     ``transforms`` (an addition): (P,3,3) per-Gaussian matrices applied to the scale/rotation covariance
     inside the op (Sigma' = T Sigma T^T, what MOSS's Python get_covariance builds); needs scales and rotations, no cov3D_precomp.
     Returns (num_rendered, out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P,), geomBuffer,
@@ -153,6 +169,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             raise RuntimeError("transforms must be (P,3,3) and comes with scales and rotations (no cov3D_precomp)")
         if debug:
             raise RuntimeError("debug mode is not available together with transforms")
+    raw_flags = int(raw_flags)
+    if raw_flags:
+        if scales.numel() == 0 or rotations.numel() == 0 or cov3D_precomp.numel() != 0 or debug:
+            raise RuntimeError("raw_flags comes with scales and rotations (no cov3D_precomp, no debug mode)")
     use_async = ASYNC.enabled and not debug and ASYNC.capacity > 0 and P > 0
     capturing = torch.cuda.is_current_stream_capturing()
     if use_async and not capturing:
@@ -164,17 +184,21 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             fwd = L.moss_raster_forward_async if use_async else L.moss_raster_forward
             if transforms is not None:
                 fwd = L.moss_raster_forward_tf                # cov3D_precomp slot carries the transforms, last int the capacity (-1 = sync)
+            if raw_flags:
+                fwd = L.moss_raster_forward_raw               # as _tf (transforms may be NULL), raw_flags before the capacity
+            in_op = transforms is not None or raw_flags
             rc = fwd(
                 _grow, 0, _grow, 1, _grow, 2,
                 P, int(degree), M,
                 p(background, "background"), W, H,
                 p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"), p(opacity, "opacity"),
                 p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"),
-                p(cov3D_precomp, "cov3D_precomp") if transforms is None else p(transforms, "transforms"),
+                p(cov3D_precomp, "cov3D_precomp") if not in_op else (None if transforms is None else p(transforms, "transforms")),
                 p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                 out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr() if P else None,
-                (int(ASYNC.capacity) if use_async else (-1 if transforms is not None else int(bool(debug)))), stream)
+                *((raw_flags,) if raw_flags else ()),
+                (int(ASYNC.capacity) if use_async else (-1 if in_op else int(bool(debug)))), stream)
         finally:
             _tls.buffers = None
         rendered = check(rc, "rasterize_gaussians")
@@ -195,8 +219,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
-                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, transforms=None):
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, transforms=None,
+                                 raw_flags=0, opacities=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:121-206.
+    ``raw_flags`` / ``opacities``: backward of the raw-parameter forward (gradients w.r.t. the raw parameters).
     Returns (dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P,1), dL_dmeans3D (P,3), dL_dcov3D (P,6),
     dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4)) -- plus dL_dtransforms (P,3,3) when ``transforms`` was given."""
     L = lib()
@@ -208,22 +234,48 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # The reference zero-fills nine tensors here (300 B per Gaussian, rasterize_points.cu:158-166); the HIP backward
     # writes every element exactly once, so plain allocations suffice.  P == 0 keeps the reference's zeros.
     alloc = torch.zeros if P == 0 else torch.empty
-    dL_dmeans3D = alloc((P, 3), **fopts)
+    def out(name, shape):
+        t = _sink(name, shape, dev)
+        return t if t is not None else alloc(shape, **fopts)
+    dL_dmeans3D = out("means3D", (P, 3))
     dL_dmeans2D = alloc((P, 3), **fopts)
     dL_dcolors = alloc((P, NUM_CHANNELS), **fopts)
     dL_dconic = alloc((P, 2, 2), **fopts)
-    dL_dopacity = alloc((P, 1), **fopts)
+    dL_dopacity = out("opacity", (P, 1))
     dL_dcov3D = alloc((P, 6), **fopts)
-    dL_dsh = None
-    if GRAD_SINK["sh"] is not None and P != 0 and M != 0:
-        cand = GRAD_SINK["sh"]()
-        if cand is not None and tuple(cand.shape) == (P, M, 3) and cand.dtype == torch.float32 and cand.device == dev and cand.is_contiguous():
-            dL_dsh = cand
-    if dL_dsh is None:
-        dL_dsh = alloc((P, M, 3), **fopts)
-    dL_dscales = alloc((P, 3), **fopts)
-    dL_drotations = alloc((P, 4), **fopts)
+    dL_dsh = out("sh", (P, M, 3)) if M != 0 else alloc((P, M, 3), **fopts)
+    dL_dscales = out("scales", (P, 3))
+    dL_drotations = out("rotations", (P, 4))
     dL_dtransforms = alloc((P, 3, 3), **fopts) if transforms is not None else None
+    raw_flags = int(raw_flags)
+    if P != 0 and raw_flags:
+        if opacities is None:
+            raise RuntimeError("the raw-parameter backward needs the raw opacities")
+        keep = []
+        def p(t, name, dtype=torch.float32):
+            ptr, c = _ptr(t, name, dtype)
+            keep.append(c)
+            return ptr
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.moss_raster_backward_raw(
+                P, int(degree), M, int(R),
+                p(background, "background"), W, H,
+                p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"), p(opacities, "opacity"),
+                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"),
+                None if transforms is None else p(transforms, "transforms"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+                float(tan_fovx), float(tan_fovy),
+                p(geomBuffer, "geomBuffer", torch.uint8), p(binningBuffer, "binningBuffer", torch.uint8),
+                p(imageBuffer, "imageBuffer", torch.uint8),
+                p(dL_dout_color, "dL_dout_color"), p(dL_dout_depth, "dL_dout_depth"), p(dL_dout_alpha, "dL_dout_alpha"),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None,
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), None if transforms is None else dL_dtransforms.data_ptr(),
+                raw_flags, stream)
+        check(rc, "rasterize_gaussians_backward")
+        res = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+        return res + (dL_dtransforms,) if transforms is not None else res
     if P != 0 and transforms is not None:
         keep = []
         def p(t, name, dtype=torch.float32):

@@ -64,13 +64,16 @@ def _call_native(fn, args, debug, dump_name, what):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                transforms=None):
-        # (the tenth input is an addition: per-Gaussian 3x3 transforms applied to the covariance inside the op)
+                transforms=None, raw_flags=0):
+        # (the tenth input is an addition: per-Gaussian 3x3 transforms applied to the covariance inside the op, SURVEY 8f row n2;
+        #  the eleventh too: which of opacities / scales / rotations are RAW parameters whose getter runs inside the op)
         rs = raster_settings
+        raw_flags = int(raw_flags)
         native_args = (
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
-            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug) + (() if transforms is None else (transforms,))
+            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug) + \
+            ((transforms, raw_flags) if raw_flags else (() if transforms is None else (transforms,)))
         (num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_native(
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
@@ -79,8 +82,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         # zero-filled image; the values computed are the same as with the reference's materialised zeros
         ctx.set_materialize_grads(False)
         ctx.has_transforms = transforms is not None
+        ctx.raw_flags = raw_flags
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
-                              geomBuffer, binningBuffer, imgBuffer, alpha, *(() if transforms is None else (transforms,)))
+                              geomBuffer, binningBuffer, imgBuffer, alpha, *(() if transforms is None else (transforms,)),
+                              *((opacities,) if raw_flags else ()))
         return color, radii, depth, alpha
 
     @staticmethod
@@ -90,26 +95,27 @@ class _RasterizeGaussians(torch.autograd.Function):
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, alpha) = saved[:11]
         transforms = saved[11] if ctx.has_transforms else None
+        raw_opacities = saved[-1] if ctx.raw_flags else None
         if grad_out_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 10
+            return (None,) * 11
         native_args = (
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,
             sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug) + \
-            (() if transforms is None else (transforms,))
+            ((transforms, ctx.raw_flags, raw_opacities) if ctx.raw_flags else (() if transforms is None else (transforms,)))
         grads = _call_native(_C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = grads[:8]
         grad_transforms = grads[8] if transforms is not None else None
         # one gradient per forward() input, in forward()'s order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms)
+                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        transforms=None):
+                        transforms=None, raw_flags=0):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, transforms)
+                                     cov3Ds_precomp, raster_settings, transforms, raw_flags)
 
 
 class GaussianRasterizer(nn.Module):
@@ -124,9 +130,12 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, transforms=None):
+                cov3D_precomp=None, transforms=None, raw_flags=0):
         """``transforms`` (an addition): (P,3,3) per-Gaussian matrices; with scales and rotations the op then builds
-        T (R S S^T R^T) T^T itself -- MOSS's Python get_covariance -- and returns a gradient for the transforms too."""
+        T (R S S^T R^T) T^T itself -- MOSS's Python get_covariance -- and returns a gradient for the transforms too.
+        ``raw_flags`` (an addition): ``_C.RAW_OPACITY | _C.RAW_SCALE | _C.RAW_ROTATION`` -- those inputs are GaussianModel's raw
+        parameters (``_opacity``, ``_scaling``, ``_rotation``); sigmoid / exp / normalize run inside the op and the gradients
+        come back w.r.t. the raw parameters (no activation kernels either side)."""
         rs = self.raster_settings
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -142,4 +151,7 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = absent if cov3D_precomp is None else cov3D_precomp
         if transforms is not None and (scales.numel() == 0 or cov3D_precomp.numel() != 0):
             raise Exception('transforms need the scale/rotation pair (and no precomputed 3D covariance)!')
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, transforms)
+        if raw_flags and (scales.numel() == 0 or cov3D_precomp.numel() != 0):
+            raise Exception('raw_flags need the scale/rotation pair (and no precomputed 3D covariance)!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, transforms,
+                                   raw_flags)

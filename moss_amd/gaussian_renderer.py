@@ -59,7 +59,13 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     ``pipe.fused_activations`` (an addition, default off): read the activated parameters from ``pc.activate(pipe.grad_bucket)``
     -- one HIP kernel instead of the five torch getters (moss_amd/activations.py); values and gradients are the same."""
-    if getattr(pipe, "fused_activations", False):
+    # ``pipe.raw_parameters_in_op`` (an addition, default off): hand the rasterizer the RAW ``_opacity / _scaling / _rotation`` and let
+    # it run sigmoid / exp / normalize inside its preprocess kernels (C ABI moss_raster_forward_raw): no activation kernel either way.
+    raw_flags = 0
+    if (getattr(pipe, "raw_parameters_in_op", False) and not pipe.compute_cov3D_python
+            and all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation"))):
+        raw_flags = 7                                        # _C.RAW_OPACITY | _C.RAW_SCALE | _C.RAW_ROTATION
+    elif getattr(pipe, "fused_activations", False):
         pc = pc.activate(getattr(pipe, "grad_bucket", None))
     xyz = pc.get_xyz
     # the zero "means2D" whose .grad receives the screen-space gradient (reference :29-33 builds it as zeros + 0 and retains its
@@ -89,15 +95,16 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         _, means3D, bweights, transforms, translation = pc.coarse_deform_c2source(
             means3D[None], viewpoint_camera.smpl_param, viewpoint_camera.big_pose_smpl_param,
             viewpoint_camera.big_pose_world_vertex[None])
-    means3D = means3D.squeeze()
+    if means3D.dim() != 2:
+        means3D = means3D.squeeze()
     means2D = screenspace_points
-    opacity = pc.get_opacity
+    opacity = pc._opacity if raw_flags else pc.get_opacity
 
     scales = rotations = cov3D_precomp = op_transforms = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier, None if transforms is None else transforms.squeeze())
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        scales, rotations = (pc._scaling, pc._rotation) if raw_flags else (pc.get_scaling, pc.get_rotation)
         # an addition (pipe.transforms_in_op): the per-Gaussian LBS transform of the covariance is applied INSIDE the op instead of
         # by the torch ops of get_covariance (the reference ignores `transforms` in this branch, gaussian_renderer/__init__.py:92-93)
         if transforms is not None and getattr(pipe, "transforms_in_op", False):
@@ -118,12 +125,33 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rendered_image, radii, depth, alpha = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
-        **({} if op_transforms is None else {"transforms": op_transforms}))
+        **({} if op_transforms is None else {"transforms": op_transforms}), **({"raw_flags": raw_flags} if raw_flags else {}))
 
-    return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha,
-            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "transforms": transforms, "translation": translation, "correct_Rs": correct_Rs, "pose_out": pose_out,
-            "lbs_weights": bweights, "means3D": means3D}
+    return RenderOutput({"render": rendered_image, "render_depth": depth, "render_alpha": alpha,
+                         "viewspace_points": screenspace_points, "radii": radii,
+                         "transforms": transforms, "translation": translation, "correct_Rs": correct_Rs, "pose_out": pose_out,
+                         "lbs_weights": bweights, "means3D": means3D})
+
+
+class RenderOutput(dict):
+    """The reference's result dict (gaussian_renderer/__init__.py:125-136).  ``visibility_filter`` (= ``radii > 0``) is computed
+    the first time it is asked for: MOSS reads it only on densification steps (train_ZJU.py:172-174), and a minimal kernel costs
+    4-5 us of a 0.33 ms step.  ``out["visibility_filter"]``, ``out.get(..)`` and ``"visibility_filter" in out`` all work;
+    ``keys()`` / ``items()`` list it once it exists."""
+    _LAZY = "visibility_filter"
+
+    def __missing__(self, key):
+        if key == self._LAZY:
+            value = dict.__getitem__(self, "radii") > 0
+            self[key] = value
+            return value
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == self._LAZY or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
 
 
 def camera_view(cam, device):
