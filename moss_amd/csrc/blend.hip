@@ -1,58 +1,41 @@
 // blend.hip -- the 16x16-tile alpha blend, forward (DGR/cuda_rasterizer/forward.cu:261-383) and backward
 // (DGR/cuda_rasterizer/backward.cu:399-587), designed for wave64 / CDNA4.
 //
-// WHY NOT "one thread per pixel, 256 threads per tile" (the reference's shape): a training view of a human puts
-// ~100k Gaussians into ~180 of 1024 tiles, 1-5k entries per tile.  The blend is a serial recurrence over a tile's
-// entry list and a single wavefront issues at most one instruction per ~4 cycles whatever its ILP, so the kernel time is
-// (instructions executed by the busiest wave) x 4 cycles while most SIMDs idle (measured: profiles/r01_notes.md).
-// The design therefore minimises the work of the busiest WAVE, not the total work:
+// WHY NOT "one thread per pixel, 256 threads per tile" (the reference's shape): a training view of a human puts ~100k Gaussians
+// into ~250 of 1024 tiles, 1-5k entries per tile.  The blend is a serial recurrence over a tile's entry list and a single
+// wavefront issues at most one instruction per ~4 cycles whatever its ILP, so the kernel time is (instructions executed by the
+// busiest wave) x 4 cycles while most SIMDs idle (measured: profiles/r01_notes.md).  The design therefore minimises the work
+// of the busiest WAVE, not the total work:
 //
-//   * a wavefront owns a small pixel block and evaluates SLOTS consecutive list entries at once:
-//         lane = pixel * SLOTS + slot,   SLOTS = 4 / 8 / 16  <->  block = 4x4 / 4x2 / 2x2 pixels;
-//     the order-dependent parts (transmittance T; the backward's suffix blend) are carried across the slots of a
-//     pixel with DPP row shifts: a log-step prefix product (SLOTS = 4: a 3-step chain that is bit-identical to the serial
-//     loop).  More slots = proportionally fewer trips through the list for the busiest wave;
-//   * a workgroup is the SLOTS waves of one 8x8 QUADRANT of the tile (4 workgroups per tile, sharing blockIdx % 8 = one
-//     XCD's L2): it stages each batch of entries ONCE into LDS, straight from the per-instance record stream the sort
-//     wrote (48 contiguous bytes per entry: coalesced, single-level loads, prefetched one batch ahead in registers);
-//   * per-wave culling: each wave tests 64 staged entries per instruction, one entry per lane, against its block
-//     (conservative bounding box of the alpha >= 1/255 ellipse, from the preprocess kernel), __ballot()s the hits and
-//     compacts their indices into a private LDS list (v_mbcnt prefix); the blend loop walks that list SLOTS entries per trip
-//     with the next trip's records prefetched;
-//   * the inner loops stay on the VECTOR unit: per-lane conditions are float selects, not lane-mask algebra -- the
-//     scalar unit is shared by every wave of a CU and was the measured bottleneck of the first version;
-//   * early out: a wave stops when all its pixels are done, the workgroup when all its waves are (forward).
+//   * a work item is ONE WAVE, there is no workgroup barrier anywhere (the first versions, one workgroup per tile quadrant
+//     with per-batch barriers, spent 38 % of their critical path waiting at those barriers; they are in the history of this
+//     file and in profiles/r01_notes.md);
+//   * heavy tiles (>= 128 entries): item = one 4x4 pixel block, lane = (pixel, slot), 4 consecutive list entries per trip; the
+//     order-dependent parts (transmittance T; the backward's suffix blend) are carried across the 4 slots of a pixel by a 3-step
+//     DPP chain that is bit-identical to the serial loop;
+//   * light tiles: item = one 8x8 quadrant, lane = pixel, entries one after the other;
+//   * the inner loops stay on the VECTOR unit: per-lane conditions are float selects, not lane-mask algebra -- the scalar unit
+//     is shared by every wave of a CU and was the measured bottleneck of the first version;
+//   * persistent workgroups of 4 independent waves (one per SIMD) pull items from per-XCD queues in LPT order.
 //
-// Backward: the reference issues 9 global float atomics per (pixel, Gaussian) pair (backward.cu:538,574-584).  Here the
-// 9 partial gradients of a trip's SLOTS entries are summed over the wave's pixels by a reduce-scatter (v_permlane32_swap
-// and v_permlane16_swap each fold TWO values one level, DPP row rotations finish), the wave sums are combined through LDS
-// in a fixed order and each (tile, entry) instance stores ONE 48-byte record per quadrant with plain coalesced stores.
-// The per-Gaussian kernel (preprocess.hip) gathers a Gaussian's records in a fixed order.  No float atomics =>
-// gradients are bitwise reproducible and no accumulator needs zero-filling.  The five suffix blends of
-// backward.cu:529-549 (colour x3, depth, alpha) enter dL/dalpha only through sum_k (x_k - accum_k) * g_k with per-pixel
-// constants g, so ONE running scalar Q = sum_k accum_k g_k is carried instead of five; (T, Q) advance through a trip's
-// slots as a prefix composition of the affine maps  T -> T/(1-a),  Q -> (1-a) Q + a u.
+// Backward: the reference issues 9 global float atomics per (pixel, Gaussian) pair (backward.cu:538,574-584).  Here the 9
+// partial gradients of a trip's entries are summed over the wave's pixels by a reduce-scatter (v_permlane32_swap and
+// v_permlane16_swap each fold TWO values one level, DPP row rotations finish) and each (entry, block) pair that was really
+// blended stores ONE 48-byte record with plain stores and sets its block's bit in the instance's mask.  The per-Gaussian kernel
+// (preprocess.hip) gathers the flagged records in a fixed order.  No float atomics => gradients are bitwise reproducible and no
+// accumulator needs zero-filling.  The five suffix blends of backward.cu:529-549 (colour x3, depth, alpha) enter dL/dalpha only
+// through sum_k (x_k - accum_k) * g_k with per-pixel constants g, so ONE running scalar Q = sum_k accum_k g_k is carried instead
+// of five; (T, Q) advance through a trip's slots as a prefix composition of the affine maps  T -> T/(1-a),  Q -> (1-a) Q + a u.
 //
-// Arithmetic: power/alpha of a (pixel, entry) pair is ONE inline function shared by both kernels (explicit fmaf chain),
-// so forward and backward take bit-identical skip decisions.
+// Arithmetic: power/alpha of a (pixel, entry) pair is ONE inline function shared by both kernels (explicit fmaf chain), so
+// forward and backward take bit-identical skip decisions.
 #include "common.h"
 
 namespace moss {
 
 namespace {
 
-constexpr int FWD_BATCH = 256;
 constexpr int NPART = 12;           // 9 partial gradients padded to 12 floats (48 B) per (wave, entry)
-constexpr int LIST_PAD = 48;        // sentinel entries behind a hit list (one trip of 16 + prefetch)
-
-template <int SLOTS> struct Lay {
-    static constexpr int NW = SLOTS;                       // waves per 8x8 quadrant = workgroup size / 64
-    static constexpr int NPIX = 64 / SLOTS;                // pixels per wave
-    static constexpr int BW = (SLOTS == 16) ? 2 : 4;       // pixel block of a wave: 4x4, 4x2, 2x2
-    static constexpr int BH = NPIX / BW;
-    static constexpr int WX = 8 / BW;                      // blocks per quadrant row
-    static constexpr int BB = (SLOTS == 16) ? 64 : 128;    // backward: entries staged per round (bounds the LDS partial sums)
-};
 
 struct PairEval { float power, G, alpha; };
 
@@ -70,36 +53,8 @@ __device__ __forceinline__ PairEval eval_pair(float dx, float dy, float A, float
 }
 
 // bounding box of an entry's alpha >= 1/255 region {x, y, hx, hy} vs. a pixel block [bx0,bx0+w] x [by0,by0+h]
-__device__ __forceinline__ bool block_hit(float4 d, float bx0, float by0, float w, float h)
-{
-    return (d.x + d.z >= bx0) && (d.x - d.z <= bx0 + w) && (d.y + d.w >= by0) && (d.y - d.w <= by0 + h);
-}
-
 // ---- cross-lane helpers (lane = pixel * SLOTS + slot; the SLOTS lanes of a pixel are contiguous inside a 16-lane DPP row)
 #define DPP_MOV(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
-// lane - k inside the 16-lane row; lanes without a source keep `fill`
-#define ROW_SHR(v, k, fill) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x110 + (k), 0xf, 0xf, false))
-
-// value of slot s-K (K compile-time) of the same pixel, `fill` if s < K
-template <int SLOTS, int K>
-__device__ __forceinline__ float from_slot_minus(float v, float fill, int slot)
-{
-    float r = ROW_SHR(v, K, fill);
-    if (SLOTS < 16) r = (slot >= K) ? r : fill;          // a 16-lane row holds 16/SLOTS pixels: do not read the neighbour's slots
-    return r;
-}
-
-// inclusive prefix product over the slots of a pixel (list order)
-template <int SLOTS>
-__device__ __forceinline__ float prefix_mul(float x, int slot)
-{
-    x *= from_slot_minus<SLOTS, 1>(x, 1.0f, slot);
-    x *= from_slot_minus<SLOTS, 2>(x, 1.0f, slot);
-    if (SLOTS > 4) x *= from_slot_minus<SLOTS, 4>(x, 1.0f, slot);
-    if (SLOTS > 8) x *= from_slot_minus<SLOTS, 8>(x, 1.0f, slot);
-    return x;
-}
-
 // butterfly all-reduce over the slots of a pixel: every lane ends with bit-identical results (commutative ops, symmetric tree)
 #define GROUP_ALLREDUCE(SLOTS, v, OP)                                          \
     {                                                                          \
@@ -111,248 +66,6 @@ __device__ __forceinline__ float prefix_mul(float x, int slot)
 #define OP_MUL(a, b) ((a) * (b))
 #define OP_ADD(a, b) ((a) + (b))
 #define OP_MAX(a, b) fmaxf((a), (b))
-
-// value held by the LAST slot of this lane's pixel
-template <int SLOTS>
-__device__ __forceinline__ float from_last_slot(float v, int lane)
-{
-    if (SLOTS == 4) return DPP_MOV(v, 0xFF);              // quad_perm:[3,3,3,3]
-    return __shfl(v, (lane | (SLOTS - 1)));
-}
-
-// Cooperative staging of a batch of list entries first, first+dir, ... : thread e < cnt owns entry e.  The loads of batch
-// k+1 are in flight (in registers) while the workgroup processes batch k.
-struct Staged { float4 a, b, c; };
-
-__device__ __forceinline__ Staged load_entry(int cnt, const float4* __restrict__ inst_rec, int first, int dir)
-{
-    Staged s;
-    const int e = threadIdx.x;
-    if (e < cnt) {
-        const float4* rec = inst_rec + 3 * (size_t)(first + dir * e);      // contiguous per tile: coalesced, single level
-        s.a = rec[0]; s.b = rec[1]; s.c = rec[2];
-    } else {
-        s.a = s.b = s.c = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    return s;
-}
-
-__device__ __forceinline__ void store_entry(const Staged& s, int cnt, float4* s_a, float4* s_b, float4* s_c)
-{
-    const int e = threadIdx.x;
-    if (e < cnt) { s_a[e] = s.a; s_b[e] = s.b; s_c[e] = s.c; }     // s_a = {x, y, hx, hy} doubles as the cull record
-}
-
-// Append the indices of the lanes with `hit` to this wave's list; returns the new length.
-__device__ __forceinline__ int append_hits(uint16_t* list, int len, bool hit, int value)
-{
-    const unsigned long long m = __ballot(hit);
-    const int pos = len + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (hit) list[pos] = (uint16_t)value;
-    return len + __popcll(m);
-}
-
-// geometry of this lane inside the tile
-template <int SLOTS>
-struct LaneGeom {
-    int slot, px, py, ox, oy, gbase;
-    __device__ __forceinline__ LaneGeom(int tile, int sub, int gx, int lane, int wv)
-    {
-        using L = Lay<SLOTS>;
-        const int tx = tile % gx, ty = tile / gx;
-        slot = lane % SLOTS;
-        const int pl = lane / SLOTS;
-        ox = tx * TILE + (sub & 1) * 8 + (wv % L::WX) * L::BW;
-        oy = ty * TILE + (sub >> 1) * 8 + (wv / L::WX) * L::BH;
-        px = ox + pl % L::BW; py = oy + pl / L::BW;
-        gbase = lane - slot;
-    }
-};
-
-// ---------------------------------------------------------------------------------------------------------
-template <int SLOTS>
-__global__ void __launch_bounds__(SLOTS * 64)
-blend_forward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
-                     uint32_t* __restrict__ queue_head,
-                     const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
-                     const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
-                     float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
-                     unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per workgroup, else NULL */)
-{
-    using L = Lay<SLOTS>;
-    constexpr int NW = L::NW, NT = NW * 64;
-    __shared__ float4 s_a[FWD_BATCH + 1];
-    __shared__ float4 s_b[FWD_BATCH + 1];
-    __shared__ float4 s_c[FWD_BATCH + 1];
-    __shared__ uint16_t s_list[NW][FWD_BATCH + LIST_PAD];
-    __shared__ int s_done[NW];
-    __shared__ int s_item;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_items = 4 * (int)header[5];                  // tile_order lists the tiles that own instances first
-    // Persistent workgroups: a fixed number per CU pull (tile, quadrant) work items from an atomic queue, tiles with the
-    // longest lists first (tile_order).  Static blockIdx -> tile placement left some CUs with 6-8 heavy workgroups and others
-    // with none (measured with in-kernel stamps: 42 % of the slowest workgroups' time was barrier wait, 11 cycles/instruction).
-    int next_item = 0;
-    if (tid == 0) next_item = (int)atomicAdd(queue_head, 1u);
-    for (;;) {
-    __syncthreads();                                         // the previous item is completely finished (LDS is reused)
-    if (tid == 0) {
-        s_item = next_item;
-        if (next_item < n_items) next_item = (int)atomicAdd(queue_head, 1u);   // returns while this item is processed
-    }
-    __syncthreads();
-    const int item = s_item;
-    if (item >= n_items) break;
-    const int tile = (int)tile_order[item >> 2], sub = item & 3;
-    const LaneGeom<SLOTS> lg(tile, sub, gx, lane, wv);
-    const int slot = lg.slot;
-    const bool inside = lg.px < W && lg.py < H;
-    const float pixx = (float)lg.px, pixy = (float)lg.py;
-    const float bx0 = (float)lg.ox, by0 = (float)lg.oy;
-    const uint32_t slot_bits = (1u << SLOTS) - 1u, below_mask = (1u << slot) - 1u;
-
-    const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
-
-    if (tid == 0) {                       // sentinel entry: opacity 0 -> alpha 0 -> contributes nothing
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_a[FWD_BATCH] = z4; s_b[FWD_BATCH] = z4; s_c[FWD_BATCH] = z4;
-    }
-    if (tid < NW) s_done[tid] = 0;
-
-    float T = 1.0f, T_stop = -1.0f;
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
-    float last_contributor = 0.0f;                                       // list positions < 2^24: exact in fp32
-    float live = inside ? 1.0f : 0.0f;
-    uint16_t* my_list = s_list[wv];
-
-    // diagnostics only (moss_raster_debug_set_stamps): cycles wave 0 spends in each phase of a batch
-#define STAMP() (stamps ? __builtin_amdgcn_s_memtime() : 0ull)
-    unsigned long long d_top = 0, d_stage = 0, d_bar = 0, d_cull = 0, d_trip = 0, n_batches = 0, n_trips = 0;
-    const unsigned long long t_begin = STAMP();
-
-    static_assert(NT >= FWD_BATCH, "one staging thread per batch entry");
-    Staged pre = load_entry(min(FWD_BATCH, n), inst_rec, (int)rg.x, 1);
-    for (int base = 0; base < n; base += FWD_BATCH) {
-        const unsigned long long t0 = STAMP();
-        __syncthreads();                                      // everybody is done reading the previous batch; s_done is current
-        bool all_done = true;
-#pragma unroll
-        for (int w = 0; w < NW; w++) all_done = all_done && (s_done[w] != 0);
-        if (all_done) break;
-        const unsigned long long t1 = STAMP();
-        const int cnt = min(FWD_BATCH, n - base);
-        store_entry(pre, cnt, s_a, s_b, s_c);
-        if (base + FWD_BATCH < n)                             // next batch's loads fly while this one is blended
-            pre = load_entry(min(FWD_BATCH, n - base - FWD_BATCH), inst_rec, (int)rg.x + base + FWD_BATCH, 1);
-        const unsigned long long t2 = STAMP();
-        __syncthreads();
-        const unsigned long long t3 = STAMP();
-        d_top += t1 - t0; d_stage += t2 - t1; d_bar += t3 - t2; n_batches++;
-        if (__ballot(live > 0.0f) == 0ull) {                  // this wave is finished; keep meeting the barriers
-            if (lane == 0) s_done[wv] = 1;
-            continue;
-        }
-
-        int len = 0;
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-            const int j = c0 + lane;
-            bool hit = j < cnt;
-            if (hit && (flags & 1)) hit = block_hit(s_a[j], bx0, by0, (float)(L::BW - 1), (float)(L::BH - 1));
-            len = append_hits(my_list, len, hit, j);
-        }
-        if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)FWD_BATCH;        // pad with the sentinel
-        const int ntrip = (flags & 2) ? 0 : (len + SLOTS - 1) / SLOTS;
-        const unsigned long long t4 = STAMP();
-        d_cull += t4 - t3; n_trips += ntrip;
-
-        int lp = slot;
-        uint32_t e = my_list[lp];
-        float4 a = s_a[e], b = s_b[e], c = s_c[e];
-        uint32_t e1 = my_list[lp + SLOTS];
-        for (int it = 0; it < ntrip; it++) {
-            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];            // prefetch the next trip's records
-            const uint32_t e2 = my_list[lp + 2 * SLOTS];
-
-            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.x, b.y, b.z, b.w);
-            const float al = pe.alpha * live;                                  // 0 for finished / outside pixels
-            const float f = 1.0f - al;
-            float X, Tb;                                                       // T behind / in front of this slot's entry
-            if (SLOTS == 4) {
-                // multiplied in list order: bit-identical to the serial loop
-                float Y;
-                X = T * f;
-                Y = DPP_MOV(X, 0x90); X = slot >= 1 ? Y * f : X;               // quad_perm:[0,0,1,2]
-                Y = DPP_MOV(X, 0x90); X = slot >= 2 ? Y * f : X;
-                Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y * f : X;
-                Y = DPP_MOV(X, 0x90);
-                Tb = slot == 0 ? T : Y;
-            } else {
-                const float Pm = prefix_mul<SLOTS>(f, slot);
-                X = T * Pm;
-                Tb = T * from_slot_minus<SLOTS, 1>(Pm, 1.0f, slot);
-            }
-            const float st = (X < 0.0001f) ? al : 0.0f;                        // > 0: this entry ends the pixel (forward.cu:351-356)
-            const unsigned long long sb = __ballot(st > 0.0f);
-            const uint32_t q = (uint32_t)(sb >> lg.gbase) & slot_bits;         // stop flags of this pixel's slots
-            const uint32_t below = q & below_mask;                             // an earlier slot already stopped the pixel
-            float wgt = al * Tb;
-            wgt = (st > 0.0f) ? 0.0f : wgt;
-            wgt = (below != 0u) ? 0.0f : wgt;
-            const float ts = (st > 0.0f) ? Tb : T_stop;
-            T_stop = (below != 0u) ? T_stop : ts;                              // the first stopping slot records the final T
-            Cr = __fmaf_rn(c.x, wgt, Cr); Cg = __fmaf_rn(c.y, wgt, Cg); Cb = __fmaf_rn(c.z, wgt, Cb);
-            weight += wgt;
-            Dacc = __fmaf_rn(c.w, wgt, Dacc);
-            last_contributor = (wgt > 0.0f) ? (float)(base + (int)e + 1) : last_contributor;
-            if (SLOTS == 4) T = DPP_MOV(X, 0xFF);
-            else { float Pall = f; GROUP_ALLREDUCE(SLOTS, Pall, OP_MUL) T *= Pall; }
-            live = (q != 0u) ? 0.0f : live;
-            if (__ballot(live > 0.0f) == 0ull) break;
-
-            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += SLOTS;
-        }
-        const bool wave_done = __ballot(live > 0.0f) == 0ull;          // all lanes vote (outside the lane-0 branch)
-        if (lane == 0) s_done[wv] = wave_done ? 1 : 0;
-        d_trip += STAMP() - t4;
-    }
-
-    if (stamps && tid == 0) {
-        unsigned long long* o = stamps + (size_t)item * 8;
-        o[0] = STAMP() - t_begin; o[1] = d_top; o[2] = d_stage; o[3] = d_bar; o[4] = d_cull; o[5] = d_trip; o[6] = n_batches; o[7] = n_trips;
-    }
-#undef STAMP
-    // combine the slots of each pixel
-    GROUP_ALLREDUCE(SLOTS, Cr, OP_ADD) GROUP_ALLREDUCE(SLOTS, Cg, OP_ADD) GROUP_ALLREDUCE(SLOTS, Cb, OP_ADD)
-    GROUP_ALLREDUCE(SLOTS, weight, OP_ADD) GROUP_ALLREDUCE(SLOTS, Dacc, OP_ADD)
-    GROUP_ALLREDUCE(SLOTS, T_stop, OP_MAX) GROUP_ALLREDUCE(SLOTS, last_contributor, OP_MAX)
-    const float Tf = T_stop >= 0.0f ? T_stop : T;
-
-    if (inside && slot == 0) {
-        const size_t pix_id = (size_t)W * lg.py + lg.px, plane = (size_t)W * H;
-        final_T[pix_id] = Tf;
-        n_contrib[pix_id] = (uint32_t)last_contributor;
-        out_color[pix_id] = __fmaf_rn(Tf, bg_color[0], Cr);
-        out_color[plane + pix_id] = __fmaf_rn(Tf, bg_color[1], Cg);
-        out_color[2 * plane + pix_id] = __fmaf_rn(Tf, bg_color[2], Cb);
-        out_alpha[pix_id] = weight;
-        out_depth[pix_id] = Dacc;
-    }
-    }   // work-item loop
-
-    // Tiles without instances get the background only (forward.cu:374-382 with an empty range).  Done AFTER the queue so that
-    // the heavy items start immediately; workgroups that run out of queued work fill these while the stragglers finish.
-    for (int i = n_items + (int)blockIdx.x; i < 4 * T_tiles; i += (int)gridDim.x) {
-        const LaneGeom<SLOTS> lg(tile_order[i >> 2], i & 3, gx, lane, wv);
-        if (lg.px < W && lg.py < H && lg.slot == 0) {
-            const size_t pix_id = (size_t)W * lg.py + lg.px, plane = (size_t)W * H;
-            final_T[pix_id] = 1.0f; n_contrib[pix_id] = 0u;
-            out_color[pix_id] = bg_color[0]; out_color[plane + pix_id] = bg_color[1]; out_color[2 * plane + pix_id] = bg_color[2];
-            out_alpha[pix_id] = 0.0f; out_depth[pix_id] = 0.0f;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // two values, one reduction level each: lanes 0-31 get a's sum over (l, l+32), lanes 32-63 get b's
@@ -376,238 +89,14 @@ __device__ __forceinline__ float row_slot_sum(float v)
     return v;
 }
 
-template <int SLOTS>
-__global__ void __launch_bounds__(SLOTS * 64)
-blend_backward_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
-                      uint32_t* __restrict__ queue_head,
-                      const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
-                      const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
-                      float* __restrict__ inst_grad /* [4][R][12] */, size_t slab_stride, int flags)
-{
-    using L = Lay<SLOTS>;
-    constexpr int NW = L::NW, NT = NW * 64, BB = L::BB;
-    __shared__ float4 s_a[BB + 1];
-    __shared__ float4 s_b[BB + 1];
-    __shared__ float4 s_c[BB + 1];
-    __shared__ uint16_t s_list[NW][BB + LIST_PAD];
-    __shared__ __attribute__((aligned(16))) float s_part[NW][BB + 1][NPART];
-    __shared__ uint32_t s_nmax;
-    __shared__ int s_item;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_items = 4 * (int)header[5];                  // only tiles that own instances
-    int next_item = 0;
-    if (tid == 0) next_item = (int)atomicAdd(queue_head, 1u);
-    for (;;) {                                               // persistent workgroup: see the forward kernel
-    __syncthreads();
-    if (tid == 0) {
-        s_item = next_item;
-        if (next_item < n_items) next_item = (int)atomicAdd(queue_head, 1u);
-    }
-    __syncthreads();
-    const int item = s_item;
-    if (item >= n_items) break;
-    const int tile = (int)tile_order[item >> 2], sub = item & 3;
-    const LaneGeom<SLOTS> lg(tile, sub, gx, lane, wv);
-    const int slot = lg.slot;
-    const bool inside = lg.px < W && lg.py < H;
-    const float pixx = (float)lg.px, pixy = (float)lg.py;
-    const float bx0 = (float)lg.ox, by0 = (float)lg.oy;
-    const size_t pix_id = (size_t)W * lg.py + lg.px, plane = (size_t)W * H;
-
-    const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
-    if (n == 0) continue;
-    float* my_grad = inst_grad + (size_t)sub * slab_stride + (size_t)rg.x * NPART;      // this quadrant's slab of the tile's records
-
-    const float T_final = inside ? final_Ts[pix_id] : 0.0f;
-    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
-    float gpr = 0.f, gpg = 0.f, gpb = 0.f, gpd = 0.f, gpa = 0.f;
-    if (inside) {
-        // a null incoming gradient = that output did not take part in the loss (zeros, without a zero-filled image)
-        if (dL_dpixels) { gpr = dL_dpixels[pix_id]; gpg = dL_dpixels[plane + pix_id]; gpb = dL_dpixels[2 * plane + pix_id]; }
-        if (dL_ddepths) gpd = dL_ddepths[pix_id];
-        if (dL_dalphas) gpa = dL_dalphas[pix_id];
-    }
-    const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-
-    if (tid == 0) {
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_a[BB] = z4; s_b[BB] = z4; s_c[BB] = z4;
-        s_nmax = 0;
-    }
-    __syncthreads();
-    // Pixel state, replicated in the pixel's lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
-    // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
-    float T = T_final, Q = 0.0f;
-
-    // entries at list positions >= n_eff are behind every pixel's last contributor: nobody visits them
-    int wave_max = last_contributor;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wave_max = max(wave_max, __shfl_xor(wave_max, d));
-    if (lane == 0) atomicMax(&s_nmax, (uint32_t)wave_max);
-    __syncthreads();
-    const int n_eff = (int)s_nmax;
-
-    for (int i = n_eff * NPART + tid; i < n * NPART; i += NT) my_grad[i] = 0.0f;
-
-    uint16_t* my_list = s_list[wv];
-    // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
-    const int row = lane >> 4, rh = row >> 1, rp = row & 1;
-    const int m0 = 2 * rp + rh, m1 = 4 + m0;
-    const bool writer = (lane & 15) < SLOTS;               // one lane per (row, slot)
-
-    static_assert(NT >= BB, "one staging thread per batch entry");
-    Staged pre = load_entry(min(BB, n_eff), inst_rec, (int)rg.x + n_eff - 1, -1);
-    for (int base = 0; base < n_eff; base += BB) {
-        const int cnt = min(BB, n_eff - base);
-        __syncthreads();                                   // previous batch fully flushed
-        store_entry(pre, cnt, s_a, s_b, s_c);
-        if (base + BB < n_eff)                             // next batch's loads fly while this one is processed
-            pre = load_entry(min(BB, n_eff - base - BB), inst_rec, (int)rg.x + n_eff - 1 - base - BB, -1);
-        {
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4* zp = reinterpret_cast<float4*>(&s_part[0][0][0]);
-            for (int i = tid; i < NW * (BB + 1) * NPART / 4; i += NT) zp[i] = z4;
-        }
-        __syncthreads();
-
-        int len = 0;
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-            const int j = c0 + lane;
-            bool hit = (j < cnt) && (n_eff - 1 - (base + j) < wave_max);
-            if (hit && (flags & 1)) hit = block_hit(s_a[j], bx0, by0, (float)(L::BW - 1), (float)(L::BH - 1));
-            len = append_hits(my_list, len, hit, j);
-        }
-        if (lane < LIST_PAD) my_list[len + lane] = (uint16_t)BB;
-        const int ntrip = (flags & 2) ? 0 : (len + SLOTS - 1) / SLOTS;
-
-        int lp = slot;
-        uint32_t e = my_list[lp];
-        float4 a = s_a[e], b = s_b[e], c = s_c[e];
-        uint32_t e1 = my_list[lp + SLOTS];
-        for (int it = 0; it < ntrip; it++) {
-            const float4 an = s_a[e1], bn = s_b[e1], cn = s_c[e1];
-            const uint32_t e2 = my_list[lp + 2 * SLOTS];
-
-            const int pos = n_eff - 1 - (base + (int)e);                   // back to front
-            const float dx = a.x - pixx, dy = a.y - pixy;
-            const PairEval pe = eval_pair(dx, dy, b.x, b.y, b.z, b.w);
-            const float al = (pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = this pair is skipped
-            const float G = (al > 0.0f) ? pe.G : 0.0f;
-            // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
-            const float mm = 1.0f - al;
-            const float rinv = __builtin_amdgcn_rcpf(mm);
-            const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));
-            const float kq = al * u;
-            float Ti, Qi, To;
-            if (SLOTS == 4) {
-                // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
-                Ti = T; Qi = Q;
-                To = Ti * rinv; float Qo = __fmaf_rn(mm, Qi, kq);
-#pragma unroll
-                for (int k = 1; k <= 3; k++) {
-                    const float yT = DPP_MOV(To, 0x90), yQ = DPP_MOV(Qo, 0x90);
-                    Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
-                    To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
-                }
-                T = DPP_MOV(To, 0xFF); Q = DPP_MOV(Qo, 0xFF);               // the pixel's state after these four entries
-            } else {
-                // inclusive prefix composition of the slots' maps: (Rp, M, K) of slots 0..s, later o earlier:
-                //   Rp = prod rinv,   M = prod mm,   K <- M_self * K_earlier + K_self
-                float Rp = rinv, M = mm, K = kq;
-#define COMPOSE_STEP(k)                                                                                  \
-                {                                                                                        \
-                    const float Re = from_slot_minus<SLOTS, k>(Rp, 1.0f, slot), Me = from_slot_minus<SLOTS, k>(M, 1.0f, slot), \
-                                Ke = from_slot_minus<SLOTS, k>(K, 0.0f, slot);                           \
-                    K = __fmaf_rn(M, Ke, K); M *= Me; Rp *= Re;                                          \
-                }
-                COMPOSE_STEP(1) COMPOSE_STEP(2) COMPOSE_STEP(4)
-                if (SLOTS > 8) COMPOSE_STEP(8)
-#undef COMPOSE_STEP
-                // state in front of this slot = maps of slots 0..s-1 applied to the pixel state
-                const float Rx = from_slot_minus<SLOTS, 1>(Rp, 1.0f, slot), Mx = from_slot_minus<SLOTS, 1>(M, 1.0f, slot),
-                            Kx = from_slot_minus<SLOTS, 1>(K, 0.0f, slot);
-                Ti = T * Rx; Qi = __fmaf_rn(Mx, Q, Kx);
-                To = Ti * rinv;
-                // the pixel's state after this trip = the last slot's inclusive maps applied to it
-                const float Rl = from_last_slot<SLOTS>(Rp, lane), Ml = from_last_slot<SLOTS>(M, lane), Kl = from_last_slot<SLOTS>(K, lane);
-                T = T * Rl; Q = __fmaf_rn(Ml, Q, Kl);
-            }
-
-            // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
-            float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
-            dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
-            const float dchannel_dcolor = al * To;
-            const float dL_dG = b.w * dL_dopa;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * b.x - gdy * b.y;
-            const float dG_ddely = -gdy * b.z - gdx * b.y;
-            const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
-            const float v3 = dL_dG * dG_ddelx * ddelx_dx;
-            const float v4 = dL_dG * dG_ddely * ddely_dy;
-            const float hdG = -0.5f * dL_dG;
-            const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
-            const float v8 = G * dL_dopa;
-
-            if (__ballot(al > 0.0f) != 0ull) {
-                // reduce-scatter over the wave's pixels, separately per slot: after fold32 the lower/upper half-waves hold
-                // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
-                const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
-                const float s0 = row_slot_sum<SLOTS>(fold16(r0, r1)), s1 = row_slot_sum<SLOTS>(fold16(r2, r3)),
-                            s2 = row_slot_sum<SLOTS>(fold16(r4, 0.0f));
-                if (writer) {
-                    float* dst = &s_part[wv][e][0];
-                    dst[m0] = s0; dst[m1] = s1;
-                    if (row == 0) dst[8] = s2;
-                }
-            }
-            a = an; b = bn; c = cn; e = e1; e1 = e2; lp += SLOTS;
-        }
-        __syncthreads();
-        // combine the wave sums in a fixed order; 16 lanes per entry write its 48-byte record contiguously
-        for (int i = tid; i < BB * 16; i += NT) {
-            const int ee = i >> 4, k = i & 15;
-            if (ee < cnt && k < NPART) {
-                float r = 0.f;
-                if (k < 9) {
-#pragma unroll
-                    for (int w = 0; w < NW; w++) r += s_part[w][ee][k];
-                }
-                const int pos = n_eff - 1 - (base + ee);
-                my_grad[(size_t)pos * NPART + k] = r;
-            }
-        }
-    }
-    }   // work-item loop
-    // Self-cleaning queue: every workgroup has made its last pull by now, so the last one to leave rewinds the head for the
-    // next backward over the same forward state (no memset node -- see raster_api.hip on hipGraph capture).
-    if (tid == 0) {
-        uint32_t* leavers = queue_head + 1;                  // header[10]
-        if (atomicAdd(leavers, 1u) == gridDim.x - 1) { *queue_head = 0u; *leavers = 0u; }
-    }
-}
-
-
-// =========================================================================================================
-// Wave-autonomous blend ("wave" implementation, the default).
-//
-// In-kernel stamps of the workgroup kernels above (profiles/r01_notes.md) showed that on the training workload the forward
-// kernel's duration EQUALS its longest (tile, quadrant) item: 100k Gaussians fall into ~180 tiles, i.e. 728 items for 768 resident
-// workgroups, so nothing is ever balanced -- and inside that longest item 38 % of the cycles were waves waiting at the batch
-// barriers for the slowest wave of their workgroup, 11 % staging.  Only ~100k (entry, 4x4 block) pairs are actually blended per
-// frame (surfaces saturate quickly); everything else is fixed per-batch overhead on the critical path.
-//
-// Here a work item is ONE WAVE = one 4x4 pixel block of a tile (16 items per tile, pulled from the same LPT-ordered queue).
-// There is no workgroup barrier anywhere: a wave reads the tile's record stream itself, 64 entries per step (three coalesced
-// 16-byte loads per lane, the next step's loads in flight), culls them against its block, compacts the hits into a private
-// LDS ring and blends them 4 per trip as before.  A wave that is done leaves at once; waves of the same tile hit in L2.
+// ---------------------------------------------------------------------------------------------------------
+// Work items.  100k Gaussians of a person fall into ~250 tiles: with one workgroup per tile quadrant nothing was ever balanced and
+// the kernel's duration equalled its longest item.  Here a work item is ONE WAVE (16 block items per heavy tile, 4 quadrant items
+// per light tile, pulled from LPT-ordered per-XCD queues); a wave that is done leaves at once; waves of the same tile hit in L2.
 // Backward: each wave stores the partial-gradient record of an (entry, block) pair it really blended into that block's slab
-// and sets the block's bit in the instance's mask; the per-Gaussian gather reads only flagged records (a fixed order ->
-// still bitwise reproducible), ~10x fewer than the one-record-per-instance-per-quadrant scheme of the workgroup kernels.
-// =========================================================================================================
+// and sets the block's bit in the instance's mask; the per-Gaussian gather reads only flagged records (a fixed order -> still
+// bitwise reproducible).
+// ---------------------------------------------------------------------------------------------------------
 
 constexpr int WAVE_BLOCKS = 16;           // 4x4-pixel blocks per tile = items per tile = gradient slabs
 
@@ -1286,29 +775,18 @@ int persistent_workgroups()
             cus = prop.multiProcessorCount;
         // wave kernels: ONE wave per SIMD.  The kernel's duration is the instruction stream of its heaviest waves, and a SIMD issues
         // one wave-instruction per 4 cycles however many waves it hosts: co-resident waves only slow the heavy ones down
-        // (measured 67 / 81 / 91 us forward for 1 / 2 / 3 workgroups per CU).  The workgroup kernels needed 3 to hide barrier waits.
-        return cus * env_int("MOSS_BLEND_WGS_PER_CU", env_int("MOSS_BLEND_IMPL", 1) ? 1 : 3);
+        // (measured 67 / 81 / 91 us forward for 1 / 2 / 3 workgroups per CU).
+        return cus * env_int("MOSS_BLEND_WGS_PER_CU", 1);
     }();
     return n;
-}
-
-int blend_slots()
-{
-    // measured on MI355X (profiles/r01_notes.md): 4 slots (4x4-pixel blocks, 4 waves per quadrant) is fastest; 8 and 16 do more
-    // total work per tile (every wave re-tests the whole batch) and lose despite their shorter per-wave trip counts
-    static const int s = env_int("MOSS_BLEND_SLOTS", 4);
-    return (s == 8 || s == 16) ? s : 4;
 }
 
 }  // anonymous namespace
 
 unsigned long long* g_stamps = nullptr;      // diagnostics buffer registered by moss_raster_debug_set_stamps (NULL = off)
 
-// 1 = wave-autonomous kernels (default), 0 = workgroup-per-quadrant kernels (kept for comparison: MOSS_BLEND_IMPL=0)
-int blend_impl() { static const int v = env_int("MOSS_BLEND_IMPL", 1); return v ? 1 : 0; }
-// gradient-record slabs per instance: one per 4x4 block (wave kernels, sparse: only blended pairs are written and flagged in
-// inst_mask) or one per 8x8 quadrant workgroup (dense)
-int blend_subgroups() { return blend_impl() ? WAVE_BLOCKS : 4; }
+// gradient-record slabs per instance: one per 4x4 block (sparse: only blended pairs are written and flagged in inst_mask)
+int blend_subgroups() { return WAVE_BLOCKS; }
 
 void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
                           float* out_color, float* out_depth, float* out_alpha, hipStream_t s)
@@ -1316,20 +794,10 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     (void)g;
     static const int flags = env_int("MOSS_BLEND_CULL", 1);
     const int T = fp.gx * fp.gy;
-    if (blend_impl()) {
-        const int wgs = min(4 * T, persistent_workgroups());           // 4 independent waves per workgroup, 16 items per tile
-        hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
-                           im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
-                           im.final_T, im.n_contrib, flags, g_stamps);
-        return;
-    }
-    const int wgs = min(4 * T, persistent_workgroups());
-#define LAUNCH_FWD(S)                                                                                                         \
-    hipLaunchKernelGGL(blend_forward_kernel<S>, dim3(wgs), dim3(S * 64), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order,           \
-                       im.header, im.header + 8, im.ranges, b.inst_rec, fp.bg_dev, out_color, out_depth, out_alpha, im.final_T,         \
-                       im.n_contrib, flags, g_stamps)
-    switch (blend_slots()) { case 8: LAUNCH_FWD(8); break; case 16: LAUNCH_FWD(16); break; default: LAUNCH_FWD(4); }
-#undef LAUNCH_FWD
+    const int wgs = min(4 * T, persistent_workgroups());               // 4 independent waves per workgroup, 16 items per tile
+    hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+                       im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                       im.final_T, im.n_contrib, flags, g_stamps);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
@@ -1339,20 +807,11 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     static const int flags = env_int("MOSS_BLEND_CULL", 1);
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());
-    float* ig = reinterpret_cast<float*>(b.inst_grad);
-    // header[9] (queue head) and header[10] (leaver count) are zero here: cleared by the forward, rewound by each backward
-    if (blend_impl()) {
-        hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
-                           im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth,
-                           dL_dalpha, ig, b.slab_stride_floats, b.inst_mask, im.header + HDR_LEAVERS, flags);
-        return;
-    }
-#define LAUNCH_BWD(S)                                                                                                         \
-    hipLaunchKernelGGL(blend_backward_kernel<S>, dim3(wgs), dim3(S * 64), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order,          \
-                       im.header, im.header + 9, im.ranges, b.inst_rec, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix, dL_ddepth,        \
-                       dL_dalpha, ig, b.slab_stride_floats, flags)
-    switch (blend_slots()) { case 8: LAUNCH_BWD(8); break; case 16: LAUNCH_BWD(16); break; default: LAUNCH_BWD(4); }
-#undef LAUNCH_BWD
+    // the queue heads and the leaver count are zero here: cleared by the forward, rewound by each backward
+    hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
+                       im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
+                       dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
+                       im.header + HDR_LEAVERS, flags);
 }
 
 }  // namespace moss

@@ -13,7 +13,7 @@
 //     clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
-//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [6]=instances needed [8]/[9]=work-queue heads of the forward/backward blend
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [6]=instances needed [16..31]=work-queue heads of the forward/backward blend
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
 //     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id); inst_tile u32[R] tile of a slot
@@ -66,7 +66,7 @@ struct GeomView {
 };
 
 // header words: [0] R, [1] longest tile list, [2] error flags, [3] inst_pos slot allocator, [4] sort chunks, [5] tiles that own
-// instances, [6] instances needed, [7] heavy tiles (list length >= 2^LIGHT_TILE_LOG2; they come first in tile_order), [8]/[9] queue heads of the workgroup blend kernels, [10] backward leaver count,
+// instances, [6] instances needed, [7] heavy tiles (list length >= 2^LIGHT_TILE_LOG2; they come first in tile_order), [8]/[9] unused, [10] backward leaver count,
 // [16..23] / [24..31] per-XCD queue heads of the wave blend kernels (forward / backward)
 constexpr int HEADER_WORDS = 32;
 constexpr int LIGHT_TILE_LOG2 = 7;     // tiles with fewer than 2^7 entries are "light": blended one pixel per lane ([7] = heavy tiles)
@@ -123,16 +123,15 @@ __device__ __forceinline__ void wave_for_each_tile(uint2 rect, int gx, uint64_t 
 #endif
 
 extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
-int blend_subgroups();       // gradient-record slabs per instance (16: wave kernels, 4: workgroup kernels), blend.hip
-int blend_impl();            // 1 = wave-autonomous blend kernels (sparse records + inst_mask), 0 = workgroup kernels
+int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
 struct BinView {
     uint32_t* point_list; uint32_t* inst_pos; uint32_t* inst_tile;
-    uint32_t* inst_mask;     // per instance (sorted order): bit b set <=> slab b holds a record for it (wave kernels)
+    uint32_t* inst_mask;     // per instance (sorted order): bit b set <=> slab b holds a record for it
     uint16_t* inst_bmask;    // per instance (sorted order): bit b set <=> its alpha >= 1/255 bounding box touches 4x4 block b of its tile
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
     float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
-    float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per blend workgroup of a tile)
+    float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per 4x4 block of a tile)
     int slabs; size_t slab_stride_floats;
     static BinView at(char* base, int R)
     {

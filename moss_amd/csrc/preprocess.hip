@@ -432,10 +432,10 @@ __device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv)   // auxiliary.h
 // STAGE_SH (requires M == 16, shs and dL_dsh given): the block's SH records are read from HBM with coalesced loads into LDS and
 // the dL_dsh records leave the same way.  Per thread a record is 48 floats at a 192-byte stride, i.e. every one of the 48 loads
 // and 48 stores of a wave would touch 64 different cache lines; through LDS (row stride 49 words: conflict-free) the global side
-// is 12 fully coalesced 16-byte accesses per lane.  SLABS > 0 fixes the number of gradient slabs at compile time so that the 3 x
-// SLABS record loads of one instance are issued together.
+// is 12 fully coalesced 16-byte accesses per lane.
+// Gradient records are sparse: slab b of an instance holds a record only if bit b of its inst_mask is set (blend.hip).
 constexpr int SH_ROW = 49;
-template <bool STAGE_SH, int SLABS>
+template <bool STAGE_SH>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float scale_modifier,
                            const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -481,7 +481,6 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     const uint32_t n_inst = in_range ? tt_raw : 0u;
-    const int n_slabs = SLABS > 0 ? SLABS : slabs;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
     float dtf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -497,7 +496,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     const uint32_t off = visible ? off_raw : 0u;
     uint32_t k_first = 0;                                    // first instance the serial loop below still has to visit
     // (buffer loads address with 32-bit byte offsets: beyond 4 GB of record slabs -- R > 5.5M instances -- the serial loop does it all)
-    if (SLABS < 0 && (unsigned long long)slabs * slab_stride_f4 * 16ull < 0xffffff00ull) {
+    if ((unsigned long long)slabs * slab_stride_f4 * 16ull < 0xffffff00ull) {
         // Sparse records, the common case (a Gaussian owns 2-3 instances, at most 16 here, with 1-2 flagged records each): walked one
         // after the other, every record costs three DEPENDENT loads (inst_pos -> inst_mask -> record) and the wave waits for its
         // lane with the most instances: stamps showed this phase taking 48k of a block's 62k cycles.  Here all positions, then all
@@ -571,20 +570,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     if (visible && n_inst <= COOP_INST) {
         for (uint32_t k = k_first; k < n_inst; k++) {
             const uint32_t pos = inst_pos[off + k];
-            if (SLABS < 0) {
-                // sparse records of the wave blend kernels: only the slabs flagged in the instance's mask, ascending
-                for (uint32_t mbits = inst_mask[pos]; mbits != 0u; mbits &= mbits - 1u) {
-                    const int sl = __ffs((int)mbits) - 1;
-                    const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                    gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
-                    gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
-                    gop += r2.x;
-                }
-                continue;
-            }
-#pragma unroll
-            for (int sl = 0; sl < n_slabs; sl++) {
+            // only the slabs flagged in the instance's mask, ascending
+            for (uint32_t mbits = inst_mask[pos]; mbits != 0u; mbits &= mbits - 1u) {
+                const int sl = __ffs((int)mbits) - 1;
                 const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
                 const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
@@ -601,7 +589,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             big &= big - 1;
             const uint32_t boff = __shfl(off, src), bn = __shfl(n_inst, src);
             float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            if (SLABS < 0) {
+            {
                 // Sparse records.  A Gaussian that covers the image owns ~1000 instances with up to 4 (light tiles) or 16 (heavy
                 // tiles) flagged records each, found through two levels of indirection (inst_pos -> inst_mask -> record): walked
                 // naively that is thousands of DEPENDENT loads for one wave (measured: +90 us per frame with ~50 such Gaussians).
@@ -670,17 +658,6 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                         }
                     }
                 }
-            } else {
-            const uint32_t items = bn * (uint32_t)n_slabs;
-            for (uint32_t j = (uint32_t)lane; j < items; j += 64u) {
-                const uint32_t k = j / (uint32_t)n_slabs, sl = j - k * (uint32_t)n_slabs;
-                const uint32_t pos = inst_pos[boff + k];
-                const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
-                acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
-                acc[8] += r2.x;
-            }
             }
 #pragma unroll
             for (int q = 0; q < 9; q++) {
@@ -1018,17 +995,14 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     const int blocks = (fp.P + threads - 1) / threads;
     const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
-#define LAUNCH_PB(STAGE, SL)                                                                                                    \
-    hipLaunchKernelGGL((preprocess_backward_kernel<STAGE, SL>), dim3(blocks), dim3(threads),                                    \
+#define LAUNCH_PB(STAGE)                                                                                                        \
+    hipLaunchKernelGGL((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
                        (STAGE) ? 2 * (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw, g_stamps)
-    // SLABS: -1 = sparse records selected by inst_mask (wave blend kernels), 4 = four dense slabs, 0 = run-time count
-    const int sl = blend_impl() ? -1 : (b.slabs == 4 ? 4 : 0);
-    if (stage) { if (sl < 0) LAUNCH_PB(true, -1); else if (sl == 4) LAUNCH_PB(true, 4); else LAUNCH_PB(true, 0); }
-    else { if (sl < 0) LAUNCH_PB(false, -1); else if (sl == 4) LAUNCH_PB(false, 4); else LAUNCH_PB(false, 0); }
+    if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
 }
 
