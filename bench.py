@@ -206,20 +206,12 @@ def main():
         _lib.profile_enable([])              # hipEvent pairs cannot be read back from inside a captured graph
         try:
             out = None
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    compute()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                g_out = compute()
-            torch.cuda.synchronize(dev)
+            from moss_amd.graphs import GraphedStep
+            graphed = GraphedStep(compute, warmup=3, device=dev)
+            g_out = graphed.outputs
 
             def graph_step():
-                graph.replay()
+                graphed()
                 if world > 1:
                     bucket.all_reduce_mean(None, world)
                     opt.step()
