@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -12 gpurun_out/t.log

@@ -286,16 +286,17 @@ def async_mode():
     dgr.set_async(False)
 
 
-def test_async_forward_equals_sync_forward(gpu, hip_lib, async_mode):
+@pytest.mark.parametrize("raw", [False, True])
+def test_async_forward_equals_sync_forward(gpu, hip_lib, async_mode, raw):
     """moss_raster_forward_async (no host read-back, capacity-bounded) runs the same kernels on the same data: image, alpha,
-    radii and every parameter gradient are BIT-IDENTICAL to the synchronous call."""
+    radii and every parameter gradient are BIT-IDENTICAL to the synchronous call (also for the raw-parameter entry points)."""
     from types import SimpleNamespace
     from moss_amd.gaussian_model import GaussianSet
     from moss_amd.gaussian_renderer import camera_view
     s = scenes.config2()
     pc = GaussianSet(s, device=gpu)
     cam = camera_view(s.camera, gpu)
-    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=raw)
     bg = torch.tensor([0.1, 0.2, 0.3], device=gpu)
     w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
     ref = _train_like_step(pc, cam, pipe, bg, w)

@@ -140,3 +140,52 @@ def test_gradients_are_bitwise_reproducible(gpu, hip_lib):
         outs.append([getattr(g, n).cpu() for n in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dcov3D", "dL_dmeans2D")])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_cfg1_raw_parameter_entry_points_against_the_oracle(gpu):
+    """moss_raster_forward_raw / _backward_raw: raw logits / log-scales / unnormalised quaternions in, image and RAW-parameter
+    gradients out, against the C oracle run on the activated values (float32 getters in numpy) with the chain rule of the getters
+    applied to its gradients in float64."""
+    from moss_amd.diff_gaussian_rasterization import _C
+    sc = scenes.config1()
+    d = hp.inputs_of(sc, "scale_rot")
+    g = torch.Generator().manual_seed(9)
+    raw_opa = torch.randn(d.P, 1, generator=g)
+    raw_scl = torch.log(d.scales)
+    raw_rot = d.rotations * (0.3 + 2.0 * torch.rand(d.P, 1, generator=g))
+    # the getters in float32, the way the kernels evaluate them
+    d.opacities = (1.0 / (1.0 + torch.exp(-raw_opa))).float()
+    d.scales = torch.exp(raw_scl).float()
+    nrm = torch.sqrt((raw_rot * raw_rot).sum(1, keepdim=True)).clamp_min(1e-12)
+    d.rotations = (raw_rot * (1.0 / nrm)).float()
+    fw = hp.oracle_forward(d)
+    dc, dd, da = hp.image_grads(d.H, d.W, seed=5)
+    gb = hp.oracle_backward(d, fw, dc, dd, da)
+
+    c = d.cam
+    e = torch.Tensor([])
+    dev = lambda t: t.to(gpu)
+    R, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
+        dev(d.bg), dev(d.means3D), e, dev(raw_opa), dev(raw_scl), dev(raw_rot), 1.0, e, dev(c.viewmatrix), dev(c.projmatrix),
+        c.tanfovx, c.tanfovy, c.H, c.W, dev(d.shs), d.degree, dev(c.campos), False, False, None, 7)
+    assert R == fw.num_rendered
+    np.testing.assert_array_equal(radii.cpu().numpy(), fw.radii)
+    ok = _stable_pixels(fw).reshape(d.H, d.W)
+    assert hp.rel_err(color.cpu().numpy()[:, ok], fw.color[:, ok]) < IMG_TOL
+    assert hp.rel_err(alpha.cpu().numpy()[:, ok], fw.alpha[:, ok]) < IMG_TOL
+    grads = _C.rasterize_gaussians_backward(
+        dev(d.bg), dev(d.means3D), radii, e, dev(raw_scl), dev(raw_rot), 1.0, e, dev(c.viewmatrix), dev(c.projmatrix),
+        c.tanfovx, c.tanfovy, dev(dc), dev(dd), dev(da), dev(d.shs), d.degree, dev(c.campos), geom, R, binning, img, alpha, False,
+        None, 7, dev(raw_opa))
+    dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot = [x.cpu().numpy() for x in grads]
+    # chain rule of the getters on the oracle's gradients (float64)
+    s = d.opacities.double().numpy()
+    want_opa = gb.dL_dopacity.astype(np.float64).reshape(-1, 1) * (s * (1 - s))
+    want_scl = gb.dL_dscales.astype(np.float64) * d.scales.double().numpy()
+    y = d.rotations.double().numpy(); gq = gb.dL_drotations.astype(np.float64); n = nrm.double().numpy()
+    want_rot = (gq - y * (y * gq).sum(1, keepdims=True)) / n
+    assert hp.rel_err(dL_dopacity, want_opa) < GRAD_TOL
+    assert hp.rel_err(dL_dscales, want_scl) < GRAD_TOL
+    assert hp.rel_err(dL_drot, want_rot) < GRAD_TOL
+    assert hp.rel_err(dL_dmeans3D, gb.dL_dmeans3D) < GRAD_TOL
+    assert hp.rel_err(dL_dsh, gb.dL_dsh) < GRAD_TOL
