@@ -1,3 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -12 gpurun_out/t.log
+timeout 300 python scripts/prebwd_stamps.py 2>&1 | tail -5
