@@ -339,7 +339,7 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
 {
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
-    static const int per_thread = env_int("MOSS_SCATTER_ITEMS", 4);
+    static const int per_thread = env_int("MOSS_SCATTER_ITEMS", 2);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;

@@ -991,7 +991,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 const float* transforms, float* dL_dtransforms, hipStream_t s)
 {
     (void)colors_precomp;
-    static const int threads = env_int("MOSS_PREBWD_THREADS", 128);
+    static const int threads = env_int("MOSS_PREBWD_THREADS", 64);
     const int blocks = (fp.P + threads - 1) / threads;
     const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
