@@ -248,12 +248,20 @@ def main():
         dgr.check_async_status()
         assert dgr._C.ASYNC.last_needed > 0
     dom_in_region = None
+    replicas_identical = None
     if not use_graph:
         dom_in_region = _lib.profile_read()[dominant]          # hipEvent pairs recorded inside the timed region
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # frame-parallel replicas must hold bit-identical parameters after the same sequence of averaged gradients
+        if hasattr(opt, "flat_params"):
+            chk = opt.flat_params.double().sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            replicas_identical = bool((lo == hi).item())
 
     # ---- per-kernel device times: eager replay of the same K iterations with a hipEvent pair around every kernel of the op -------
     # (graph mode: events inside a replayed graph cannot be read back, so this replay is also where the dominant kernel's launch
@@ -320,6 +328,8 @@ def main():
         "step_hbm_frac": round(total_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
     }
 
+    if replicas_identical is not None:
+        result["replicas_identical"] = replicas_identical
     if world == 1:
         result["densify_side_ms"] = densify_side(pc, out)
     if world == 1 and not args.no_cpu_baseline:
