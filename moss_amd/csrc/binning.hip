@@ -249,30 +249,39 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
 #pragma unroll
         for (int by = 0; by < 4; by++) if (ym & (1u << by)) bmask |= xm << (4 * by);
         // Refinement: the box is loose for elongated, rotated Gaussians.  A pixel can only pass the alpha >= 1/255 test if
-        // q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy <= tau = ln(255 opacity) (forward.cu:336-350), so a block whose MINIMUM of the convex
-        // form q over its pixel rectangle exceeds tau (plus a margin for fp32 rounding: 1e-4 relative + 1e-3 absolute, against
-        // |q| <= 5.6 at the threshold) cannot contribute and loses its bit.  Only done for finite extents (otherwise the box
-        // decision stands).  Every wasted (entry, block) pair costs a quarter of a blend trip, forward and backward.
+        // q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy <= tau = ln(255 opacity) (forward.cu:336-350), i.e. inside the ellipse
+        // A dx^2 + 2 B dx dy + C dy^2 <= K.  K = 2 (tau + 1e-3) / 0.9999 carries the margin for fp32 rounding (1e-4 relative + 1e-3
+        // absolute, against |q| <= 5.6 at the threshold).  A block [x0, x0+3] x [y0, y0+3] (pixel centres) meets the ellipse exactly
+        // if [x0, x0+3] overlaps the x-extent of (ellipse intersected with the strip y in [y0, y0+3]) -- that intersection is
+        // convex, so its x-projection is an interval [xl, xr], attained where the strip comes closest to the ellipse's leftmost /
+        // rightmost point (-+X_R, -+Y_R): one pair of square roots per block ROW instead of a constrained minimum per block (this
+        // kernel spent most of its 580 wave-instructions per 64 instances on the latter).  Only done for finite extents and a
+        // positive-definite conic (otherwise the box decision stands).  Every wasted (entry, block) pair costs a quarter of a blend
+        // trip, forward and backward.
         const float A = gb.x, B = gb.y, C = gb.z, opa = gb.w;
-        if (bmask != 0u && ga.z < 3.0e38f && ga.w < 3.0e38f && A > 0.0f && C > 0.0f && opa > 0.0f) {
-            const float tau = logf(255.0f * opa);
-            const float invA = 1.0f / A, invC = 1.0f / C;
+        const float det = A * C - B * B;
+        if (bmask != 0u && ga.z < 3.0e38f && ga.w < 3.0e38f && A > 0.0f && C > 0.0f && det > 0.0f && opa > 0.0f) {
+            const float K = 2.0f * (logf(255.0f * opa) + 1.0e-3f) / 0.9999f;
             uint32_t keep = 0u;
+            if (K >= 0.0f) {
+                const float inv_det = 1.0f / det, invA = 1.0f / A;
+                const float aK = A * K;
+                const float Ymax = sqrtf(aK * inv_det);                   // |dy| on the ellipse
+                const float X_R = sqrtf(C * K * inv_det), Y_R = -B * X_R / C;     // its rightmost point
+                const float slack = 1.0e-3f + 1.0e-5f * (fabsf(ga.x) + X_R);      // rounding of the roots / divisions, in pixels
+                const float bx_first = (float)(tx * TILE) - ga.x, by_first = (float)(ty * TILE) - ga.y;
 #pragma unroll
-            for (int by = 0; by < 4; by++) {
+                for (int by = 0; by < 4; by++) {
+                    const float y0 = by_first + (float)(4 * by), y1 = y0 + 3.0f;
+                    if (y0 > Ymax + slack || y1 < -Ymax - slack) continue;            // the strip misses the ellipse
+                    const float yr = fminf(fmaxf(Y_R, y0), y1), yl = fminf(fmaxf(-Y_R, y0), y1);
+                    const float xr = (-B * yr + sqrtf(fmaxf(aK - det * yr * yr, 0.0f))) * invA + slack;
+                    const float xl = (-B * yl - sqrtf(fmaxf(aK - det * yl * yl, 0.0f))) * invA - slack;
 #pragma unroll
-                for (int bx = 0; bx < 4; bx++) {
-                    const float x0 = (float)(tx * TILE + 4 * bx) - ga.x, x1 = x0 + 3.0f;       // rectangle in d = pixel - mean
-                    const float y0 = (float)(ty * TILE + 4 * by) - ga.y, y1 = y0 + 3.0f;
-                    float qmin = 0.0f;
-                    if (!(x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f)) {
-                        // the minimum lies on the boundary: each edge is a 1-D quadratic, minimised at its clamped vertex
-                        auto qf = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
-                        const float ya = fminf(fmaxf(-B * x0 * invC, y0), y1), yb = fminf(fmaxf(-B * x1 * invC, y0), y1);
-                        const float xa = fminf(fmaxf(-B * y0 * invA, x0), x1), xb = fminf(fmaxf(-B * y1 * invA, x0), x1);
-                        qmin = fminf(fminf(qf(x0, ya), qf(x1, yb)), fminf(qf(xa, y0), qf(xb, y1)));
+                    for (int bx = 0; bx < 4; bx++) {
+                        const float x0 = bx_first + (float)(4 * bx);
+                        if (x0 + 3.0f >= xl && x0 <= xr) keep |= 1u << (4 * by + bx);
                     }
-                    if (!(qmin * 0.9999f - 1.0e-3f > tau)) keep |= 1u << (4 * by + bx);    // (NaN keeps the bit)
                 }
             }
             bmask &= keep;
