@@ -113,6 +113,8 @@ def _declare(lib):
     lib.moss_gaussian_activate_forward.argtypes = [_i, _i] + [_p] * 12
     lib.moss_gaussian_activate_backward.restype = _i
     lib.moss_gaussian_activate_backward.argtypes = [_i, _i] + [_p] * 15
+    lib.moss_raster_debug_set_cull.restype = None
+    lib.moss_raster_debug_set_cull.argtypes = [_i]
     lib.moss_raster_profile_enable.restype = None
     lib.moss_raster_profile_enable.argtypes = [C.c_uint32]
     lib.moss_raster_profile_read.restype = _i

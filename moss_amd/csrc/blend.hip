@@ -784,6 +784,7 @@ int persistent_workgroups()
 }  // anonymous namespace
 
 unsigned long long* g_stamps = nullptr;      // diagnostics buffer registered by moss_raster_debug_set_stamps (NULL = off)
+int g_cull_override = -1;                    // moss_raster_debug_set_cull
 
 // gradient-record slabs per instance: one per 4x4 block (sparse: only blended pairs are written and flagged in inst_mask)
 int blend_subgroups() { return WAVE_BLOCKS; }
@@ -792,7 +793,8 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
                           float* out_color, float* out_depth, float* out_alpha, hipStream_t s)
 {
     (void)g;
-    static const int flags = env_int("MOSS_BLEND_CULL", 1);
+    static const int env_flags = env_int("MOSS_BLEND_CULL", 1);
+    const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());               // 4 independent waves per workgroup, 16 items per tile
     hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
@@ -804,7 +806,8 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
                            const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, hipStream_t s)
 {
     (void)g;
-    static const int flags = env_int("MOSS_BLEND_CULL", 1);
+    static const int env_flags = env_int("MOSS_BLEND_CULL", 1);
+    const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());
     // the queue heads and the leaver count are zero here: cleared by the forward, rewound by each backward

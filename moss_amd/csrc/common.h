@@ -123,6 +123,7 @@ __device__ __forceinline__ void wave_for_each_tile(uint2 rect, int gx, uint64_t 
 #endif
 
 extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
+extern int g_cull_override;            // -1 = MOSS_BLEND_CULL decides; 0 / 1 = block-mask culling forced off / on (diagnostics), blend.hip
 int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
 struct BinView {

@@ -412,6 +412,7 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
 }
 
 void moss_raster_debug_set_stamps(unsigned long long* device_buffer) { moss::g_stamps = device_buffer; }
+void moss_raster_debug_set_cull(int mode) { moss::g_cull_override = mode; }
 
 void moss_raster_profile_enable(uint32_t stage_mask)
 {
