@@ -63,3 +63,15 @@ def qclass(n):
     b = n.bit_length() - 1
     return (b << 2) | ((n >> max(b - 2, 0)) & 3)
 order_sim(sorted(ranks, key=lambda r: (-qclass(n_of_rank[r]), r)), "quarter-octave classes")
+# (g) tiles ordered by their MEASURED cost (what the backward could know from the forward of the same frame)
+tile_sum = {r: sum(length[r * 16 + b] for b in range(16)) for r in ranks}
+tile_max = {r: max(length[r * 16 + b] for b in range(16)) for r in ranks}
+def order_sim_per_queue(key, label):
+    queues = [[] for _ in range(8)]
+    for q in range(8):
+        mine = sorted([r for k, r in enumerate(ranks) if k % 8 == q], key=key)       # same tile -> queue assignment, new order inside
+        for r in mine:
+            queues[q].extend(float(length[r * 16 + b]) for b in range(16) if length[r * 16 + b] > 0)
+    print("%-29s: makespan %d (mean %d)" % ((label,) + simulate(queues)))
+order_sim_per_queue(lambda r: -tile_sum[r], "queue tiles by measured sum")
+order_sim_per_queue(lambda r: -tile_max[r], "queue tiles by measured max")
