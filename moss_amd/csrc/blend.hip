@@ -343,7 +343,7 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
                                                    HeavyLds* L, const float* __restrict__ bg_color, float* __restrict__ out_color,
                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
-                                                   unsigned long long* stamp_out, uint32_t* __restrict__ item_cost)
+                                                   unsigned long long* stamp_out)
 {
     const int slot = lane & 3, pl = lane >> 2, gbase = lane & ~3;
     const uint32_t below_mask = (1u << slot) - 1u;
@@ -357,8 +357,7 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
     const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;     // culling switched off (diagnostics): every entry is a hit
 #define STAMP() (stamp_out ? __builtin_amdgcn_s_memtime() : 0ull)
     const unsigned long long t_begin = STAMP();
-    unsigned long long d_trip = 0, n_rounds = 0;
-    uint32_t n_trips = 0;
+    unsigned long long d_trip = 0, n_rounds = 0, n_trips = 0;
 
     float T = 1.0f, T_stop = -1.0f;
     float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
@@ -470,12 +469,9 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
         if (final_round) break;
     }
     __builtin_amdgcn_s_waitcnt(0);                           // no DMA may still be writing this wave's LDS when the next item starts
-    // What this block cost, for the backward's queue order (rank_heavy_tiles): trips dominate an item's duration.  A plain store --
-    // an atomicMax per tile, performed at the memory side, held up the in-order vmcnt of the next item's loads (+2 us per kernel).
-    if (lane == 0) item_cost[16 * (size_t)tile + blk] = n_trips;
     if (stamp_out && lane == 0) {
         stamp_out[0] = STAMP() - t_begin; stamp_out[1] = (unsigned long long)n; stamp_out[2] = 0; stamp_out[3] = 0; stamp_out[4] = 0;
-        stamp_out[5] = d_trip; stamp_out[6] = n_rounds; stamp_out[7] = (unsigned long long)n_trips;
+        stamp_out[5] = d_trip; stamp_out[6] = n_rounds; stamp_out[7] = n_trips;
     }
 #undef STAMP
 
@@ -669,7 +665,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
 // heavy (16 block items each), the rest light (4 quadrant items each).
 struct WaveItem { int tile, sub, rank; bool heavy, valid; };
 __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int nq, int qx, int hx, int n_work,
-                                              const uint32_t* __restrict__ tile_order, const uint32_t* s_reordered /* LDS or NULL */, int hr)
+                                              const uint32_t* __restrict__ tile_order)
 {
     int qi = 0;
     if (lane == 0) qi = (int)atomicAdd(my_head, 1u);
@@ -680,44 +676,8 @@ __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int n
     it.sub = it.heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
     it.rank = k * nq + qx;
     it.valid = it.rank < n_work;
-    it.tile = it.valid ? (int)((s_reordered != nullptr && k < hr) ? s_reordered[k] : tile_order[it.rank]) : 0;
+    it.tile = it.valid ? (int)tile_order[it.rank] : 0;
     return it;
-}
-
-// The backward blend pulls a queue's heaviest tiles in the order of the cost the FORWARD just measured for them (trips of the tile's
-// longest block: the maximum over ImageView::item_cost[tile][0..15]): a list-scheduling simulation on measured item lengths (scripts/lpt_sim.py) put the
-// makespan of the power-of-two length-class order at 97-98k cycles and this order at 90k = the longest item, while any order by
-// list length was no better than the classes.  Every wave ranks the first REORDER tiles of ITS queue itself when it starts (they
-// are the heaviest classes; cost descending, queue position as the tie-break; <= 2 loads and ~REORDER^2 / 64 compares per lane): no
-// wave waits for another, and nothing is added to the end of the forward kernel (a ranking pass by the last wave to leave a queue
-// cost the forward +2.8 us for -3.6 us in the backward).
-constexpr int REORDER = 128;
-__device__ __forceinline__ void rank_heavy_tiles(int lane, int nq, int qx, int hr, const uint32_t* __restrict__ tile_order,
-                                                 const uint32_t* __restrict__ item_cost, uint32_t* s_cost, uint32_t* s_tile)
-{
-    uint32_t my_tile[REORDER / 64], my_cost[REORDER / 64];
-#pragma unroll
-    for (int u = 0; u < REORDER / 64; u++) {
-        const int k = 64 * u + lane;
-        my_tile[u] = tile_order[min(k, hr - 1) * nq + qx];
-        const uint4* c4 = reinterpret_cast<const uint4*>(item_cost + 16 * (size_t)my_tile[u]);
-        const uint4 a = c4[0], b = c4[1], c = c4[2], d = c4[3];
-        my_cost[u] = max(max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))),
-                         max(max(max(c.x, c.y), max(c.z, c.w)), max(max(d.x, d.y), max(d.z, d.w))));
-        if (k < hr) s_cost[k] = my_cost[u];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int u = 0; u < REORDER / 64; u++) {
-        const int k = 64 * u + lane;
-        int before = 0;
-        for (int j = 0; j < hr; j++) {
-            const uint32_t c = s_cost[j];
-            before += (c > my_cost[u] || (c == my_cost[u] && j < k)) ? 1 : 0;
-        }
-        if (k < hr) s_tile[before] = my_tile[u];
-    }
-    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ void __launch_bounds__(256)
@@ -726,8 +686,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
                           const uint16_t* __restrict__ inst_bmask,
                           const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                           float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
-                          unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */,
-                          uint32_t* __restrict__ item_cost)
+                          unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */)
 {
     __shared__ float4 s_ring[4][64][3];                     // light path: the current 64 records of a wave
     __shared__ HeavyLds s_heavy[4];                         // heavy path: per-wave hit list and record ring (28 KB each)
@@ -737,12 +696,12 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
     for (;;) {
-        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order, nullptr, 0);
+        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order);
         if (!it.valid) break;
         if (it.heavy)
             heavy_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, out_color,
                                out_depth, out_alpha, final_T, n_contrib, flags,
-                               stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr, item_cost);
+                               stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr);
         else
             light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, s_ring[wv], bg_color, out_color, out_depth,
                                out_alpha, final_T, n_contrib, flags);
@@ -765,8 +724,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
 }
 
 __global__ void __launch_bounds__(256)
-blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ item_cost,
-                           const uint32_t* __restrict__ header,
+blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
                            uint32_t* __restrict__ queue_head, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
                            const uint16_t* __restrict__ inst_bmask,
                            const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -781,11 +739,8 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
-    __shared__ uint32_t s_cost[4][REORDER], s_tile[4][REORDER];
-    const int hr = (flags & 4) ? 0 : min(hx, REORDER);          // flags bit 2 (MOSS_BLEND_CULL=5): class order, for A/B measurements
-    if (hr > 0) rank_heavy_tiles(lane, nq, qx, hr, tile_order, item_cost, s_cost[wv], s_tile[wv]);
     for (;;) {
-        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order, s_tile[wv], hr);
+        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order);
         if (!it.valid) break;
         if (it.heavy)
             heavy_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
@@ -844,7 +799,7 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     const int wgs = min(4 * T, persistent_workgroups());               // 4 independent waves per workgroup, 16 items per tile
     hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                        im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
-                       im.final_T, im.n_contrib, flags, g_stamps, im.item_cost);
+                       im.final_T, im.n_contrib, flags, g_stamps);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
@@ -856,7 +811,7 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());
     // the queue heads and the leaver count are zero here: cleared by the forward, rewound by each backward
-    hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.item_cost, im.header,
+    hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
                        im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
                        dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
                        im.header + HDR_LEAVERS, flags);

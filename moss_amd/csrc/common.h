@@ -74,8 +74,6 @@ constexpr int HDR_FWD_HEADS = 16, HDR_BWD_HEADS = 24, HDR_LEAVERS = 10, NUM_XCD_
 struct ImageView {
     uint32_t* header;
     uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base; uint32_t* tile_order;
-    uint32_t* item_cost;     // [tile][16] (heavy tiles): trips each 4x4 block took in the forward blend (plain stores, every block of a
-                             // heavy tile writes its word every frame); the backward blend orders its queues by max over a tile
     float* final_T; uint32_t* n_contrib;
     static ImageView at(char* base, int W, int H)
     {
@@ -84,7 +82,6 @@ struct ImageView {
         v.header = carve<uint32_t>(p, HEADER_WORDS);
         v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
         v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T); v.tile_order = carve<uint32_t>(p, T);
-        v.item_cost = carve<uint32_t>(p, 16 * T);
         v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
         return v;
     }
