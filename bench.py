@@ -319,9 +319,10 @@ def main():
                      # PMC bytes were collected on the headline workload (profiles/pmc_latest.json): null for any other
                      "traffic": _pmc_traffic(dominant) if (args.config == "cfg3" and args.mode == "scale_rot") else None,
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
-                     "timing": ("hipEvent pairs on the launch stream over an eager replay of the SAME K iterations (parameters and "
-                                "optimizer state restored to the start of the graph-replay timed region)") if use_graph else
-                               "hipEvent pairs on the launch stream inside the timed region"},
+                     "timing": ("hipEvents attached to the kernel (hipExtLaunchKernelGGL start/stop) on its launch stream, over an eager "
+                                "replay of the SAME K iterations (parameters and optimizer state restored to the start of the "
+                                "graph-replay timed region)") if use_graph else
+                               "hipEvents attached to the kernel (hipExtLaunchKernelGGL start/stop) on its launch stream, inside the timed region"},
         "stages_ms": stage_ms,
         "rasterizer_ms_per_step": round(raster_ms, 4),
         "step_algorithmic_bytes": int(total_bytes),

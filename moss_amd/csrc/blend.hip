@@ -797,7 +797,7 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());               // 4 independent waves per workgroup, 16 items per tile
-    hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+    MOSS_LAUNCH_TIMED(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                        im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                        im.final_T, im.n_contrib, flags, g_stamps);
 }
@@ -811,7 +811,7 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());
     // the queue heads and the leaver count are zero here: cleared by the forward, rewound by each backward
-    hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
+    MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
                        im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
                        dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
                        im.header + HDR_LEAVERS, flags);

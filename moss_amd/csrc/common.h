@@ -23,6 +23,7 @@
 //                          backward: per-instance partial gradients, 3 float4 per instance and slab
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 #include "moss_raster.h"
@@ -121,6 +122,21 @@ __device__ __forceinline__ void wave_for_each_tile(uint2 rect, int gx, uint64_t 
     }
 }
 #endif
+
+// Per-kernel timing (moss_raster_profile_*): while a single-kernel stage is being timed, its launcher dispatches through
+// hipExtLaunchKernelGGL with the stage's two events attached to the KERNEL (begin / end of execution, what rocprofv3 reports),
+// instead of hipEventRecord calls around the launch (which also see the launch latency in front of the kernel: +5-10 us eager).
+struct StageEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
+extern thread_local StageEvents g_stage_events;          // raster_api.hip
+#define MOSS_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                                          \
+    do {                                                                                                                  \
+        if (moss::g_stage_events.start != nullptr && !moss::g_stage_events.used) {                                        \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, moss::g_stage_events.start, moss::g_stage_events.stop, 0, __VA_ARGS__); \
+            moss::g_stage_events.used = true;                                                                             \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                            \
+        }                                                                                                                 \
+    } while (0)
 
 extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
 extern int g_cull_override;            // -1 = MOSS_BLEND_CULL decides; 0 / 1 = block-mask culling forced off / on (diagnostics), blend.hip

@@ -976,7 +976,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     const int stage_sh = (fp.M == 16 && shs != nullptr && colors_precomp == nullptr && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 &&
                           lds_h + lds_s <= 65536 /* default dynamic-LDS limit of a launch */ && env_int("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
     const size_t lds = lds_h + (stage_sh ? lds_s : 0);
-    hipLaunchKernelGGL(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
+    MOSS_LAUNCH_TIMED(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh,
@@ -996,7 +996,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
 #define LAUNCH_PB(STAGE)                                                                                                        \
-    hipLaunchKernelGGL((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
+    MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
                        (STAGE) ? 2 * (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \

@@ -10,6 +10,8 @@
 
 using namespace moss;
 
+namespace moss { thread_local StageEvents g_stage_events; }
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -62,12 +64,15 @@ struct StageTimer {
             std::lock_guard<std::mutex> lk(g_prof.m);
             a = g_prof.get(); b = g_prof.get();
             if (a) (void)hipEventRecord(a, s);
+            // single-kernel stages: the launcher may attach the two events to the kernel itself (MOSS_LAUNCH_TIMED)
+            if (a && b) { g_stage_events.start = a; g_stage_events.stop = b; g_stage_events.used = false; }
         }
     }
     ~StageTimer()
     {
         if (a && b) {
-            (void)hipEventRecord(b, s);
+            if (!g_stage_events.used) (void)hipEventRecord(b, s);      // multi-kernel stage, or nothing was launched
+            g_stage_events = StageEvents();
             std::lock_guard<std::mutex> lk(g_prof.m);
             g_prof.recs.push_back({stage, a, b});
         }
