@@ -2,8 +2,12 @@
 # over the eager-launch form of the same bench step.  Outputs under gpurun_out/r01_final/ ; copy the summaries into profiles/.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r01_final; rm -rf $OUT; mkdir -p $OUT/pmc; cd /tmp
+# the bench line as the driver sees it (no profiler attached), then the same command under rocprofv3 (whose tool perturbs the
+# bench's own kernel-attached events by ~10 %: its line is kept beside the kernel statistics for reference only)
+python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_plain_stdout.log 2>&1
+grep "^{\"metric\"" $OUT/bench_plain_stdout.log > $OUT/bench_line.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_stdout.log 2>&1
-grep "^{\"metric\"" $OUT/bench_stdout.log > $OUT/bench_line.json
+grep "^{\"metric\"" $OUT/bench_stdout.log > $OUT/bench_line_under_rocprof.json
 pmc() { n=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc -o $n -- python3 $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 30 --warmup 10 --no-cpu-baseline > $OUT/pmc/$n.log 2>&1
 }
