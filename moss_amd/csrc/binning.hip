@@ -208,7 +208,14 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, con
                     const uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
                     float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), instances are in tile order, and
+    // neighbouring tiles gather the same Gaussians' 64-byte records: XCD k takes the k-th contiguous eighth of the instance blocks
+    // (counted from the device-side R, the grid is only an upper bound), so a Gaussian's record is fetched into one or two L2s
+    // instead of all eight.
+    const int n_blocks = ((int)header[0] + 255) / 256;
+    const int per_xcd = n_blocks / 8, extra = n_blocks % 8, xcd = (int)blockIdx.x % 8, nth = (int)blockIdx.x / 8;
+    if (nth >= per_xcd + (xcd < extra ? 1 : 0)) return;
+    const int i = (xcd * per_xcd + min(xcd, extra) + nth) * 256 + (int)threadIdx.x;
     if (i >= (int)header[0]) return;
     inst_mask[i] = 0u;                                        // no gradient record yet (set by the backward blend)
     const uint32_t tile = inst_tile[i];
