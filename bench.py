@@ -84,8 +84,15 @@ def main():
     from moss_amd import dist as mdist
     from moss_amd import scenes, _lib
     if not os.path.exists(_lib.LIB_PATH):               # normally built by __graft_entry__.build(); hipcc is on the GPU box too
-        from moss_amd import build as hip_build
-        hip_build.build()
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            from moss_amd import build as hip_build
+            hip_build.build()
+        else:                                           # one rank builds, the others wait for the file
+            for _ in range(1200):
+                if os.path.exists(_lib.LIB_PATH):
+                    break
+                time.sleep(0.5)
+            time.sleep(2.0)
     from moss_amd.gaussian_model import GaussianSet
     from moss_amd.gaussian_renderer import render, camera_view
     from moss_amd.loss import training_loss_fused as training_loss, backward_from_loss     # HIP-fused L1 + SSIM + mask loss
