@@ -124,9 +124,31 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
             wave_for_each_tile(r, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < T; i += blockDim.x) {
-            const uint32_t c = s_cnt[i];
-            if (c) { s_base[i] = ranges[i].x + atomicAdd(&tile_cursor[i], c); s_cnt[i] = 0; }
+        // One returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket.  Four tiles per thread at a
+        // time, as BUFFER atomics whose offset is out of range for an empty tile (dropped without a memory request, returns 0):
+        // no branch around the atomic, so the four are in flight together -- inside `if (c)` each one was followed by a full
+        // s_waitcnt (a device-scope returning atomic is ~2 us) and a thread's tiles were reserved one round trip after the other.
+        {
+            const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc((void*)tile_cursor, 0, 0xffffff00u, 0x00020000u);
+            for (int b0 = 0; b0 < T; b0 += 4 * (int)blockDim.x) {
+                uint32_t c[4], start[4], old[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    c[u] = i < T ? s_cnt[i] : 0u;
+                    start[u] = ranges[min(i, T - 1)].x;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    old[u] = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)c[u], rs_cur, c[u] ? (uint32_t)i * 4u : 0xfffffffcu /* out of range AND dword-aligned: a misaligned atomic faults before the range check */, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    if (c[u]) { s_base[i] = start[u] + old[u]; s_cnt[i] = 0; }
+                }
+            }
         }
         __syncthreads();
     }
