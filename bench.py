@@ -221,8 +221,13 @@ def main():
             graphed = GraphedStep(compute, warmup=3, device=dev)
             g_out = graphed.outputs
 
+            replays = [0]
+
             def graph_step():
                 graphed()
+                replays[0] += 1
+                if replays[0] % 512 == 0:        # long runs: the scene grows while it trains; re-capture before the baked-in
+                    graphed.check()              # binning capacity overflows (one synchronisation per 512 steps)
                 if world > 1:
                     bucket.all_reduce_mean(None, world)
                     opt.step()
