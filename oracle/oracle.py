@@ -21,7 +21,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmoss_oracle.so")
+_LIB64_PATH = os.path.join(_HERE, "_build", "libmoss_oracle_f64.so")   # the same source compiled with float -> double (Makefile)
 _lib = None
+_lib64 = None
 
 BLOCK_X = 16
 BLOCK_Y = 16
@@ -30,7 +32,8 @@ BLOCK_Y = 16
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds).  Returns the path of the shared object."""
     src = os.path.join(_HERE, "moss_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    stale = lambda p: not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src)
+    if force or stale(_LIB_PATH) or stale(_LIB64_PATH):
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -45,6 +48,16 @@ def lib() -> C.CDLL:
         _lib.oracle_get_higher_msb.restype = C.c_uint32
         _lib.oracle_get_higher_msb.argtypes = [C.c_uint32]
     return _lib
+
+
+def lib64() -> C.CDLL:
+    """The float64 build of the same source: every `float` of moss_oracle.c is a `double` here (arrays AND scalars)."""
+    global _lib64
+    if _lib64 is None:
+        build()
+        _lib64 = C.CDLL(_LIB64_PATH)
+        _lib64.oracle_preprocess.restype = C.c_int
+    return _lib64
 
 
 def _p(a):
@@ -96,9 +109,17 @@ def dist2(points):
 
 def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
             viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered=False,
-            want_margin=True, transforms=None):
+            want_margin=True, transforms=None, f64=False, binning_from=None):
     """Returns a namespace with the reference's outputs (color (3,H,W), depth (1,H,W), alpha (1,H,W),
-    radii (P,), num_rendered) and every intermediate."""
+    radii (P,), num_rendered) and every intermediate.
+
+    ``f64=True`` (the ADJUDICATOR, not the reference's arithmetic): the float64 build of the same source evaluates preprocess and
+    the blend in double precision.  The integer structure of the frame -- which Gaussians are in which tile, in which order --
+    is taken from ``binning_from`` (a float32 forward of the same inputs: radii, tiles_touched, point_list, ranges), so that the
+    float64 run differentiates THE SAME function of the inputs as the float32 paths it adjudicates."""
+    if f64:
+        return _forward64(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                          viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, transforms, binning_from)
     L = lib()
     bg = _f32(bg); means3D = _f32(means3D); opacities = _f32(opacities)
     viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
@@ -158,48 +179,102 @@ def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_mod
     return o
 
 
+def _forward64(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+               viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, transforms, fw32):
+    """float64 preprocess + blend over the float32 run's tile lists (see forward(f64=True))."""
+    assert fw32 is not None, "the float64 adjudicator needs the float32 forward whose tile lists it shares (binning_from=)"
+    L = lib64()
+    f64 = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32), dtype=np.float64)   # fp32 INPUTS, exactly
+    opt = lambda a: None if (a is None or np.asarray(a).size == 0) else f64(a)
+    bg = f64(bg); means3D = f64(means3D); opacities = f64(opacities)
+    viewmatrix = f64(viewmatrix); projmatrix = f64(projmatrix); campos = f64(campos)
+    colors_precomp = opt(colors_precomp); scales = opt(scales); rotations = opt(rotations); cov3D_precomp = opt(cov3D_precomp); sh = opt(sh)
+    transforms = None if transforms is None else np.ascontiguousarray(f64(transforms).reshape(-1, 9))
+    P = means3D.shape[0]
+    M = 0 if sh is None else sh.shape[1]
+    N = W * H
+    d = C.c_double
+    o = SimpleNamespace(P=P, W=W, H=H, M=M, D=degree, grid=fw32.grid, f64=True)
+    o.color = np.zeros((3, H, W)); o.depth = np.zeros((1, H, W)); o.alpha = np.zeros((1, H, W))
+    o.radii = np.zeros(P, np.int32)
+    o.num_rendered = fw32.num_rendered
+    if P == 0:
+        return o
+    o.means2D = np.zeros((P, 2)); o.depths = np.zeros(P); o.cov3D = np.zeros((P, 6)); o.rgb = np.zeros((P, 3))
+    o.conic_opacity = np.zeros((P, 4)); o.tiles_touched = np.zeros(P, np.uint32); o.clamped = np.zeros((P, 3), np.uint8)
+    L.oracle_preprocess(
+        C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D), _p(scales), d(float(np.float32(scale_modifier))), _p(rotations),
+        _p(opacities), _p(sh), _p(cov3D_precomp), _p(colors_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
+        C.c_int(W), C.c_int(H), d(float(np.float32(tan_fovx))), d(float(np.float32(tan_fovy))), C.c_int(0),
+        _p(o.radii), _p(o.means2D), _p(o.depths), _p(o.cov3D), _p(o.rgb), _p(o.conic_opacity),
+        _p(o.tiles_touched), _p(o.clamped), _p(transforms))
+    # the frame's integer structure is the float32 run's: same visible set, same tile lists, same order
+    o.radii64 = o.radii
+    o.radii = fw32.radii; o.tiles_touched = fw32.tiles_touched
+    o.point_list = fw32.point_list; o.ranges = fw32.ranges; o.point_list_keys = fw32.point_list_keys
+    o.final_T = np.zeros(N); o.n_contrib = np.zeros(N, np.uint32); o.margin = np.ones(N)
+    o.features = colors_precomp if colors_precomp is not None else o.rgb
+    L.oracle_render_forward(C.c_int(W), C.c_int(H), _p(o.ranges), _p(o.point_list), _p(o.means2D),
+                            _p(np.ascontiguousarray(o.features)), _p(o.depths), _p(o.conic_opacity), _p(bg),
+                            _p(o.color), _p(o.depth), _p(o.alpha), _p(o.final_T), _p(o.n_contrib), _p(o.margin))
+    return o
+
+
 def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None):
     """``fw`` is the namespace returned by :func:`forward`.  Returns the reference's 8 gradient arrays
-    (rasterize_points.cu:205) plus dL_dconic as a namespace."""
-    L = lib()
-    bg = _f32(bg); means3D = _f32(means3D)
-    viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
-    colors_precomp = _opt(colors_precomp); scales = _opt(scales); rotations = _opt(rotations)
-    cov3D_precomp = _opt(cov3D_precomp); sh = _opt(sh)
-    transforms = None if transforms is None else np.ascontiguousarray(_f32(transforms).reshape(-1, 9))
+    (rasterize_points.cu:205) plus dL_dconic as a namespace.  A float64 ``fw`` (forward(f64=True)) runs the float64 build."""
+    is64 = bool(getattr(fw, "f64", False))
+    L = lib64() if is64 else lib()
+    dt = np.float64 if is64 else np.float32
+    cf = (lambda v: C.c_double(float(np.float32(v)))) if is64 else (lambda v: C.c_float(v))
+    if is64:
+        _f = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32), dtype=np.float64)
+        _o = lambda a: None if (a is None or np.asarray(a).size == 0) else _f(a)
+    else:
+        _f, _o = _f32, _opt
+    bg = _f(bg); means3D = _f(means3D)
+    viewmatrix = _f(viewmatrix); projmatrix = _f(projmatrix); campos = _f(campos)
+    colors_precomp = _o(colors_precomp); scales = _o(scales); rotations = _o(rotations)
+    cov3D_precomp = _o(cov3D_precomp); sh = _o(sh)
+    transforms = None if transforms is None else np.ascontiguousarray(_f(transforms).reshape(-1, 9))
     P = means3D.shape[0]
     M = 0 if sh is None else sh.shape[1]
     H, W = fw.H, fw.W
     g = SimpleNamespace()
-    g.dL_dmeans3D = np.zeros((P, 3), np.float32)                            # rasterize_points.cu:158-166
-    g.dL_dmeans2D = np.zeros((P, 3), np.float32)
-    g.dL_dcolors = np.zeros((P, 3), np.float32)
-    g.dL_dconic = np.zeros((P, 2, 2), np.float32)
-    g.dL_dopacity = np.zeros((P, 1), np.float32)
-    g.dL_dcov3D = np.zeros((P, 6), np.float32)
-    g.dL_dsh = np.zeros((P, M, 3), np.float32)
-    g.dL_dscales = np.zeros((P, 3), np.float32)
-    g.dL_drotations = np.zeros((P, 4), np.float32)
-    g.dL_dtransforms = np.zeros((P, 3, 3), np.float32)
+    g.dL_dmeans3D = np.zeros((P, 3), dt)                            # rasterize_points.cu:158-166
+    g.dL_dmeans2D = np.zeros((P, 3), dt)
+    g.dL_dcolors = np.zeros((P, 3), dt)
+    g.dL_dconic = np.zeros((P, 2, 2), dt)
+    g.dL_dopacity = np.zeros((P, 1), dt)
+    g.dL_dcov3D = np.zeros((P, 6), dt)
+    g.dL_dsh = np.zeros((P, M, 3), dt)
+    g.dL_dscales = np.zeros((P, 3), dt)
+    g.dL_drotations = np.zeros((P, 4), dt)
+    g.dL_dtransforms = np.zeros((P, 3, 3), dt)
     if P == 0:
         return g
-    dpix = _f32(dL_dout_color).reshape(3, H, W)
-    ddep = _f32(dL_dout_depth).reshape(H * W)
-    dalp = _f32(dL_dout_alpha).reshape(H * W)
+    dpix = _f(dL_dout_color).reshape(3, H, W)
+    ddep = _f(dL_dout_depth).reshape(H * W)
+    dalp = _f(dL_dout_alpha).reshape(H * W)
     color_ptr = colors_precomp if colors_precomp is not None else fw.rgb    # rasterizer_impl.cu:397
     L.oracle_render_backward(C.c_int(P), C.c_int(W), C.c_int(H), _p(fw.ranges), _p(fw.point_list), _p(bg),
                              _p(fw.means2D), _p(fw.conic_opacity), _p(np.ascontiguousarray(color_ptr)), _p(fw.depths),
                              _p(fw.final_T), _p(fw.n_contrib), _p(dpix), _p(ddep), _p(dalp),
                              _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors))
     cov3D_ptr = cov3D_precomp if cov3D_precomp is not None else fw.cov3D    # rasterizer_impl.cu:424
-    focal_y = np.float32(H) / (np.float32(2.0) * np.float32(tan_fovy))      # rasterizer_impl.cu:388-389
-    focal_x = np.float32(W) / (np.float32(2.0) * np.float32(tan_fovx))
+    if is64:
+        focal_y = H / (2.0 * float(np.float32(tan_fovy))); focal_x = W / (2.0 * float(np.float32(tan_fovx)))
+        fx_c, fy_c = C.c_double(focal_x), C.c_double(focal_y)
+    else:
+        focal_y = np.float32(H) / (np.float32(2.0) * np.float32(tan_fovy))      # rasterizer_impl.cu:388-389
+        focal_x = np.float32(W) / (np.float32(2.0) * np.float32(tan_fovx))
+        fx_c, fy_c = C.c_float(focal_x), C.c_float(focal_y)
     L.oracle_compute_cov2d_backward(C.c_int(P), _p(means3D), _p(fw.radii), _p(np.ascontiguousarray(cov3D_ptr)),
-                                    C.c_float(focal_x), C.c_float(focal_y), C.c_float(tan_fovx), C.c_float(tan_fovy),
+                                    fx_c, fy_c, cf(tan_fovx), cf(tan_fovy),
                                     _p(viewmatrix), _p(g.dL_dconic), _p(g.dL_dmeans3D), _p(g.dL_dcov3D))
     L.oracle_preprocess_backward(C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D), _p(fw.radii), _p(sh),
-                                 _p(fw.clamped), _p(scales), _p(rotations), C.c_float(scale_modifier), _p(projmatrix),
+                                 _p(fw.clamped), _p(scales), _p(rotations), cf(scale_modifier), _p(projmatrix),
                                  _p(campos), _p(g.dL_dmeans2D), _p(g.dL_dmeans3D), _p(g.dL_dcolors), _p(g.dL_dcov3D),
                                  _p(g.dL_dsh), _p(g.dL_dscales), _p(g.dL_drotations), _p(transforms), _p(g.dL_dtransforms))
     return g
@@ -266,3 +341,58 @@ def knn_exhaustive(ref, query, k):
         idx[s:s + 2048] = order
         dist[s:s + 2048] = np.sqrt(np.take_along_axis(d, order, axis=1))
     return dist, idx
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Per-Gaussian error scales (test infrastructure).  A gradient component of one Gaussian is a sum over pixels of terms that may
+# cancel; an fp32 evaluation of it -- the reference's atomics, this repository's kernels, the float32 oracle -- carries an error
+# proportional to the sum of the ABSOLUTE terms, whatever the order.  gradient_scales() returns that sum for every output element:
+# the blend-level masses from oracle_render_backward_mass, pushed through each Gaussian's (linear) cov2D / projection / SH /
+# cov3D backward by nine unit probes.  Tests state per-Gaussian bars as  |a - b| <= rel * scale  with these scales.
+
+def gradient_scales(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                    projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None):
+    """{name: float64 array shaped like the gradient} for the names of backward()'s namespace (dL_dconic excluded)."""
+    assert not getattr(fw, "f64", False), "scales come from the float32 restatement"
+    L = lib()
+    P, H, W = fw.P, fw.H, fw.W
+    bgf = _f32(bg)
+    color_ptr = _opt(colors_precomp) if _opt(colors_precomp) is not None else fw.rgb
+    mass = np.zeros((P, 9), np.float64)
+    scratch = [np.zeros((P, 3), np.float32), np.zeros((P, 2, 2), np.float32), np.zeros((P, 1), np.float32), np.zeros((P, 3), np.float32)]
+    L.oracle_render_backward_mass(C.c_int(P), C.c_int(W), C.c_int(H), _p(fw.ranges), _p(fw.point_list), _p(bgf),
+                                  _p(fw.means2D), _p(fw.conic_opacity), _p(np.ascontiguousarray(color_ptr)), _p(fw.depths),
+                                  _p(fw.final_T), _p(fw.n_contrib), _p(_f32(dL_dout_color).reshape(3, H, W)),
+                                  _p(_f32(dL_dout_depth).reshape(H * W)), _p(_f32(dL_dout_alpha).reshape(H * W)),
+                                  _p(scratch[0]), _p(scratch[1]), _p(scratch[2]), _p(scratch[3]), _p(mass))
+    names = ["dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dtransforms"]
+    out = {"dL_dcolors": mass[:, 0:3].copy(), "dL_dmeans2D": np.concatenate([mass[:, 3:5], np.zeros((P, 1))], 1),
+           "dL_dopacity": mass[:, 8:9].copy()}
+    acc = None
+    means3D32 = _f32(means3D); view = _f32(viewmatrix); proj = _f32(projmatrix); cam = _f32(campos)
+    sc = _opt(scales); rt = _opt(rotations); c3 = _opt(cov3D_precomp); shs = _opt(sh)
+    tf = None if transforms is None else np.ascontiguousarray(_f32(transforms).reshape(-1, 9))
+    M = 0 if shs is None else shs.shape[1]
+    cov3D_ptr = c3 if c3 is not None else fw.cov3D
+    focal_y = np.float32(H) / (np.float32(2.0) * np.float32(tan_fovy)); focal_x = np.float32(W) / (np.float32(2.0) * np.float32(tan_fovx))
+    for j in range(8):                                       # unit probes: colour 0-2, mean2D 3-4, conic 5-7 (opacity passes through)
+        dcol = np.zeros((P, 3), np.float32); dm2 = np.zeros((P, 3), np.float32); dcon = np.zeros((P, 2, 2), np.float32)
+        if j < 3: dcol[:, j] = 1.0
+        elif j < 5: dm2[:, j - 3] = 1.0
+        else: dcon.reshape(P, 4)[:, (0, 1, 3)[j - 5]] = 1.0
+        g = {"dL_dmeans3D": np.zeros((P, 3), np.float32), "dL_dcov3D": np.zeros((P, 6), np.float32), "dL_dsh": np.zeros((P, M, 3), np.float32),
+             "dL_dscales": np.zeros((P, 3), np.float32), "dL_drotations": np.zeros((P, 4), np.float32), "dL_dtransforms": np.zeros((P, 3, 3), np.float32)}
+        L.oracle_compute_cov2d_backward(C.c_int(P), _p(means3D32), _p(fw.radii), _p(np.ascontiguousarray(cov3D_ptr)),
+                                        C.c_float(focal_x), C.c_float(focal_y), C.c_float(tan_fovx), C.c_float(tan_fovy),
+                                        _p(view), _p(dcon), _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]))
+        L.oracle_preprocess_backward(C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D32), _p(fw.radii), _p(shs),
+                                     _p(fw.clamped), _p(sc), _p(rt), C.c_float(scale_modifier), _p(proj),
+                                     _p(cam), _p(dm2), _p(g["dL_dmeans3D"]), _p(dcol), _p(g["dL_dcov3D"]),
+                                     _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]), _p(tf), _p(g["dL_dtransforms"]))
+        if acc is None:
+            acc = {n: np.zeros(g[n].shape, np.float64) for n in names}
+        mj = mass[:, j]
+        for n in names:
+            acc[n] += np.abs(g[n].astype(np.float64)) * mj.reshape((P,) + (1,) * (g[n].ndim - 1))
+    out.update(acc)
+    return out

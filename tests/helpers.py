@@ -152,3 +152,47 @@ def replace_forward_state(fw, e):
     f2 = copy.copy(fw)
     f2.final_T = e.final_T.copy(); f2.n_contrib = e.n_contrib.copy()
     return f2
+
+
+def oracle_forward64(d, fw32):
+    """The float64 ADJUDICATOR over the float32 oracle's tile lists (oracle.forward(f64=True))."""
+    c = d.cam
+    return oracle.forward(d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), d.opacities.numpy(), _np(d.scales),
+                          _np(d.rotations), d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(),
+                          c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms),
+                          f64=True, binning_from=fw32)
+
+
+def oracle_gradient_scales(d, fw, dc, dd, da):
+    """Per-element error scales (sum of absolute contributions) of every gradient, see oracle.gradient_scales."""
+    c = d.cam
+    return oracle.gradient_scales(fw, d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), _np(d.scales), _np(d.rotations),
+                                  d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(), c.tanfovx,
+                                  c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
+
+
+def stable_mask(d, *fws, thr=1e-4):
+    """(H,W) float mask of the pixels whose every decision (power > 0, alpha < 1/255, T < 1e-4) is further than `thr` (relative)
+    from its threshold in ALL the given oracle forwards: there every implementation takes the same branches, so differences are
+    arithmetic only.  Multiply the incoming image gradients by it to compare backward passes end to end."""
+    ok = np.ones(d.H * d.W, bool)
+    for fw in fws:
+        ok &= np.asarray(fw.margin) > thr
+    return torch.from_numpy(ok.reshape(d.H, d.W).astype(np.float32))
+
+
+def cosine_gap(a, b):
+    """1 - cos(a, b) over the whole tensor (float64)."""
+    a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
+    den = np.sqrt((a * a).sum() * (b * b).sum())
+    return 0.0 if den == 0.0 else float(1.0 - (a * b).sum() / den)
+
+
+def scaled_err(a, b, scale):
+    """max over elements of |a - b| / scale, over the elements whose scale is positive; elements with a zero scale (no pixel
+    contributes to them) must agree exactly."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64); s = np.asarray(scale, dtype=np.float64).reshape(a.shape)
+    pos = s > 0
+    dead = float(np.abs(a - b)[~pos].max()) if (~pos).any() else 0.0
+    live = float((np.abs(a - b)[pos] / s[pos]).max()) if pos.any() else 0.0
+    return live, dead

@@ -2,11 +2,19 @@
 
 Bars (BASELINE.json north_star):
   * BIT-EXACT for integer work: radii, tiles_touched, depth bits, the sorted (tile<<32|depth) keys, the sorted
-    Gaussian ids, the per-tile ranges; n_contrib on every pixel whose decisions are not within rounding of a threshold;
-  * floating point, stated tolerances (scale-aware infinity norm  max|a-b| / max|b|):
+    Gaussian ids, the per-tile ranges; n_contrib on every pixel whose decisions are not within rounding of a threshold
+    (the blend kernels evaluate exp() with the hardware's v_exp_f32 and 1/(1-alpha) with v_rcp_f32, ~1 ulp each, where the
+    reference calls expf() and divides: a pixel whose test sits within FRAGILE of its threshold may take the other branch);
+  * floating point, stated tolerances:
       preprocess outputs (means2D, conic, rgb, cov3D)  : exact equality (same operation order, no contraction)
-      images (colour, depth, alpha, final_T)            : IMG_TOL  = 2e-5   (hardware exp2 vs glibc expf, FMA contraction)
-      gradients                                         : GRAD_TOL = 2e-4   (fp32 summation order over up to 256 px x tiles)
+      images (colour, depth, alpha, final_T)            : IMG_TOL  = 2e-5 of the largest value
+      gradients, per tensor                             : GRAD_TOL = 2e-4 of the largest value AND 1 - cosine <= COS_GAP_TOL
+      gradients, per Gaussian and element               : |hip - oracle| <= PER_GAUSSIAN_TOL x the element's CONTRIBUTION MASS
+        (sum over pixels of the absolute terms behind it, oracle.gradient_scales): an fp32 sum carries an error proportional to
+        that mass, not to the possibly cancelled result, so this is the scale at which a single Gaussian's gradient -- a small
+        opacity, a degree-3 SH coefficient -- can be called right or wrong; elements without any contribution must be exactly 0.
+        The float32 oracle itself sits up to ~1e-3 of the mass away from the float64 evaluation on cfg3 (T = T / (1 - alpha)
+        chains through alpha ~ 0.99); tests/test_gpu_parity_hardened.py adjudicates both against float64.
 """
 import numpy as np
 import pytest
@@ -19,6 +27,8 @@ pytestmark = pytest.mark.gpu
 
 IMG_TOL = 2e-5
 GRAD_TOL = 2e-4
+COS_GAP_TOL = 1e-6
+PER_GAUSSIAN_TOL = 5e-3
 FRAGILE = 2e-5      # pixels whose oracle decision margin is below this may legitimately flip a threshold
 
 
@@ -59,7 +69,23 @@ def _check_forward(d, gpu, check_images=True, max_fragile=2e-3):
     return fw, t, e
 
 
-def _check_backward(d, gpu, fw, t, e, zero_depth=False, tol=GRAD_TOL):
+def check_gradients(got, ref, scales, tol=GRAD_TOL, per_gaussian=PER_GAUSSIAN_TOL, cos_gap=COS_GAP_TOL):
+    """The three gradient bars of this suite (see the module docstring) for {name: array} against {name: array}.  Returns
+    {name: (relative max error, 1 - cosine, largest |diff| / contribution mass)}."""
+    errs, bad = {}, {}
+    for name, r in ref.items():
+        a = np.asarray(got[name])
+        assert a.shape == r.shape, name
+        assert np.isfinite(a).all(), name
+        live, dead = hp.scaled_err(a, r, scales[name]) if name in scales else (0.0, 0.0)
+        errs[name] = (hp.rel_err(a, r), hp.cosine_gap(a, r), live)
+        if errs[name][0] > tol or errs[name][1] > cos_gap or live > per_gaussian or dead != 0.0:
+            bad[name] = errs[name] + (dead,)
+    assert not bad, f"gradient mismatch (rel max, 1-cos, per-Gaussian scaled, dead-element diff): {bad}"
+    return errs
+
+
+def _check_backward(d, gpu, fw, t, e, zero_depth=False, tol=GRAD_TOL, per_gaussian=PER_GAUSSIAN_TOL, cos_gap=COS_GAP_TOL):
     dc, dd, da = hp.image_grads(d.H, d.W, zero_depth=zero_depth)
     g = hp.hip_backward(d, t, dc, dd, da, gpu)
     # backward arithmetic in isolation: the oracle backward consumes the HIP forward's (final_T, n_contrib)
@@ -69,14 +95,9 @@ def _check_backward(d, gpu, fw, t, e, zero_depth=False, tol=GRAD_TOL):
              ("dL_dscales", ref.dL_dscales), ("dL_drotations", ref.dL_drotations)]
     if getattr(d, "transforms", None) is not None:            # n2 extension: transform applied inside the op
         pairs.append(("dL_dtransforms", ref.dL_dtransforms))
-    errs = {}
-    for name, r in pairs:
-        got = getattr(g, name).cpu().numpy()
-        assert got.shape == r.shape, name
-        assert np.isfinite(got).all(), name
-        errs[name] = hp.rel_err(got, r)
-    bad = {k: v for k, v in errs.items() if v > tol}
-    assert not bad, f"gradient mismatch {bad}"
+    errs = check_gradients({name: getattr(g, name).cpu().numpy() for name, _ in pairs}, dict(pairs),
+                           hp.oracle_gradient_scales(d, hp.replace_forward_state(fw, e), dc, dd, da), tol=tol, per_gaussian=per_gaussian, cos_gap=cos_gap)
+    g.errors = errs
     # culled Gaussians get exactly zero everywhere
     inv = torch.from_numpy(fw.radii <= 0)
     if inv.any():
