@@ -219,7 +219,6 @@ def main():
             out = None
             from moss_amd.graphs import GraphedStep
             graphed = GraphedStep(compute, warmup=3, device=dev)
-            g_out = graphed.outputs
 
             replays = [0]
 
@@ -231,7 +230,7 @@ def main():
                 if world > 1:
                     bucket.all_reduce_mean(None, world)
                     opt.step()
-                return g_out
+                return graphed.outputs                       # (re-bound by a re-capture: never cache it)
 
             for _ in range(5):
                 graph_step()

@@ -11,6 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmoss_raster.so")
+EXT_PATH = os.path.join(_HERE, "lib", "_moss_C.so")      # the compiled PyTorch extension (csrc/torch_binding.cpp) over the same C ABI
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -139,6 +140,34 @@ def lib() -> C.CDLL:
                 _declare(handle)
                 _lib = handle
     return _lib
+
+
+_ext = None
+
+
+def ext():
+    """Load (once) and return the compiled PyTorch-ROCm extension module ``_moss_C`` (rasterize_gaussians,
+    rasterize_gaussians_backward, mark_visible: the reference's ``_C``).  Raises ImportError if it has not been built."""
+    global _ext
+    if _ext is None:
+        with _lock:
+            if _ext is None:
+                if not os.path.exists(EXT_PATH):
+                    raise ImportError(
+                        f"{EXT_PATH} is missing: the PyTorch extension of the MI355X rasterizer has not been built "
+                        "(run `python -m moss_amd.build`); there is no CPU/PyTorch fallback for this op")
+                lib()                                        # libmoss_raster.so first: _moss_C.so links against it
+                import importlib.machinery
+                import importlib.util
+                import torch  # noqa: F401  (libtorch must be loaded before the extension)
+                loader = importlib.machinery.ExtensionFileLoader("_moss_C", EXT_PATH)
+                spec = importlib.util.spec_from_loader("_moss_C", loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                if mod.abi_version() != lib().moss_abi_version():
+                    raise ImportError("moss_amd/lib/_moss_C.so and libmoss_raster.so disagree on the ABI version: rebuild both")
+                _ext = mod
+    return _ext
 
 
 STAGES = ["preprocess_fwd", "scan", "scatter", "tile_sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libmoss_raster.so")
+EXT = os.path.join(OUT_DIR, "_moss_C.so")                # PyTorch-ROCm extension module over the C ABI (csrc/torch_binding.cpp)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -65,9 +66,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if failed:
         raise RuntimeError("hipcc failed")
     if force or procs or _newer(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
-        subprocess.check_call(cmd)
+        # link under a temporary name and rename: a process that finds LIB never sees a half-written file
+        tmp = LIB + f".tmp{os.getpid()}"
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs)
+        os.replace(tmp, LIB)
+    build_torch_extension(force=force, verbose=verbose)
     return LIB
+
+
+def build_torch_extension(force: bool = False, verbose: bool = False) -> str:
+    """moss_amd/lib/_moss_C.so: host-only C++ (g++), the torch glue of the reference's rasterize_points.cu over the C ABI."""
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    if not (force or _newer(EXT, [src, os.path.join(ROOT, "include", "moss_raster.h"), os.path.abspath(__file__)])):
+        return EXT
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include"),
+                                os.path.join(ROOT, "include")]
+    tmp = EXT + f".tmp{os.getpid()}"
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_moss_C",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-Wno-deprecated-declarations"]
+    for i in inc:
+        cmd += ["-I", i]
+    cmd += [src, "-o", tmp, "-L", tlib, "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+            "-L", OUT_DIR, "-lmoss_raster", f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, EXT)
+    return EXT
 
 
 if __name__ == "__main__":

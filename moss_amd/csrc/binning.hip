@@ -364,6 +364,19 @@ void launch_clear(void* ptr, size_t bytes, hipStream_t s)
     hipLaunchKernelGGL(clear_words_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(ptr), n16);
 }
 
+__global__ void __launch_bounds__(256) zero_floats_kernel(float* __restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0f;
+}
+
+// Zero n floats of any alignment with a kernel (capture-safe, see launch_clear).
+void launch_zero_floats(float* ptr, size_t n, hipStream_t s)
+{
+    if (n == 0) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(blocks), dim3(256), 0, s, ptr, n);
+}
+
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s)
 {
     (void)P; (void)g;

@@ -198,6 +198,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
 
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);
+void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);  // duplicateWithKeys
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s);

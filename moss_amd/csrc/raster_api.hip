@@ -126,9 +126,11 @@ static int forward_impl(
     if (P == 0) {
         // rasterize_points.cu:68-83: zero-filled outputs, nothing else happens.  (Outputs here are caller-allocated
         // and possibly uninitialised, so fill them; the background is NOT composited in the reference either.)
-        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), s));
-        HIP_TRY(hipMemsetAsync(out_depth, 0, N * sizeof(float), s));
-        HIP_TRY(hipMemsetAsync(out_alpha, 0, N * sizeof(float), s));
+        // (with kernels, not hipMemsetAsync: memset nodes did not re-execute on hipGraph replay with ROCm 7.2, see launch_clear)
+        launch_zero_floats(out_color, 3 * N, s);
+        launch_zero_floats(out_depth, N, s);
+        launch_zero_floats(out_alpha, N, s);
+        HIP_TRY(hipGetLastError());
         return 0;
     }
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) return fail(MOSS_ERR_INVALID_ARG, "null required input");

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from ._C import set_async, check_async_status, set_grad_sink  # noqa: F401  (opt-in: asynchronous forward / graph capture, dL_dsh sink)
+from ._C import RasterContext, set_async, check_async_status, set_grad_sink  # noqa: F401  (opt-in: asynchronous forward / graph capture, gradient sinks; per-rasterizer state)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -64,16 +64,17 @@ def _call_native(fn, args, debug, dump_name, what):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                transforms=None, raw_flags=0):
+                transforms=None, raw_flags=0, context=None):
         # (the tenth input is an addition: per-Gaussian 3x3 transforms applied to the covariance inside the op, SURVEY 8f row n2;
-        #  the eleventh too: which of opacities / scales / rotations are RAW parameters whose getter runs inside the op)
+        #  the eleventh too: which of opacities / scales / rotations are RAW parameters whose getter runs inside the op;
+        #  the twelfth: the RasterContext -- asynchronous-forward policy and gradient sinks -- of the rasterizer that calls)
         rs = raster_settings
         raw_flags = int(raw_flags)
         native_args = (
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
-            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug) + \
-            ((transforms, raw_flags) if raw_flags else (() if transforms is None else (transforms,)))
+            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, transforms, raw_flags, context)
+        ctx.context = context
         (num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_native(
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
@@ -97,31 +98,34 @@ class _RasterizeGaussians(torch.autograd.Function):
         transforms = saved[11] if ctx.has_transforms else None
         raw_opacities = saved[-1] if ctx.raw_flags else None
         if grad_out_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 11
+            return (None,) * 12
         native_args = (
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,
-            sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug) + \
-            ((transforms, ctx.raw_flags, raw_opacities) if ctx.raw_flags else (() if transforms is None else (transforms,)))
+            sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug,
+            transforms, ctx.raw_flags, raw_opacities, ctx.context)
         grads = _call_native(_C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = grads[:8]
         grad_transforms = grads[8] if transforms is not None else None
         # one gradient per forward() input, in forward()'s order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms, None)
+                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        transforms=None, raw_flags=0):
+                        transforms=None, raw_flags=0, context=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, transforms, raw_flags)
+                                     cov3Ds_precomp, raster_settings, transforms, raw_flags, context)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings):
+    def __init__(self, raster_settings, context=None):
+        """``context`` (an addition): a :class:`RasterContext` -- the asynchronous-forward policy and gradient sinks of THIS
+        rasterizer; None = the process-wide default one (``set_async`` / ``set_grad_sink`` without a context configure that)."""
         super().__init__()
         self.raster_settings = raster_settings
+        self.context = context
 
     def markVisible(self, positions):
         """Boolean (P,) mask of the points that pass the near-plane test of this camera."""
@@ -154,4 +158,4 @@ class GaussianRasterizer(nn.Module):
         if raw_flags and (scales.numel() == 0 or cov3D_precomp.numel() != 0):
             raise Exception('raw_flags need the scale/rotation pair (and no precomputed 3D covariance)!')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, transforms,
-                                   raw_flags)
+                                   raw_flags, self.context)

@@ -55,6 +55,7 @@ class GradBucket:
         self.loss_slot = self.flat[off:off + 1]
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {}
+        self._handed_out = set()
         self._avg_ok = None
         o = 0
         for p, n in zip(self.params, self.sizes):
@@ -72,14 +73,21 @@ class GradBucket:
         """Start of a step in direct mode: parameters carry no .grad, so autograd adopts whatever tensor backward returns."""
         for p in self.params:
             p.grad = None
+        self._handed_out.clear()
 
     def sink_for(self, param):
         """A NEW view object of `param`'s slice of the bucket (or None if it is not in the bucket).  A gradient-producing op
         writes its result there and returns the view; autograd's AccumulateGrad adopts a fresh, exclusively-owned tensor as
-        .grad without copying it."""
+        .grad without copying it.
+
+        SINGLE USE per step: the producing kernels OVERWRITE the slice, so the second producer of the same parameter's gradient in
+        one backward pass (two views rendered before one loss.backward(), gradient accumulation, a retained graph run again) gets
+        None, writes into a fresh tensor of its own, and autograd ADDS that to the slice the first one filled -- instead of
+        overwriting memory .grad already aliases.  ``detach_grads()`` (start of the next step) re-arms every slice."""
         off = self._offset.get(id(param))
-        if off is None:
+        if off is None or id(param) in self._handed_out:
             return None
+        self._handed_out.add(id(param))
         return self.flat[off:off + param.numel()].view_as(param)
 
     def collect(self):

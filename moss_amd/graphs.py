@@ -9,7 +9,8 @@ Rules the captured function must follow (``bench.py`` and tests/test_gpu_ops.py:
 * run the step eagerly a few times first (the first synchronous forward sizes the binning capacity; allocator warm-up);
 * return only DETACHED tensors: an output that still has a ``grad_fn`` keeps the step's autograd graph alive into the next replay;
 * no ``hipMemsetAsync`` inside (memset nodes did not re-execute on replay with ROCm 7.2: clear with a kernel), no host reads;
-* call ``step.check()`` every few hundred steps (or ``diff_gaussian_rasterization.check_async_status()`` after the last replay):
+* call ``step.check()`` every few hundred steps (or ``diff_gaussian_rasterization.check_async_status()`` after the last replay; a
+  frame that overflowed is counted in ``step.dropped_frames`` and the step is re-captured with the grown capacity, not raised):
   the binning capacity is baked into the graph, and a scene whose instance count grows needs a re-capture before it overflows.
 """
 from __future__ import annotations
@@ -23,20 +24,23 @@ class GraphedStep:
     """``step = GraphedStep(fn, warmup=3)``; ``out = step()`` replays the captured ``fn`` and returns the (static) outputs of the
     capture.  ``fn`` takes no arguments: it reads its inputs from tensors that are updated in place between replays."""
 
-    def __init__(self, fn, warmup: int = 3, device=None):
+    def __init__(self, fn, warmup: int = 3, device=None, context=None):
         self.fn = fn
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._capture(warmup)
+        self.context = context                               # the RasterContext whose capacity is baked into the graph (None: the default one)
+        self.recaptures = 0
+        self.dropped_frames = 0                              # frames that overflowed the baked-in capacity (they rendered nothing)
+        self._capture(max(int(warmup), 1))
 
     def _capture(self, warmup):
         from .diff_gaussian_rasterization import _C
         fn, dev = self.fn, self.device
-        self.captured_capacity = _C.ASYNC.capacity           # the binning capacity is a kernel argument: baked into the graph
+        self.captured_capacity = (self.context or _C.DEFAULT).capacity   # the binning capacity is a kernel argument: baked into the graph
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):
+            for _ in range(int(warmup)):                     # (0 on a re-capture: fn() has side effects -- it is a training step)
                 fn()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -54,8 +58,17 @@ class GraphedStep:
         (raises like ``check_async_status`` if it did not) and, when the instance count has drifted to within 25 % of the captured
         capacity, captures the step again with the grown one.  Returns True if it re-captured."""
         from .diff_gaussian_rasterization import _C
-        _C.check_async_status()
-        if _C.ASYNC.capacity != self.captured_capacity:
-            self._capture(warmup=1)
+        cx = self.context or _C.DEFAULT
+        try:
+            cx.check_status()
+        except RuntimeError as e:
+            if "binning" not in str(e):
+                raise
+            self.dropped_frames += 1                         # the frame rendered nothing; check_status already grew the capacity
+        if cx.capacity != self.captured_capacity:
+            # no eager warm-up run: the step was running a moment ago, and an eager fn() would be one more (uncounted) training step.
+            # NOTE self.outputs is re-bound: callers must read step.outputs / the return value of step() afresh after a check().
+            self._capture(warmup=0)
+            self.recaptures += 1
             return True
         return False

@@ -860,3 +860,58 @@ def test_block_mask_culling_never_changes_a_result(gpu, hip_lib):
                 assert torch.equal(a, b)
     finally:
         hip_lib.moss_raster_debug_set_cull(-1)
+
+
+def test_two_renders_into_one_backward_with_gradient_sinks(gpu, hip_lib):
+    """a gradient sink is OVERWRITTEN by the backward kernel, so when a parameter receives gradients from two rasterizer
+    calls in one autograd pass (two views before one loss.backward()) the second call must not be handed the slice .grad already
+    aliases.  GradBucket.sink_for is single-use per step: the result is the SUM of both views' gradients, as without sinks.
+    Also: two RasterContexts in one process keep separate sinks and asynchronous-forward state."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    from moss_amd import diff_gaussian_rasterization as dgr
+    from moss_amd.dist import GradBucket
+    s = scenes.config2()
+    poses = scenes.look_at_ring(8)
+    cams = []
+    for R_, t_ in (poses[0], poses[1]):
+        c0 = s.camera
+        cams.append(camera_view(scenes.make_camera(c0.W, c0.H, float(c0.K[0, 0]), float(c0.K[1, 1]), float(c0.K[0, 2]), float(c0.K[1, 2]), R_, t_), gpu))
+    bg = torch.zeros(3, device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+
+    def two_view_loss(pc, pipe):
+        tot = 0.0
+        for cam in cams:
+            out = render(cam, pc, pipe, bg)
+            tot = tot + (out["render"] * w).sum() + out["render_alpha"].sum()
+        return tot
+
+    # reference: no sinks, autograd accumulates
+    pc0 = GaussianSet(s, device=gpu, unified_features=True)
+    pipe0 = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True)
+    two_view_loss(pc0, pipe0).backward()
+    want = {n: p.grad.detach().clone() for n, p in pc0.named_parameters()}
+    # with sinks, in a context of its own
+    ctx = dgr.RasterContext()
+    pc = GaussianSet(s, device=gpu, unified_features=True)
+    bucket = GradBucket(list(pc.parameters()))
+    ctx.set_grad_sink(sh=lambda: bucket.sink_for(pc._features), means3D=lambda: bucket.sink_for(pc._xyz),
+                      opacity=lambda: bucket.sink_for(pc._opacity), scales=lambda: bucket.sink_for(pc._scaling),
+                      rotations=lambda: bucket.sink_for(pc._rotation))
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True, raster_context=ctx)
+    for _ in range(2):                                       # twice: detach_grads() re-arms the slices for the next step
+        bucket.detach_grads()
+        two_view_loss(pc, pipe).backward()
+        bucket.collect()
+        for n, p in pc.named_parameters():
+            assert hp.rel_err(p.grad.cpu().numpy(), want[n].cpu().numpy()) < 1e-6, n
+    assert all(v is None for v in dgr._C.DEFAULT.sinks.values())          # the default context never saw these sinks
+    # asynchronous-forward state is per context too
+    ctx.set_async(True)
+    try:
+        render(cams[0], pc, pipe, bg)
+        assert ctx.capacity > 0 and dgr._C.DEFAULT.capacity == 0 and not dgr._C.DEFAULT.enabled
+    finally:
+        ctx.set_async(False)

@@ -8,7 +8,7 @@ Bars (BASELINE.json north_star):
   * floating point, stated tolerances:
       preprocess outputs (means2D, conic, rgb, cov3D)  : exact equality (same operation order, no contraction)
       images (colour, depth, alpha, final_T)            : IMG_TOL  = 2e-5 of the largest value
-      gradients, per tensor                             : GRAD_TOL = 2e-4 of the largest value AND 1 - cosine <= COS_GAP_TOL
+      gradients, per tensor                             : GRAD_TOL = 2e-5 of the largest value AND 1 - cosine <= COS_GAP_TOL = 1e-9
       gradients, per Gaussian and element               : |hip - oracle| <= PER_GAUSSIAN_TOL x the element's CONTRIBUTION MASS
         (sum over pixels of the absolute terms behind it, oracle.gradient_scales): an fp32 sum carries an error proportional to
         that mass, not to the possibly cancelled result, so this is the scale at which a single Gaussian's gradient -- a small
@@ -26,9 +26,9 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 IMG_TOL = 2e-5
-GRAD_TOL = 2e-4
-COS_GAP_TOL = 1e-6
-PER_GAUSSIAN_TOL = 5e-3
+GRAD_TOL = 2e-5           # round 1: 2e-4.  Measured (profiles/r02_parity_report.json): <= 8e-7 on every configuration
+COS_GAP_TOL = 1e-9        # measured <= 3e-13
+PER_GAUSSIAN_TOL = 2e-3   # measured <= 4e-4 (cfg5, rotation gradients through 1/(1-alpha) chains); typical 1e-6
 FRAGILE = 2e-5      # pixels whose oracle decision margin is below this may legitimately flip a threshold
 
 

@@ -303,3 +303,47 @@ def test_densify_stats_and_exhaustive_knn_restatements():
     d, i = oracle.knn_exhaustive(ref, np.array([[0.9, 0, 0], [0, 1.5, 0]], dtype=np.float32), 3)
     assert i.tolist() == [[1, 3, 0], [2, 0, 1]]                              # the duplicate keeps the lower index in front
     np.testing.assert_allclose(d[0], [0.1, 0.1, 0.9], rtol=1e-6)
+
+
+def test_float64_adjudicator_build_agrees_with_the_float32_oracle():
+    """oracle/_build/libmoss_oracle_f64.so is the same source with float -> double: on cfg1 (no pixel near a threshold) it takes the
+    same decisions and its images / gradients differ from the float32 build by float32 rounding only."""
+    from tests import helpers as hp
+    for mode in ("scale_rot", "precomp", "lbs"):
+        d = hp.inputs_of(scenes.config1(), mode)
+        fw = hp.oracle_forward(d)
+        fw64 = hp.oracle_forward64(d, fw)
+        assert fw64.color.dtype == np.float64
+        np.testing.assert_array_equal(fw64.radii64, fw.radii)
+        m = hp.stable_mask(d, fw, fw64, thr=1e-4).numpy().astype(bool)
+        assert m.mean() > 0.99
+        np.testing.assert_array_equal(fw64.n_contrib[m.reshape(-1)], fw.n_contrib[m.reshape(-1)])
+        assert np.abs(fw64.color - fw.color)[:, m].max() < 5e-6
+        dc, dd, da = hp.image_grads(d.H, d.W)
+        mt = torch.from_numpy(m.astype(np.float32))
+        dc, dd, da = dc * mt, dd * mt, da * mt
+        g32, g64 = hp.oracle_backward(d, fw, dc, dd, da), hp.oracle_backward(d, fw64, dc, dd, da)
+        sc = hp.oracle_gradient_scales(d, fw, dc, dd, da)
+        for name, scale in sc.items():
+            a, b = getattr(g32, name), getattr(g64, name)
+            if not b.size:
+                continue
+            live, dead = hp.scaled_err(a, b, scale)
+            assert dead == 0.0, name                         # no contribution mass <=> exactly zero in both builds
+            assert live < 1e-4, (name, live)                 # float32 rounding, in units of the contribution mass
+            assert hp.cosine_gap(a, b) < 1e-10, name
+
+
+def test_contribution_mass_bounds_the_gradient_and_is_zero_where_nothing_contributes():
+    from tests import helpers as hp
+    d = hp.inputs_of(scenes.config1(), "scale_rot")
+    fw = hp.oracle_forward(d)
+    dc, dd, da = hp.image_grads(d.H, d.W)
+    g = hp.oracle_backward(d, fw, dc, dd, da)
+    sc = hp.oracle_gradient_scales(d, fw, dc, dd, da)
+    for name in ("dL_dcolors", "dL_dopacity", "dL_dmeans2D", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dcov3D"):
+        a = np.abs(getattr(g, name).astype(np.float64)); s = sc[name].reshape(a.shape)
+        assert (a <= s * (1 + 1e-4) + 1e-30).all(), name     # |sum of terms| <= sum of |terms|
+        assert (a[s == 0] == 0).all(), name
+    untouched = sc["dL_dopacity"].reshape(-1) == 0            # Gaussians no stable pixel blends (cfg1 culls none)
+    assert (sc["dL_dmeans3D"][untouched] == 0).all() and (sc["dL_dsh"][untouched] == 0).all()
