@@ -7,15 +7,20 @@ One STEP = one training iteration on one view of the `configs[2]` workload (100k
 Inputs are resident in HBM before the timed region.  N>1 is frame-parallel (one camera per rank, replicas of the
 Gaussians, weak scaling): value = N * steps / max-over-ranks time.
 
-Launch: python bench.py [--gpus 1 --steps K --warmup W]      or, for N>1,
-        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Launch: python bench.py [--gpus N --steps K --warmup W]
+  N > 1 without a torchrun environment: this process starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+  --master-addr 127.0.0.1 --master-port <free> bench.py ...` itself (BEFORE it touches a GPU), relays rank 0's JSON line and exits
+  non-zero if any rank failed.  Under torchrun (RANK / WORLD_SIZE set, as the driver launches it) it is one rank of the job.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,8 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0
-HBM_ACHIEVABLE_GBS = 5924.0           # measured: scripts/hbm_bandwidth.py (triad, 1 GiB buffers), profiles/r01_hbm_bandwidth.json      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s nominal
+HBM_ACHIEVABLE_GBS = 5924.0           # measured on this part: scripts/hbm_bandwidth.py (triad, 1 GiB buffers), profiles/r01_hbm_bandwidth.json
+MIN_TIMED_MS = 50.0                   # a timed region shorter than this is re-measured over LONG_STEPS steps as well (reported beside)
+LONG_STEPS = 200
 
 
 def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
@@ -44,7 +51,7 @@ def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
     return fwd, bwd
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -76,35 +83,242 @@ def main():
                          "ZJU-MoCap frames; smooth = a full-frame smooth colour field (drives a few dozen Gaussians to cover the "
                          "whole image within ~250 steps, a regime real captures do not have)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
     ap.add_argument("--cpu-iters", type=int, default=20,
                     help="iterations of the CPU oracle baseline (about 0.57 s each on one core: 20 = the 10-30 s sample the contract asks for)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="TEST HOOK (tests/test_host_cpu.py): no GPU work at all -- every rank stands in for its step with a host-side "
+                         "gradient bucket, so that the launcher, the rendezvous, the all-reduce, the max-over-ranks timing and the JSON "
+                         "schema of the N > 1 path can be exercised on a machine without GPUs (backend gloo)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 started as a plain `python bench.py --gpus N`: become the launcher.  Nothing here may touch the GPU -- on this pool a
+# process that has initialised HIP must not exec or be replaced, so the children are started first and this process only waits.
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(argv):
+    args = parse_args(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] {args.gpus}-rank job failed (exit code {proc.returncode}, JSON line {'missing' if line is None else 'present'})", file=sys.stderr)
+        return proc.returncode or 1
+    res = json.loads(line)
+    if res.get("n_gpus") != args.gpus:
+        print(f"[bench] asked for {args.gpus} ranks, the job reported {res.get('n_gpus')}", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+class Harness:
+    """One configuration of the training step on this rank: model, optimizer, gradient bucket, rasterizer context, step functions."""
+
+    n_exchange = 0
+
+    def __init__(self, args, dev, rank, world, scene, cam, gt, gt_mask, bg, *, mode, activations, torch_activations, torch_adamw,
+                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None):
+        import torch
+        from types import SimpleNamespace
+        from moss_amd import dist as mdist
+        from moss_amd import diff_gaussian_rasterization as dgr
+        from moss_amd.gaussian_model import GaussianSet
+        from moss_amd.gaussian_renderer import render
+        from moss_amd import loss as mloss
+        self.torch, self.dev, self.world, self.args = torch, dev, world, args
+        self.mode, self.forward = mode, forward
+        self.ctx = dgr.RasterContext()                       # this harness's own asynchronous-forward state and gradient sinks
+        unified = not torch_adamw and not torch_activations
+        self.pc = pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
+        self.pipe = pipe = SimpleNamespace(
+            convert_SHs_python=False, compute_cov3D_python=(mode in ("precomp", "lbs_python")), debug=False,
+            fused_activations=not torch_activations, transforms_in_op=(mode == "lbs"),
+            raw_parameters_in_op=(not torch_activations and activations == "in_op" and unified and mode in ("scale_rot", "lbs")),
+            raster_context=self.ctx)
+        self.lbs_T = lbs_T
+        self.bucket = bucket = mdist.GradBucket(list(pc.parameters()))
+        pipe.grad_bucket = bucket
+        if torch_adamw:
+            self.opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15)          # scene/gaussian_model.py:226
+        else:
+            from moss_amd.optim import FlatAdamW
+            self.opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)     # same rule, one kernel over the bucket
+        self.use_graph = bool(graph) and forward == "async" and not torch_adamw and caller_side is None
+        self.ctx.set_async(forward == "async")
+        if unified:
+            sinks = {"sh": lambda: bucket.sink_for(pc._features)}             # dL_dsh is written straight into the gradient bucket
+            if pipe.raw_parameters_in_op:                                     # ... and so are the raw-parameter gradients
+                sinks.update(opacity=lambda: bucket.sink_for(pc._opacity), scales=lambda: bucket.sink_for(pc._scaling),
+                             rotations=lambda: bucket.sink_for(pc._rotation))
+                if lbs_T is None:                                             # (with a transform the means are not the parameter)
+                    sinks["means3D"] = lambda: bucket.sink_for(pc._xyz)
+            self.ctx.set_grad_sink(**sinks)
+        training_loss = mloss.training_loss_fused if fused_loss else mloss.training_loss
+        self.caller_side = caller_side
+        stats = None
+        if caller_side == "torch":
+            # the three statistics MOSS keeps on GaussianModel (scene/gaussian_model.py:198,204-205), updated with its own torch expressions
+            P = scene.means3D.shape[0]
+            stats = SimpleNamespace(xyz_gradient_accum=torch.zeros((P, 1), device=dev), denom=torch.zeros((P, 1), device=dev),
+                                    max_radii2D=torch.zeros((P,), device=dev))
+        elif caller_side == "fused":
+            from moss_amd.densify import DensifyStats
+            stats = DensifyStats(scene.means3D.shape[0], device=dev)
+        self.stats = stats
+
+        def compute():                      # everything of a step that is local to this rank
+            if torch_adamw:
+                self.opt.zero_grad(set_to_none=True)
+            elif pipe.fused_activations:
+                bucket.detach_grads()       # gradients are WRITTEN into the bucket by the backward kernels
+            else:
+                bucket.attach()             # zero the bucket; autograd accumulates into it
+            out = render(cam, pc, pipe, bg, transforms=lbs_T)
+            if fused_loss:
+                # the loss kernels write [loss, L1, SSIM, mask] into the bucket's tail: it travels with the gradients, no copy
+                loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
+                mloss.backward_from_loss(loss)
+            else:
+                loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask)
+                loss.backward()
+            if caller_side == "torch":
+                # train_ZJU.py:101,171-174 + GaussianModel.add_densification_stats (scene/gaussian_model.py:815-817), as written there
+                vis, radii, vsp = out["visibility_filter"], out["radii"], out["viewspace_points"]
+                stats.max_radii2D[vis] = torch.max(stats.max_radii2D[vis], radii[vis])
+                stats.xyz_gradient_accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
+                stats.denom[vis] += 1
+            elif caller_side == "fused":
+                stats.add(out["radii"], out["viewspace_points"].grad)
+                _ = out["visibility_filter"]
+            if not torch_adamw and pipe.fused_activations:
+                bucket.collect()
+            if world == 1:
+                self.opt.step()
+            # detached: holding an output with a grad_fn would keep this step's autograd graph (and its AccumulateGrad nodes,
+            # bound to the stream they were created on) alive into the next step / into graph capture
+            return {"radii": out["radii"]}
+
+        self.compute = compute
+        self.step = self.eager_step
+        self.graphed = None
+        self.graph_note = "eager launches"
+        self.t_allreduce = self.t_adamw = 0.0
+        self._ev = None
+        self._ev_pending = False
+
+    def exchange(self):
+        """N > 1: ONE RCCL all-reduce of the flat gradient bucket (+ loss slot), then AdamW; both timed with event pairs."""
+        torch = self.torch
+        if self._ev is None:
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        if self._ev_pending:                                 # the previous step's pairs (long complete: no stall)
+            self._ev[2].synchronize()
+            self.t_allreduce += self._ev[0].elapsed_time(self._ev[1]); self.t_adamw += self._ev[1].elapsed_time(self._ev[2])
+            self.n_exchange += 1
+        e0, e1, e2 = self._ev
+        e0.record()
+        self.bucket.all_reduce_mean(None, self.world)
+        e1.record()
+        self.opt.step()
+        e2.record()
+        self._ev_pending = True
+
+    def eager_step(self):
+        out = self.compute()
+        if self.world > 1:
+            self.exchange()
+        return out
+
+    def capture(self):
+        """The first (synchronous) forward sized the binning buffer; nothing in compute() talks to the host any more, so the whole
+        per-rank step is captured once and replayed: its launches become one hipGraphLaunch."""
+        from moss_amd.graphs import GraphedStep
+        self.graphed = graphed = GraphedStep(self.compute, warmup=3, device=self.dev, context=self.ctx)
+        replays = [0]
+
+        def graph_step():
+            graphed()
+            replays[0] += 1
+            if replays[0] % 512 == 0:        # long runs: the scene grows while it trains; re-capture before the baked-in
+                graphed.check()              # binning capacity overflows (one synchronisation per 512 steps)
+            if self.world > 1:
+                self.exchange()
+            return graphed.outputs           # (re-bound by a re-capture: never cache it)
+
+        for _ in range(5):
+            graph_step()
+        self.torch.cuda.synchronize(self.dev)
+        self.step = graph_step
+        self.graph_note = "one hipGraph replay per step" + (" + eager RCCL all-reduce and AdamW" if self.world > 1 else "")
+
+    def time_steps(self, n, barrier=None):
+        torch = self.torch
+        if barrier:
+            barrier()
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(n):
+            out = self.step()
+        torch.cuda.synchronize(self.dev)
+        if barrier:
+            barrier()
+        return time.perf_counter() - t0, out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(argv))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
 
     import torch
     from moss_amd import dist as mdist
     from moss_amd import scenes, _lib
-    if not os.path.exists(_lib.LIB_PATH):               # normally built by __graft_entry__.build(); hipcc is on the GPU box too
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.EXT_PATH)):   # normally built by __graft_entry__.build(); hipcc is on the GPU box too
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             from moss_amd import build as hip_build
-            hip_build.build()
-        else:                                           # one rank builds, the others wait for the file
-            for _ in range(1200):
-                if os.path.exists(_lib.LIB_PATH):
+            hip_build.build()                               # (links under a temporary name and renames: never a half-written file)
+        else:                                               # one rank builds, the others wait for the files
+            for _ in range(2400):
+                if os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.EXT_PATH):
                     break
                 time.sleep(0.5)
-            time.sleep(2.0)
     from moss_amd.gaussian_model import GaussianSet
     from moss_amd.gaussian_renderer import render, camera_view
-    from moss_amd.loss import training_loss_fused as training_loss, backward_from_loss     # HIP-fused L1 + SSIM + mask loss
     from types import SimpleNamespace
 
     rank, world, local_rank = mdist.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks (python bench.py --gpus N does it itself)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if os.environ.get("MOSS_FORCE_DEVICE"):             # testing aid: several ranks on one GPU (with MOSS_DIST_BACKEND=gloo)
         local_rank = int(os.environ["MOSS_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    rccl_ranks = None
+    if world > 1:
+        rccl_ranks = torch.distributed.get_world_size()
+        assert rccl_ranks == args.gpus, f"the communicator has {rccl_ranks} ranks, --gpus {args.gpus}"
 
     # ---- workload (identical Gaussians on every rank, one camera per rank) ---------------------------------
     poses = scenes.look_at_ring(max(world, 8))
@@ -116,17 +330,11 @@ def main():
         scene.camera = scenes.make_camera(c0.W, c0.H, float(c0.K[0, 0]), float(c0.K[1, 1]), float(c0.K[0, 2]), float(c0.K[1, 2]), R_, t_)
     cam = camera_view(scene.camera, dev)
     H, W = scene.camera.H, scene.camera.W
-    # SH coefficients as one (P,16,3) parameter (no per-step concat) whenever the flat optimizer can give dc / rest their two rates
-    unified = not args.torch_adamw and not args.torch_activations
-    pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
-    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=(args.mode in ("precomp", "lbs_python")), debug=False,
-                           fused_activations=not args.torch_activations, transforms_in_op=(args.mode == "lbs"),
-                           raw_parameters_in_op=(not args.torch_activations and args.activations == "in_op" and unified
-                                                 and args.mode in ("scale_rot", "lbs")))
-    lbs_T = None
-    if args.mode in ("lbs", "lbs_python"):
+
+    def lbs_transforms():
         gT = torch.Generator().manual_seed(1234)
-        lbs_T = (torch.eye(3) + 0.05 * torch.randn(scene.means3D.shape[0], 3, 3, generator=gT)).to(dev)
+        return (torch.eye(3) + 0.05 * torch.randn(scene.means3D.shape[0], 3, 3, generator=gT)).to(dev)
+
     bg = torch.zeros(3, device=dev)
     if args.target == "smooth":
         gt = scenes.synthetic_target(H, W).to(dev)
@@ -139,50 +347,11 @@ def main():
         gt = gt_out["render"].detach().clamp(0, 1).contiguous()
         gt_mask = (gt_out["render_alpha"].detach() > 0.5).float().contiguous()
         del gt_out, gt_scene
-    bucket = mdist.GradBucket(list(pc.parameters()))
-    pipe.grad_bucket = bucket
-    if args.torch_adamw:
-        opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15, fused=True)      # gaussian_model.py:226
-    else:
-        from moss_amd.optim import FlatAdamW
-        opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)         # same rule, one kernel over the bucket
-    from moss_amd import diff_gaussian_rasterization as dgr
-    use_graph = bool(args.graph) and args.forward == "async" and not args.torch_adamw
-    dgr.set_async(args.forward == "async")
-    if unified:
-        sinks = {"sh": lambda: bucket.sink_for(pc._features)}             # dL_dsh is written straight into the gradient bucket
-        if pipe.raw_parameters_in_op:                                     # ... and so are the raw-parameter gradients
-            sinks.update(opacity=lambda: bucket.sink_for(pc._opacity), scales=lambda: bucket.sink_for(pc._scaling),
-                         rotations=lambda: bucket.sink_for(pc._rotation))
-            if lbs_T is None:                                             # (with a transform the means are not the parameter)
-                sinks["means3D"] = lambda: bucket.sink_for(pc._xyz)
-        dgr.set_grad_sink(**sinks)
 
-    def compute():                      # everything of a step that is local to this rank
-        if pipe.fused_activations:
-            bucket.detach_grads()       # gradients are WRITTEN into the bucket by the activation backward kernel
-        else:
-            bucket.attach()             # zero the bucket; autograd accumulates into it
-        out = render(cam, pc, pipe, bg, transforms=lbs_T)
-        # the loss kernels write [loss, L1, SSIM, mask] into the bucket's tail: it travels with the gradients, no copy
-        loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
-        backward_from_loss(loss)
-        if pipe.fused_activations:
-            bucket.collect()
-        if world == 1:
-            opt.step()
-        # detached: holding an output with a grad_fn would keep this step's autograd graph (and its AccumulateGrad nodes,
-        # bound to the stream they were created on) alive into the next step / into graph capture
-        return {"radii": out["radii"]}
-
-    def eager_step():
-        out = compute()
-        if world > 1:
-            bucket.all_reduce_mean(None, world)          # ONE RCCL all-reduce of the flat gradient bucket (+ loss slot)
-            opt.step()
-        return out
-
-    step = eager_step
+    h = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
+                torch_activations=args.torch_activations, torch_adamw=args.torch_adamw, forward=args.forward, graph=args.graph,
+                lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None)
+    opt, bucket, pc = h.opt, h.bucket, h.pc
 
     t_start = time.perf_counter()
 
@@ -202,7 +371,7 @@ def main():
         if i == n_warm // 2 and i > 0:
             torch.cuda.synchronize(dev)
             _lib.profile_read()              # discard the first half: first launches include code-object loading
-        out = step()
+        out = h.step()
     torch.cuda.synchronize(dev)
     prof = _lib.profile_read()
     stage_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
@@ -210,57 +379,37 @@ def main():
     _lib.profile_enable([dominant])          # two events per step around the dominant kernel only
 
     note(f"warmup done; stages {stage_ms}")
-    graph_note = "eager launches"
+    use_graph = h.use_graph
     if use_graph:
-        # The first (synchronous) forward above sized the binning buffer; nothing in compute() talks to the host any more, so
-        # the whole per-rank step is captured once and replayed: ~50 launches become one hipGraphLaunch.
         _lib.profile_enable([])              # hipEvent pairs cannot be read back from inside a captured graph
         try:
             out = None
-            from moss_amd.graphs import GraphedStep
-            graphed = GraphedStep(compute, warmup=3, device=dev)
-
-            replays = [0]
-
-            def graph_step():
-                graphed()
-                replays[0] += 1
-                if replays[0] % 512 == 0:        # long runs: the scene grows while it trains; re-capture before the baked-in
-                    graphed.check()              # binning capacity overflows (one synchronisation per 512 steps)
-                if world > 1:
-                    bucket.all_reduce_mean(None, world)
-                    opt.step()
-                return graphed.outputs                       # (re-bound by a re-capture: never cache it)
-
-            for _ in range(5):
-                graph_step()
-            torch.cuda.synchronize(dev)
-            step = graph_step
-            graph_note = "one hipGraph replay per step" + (" + eager RCCL all-reduce and AdamW" if world > 1 else "")
+            h.capture()
         except Exception as e:                                   # keep measuring: same kernels, launched one by one
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize(dev)
             use_graph = False
+            h.step = h.eager_step
             _lib.profile_enable([dominant])
 
     # The step trains (AdamW moves the Gaussians), so the workload drifts from iteration to iteration.  The measurement passes after
     # the timed region restore this snapshot and REPLAY THE SAME K ITERATIONS (the kernels are deterministic), so the per-kernel
     # durations they report belong to exactly the frames the timed region rendered.
     snap = opt.snapshot() if hasattr(opt, "snapshot") else None
+    h.t_allreduce = h.t_adamw = 0.0
+    h.n_exchange = 0
     note("entering timed region")
     # ---- timed region: EXACTLY K steps between barrier+sync pairs -------------------------------------------
-    barrier(); torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize(dev); barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, out = h.time_steps(args.steps, barrier)
     note(f"timed region done: {elapsed:.3f}s")
     if args.forward == "async":
         # the last frame of the timed region (graph mode: the graph's own buffers) rendered within its binning capacity, i.e. it
         # really did the work; an overflowed frame would have produced a background image and is an error here
-        dgr.check_async_status()
-        assert dgr._C.ASYNC.last_needed > 0
+        h.ctx.check_status()
+        assert h.ctx.last_needed > 0
+    exchange_ms = None
+    if world > 1 and h.n_exchange:
+        exchange_ms = (h.t_allreduce / h.n_exchange, h.t_adamw / h.n_exchange)
     dom_in_region = None
     replicas_identical = None
     if not use_graph:
@@ -276,6 +425,16 @@ def main():
             torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
             torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
             replicas_identical = bool((lo == hi).item())
+    # a timed region of a few milliseconds says little: measure LONG_STEPS more steps as well and report both
+    long_run = None
+    if 1e3 * elapsed < MIN_TIMED_MS and args.steps < LONG_STEPS:
+        t_long, _ = h.time_steps(LONG_STEPS, barrier)
+        if world > 1:
+            tt = torch.tensor([t_long], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t_long = float(tt.item())
+        long_run = {"steps": LONG_STEPS, "value": round(world * LONG_STEPS / t_long, 3), "ms_per_step": round(1e3 * t_long / LONG_STEPS, 4),
+                    "why": f"the {args.steps}-step timed region lasted {1e3 * elapsed:.1f} ms (< {MIN_TIMED_MS:.0f} ms)"}
 
     # ---- per-kernel device times: eager replay of the same K iterations with a hipEvent pair around every kernel of the op -------
     # (graph mode: events inside a replayed graph cannot be read back, so this replay is also where the dominant kernel's launch
@@ -284,7 +443,7 @@ def main():
         opt.restore(snap)
     _lib.profile_enable(None)
     for _ in range(args.steps):
-        out = eager_step()
+        out = h.eager_step()
     torch.cuda.synchronize(dev)
     prof = _lib.profile_read()
     _lib.profile_enable([])
@@ -298,12 +457,11 @@ def main():
         return
 
     if args.forward == "async":
-        dgr.check_async_status()                 # also brings num_rendered of the last replayed frame to the host
+        h.ctx.check_status()                 # also brings num_rendered of the last replayed frame to the host
     # ---- measured problem statistics and the roofline -------------------------------------------------------
     radii = out["radii"]
     P = int(radii.numel()); Pv = int((radii > 0).sum().item())
-    from moss_amd.diff_gaussian_rasterization import _C
-    R = int(_C.last_num_rendered)
+    R = int(h.ctx.last_needed if args.forward == "async" else h.ctx.last_num_rendered)
     N = H * W
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"))
@@ -313,6 +471,14 @@ def main():
     total_bytes = sum(all_b.values())
     iters_per_s = world * args.steps / elapsed
     raster_ms = sum(stage_ms.values())
+    headline = args.config == "cfg3" and args.mode == "scale_rot"
+    pmc = _pmc_traffic() if headline else {}
+    # every stage against the roofline, not only the dominant one (durations: kernel-attached events of the eager replay)
+    stages = {}
+    for k, ms in stage_ms.items():
+        gbs = all_b[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        stages[k] = {"ms": ms, "algorithmic_bytes": int(all_b[k]), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
+                     "traffic": pmc.get(k)}
 
     result = {
         "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)" if args.config == "cfg3" else f"train iters/sec ({args.config})",
@@ -323,33 +489,91 @@ def main():
                                f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
                    if args.config == "cfg3" else args.config,
                    "target": args.target, "input_mode": args.mode,
-                   "activations": "torch" if args.torch_activations else ("in_op" if pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
+                   "activations": "torch" if args.torch_activations else ("in_op" if h.pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
-                   "forward": args.forward, "launch": graph_note},
+                   "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
+                   "glue": "compiled PyTorch-ROCm extension moss_amd/lib/_moss_C.so over the C ABI of libmoss_raster.so"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
                      # the best a plain streaming kernel reaches on this part (profiles/r01_hbm_bandwidth.json: triad over 1 GiB buffers)
                      "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),
-                     # PMC bytes were collected on the headline workload (profiles/pmc_latest.json): null for any other
-                     "traffic": _pmc_traffic(dominant) if (args.config == "cfg3" and args.mode == "scale_rot") else None,
+                     # PMC bytes were collected on the headline workload with exactly these kernel sources (profiles/pmc_latest.json is
+                     # stamped with the sha256 of moss_amd/csrc/): null for any other workload or any other source state
+                     "traffic": pmc.get(dominant),
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
                      "timing": ("hipEvents attached to the kernel (hipExtLaunchKernelGGL start/stop) on its launch stream, over an eager "
                                 "replay of the SAME K iterations (parameters and optimizer state restored to the start of the "
                                 "graph-replay timed region)") if use_graph else
                                "hipEvents attached to the kernel (hipExtLaunchKernelGGL start/stop) on its launch stream, inside the timed region"},
         "stages_ms": stage_ms,
+        "stages": stages,
         "rasterizer_ms_per_step": round(raster_ms, 4),
         "step_algorithmic_bytes": int(total_bytes),
         "step_hbm_frac": round(total_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
     }
-
-    if replicas_identical is not None:
+    if long_run is not None:
+        result["long_run"] = long_run
+    if h.graphed is not None:
+        result["graph_recaptures"], result["dropped_frames"] = h.graphed.recaptures, h.graphed.dropped_frames
+    if world > 1:
+        result["rccl_ranks"] = rccl_ranks
+        result["backend"] = torch.distributed.get_backend()
         result["replicas_identical"] = replicas_identical
+        if exchange_ms is not None:
+            result["allreduce_ms"], result["adamw_ms"] = round(exchange_ms[0], 4), round(exchange_ms[1], 4)
+            result["allreduce_bytes"] = int(bucket.flat.numel() * 4)
     if world == 1:
         result["densify_side_ms"] = densify_side(pc, out)
+    if world == 1 and not args.no_callers and headline:
+        del h, opt, bucket, pc
+        torch.cuda.empty_cache()
+        result["callers"] = caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_transforms())
+        result["value_dropin"] = result["callers"]["dropin_unchanged"].get("value")
+        result["value_lbs_in_op"] = result["callers"]["lbs_in_op"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
+        result["cpu_baseline_autograd"] = cpu_baseline_autograd()
     print(json.dumps(result))
+
+
+def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, warmup=10):
+    """The same workload the way other callers drive the op, reported BESIDE the headline (never as `value`):
+      dropin_unchanged   MOSS's call pattern with nothing but the three packages swapped: compute_cov3D_python=True with per-Gaussian
+                         transforms (gaussian_renderer/__init__.py:88-91, arguments/__init__.py:60), the five torch getters, the
+                         reference's torch loss (utils/loss_utils.py), torch.optim.AdamW over the six groups, synchronous forward,
+                         eager launches, visibility_filter + the densification statistics every step with MOSS's own torch
+                         expressions (train_ZJU.py:101,171-174)
+      dropin_fused_sides the same call pattern with the caller-side rows of SURVEY 8(f) switched to this repository's kernels: fused
+                         L1+SSIM loss, DensifyStats, flat AdamW, fused activation kernels (still cov3D_precomp from Python, still
+                         synchronous and eager)
+      lbs_in_op          the transforms applied inside the op (raw parameters, asynchronous forward, one hipGraph per step)"""
+    import torch
+    res = {}
+    specs = {
+        "dropin_unchanged": dict(mode="lbs_python", activations="fused", torch_activations=True, torch_adamw=True, forward="sync", graph=0,
+                                 fused_loss=False, caller_side="torch"),
+        "dropin_fused_sides": dict(mode="lbs_python", activations="fused", torch_activations=False, torch_adamw=False, forward="sync", graph=0,
+                                   fused_loss=True, caller_side="fused"),
+        "lbs_in_op": dict(mode="lbs", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
+    }
+    for name, kw in specs.items():
+        try:
+            h = Harness(args, dev, 0, 1, scene, cam, gt, gt_mask, bg, lbs_T=lbs_T, **kw)
+            for _ in range(warmup):
+                h.step()
+            torch.cuda.synchronize(dev)
+            if h.use_graph:
+                h.capture()
+            dt, _ = h.time_steps(steps)
+            if kw["forward"] == "async":
+                h.ctx.check_status()
+            res[name] = {"value": round(steps / dt, 2), "unit": "iters/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+                         "launch": h.graph_note if h.use_graph else "eager launches", "forward": kw["forward"]}
+            del h
+        except Exception as e:                               # a side measurement must not take the headline down with it
+            res[name] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+        torch.cuda.empty_cache()
+    return res
 
 
 def densify_side(pc, out):
@@ -374,23 +598,37 @@ def densify_side(pc, out):
     return res
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/pmc_latest.json), or None."""
+def csrc_sha256():
+    """sha256 over the kernel sources (moss_amd/csrc/*, sorted by name): ties a committed counter summary to the code it measured."""
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "moss_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            hsh.update(name.encode()); hsh.update(f.read())
+    return hsh.hexdigest()
+
+
+def _pmc_traffic():
+    """{stage or kernel: HBM bytes per launch} from the committed rocprofv3 --pmc summary (profiles/pmc_latest.json) IF it was
+    measured on the kernel sources of this checkout (its `csrc_sha256` stamp matches), else {} (traffic: null)."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            data = json.load(f)
+        if data.get("csrc_sha256") != csrc_sha256():
+            return {}
+        return {k: v.get("hbm_bytes_per_launch") for k, v in data.items() if isinstance(v, dict)}
     except Exception:
-        return None
+        return {}
 
 
 def cpu_baseline(scene, args, gt, gt_mask):
     """The CPU oracle (single-threaded C port of the reference algorithm) + the same loss in torch on ONE thread, timed on
     this box's host cores on a bounded sample of the same workload.  A reported baseline, never the product path."""
-    import numpy as np
     import torch
     from moss_amd.loss import training_loss
     from tests import helpers as hp
+    nthreads = torch.get_num_threads()
     torch.set_num_threads(1)
     d = hp.inputs_of(scene, "precomp" if args.mode == "lbs_python" else ("scale_rot" if args.mode == "lbs" else args.mode))
     gt_c, mask_c = gt.cpu(), gt_mask.cpu()
@@ -404,9 +642,87 @@ def cpu_baseline(scene, args, gt, gt_mask):
         loss.backward()
         hp.oracle_backward(d, fw, img.grad, torch.zeros(1, d.H, d.W), alpha.grad)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(nthreads)
     return {"value": round(n / dt, 4), "unit": "iters/s", "cores": 1, "kind": "port",
             "sample": f"{n} full iterations of the same workload (C oracle fwd+bwd + torch loss, 1 thread) in {dt:.1f} s",
             "host_cores_available": os.cpu_count()}
+
+
+def cpu_baseline_autograd(budget_s=8.0):
+    """The baseline north_star names: the naive PyTorch-autograd per-pixel rasterizer (oracle/autograd_rasterizer.py, float64) on the
+    host cores, fwd+bwd, on BASELINE configs[0] (256 Gaussians, 128x128 -- the case it is meant for; it takes its tile lists from
+    the C oracle's binning, which is inside the timed iteration).  A reported, non-target baseline."""
+    import torch
+    from moss_amd import scenes
+    from oracle import autograd_rasterizer as ag
+    from tests import helpers as hp
+    d = hp.inputs_of(scenes.config1(), "scale_rot"); c = d.cam
+    f64 = lambda t: t.double()
+
+    def it():
+        fw = hp.oracle_forward(d)
+        leaf = lambda t: t.double().clone().requires_grad_(True)
+        means, opa, shs, scl, rot = leaf(d.means3D), leaf(d.opacities), leaf(d.shs), leaf(d.scales), leaf(d.rotations)
+        col, dep, alp = ag.render(fw, means, opa, f64(c.viewmatrix), f64(c.projmatrix), f64(c.campos), c.tanfovx, c.tanfovy, f64(d.bg),
+                                  d.degree, shs=shs, scales=scl, rotations=rot, cov3D_precomp=None)
+        (col.sum() + alp.sum()).backward()
+    it()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < 200:
+        it(); n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "iters/s", "cores": torch.get_num_threads(), "host_cores_available": os.cpu_count(), "kind": "port",
+            "workload": "BASELINE configs[0]: 256 Gaussians, 128x128, fwd+bwd", "sample": f"{n} iterations in {dt:.1f} s",
+            "what": "naive PyTorch-autograd rasterizer (oracle/autograd_rasterizer.py, float64, torch intra-op threads as stated)"}
+
+
+def dry_run_cpu(args):
+    """TEST HOOK: the N-rank control flow of this file without any GPU (see --dry-run-cpu)."""
+    import torch
+    import torch.distributed as dist
+    from moss_amd import dist as mdist
+    os.environ.setdefault("MOSS_DIST_BACKEND", "gloo")
+    rank, world, _ = mdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ranks = dist.get_world_size() if world > 1 else 1
+    params = [torch.nn.Parameter(torch.zeros(1000, 3)), torch.nn.Parameter(torch.zeros(1000, 16, 3))]
+    bucket = mdist.GradBucket(params)
+    flat_params = torch.zeros(bucket.flat.numel() - 4)
+    t_ar = [0.0]
+
+    def step():
+        bucket.flat.fill_(float(rank + 1))                   # "the backward": rank-dependent gradients
+        t0 = time.perf_counter()
+        bucket.all_reduce_mean(None, world)
+        t_ar[0] += time.perf_counter() - t0
+        flat_params.add_(bucket.flat[:-4], alpha=-0.1)       # "the optimizer"
+    for _ in range(max(args.warmup, 1)):
+        step()
+    t_ar[0] = 0.0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    identical = True
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        chk = flat_params.double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        identical = bool((lo == hi).item())
+        assert abs(float(bucket.flat[0]) - (world + 1) / 2.0) < 1e-6          # the mean of 1..world
+    if rank == 0:
+        print(json.dumps({"metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)", "value": round(world * args.steps / elapsed, 3),
+                          "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "DRY RUN: no GPU work (launcher / collective plumbing test)",
+                          "config": {"workload": "dry run"}, "rccl_ranks": ranks, "backend": dist.get_backend() if world > 1 else None,
+                          "replicas_identical": identical, "allreduce_ms": round(1e3 * t_ar[0] / args.steps, 4), "adamw_ms": 0.0}))
 
 
 if __name__ == "__main__":

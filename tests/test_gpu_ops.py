@@ -561,7 +561,9 @@ def test_unified_features_step_equals_separate_features(gpu, hip_lib):
             r = render(cam, pc, pipe, bg)
             ((r["render"] * w).sum() + r["render_alpha"].sum()).backward()
             if uni:
-                assert pc._features.grad.data_ptr() == bucket.sink_for(pc._features).data_ptr()      # adopted, not copied
+                off = bucket._offset[id(pc._features)]
+                assert pc._features.grad.data_ptr() == bucket.flat[off:off + 1].data_ptr()      # adopted, not copied
+                assert bucket.sink_for(pc._features) is None                                   # single use per step (re-armed by detach_grads)
             bucket.collect()
             assert not torch.isnan(bucket.flat[:-4]).any()
             feat_grad = pc._features.grad if uni else torch.cat((pc._features_dc.grad, pc._features_rest.grad), dim=1)

@@ -123,7 +123,9 @@ def _rank_main(rank, world, port, q):
     loss.backward()
     assert params[0].grad.data_ptr() == bucket.views[0].data_ptr()          # no pack copy
     got_loss = bucket.all_reduce_mean(loss, world).clone()
-    q.put((rank, params[0].grad.clone(), params[1].grad.clone(), got_loss))
+    # numpy, not tensors: a tensor crosses a multiprocessing queue as a file descriptor served by THIS process, which may have
+    # exited by the time the parent unpickles it
+    q.put((rank, params[0].grad.numpy().copy(), params[1].grad.numpy().copy(), got_loss.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -142,6 +144,7 @@ def test_frame_parallel_gradient_bucket_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, g0, g1, loss in res:
+        g0, g1, loss = torch.from_numpy(g0), torch.from_numpy(g1), torch.from_numpy(loss)
         assert torch.allclose(g0, torch.full((5, 3), 1.5))                  # mean of 1 and 2
         assert torch.allclose(g1, torch.full((7,), 15.0))                   # mean of 10 and 20
         assert torch.allclose(loss, torch.tensor([(15.0 + 30.0) / 2]))      # mean of the two ranks' losses
@@ -159,7 +162,7 @@ def _stats_rank_main(rank, world, port, q):
     stats.denom[:, 0] = torch.tensor([2.0, 0.0, 1.0, 0.0, 1.0, 0.0]) + rank
     stats.max_radii2D[:] = torch.tensor([3.0, 0.0, 9.0, 0.0, 1.0, 0.0]) if rank == 0 else torch.tensor([4.0, 7.0, 2.0, 0.0, 1.0, 0.0])
     stats.sync()
-    q.put((rank, stats.xyz_gradient_accum.clone(), stats.denom.clone(), stats.max_radii2D.clone(), stats.mean_grads().clone()))
+    q.put((rank, stats.xyz_gradient_accum.numpy().copy(), stats.denom.numpy().copy(), stats.max_radii2D.numpy().copy(), stats.mean_grads().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -178,6 +181,7 @@ def test_densification_statistics_sync_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, acc, den, mr, mean in res:
+        acc, den, mr, mean = (torch.from_numpy(x) for x in (acc, den, mr, mean))
         assert torch.equal(acc[:, 0], torch.tensor([3.0, 0.0, 6.0, 0.0, 1.5, 0.0]))
         assert torch.equal(den[:, 0], torch.tensor([5.0, 1.0, 3.0, 1.0, 3.0, 1.0]))
         assert torch.equal(mr, torch.tensor([4.0, 7.0, 9.0, 0.0, 1.0, 0.0]))
@@ -197,3 +201,28 @@ def test_densify_ops_refuse_cpu_tensors(hip_lib):
     assert hip_lib.moss_knn_grid_workspace_bytes(100000) > 100000 * 24
     assert hip_lib.moss_knn_grid_build(0, None, None, 0, None) != 0          # argument validation happens before any launch
     assert hip_lib.moss_neighbour_kl(-1, 0, None, None, None, None, None, None) != 0
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment must start two ranks itself (it used to run one GPU
+    silently and print n_gpus: 1), relay rank 0's single JSON line, and carry rccl_ranks / allreduce_ms / adamw_ms /
+    replicas_identical.  --dry-run-cpu swaps the GPU step for a host-side gradient bucket so the launcher, the rendezvous, the
+    all-reduce (gloo) and the max-over-ranks timing run on a machine without GPUs."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["MOSS_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run-cpu"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
+    assert res["replicas_identical"] is True and res["backend"] == "gloo"
+    assert res["allreduce_ms"] >= 0.0 and "adamw_ms" in res and res["value"] > 0
+    # a rank that fails takes the launcher down with a non-zero exit code and no JSON line
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)         # no GPU here: every rank asserts
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
