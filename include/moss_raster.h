@@ -376,6 +376,8 @@ void moss_raster_profile_enable(uint32_t stage_mask);
 /* Diagnostics: register a device buffer of 8 x (4 * padded tile count) uint64; while set, the forward blend kernel stores per
  * workgroup {total, barrier-1, staging, barrier-2, cull, trips} cycles of its first wave and {batches, trips} counts. NULL = off. */
 void moss_raster_debug_set_stamps(unsigned long long* device_buffer);
+/* the same for the backward blend kernel: 16 words per wave (start, end of the segment phase, end, item counts and cycle sums) */
+void moss_raster_debug_set_bwd_stamps(unsigned long long* device_buffer);
 /* Diagnostics: override the blend kernels' use of the per-instance block masks (1 = use them, the default; 0 = treat every entry as a
  * hit for every 4x4 block; -1 = back to the MOSS_BLEND_CULL environment default).  The masks only SKIP pairs that cannot reach
  * alpha >= 1/255: final_T, n_contrib and all gradients are bit-identical either way, the images equal up to fp32 summation order

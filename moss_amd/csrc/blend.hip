@@ -313,18 +313,27 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
 // trips = 8k+ cycles of blending, which covers the DMA latency), issues their DMAs, then blends the previous round's records.  Fetching them into registers
 // inside the trip loop (first version of this scheme) made every trip wait on L2: 640 instead of 520 cycles per trip.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LCAP = 1024, LMASK = LCAP - 1;     // per-wave list of hit positions
+constexpr int LCAP = 1024;                       // per-wave list of hit positions (forward kernel)
 constexpr int CHAPTER = 8;                       // 64-entry groups of block masks turned into hit masks at a time (512 entries)
 constexpr int ROUND_HITS = 64;                   // a scan round ends once it has found this many new hits (<= 127 with its last group)
-constexpr int RCAP = 512, RMASK = RCAP - 1;      // per-wave record ring (slots; a multiple of the 64-slot DMA batch): the hits of
+constexpr int RCAP = 512;                        // per-wave record ring (slots; a multiple of the 64-slot DMA batch): the hits of
                                                  // two rounds (<= 2 x 128 + 3 carried) plus one batch of slack
-struct HeavyLds { float4 a[RCAP], b[RCAP], c[RCAP]; uint32_t lst[LCAP]; };
+// The backward kernel's items are short since the forward cuts the lists into depth segments, and it wants SEVERAL waves per SIMD
+// (an item starts with a chain of dependent loads that only another wave's arithmetic can hide): a quarter of the forward's LDS.
+// Rounds of >= 24 new hits (<= 87 with their last group): two rounds + 3 carried + one batch of slack = 241 <= 256 slots.
+constexpr int LCAP_BWD = 256, RCAP_BWD = 256, ROUND_HITS_BWD = 24;
+template <int RC, int LC>
+struct HeavyLdsT { float4 a[RC], b[RC], c[RC]; uint32_t lst[LC]; static constexpr int RMASK = RC - 1, LMASK = LC - 1; };
+typedef HeavyLdsT<RCAP, LCAP> HeavyLds;
+typedef HeavyLdsT<RCAP_BWD, LCAP_BWD> HeavyLdsBwd;
 
 // Issue the DMA batches that cover list entries [from, to): batch q = entries 64q .. 64q+63 -> ring slots (64q & RMASK) + lane.
 // Lanes whose entry is not in the list yet copy the tile's first record (overwritten when the batch is re-issued with that
 // entry; never read before); lanes whose entry was fetched before re-copy the same record.
-__device__ __forceinline__ void dma_records(HeavyLds* L, const float4* __restrict__ recs, int from, int to, int nlist, int lane)
+template <typename LDS>
+__device__ __forceinline__ void dma_records(LDS* L, const float4* __restrict__ recs, int from, int to, int nlist, int lane)
 {
+    constexpr int LMASK = LDS::LMASK, RMASK = LDS::RMASK;
     for (int q = from >> 6; q <= (to - 1) >> 6; q++) {
         const int li = 64 * q + lane;
         const uint32_t p = li < nlist ? L->lst[li & LMASK] : 0u;
@@ -338,13 +347,29 @@ __device__ __forceinline__ void dma_records(HeavyLds* L, const float4* __restric
 
 struct Fetched { float4 a, b, c; float pos1, valid; };   // pos1 = 1-based list position; valid = 0 for a padding slot
 
+// ---- depth segments (see common.h): per-wave emission state of the forward kernel.  Every forward wave owns a private range of
+// slots in its XCD's region and fills it front to back: NO atomics and NO global-memory traffic while a block is being blended (a
+// returning atomic and three stores per cut, waited for by the next round's `s_waitcnt 0`, cost the forward kernel 6 us: measured).
+// The cuts of a block wait in LDS; the end of the item writes them out.  A full range simply ends the cutting (the uncut remainder
+// of a block's list is the block's own backward item, as before), so the range size is a tuning knob, not a correctness bound.
+struct SegEmit {
+    uint4* desc; float* state;   // this wave's slot range
+    uint32_t cap;                // slots in the range
+    uint32_t count;              // slots filled so far
+    int seg_hits;                // hits per segment (a power of two, multiple of 4)
+    float* cut_sums;             // LDS, per wave: [MAX_CUTS][16 pixels][6] -- T at the cut + the five sums the piece in front of it collected
+    uint2* cut_pos;              // LDS, per wave: [MAX_CUTS] -- {first position, end position} of that piece
+};
+constexpr int MAX_CUTS = 16;     // cuts per block (a block with more than MAX_CUTS * SEG_HITS blended hits keeps the rest as its own item)
+
 __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
                                                    const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
                                                    HeavyLds* L, const float* __restrict__ bg_color, float* __restrict__ out_color,
                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
-                                                   unsigned long long* stamp_out)
+                                                   unsigned long long* stamp_out, SegEmit& se, uint32_t* __restrict__ tail_start)
 {
+    constexpr int LMASK = HeavyLds::LMASK, RMASK = HeavyLds::RMASK;
     const int slot = lane & 3, pl = lane >> 2, gbase = lane & ~3;
     const uint32_t below_mask = (1u << slot) - 1u;
     const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
@@ -393,6 +418,36 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
         T = DPP_MOV(X, 0xFF);
         live = (q != 0u) ? 0.0f : live;
         return __ballot(live > 0.0f) == 0ull;
+    };
+
+    // A cut after the hit at list position p_cur - 1: everything this block blended from p_prev up to here becomes a backward work
+    // item of its own.  What that item needs is the pixel state at ITS FAR END: T (known now) and the suffix blends -- the sums of
+    // everything BEHIND the cut, which only exist once the block is finished.  So every piece accumulates its five sums FROM ZERO
+    // (the running totals are carried separately: tC*), the pieces' sums wait in LDS, and the end of the item adds them up from the back
+    // (far pieces are small numbers: summed among themselves they keep their relative precision, where final_total - prefix_total
+    // would lose it to the rounding of the large near pieces -- measured: 6x the float32 oracle's error against float64).
+    int p_prev = 0, n_cuts = 0;
+    float tCr = 0.f, tCg = 0.f, tCb = 0.f, tD = 0.f, tW = 0.f;          // totals of the pieces already cut off (per pixel, all four lanes)
+    auto emit_cut = [&](int p_cur) {
+        if (n_cuts == MAX_CUTS || se.count + (uint32_t)n_cuts >= se.cap) return;
+        GROUP_ALLREDUCE(4, Cr, OP_ADD) GROUP_ALLREDUCE(4, Cg, OP_ADD) GROUP_ALLREDUCE(4, Cb, OP_ADD)
+        GROUP_ALLREDUCE(4, Dacc, OP_ADD) GROUP_ALLREDUCE(4, weight, OP_ADD)
+        if (slot == 0) {
+            float* cs = se.cut_sums + (n_cuts * 16 + pl) * 6;
+            cs[0] = T; cs[1] = Cr; cs[2] = Cg; cs[3] = Cb; cs[4] = Dacc; cs[5] = weight;
+        }
+        if (lane == 0) se.cut_pos[n_cuts] = make_uint2((uint32_t)p_prev, (uint32_t)p_cur);
+        tCr += Cr; tCg += Cg; tCb += Cb; tD += Dacc; tW += weight;
+        Cr = 0.f; Cg = 0.f; Cb = 0.f; Dacc = 0.f; weight = 0.f;
+        p_prev = p_cur;
+        n_cuts++;
+    };
+    // after a trip that consumed four real hits and left `hits_done` behind it: cut if that count is a multiple of the segment length
+    auto maybe_cut = [&](const Fetched& f, int hits_done, bool last_of_all) {
+        if ((hits_done & (se.seg_hits - 1)) != 0 || last_of_all) return;
+        const int last_pos1 = (int)__builtin_amdgcn_readlane(__float_as_int(f.pos1), 3);      // slot 3 of pixel 0: the trip's last hit
+        const int last_valid = (int)__builtin_amdgcn_readlane(__float_as_int(f.valid), 3);
+        if (last_valid != 0) emit_cut((int)__int_as_float(last_pos1));
     };
 
     // list entries: [0, C) blended, [C, F) records requested by DMA, [F, nlist) found by the scan but not requested yet
@@ -459,9 +514,11 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
             for (int t = 0; t < ntrip; t += 2) {
                 const Fetched f1 = get(t + 1);                                             // next trip's LDS reads under this trip
                 if (trip(f0)) { finished = true; break; }
+                maybe_cut(f0, C + 4 * (t + 1), final_round && t + 1 >= ntrip);
                 if (t + 1 >= ntrip) break;
                 f0 = get(t + 2);
                 if (trip(f1)) { finished = true; break; }
+                maybe_cut(f1, C + 4 * (t + 2), final_round && t + 2 >= ntrip);
             }
             C += 4 * ntrip;
             d_trip += STAMP() - t4;
@@ -479,7 +536,31 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
     GROUP_ALLREDUCE(4, Cr, OP_ADD) GROUP_ALLREDUCE(4, Cg, OP_ADD) GROUP_ALLREDUCE(4, Cb, OP_ADD)
     GROUP_ALLREDUCE(4, weight, OP_ADD) GROUP_ALLREDUCE(4, Dacc, OP_ADD)
     GROUP_ALLREDUCE(4, T_stop, OP_MAX) GROUP_ALLREDUCE(4, last_contributor, OP_MAX)
+    if (n_cuts > 0) {
+        // Write the block's pieces out: descriptor, T at the piece's far end, and the suffix blends there -- the sums of everything
+        // behind it, added up from the back: behind the last cut lies what was collected since (Cr ...).
+        __builtin_amdgcn_wave_barrier();
+        float sr = Cr, sg = Cg, sb = Cb, sd = Dacc, sw = weight;
+        for (int k = n_cuts - 1; k >= 0; k--) {
+            const uint32_t idx = se.count + (uint32_t)k;
+            const float* cs = se.cut_sums + (k * 16 + pl) * 6;
+            if (slot == 0) {
+                float2* st = reinterpret_cast<float2*>(se.state + (size_t)idx * SEG_STATE_FLOATS + 6 * pl);
+                st[0] = make_float2(cs[0], sr); st[1] = make_float2(sg, sb); st[2] = make_float2(sd, sw);
+            }
+            if (lane == 0) {
+                // {tile | block << 28, first instance of the tile, first position, end position}: all a backward item needs, in ONE load
+                const uint2 pp = se.cut_pos[k];
+                se.desc[idx] = make_uint4((uint32_t)tile | ((uint32_t)blk << 28), rg.x, pp.x, pp.y);
+            }
+            sr += cs[1]; sg += cs[2]; sb += cs[3]; sd += cs[4]; sw += cs[5];
+        }
+        __builtin_amdgcn_wave_barrier();
+        se.count += (uint32_t)n_cuts;
+        Cr += tCr; Cg += tCg; Cb += tCb; Dacc += tD; weight += tW;     // the pixel's totals
+    }
     const float Tf = T_stop >= 0.0f ? T_stop : T;
+    if (lane == 0) tail_start[(size_t)tile * WAVE_BLOCKS + blk] = (uint32_t)p_prev;   // the block's own backward item starts here
     if (inside && slot == 0) {
         const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
         final_T[pix_id] = Tf;
@@ -494,12 +575,18 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
 
 __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
                                                     const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
-                                                    HeavyLds* L, const float* __restrict__ bg_color,
+                                                    HeavyLdsBwd* L, const float* __restrict__ bg_color,
                                                     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                                                     const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths,
                                                     const float* __restrict__ dL_dalphas, float* __restrict__ inst_grad,
-                                                    size_t slab_stride, uint32_t* __restrict__ inst_mask, int flags)
+                                                    size_t slab_stride, uint32_t* __restrict__ inst_mask, int flags,
+                                                    int lo, int hi_limit, const float* __restrict__ seg_state)
 {
+    // Walks the list positions [lo, end) of the block back to front.  seg_state == NULL: the block's own item -- its range ends where
+    // the list ends for these pixels (end = the largest n_contrib), so every pixel starts from (T_final, Q = 0), exactly the
+    // reference's start (backward.cu:440-447).  seg_state != NULL: a depth segment cut by the forward kernel (end = hi_limit) -- the
+    // pixels still alive at its far end start from the state the forward left there (see below).
+    constexpr int LMASK = HeavyLdsBwd::LMASK, RMASK = HeavyLdsBwd::RMASK, ROUND_HITS = ROUND_HITS_BWD;
     const int slot = lane & 3, pl = lane >> 2;
     // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
     const int row = lane >> 4, rh = row >> 1, rp = row & 1;
@@ -515,10 +602,13 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     const float T_final = inside ? final_Ts[pix_id] : 0.0f;
     const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
     // entries at list positions >= n_eff are behind every pixel's last contributor: nobody visits them
-    int n_eff = last_contributor;
+    int n_eff = hi_limit;                                    // a segment ends where the forward cut it (entries behind a pixel's last
+    if (seg_state == nullptr) {                              // contributor are masked per pixel): its mask loads need not wait for n_contrib
+        n_eff = last_contributor;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d));
-    if (n_eff == 0) return;                                  // nothing was blended into this block: no record, no mask bit
+        for (int d = 32; d >= 1; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d));
+    }
+    if (n_eff <= lo) return;                                 // nothing was blended into this range: no record, no mask bit
 
     float gpr = 0.f, gpg = 0.f, gpb = 0.f, gpd = 0.f, gpa = 0.f;
     if (inside) {
@@ -538,6 +628,16 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     // Pixel state, replicated in the pixel's lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
     // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
     float T = T_final, Q = 0.0f;
+    if (seg_state != nullptr && inside && last_contributor > hi_limit) {
+        // This pixel blends entries BEHIND the segment's far end, so it does not start from the end of its list.  There, T is what
+        // the forward had, and the reference's suffix blends accum_x (backward.cu:529,543,548 unrolled: sum over the entries k behind
+        // of x_k alpha_k T_k, seen from T = 1) are the sums the forward collected behind the cut, divided by T:  Q = sum_x accum_x g_x.
+        const float* st = seg_state + 6 * pl;
+        const float2 s0 = *reinterpret_cast<const float2*>(st), s1 = *reinterpret_cast<const float2*>(st + 2),
+                     s2 = *reinterpret_cast<const float2*>(st + 4);
+        T = s0.x;
+        Q = __fmaf_rn(s0.y, gpr, __fmaf_rn(s1.x, gpg, __fmaf_rn(s1.y, gpb, __fmaf_rn(s2.x, gpd, s2.y * gpa)))) / T;
+    }
 
     auto trip = [&](const Fetched& f) {
         const int pos = (int)f.pos1 - 1;
@@ -612,7 +712,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
 #pragma unroll
                 for (int k = 0; k < CHAPTER; k++) {
                     const int idx = n_eff - 1 - (scan_off + 64 * k + lane);
-                    const unsigned long long b = __ballot(idx >= 0 && (((nx[k] | all_hit) >> blk) & 1u) != 0u);
+                    const unsigned long long b = __ballot(idx >= lo && (((nx[k] | all_hit) >> blk) & 1u) != 0u);
                     bl = lane == k ? b : bl;
                 }
                 vb_lo = (uint32_t)bl; vb_hi = (uint32_t)(bl >> 32);
@@ -630,7 +730,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
                 nlist += c; new_hits += c;
             }
             scan_off += 64;
-            scan_done = scan_off >= n_eff;
+            scan_done = scan_off >= n_eff - lo;
         }
         __builtin_amdgcn_wave_barrier();
         if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
@@ -664,12 +764,17 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
 // algorithmic bytes).  Tiles are dealt to the queues in LPT order, rank r -> queue r % nq; of a queue's tiles the first hx are
 // heavy (16 block items each), the rest light (4 quadrant items each).
 struct WaveItem { int tile, sub, rank; bool heavy, valid; };
+// The FIRST item of a wave is its own rank among the waves of its queue -- no atomic: with one returning atomic per wave at kernel
+// start the last of 1024 waves waited 2-12 us for its first item (same-line atomics serialise, see common.h).  Later items:
+// (waves of the queue) + the value of the queue head.
 __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int nq, int qx, int hx, int n_work,
-                                              const uint32_t* __restrict__ tile_order)
+                                              const uint32_t* __restrict__ tile_order, int first_rank, int q_waves)
 {
-    int qi = 0;
-    if (lane == 0) qi = (int)atomicAdd(my_head, 1u);
-    qi = __builtin_amdgcn_readfirstlane(qi);
+    int qi = first_rank;
+    if (first_rank < 0) {
+        if (lane == 0) qi = (int)atomicAdd(my_head, 1u) + q_waves;
+        qi = __builtin_amdgcn_readfirstlane(qi);
+    }
     WaveItem it;
     it.heavy = qi < WAVE_BLOCKS * hx;
     const int k = it.heavy ? (qi >> 4) : hx + ((qi - WAVE_BLOCKS * hx) >> 2);
@@ -686,26 +791,46 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
                           const uint16_t* __restrict__ inst_bmask,
                           const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                           float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
-                          unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */)
+                          unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */,
+                          uint4* __restrict__ seg_desc, float* __restrict__ seg_state, uint32_t seg_cap, int seg_hits,
+                          uint32_t* __restrict__ tail_start, uint32_t* __restrict__ seg_counts)
 {
-    __shared__ float4 s_ring[4][64][3];                     // light path: the current 64 records of a wave
-    __shared__ HeavyLds s_heavy[4];                         // heavy path: per-wave hit list and record ring (28 KB each)
+    __shared__ HeavyLds s_heavy[4];                         // heavy path: per-wave hit list and record ring (28 KB each); a light item
+    __shared__ float s_cut_sums[4][MAX_CUTS * 16 * 6];      // uses the first 3 KB as its record ring.  Per wave: the cuts of the current block
+    __shared__ uint2 s_cut_pos[4][MAX_CUTS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(&s_heavy[wv]);
     const int n_work = (int)header[5];                       // tile_order lists the tiles that own instances first
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
+    const int q_waves = 4 * (((int)gridDim.x - qx + nq - 1) / nq);     // waves that pull from this queue
+    const int my_rank = ((int)blockIdx.x / nq) * 4 + wv;               // this wave's rank among them
+    // this wave's private slot range: region of its XCD, q_waves equal shares
+    SegEmit se;
+    {
+        const uint32_t share = seg_cap / (uint32_t)max(q_waves, 1);
+        const size_t first = (size_t)qx * seg_cap + (size_t)my_rank * share;
+        se.desc = seg_desc + first; se.state = seg_state + first * SEG_STATE_FLOATS;
+        se.cap = (seg_hits > 0 && q_waves <= MAX_FWD_QUEUE_WAVES) ? share : 0u;
+        se.count = 0u; se.seg_hits = seg_hits > 0 ? seg_hits : (1 << 30);
+        se.cut_sums = s_cut_sums[wv]; se.cut_pos = s_cut_pos[wv];
+    }
+    int first_rank = my_rank;
     for (;;) {
-        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order);
+        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, tile_order, first_rank, q_waves);
+        first_rank = -1;
         if (!it.valid) break;
         if (it.heavy)
             heavy_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, out_color,
                                out_depth, out_alpha, final_T, n_contrib, flags,
-                               stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr);
+                               stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr, se, tail_start);
         else
-            light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, s_ring[wv], bg_color, out_color, out_depth,
+            light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
                                out_alpha, final_T, n_contrib, flags);
     }
+    // how many of its slots this wave filled (EVERY wave writes its count: the backward kernel sums them per region)
+    if (lane == 0 && my_rank < MAX_FWD_QUEUE_WAVES) seg_counts[(size_t)qx * MAX_FWD_QUEUE_WAVES + my_rank] = se.count;
 
     // Tiles without instances get the background only (forward.cu:374-382 with an empty range); done after the queue so that
     // the heavy items start immediately.
@@ -730,33 +855,101 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
                            const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                            const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
                            float* __restrict__ inst_grad /* [16][R][12] */, size_t slab_stride, uint32_t* __restrict__ inst_mask,
-                           uint32_t* __restrict__ leavers, int flags)
+                           int flags, unsigned long long* __restrict__ wstamps /* diagnostics: 16 words per wave, else NULL */,
+                           const uint4* __restrict__ seg_desc, const float* __restrict__ seg_state, uint32_t seg_cap,
+                           const uint32_t* __restrict__ tail_start, const uint32_t* __restrict__ seg_counts, int fwd_grid)
 {
-    __shared__ float4 s_ring[4][64][3];
-    __shared__ HeavyLds s_heavy[4];
+    __shared__ HeavyLdsBwd s_heavy[4];                       // per wave: 13 KB; a light item uses its first 3 KB as the record ring
+    __shared__ uint32_t s_prefix[MAX_FWD_QUEUE_WAVES];       // inclusive prefix sums of the forward waves' segment counts (this XCD's region)
+    static_assert(sizeof(HeavyLdsBwd) >= 64 * 3 * sizeof(float4), "the light path's ring lives inside the heavy path's LDS");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(&s_heavy[wv]);
     const int n_work = (int)header[5];
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
-    for (;;) {
-        const WaveItem it = pull_item(queue_head + qx, lane, nq, qx, hx, n_work, tile_order);
-        if (!it.valid) break;
-        if (it.heavy)
-            heavy_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
-                                n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
-        else
-            light_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, s_ring[wv], bg_color, final_Ts, n_contrib,
-                                dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
-    }
-    // Self-cleaning queue: every wave has made its last pull by now, so the last one to leave rewinds the heads for the next
-    // backward over the same forward state (no memset node -- see raster_api.hip on hipGraph capture).
-    if (lane == 0) {
-        if (atomicAdd(leavers, 1u) == gridDim.x * 4u - 1u) {
-            for (int q = 0; q < NUM_XCD_QUEUES; q++) queue_head[q] = 0u;
-            *leavers = 0u;
+    // queue_head = the line Q_BWD of the queue area; the segment pop heads are the lines Q_SEG_HEAD
+    uint32_t* const seg_heads = queue_head + (size_t)(Q_SEG_HEAD - Q_BWD) * QLINE_WORDS;
+    const int q_waves = 4 * (((int)gridDim.x - qx + nq - 1) / nq);
+    int first_rank = ((int)blockIdx.x / nq) * 4 + wv;
+#define WSTAMP() (wstamps ? __builtin_amdgcn_s_memtime() : 0ull)
+    const unsigned long long t_start = WSTAMP();
+    unsigned long long n_seg = 0, c_seg = 0, c_pop = 0, n_tail = 0, c_tail = 0, c_tailpop = 0;
+    // ---- 1. the depth segments the forward kernel cut on this XCD (pieces of SEG_HITS hits of the heavy tiles' lists; the records of
+    // those tiles are in this L2).  A wave's first segment is its rank among the queue's waves, later ones come from the region's pop head
+    // (one returning atomic on the region's own cache line, AFTER the item: requesting the next one while the current item runs --
+    // tried -- lets every wave sit on two items, and with fewer than two items per wave that decided the kernel's length).
+    if (!(flags & 16)) {
+        // The forward waves of this XCD filled private slot ranges; their counts give every segment of the region a flat index.  Each
+        // wave builds the prefix table itself (all four waves of the workgroup write the same values: no barrier needed).
+        const int fq = min(NUM_XCD_QUEUES, fwd_grid);
+        const int f_waves = qx < fq ? 4 * ((fwd_grid - qx + fq - 1) / fq) : 0;              // forward waves that fed this region
+        uint32_t total = 0u;
+        if (f_waves > 0 && f_waves <= MAX_FWD_QUEUE_WAVES) {
+            const uint32_t* cnt = seg_counts + (size_t)qx * MAX_FWD_QUEUE_WAVES;
+            uint32_t carry = 0u;
+            for (int b0 = 0; b0 < f_waves; b0 += 64) {
+                uint32_t v = b0 + lane < f_waves ? cnt[b0 + lane] : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)v, d); if (lane >= d) v += y; }
+                v += carry;
+                if (b0 + lane < f_waves) s_prefix[b0 + lane] = v;
+                carry = (uint32_t)__shfl((int)v, 63);
+            }
+            total = carry;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t share = seg_cap / (uint32_t)max(f_waves, 1);
+        uint32_t* const head = seg_heads + (size_t)qx * QLINE_WORDS;
+        uint32_t i = (uint32_t)first_rank;
+        while (i < total) {
+            const unsigned long long tp0 = WSTAMP();
+            // flat index -> (forward wave, slot in its range): first wave whose inclusive prefix exceeds i
+            int lo_w = 0, hi_w = f_waves - 1;
+            while (lo_w < hi_w) { const int mid = (lo_w + hi_w) >> 1; if (s_prefix[mid] <= i) lo_w = mid + 1; else hi_w = mid; }
+            const uint32_t before = lo_w > 0 ? s_prefix[lo_w - 1] : 0u;
+            const size_t slot_idx = (size_t)qx * seg_cap + (size_t)lo_w * share + (i - before);
+            const uint4 d = seg_desc[slot_idx];
+            const unsigned long long tp1 = WSTAMP();
+            c_pop += tp1 - tp0;
+            n_seg++;
+            // {tile | block << 28, first instance of the tile, first position, end position}: everything the item needs in ONE load
+            heavy_backward_item(W, H, gx, (int)(d.x & 0x0fffffffu), (int)(d.x >> 28), lane, make_uint2(d.y, d.y + d.w), inst_rec, inst_bmask,
+                                &s_heavy[wv], bg_color, final_Ts, n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride,
+                                inst_mask, flags, (int)d.z, (int)d.w, (flags & 64) ? nullptr : seg_state + slot_idx * SEG_STATE_FLOATS);
+            c_seg += WSTAMP() - tp1;
+            uint32_t nxt = 0u;
+            if (lane == 0) nxt = atomicAdd(head, 1u) + (uint32_t)q_waves;
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
         }
     }
+    const unsigned long long t_phase1 = WSTAMP();
+    // ---- 2. every block's own item: the part of its list behind the last cut (the whole list if it was never cut)
+    for (;;) {
+        const unsigned long long tq0 = WSTAMP();
+        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, tile_order, first_rank, q_waves);
+        first_rank = -1;
+        const unsigned long long tq1 = WSTAMP();
+        c_tailpop += tq1 - tq0;
+        if (!it.valid) break;
+        n_tail++;
+        if (it.heavy)
+            heavy_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
+                                n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags,
+                                (flags & 32) ? 0 : (int)tail_start[(size_t)it.tile * WAVE_BLOCKS + it.sub], 0x7fffffff, nullptr);
+        else
+            light_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
+                                dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
+        c_tail += WSTAMP() - tq1;
+    }
+    if (wstamps && lane == 0) {
+        unsigned long long* w = wstamps + ((size_t)blockIdx.x * 4 + wv) * 16;
+        w[0] = t_start; w[1] = t_phase1; w[2] = WSTAMP(); w[3] = n_seg; w[4] = c_seg; w[5] = c_pop; w[6] = 0; w[7] = n_tail;
+        w[8] = c_tail; w[9] = c_tailpop; w[10] = (unsigned long long)qx;
+    }
+#undef WSTAMP
+    // (the queue heads of this kernel are rewound by the per-Gaussian backward kernel that follows it on the stream -- a counter that
+    // every wave increments on its way out was 1024 serialised atomics at the very end of the kernel)
 }
 
 int env_int(const char* name, int dflt)
@@ -784,6 +977,7 @@ int persistent_workgroups()
 }  // anonymous namespace
 
 unsigned long long* g_stamps = nullptr;      // diagnostics buffer registered by moss_raster_debug_set_stamps (NULL = off)
+unsigned long long* g_bwd_stamps = nullptr;  // ... by moss_raster_debug_set_bwd_stamps: 16 words per wave of the backward blend kernel
 int g_cull_override = -1;                    // moss_raster_debug_set_cull
 
 // gradient-record slabs per instance: one per 4x4 block (sparse: only blended pairs are written and flagged in inst_mask)
@@ -797,9 +991,12 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
     const int T = fp.gx * fp.gy;
     const int wgs = min(4 * T, persistent_workgroups());               // 4 independent waves per workgroup, 16 items per tile
+    // hits per depth segment of the backward (0 = never cut: every block is ONE backward item, the round-1 behaviour)
+    static const int seg_hits_env = [] { const int v = env_int("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
+    const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
     MOSS_LAUNCH_TIMED(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
-                       im.header + HDR_FWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
-                       im.final_T, im.n_contrib, flags, g_stamps);
+                       im.queues + (size_t)Q_FWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                       im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
@@ -807,14 +1004,25 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
 {
     (void)g;
     static const int env_flags = env_int("MOSS_BLEND_CULL", 1);
-    const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
+    // diagnostics (results are wrong with any of them): 16 = skip the segment items, 32 = block items ignore the cuts, 64 = segment
+    // items start from (T_final, 0)
+    static const int dbg = env_int("MOSS_BWD_DEBUG", 0) & (16 | 32 | 64);
+    const int flags = (g_cull_override >= 0 ? g_cull_override : env_flags) | dbg;
     const int T = fp.gx * fp.gy;
-    const int wgs = min(4 * T, persistent_workgroups());
-    // the queue heads and the leaver count are zero here: cleared by the forward, rewound by each backward
+    // Workgroups per CU: 52.5 KB of LDS each, so up to three fit; never more than are RESIDENT together (a wave's first work item is
+    // its rank in the queue: a workgroup that only starts when another one has left would sit on its items until then).
+    static const int bwd_wgs_per_cu = [] {
+        int occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, blend_backward_wave_kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        return std::max(1, std::min(occ, env_int("MOSS_BWD_WGS_PER_CU", 3)));
+    }();
+    const int wgs = min(4 * T, persistent_workgroups() * bwd_wgs_per_cu);
+    // the queue heads are zero here: cleared by the forward, rewound after each backward (preprocess_backward_kernel)
     MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
-                       im.header + HDR_BWD_HEADS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
+                       im.queues + (size_t)Q_BWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
                        dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
-                       im.header + HDR_LEAVERS, flags);
+                       flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
+                       min(4 * T, persistent_workgroups()) /* the forward kernel's grid */);
 }
 
 }  // namespace moss

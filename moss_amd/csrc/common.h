@@ -71,23 +71,49 @@ struct GeomView {
 // [16..23] / [24..31] per-XCD queue heads of the wave blend kernels (forward / backward)
 constexpr int HEADER_WORDS = 32;
 constexpr int LIGHT_TILE_LOG2 = 7;     // tiles with fewer than 2^7 entries are "light": blended one pixel per lane ([7] = heavy tiles)
-constexpr int HDR_FWD_HEADS = 16, HDR_BWD_HEADS = 24, HDR_LEAVERS = 10, NUM_XCD_QUEUES = 8;
+constexpr int NUM_XCD_QUEUES = 8;
+// Depth segments of the backward blend (blend.hip): while it blends a heavy 4x4 block front to back, the forward kernel cuts the
+// block's hit list every SEG_HITS hits and leaves, per cut, a descriptor {tile, block, first position, end position} plus the pixel
+// state AT THE END of the piece (T and the five running sums, 16 pixels x 6 floats).  The backward kernel then processes every
+// piece as a work item of its own -- a long list is walked by several waves at once instead of back to front by one.
+// Every queue word lives in a cache line of its own (QLINE_WORDS apart): atomics on words of ONE line are executed one after the
+// other for the whole device, ~11.4 ns each whatever their addresses inside the line (scripts/micro/atomic_queue.hip: eight queue
+// heads in eight consecutive words behaved like a single counter -- the last of 1024 waves got its first work item 12 us after
+// the kernel started).  Lines: Q_FWD + xcd / Q_BWD + xcd = work-queue heads of the forward / backward blend, Q_SEG_ALLOC + xcd =
+// segment slots handed out by the forward, Q_SEG_HEAD + xcd = segment pop heads of the backward.
+constexpr int QLINE_WORDS = 64;
+constexpr int Q_FWD = 0, Q_BWD = 8, Q_SEG_ALLOC = 16, Q_SEG_HEAD = 24, Q_LINES = 32;
+constexpr int MAX_FWD_QUEUE_WAVES = 128;    // forward waves per XCD region the segment bookkeeping supports (MI355X, one workgroup per CU: 128); more = no cuts
+constexpr int SEG_STATE_FLOATS = 16 * 6;      // per segment and pixel of the block: T at the segment's far end + the five sums
+                                              // (r, g, b, depth, weight) of everything the pixel blends BEHIND it
+inline size_t seg_region_cap(int R) { return (size_t)(R > 0 ? R : 0) / 128 + 4096; }   // slots per XCD region (shared equally by its forward waves)
 struct ImageView {
     uint32_t* header;
+    uint32_t* queues;        // Q_LINES cache lines of QLINE_WORDS words, one counter each (cleared with the header)
     uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base; uint32_t* tile_order;
     float* final_T; uint32_t* n_contrib;
+    uint32_t* tail_start;    // per (tile, 4x4 block): list position where the part of the block's list NOT covered by depth segments begins
+    uint32_t* seg_counts;    // [NUM_XCD_QUEUES][MAX_FWD_QUEUE_WAVES]: segments each forward wave left in its slot range
     static ImageView at(char* base, int W, int H)
     {
         ImageView v; char* p = base;
         size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
         v.header = carve<uint32_t>(p, HEADER_WORDS);
+        v.queues = carve<uint32_t>(p, (size_t)Q_LINES * QLINE_WORDS);
         v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
         v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T); v.tile_order = carve<uint32_t>(p, T);
         v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
+        v.tail_start = carve<uint32_t>(p, 16 * T);
+        v.seg_counts = carve<uint32_t>(p, (size_t)NUM_XCD_QUEUES * MAX_FWD_QUEUE_WAVES);
         return v;
     }
-    static size_t bytes(int W, int H) { char* z = nullptr; ImageView v = at(z, W, H); return (size_t)((char*)v.n_contrib - z) + align_up((size_t)W * H * 4); }
-    // header + tile_count + tile_cursor are contiguous (each carved at 16-byte granularity or coarser): one clear covers them
+    static size_t bytes(int W, int H)
+    {
+        char* z = nullptr; ImageView v = at(z, W, H);
+        const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        return (size_t)((char*)v.seg_counts - z) + align_up((size_t)NUM_XCD_QUEUES * MAX_FWD_QUEUE_WAVES * 4);
+    }
+    // header + queues + tile_count + tile_cursor are contiguous (each carved at 16-byte granularity or coarser): one clear covers them
     size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
 };
 
@@ -139,6 +165,7 @@ extern thread_local StageEvents g_stage_events;          // raster_api.hip
     } while (0)
 
 extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
+extern unsigned long long* g_bwd_stamps;   // optional per-wave stamps of the backward blend kernel (diagnostics), blend.hip
 extern int g_cull_override;            // -1 = MOSS_BLEND_CULL decides; 0 / 1 = block-mask culling forced off / on (diagnostics), blend.hip
 int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
@@ -149,6 +176,9 @@ struct BinView {
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
     float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
     float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per 4x4 block of a tile)
+    uint4* seg_desc;         // NUM_XCD_QUEUES regions of seg_cap descriptors {tile, block, first position, end position}
+    float* seg_state;        // SEG_STATE_FLOATS per descriptor
+    uint32_t seg_cap;        // slots per region
     int slabs; size_t slab_stride_floats;
     static BinView at(char* base, int R)
     {
@@ -159,6 +189,9 @@ struct BinView {
         b.inst_mask = carve<uint32_t>(p, n);
         b.inst_bmask = carve<uint16_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);
+        b.seg_cap = (uint32_t)seg_region_cap(R);
+        b.seg_desc = carve<uint4>(p, (size_t)NUM_XCD_QUEUES * b.seg_cap);
+        b.seg_state = carve<float>(p, (size_t)NUM_XCD_QUEUES * b.seg_cap * SEG_STATE_FLOATS);
         b.inst_grad = reinterpret_cast<float4*>(p);
         b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);
         return b;
@@ -191,7 +224,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* opacities /* only read in raw mode */,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
-                                GeomView g, BinView b, const uint32_t* header,
+                                GeomView g, BinView b, const uint32_t* header, uint32_t* queues /* backward heads are rewound here */,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                                 const float* transforms, float* dL_dtransforms, hipStream_t s);

@@ -449,8 +449,16 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                            const float* __restrict__ transforms, float* __restrict__ dL_dtransforms,
                            const float* __restrict__ opacities /* raw mode only */, int raw,
-                           unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */)
+                           unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */,
+                           uint32_t* __restrict__ queues)
 {
+    // Rewind the work-queue heads of the blend-backward kernel that ran just before this one on the stream, so that another backward
+    // over the same forward state (retain_graph) starts from zero again.  (The forward clears them per frame; doing it HERE instead
+    // of by the last wave to leave the blend kernel keeps 1024 same-address atomics off that kernel's critical path.)
+    if (queues != nullptr && blockIdx.x == 0 && threadIdx.x < 2 * NUM_XCD_QUEUES) {
+        const int line = threadIdx.x < NUM_XCD_QUEUES ? Q_BWD + (int)threadIdx.x : Q_SEG_HEAD + (int)threadIdx.x - NUM_XCD_QUEUES;
+        queues[(size_t)line * QLINE_WORDS] = 0u;
+    }
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then the same for dL_dsh out
 #define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
     PSTAMP(0);
@@ -985,7 +993,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                                GeomView g, BinView b, const uint32_t* header,
+                                GeomView g, BinView b, const uint32_t* header, uint32_t* queues,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                                 const float* transforms, float* dL_dtransforms, hipStream_t s)
@@ -1001,7 +1009,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw, g_stamps)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw, g_stamps, queues)
     if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
 }

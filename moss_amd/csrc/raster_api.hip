@@ -288,7 +288,7 @@ static int backward_impl(
         STAGE_CHECK("blend_backward");
     }
     { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
-      launch_preprocess_backward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, im.header,
+      launch_preprocess_backward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, im.header, im.queues,
                                  dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                                  transforms, dL_dtransforms, s); }
     STAGE_CHECK("preprocess_backward");
@@ -419,6 +419,7 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
 }
 
 void moss_raster_debug_set_stamps(unsigned long long* device_buffer) { moss::g_stamps = device_buffer; }
+void moss_raster_debug_set_bwd_stamps(unsigned long long* device_buffer) { moss::g_bwd_stamps = device_buffer; }
 void moss_raster_debug_set_cull(int mode) { moss::g_cull_override = mode; }
 
 void moss_raster_profile_enable(uint32_t stage_mask)
