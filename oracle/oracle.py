@@ -221,9 +221,12 @@ def _forward64(bg, means3D, colors_precomp, opacities, scales, rotations, scale_
 
 
 def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-             projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None):
+             projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None,
+             f32_accumulators=False):
     """``fw`` is the namespace returned by :func:`forward`.  Returns the reference's 8 gradient arrays
-    (rasterize_points.cu:205) plus dL_dconic as a namespace.  A float64 ``fw`` (forward(f64=True)) runs the float64 build."""
+    (rasterize_points.cu:205) plus dL_dconic as a namespace.  A float64 ``fw`` (forward(f64=True)) runs the float64 build.
+    ``f32_accumulators``: the blend backward adds its per-pixel terms in float32 in loop order -- one of the orders the reference's
+    atomicAdd can take -- instead of in double (the default: the centre of that distribution)."""
     is64 = bool(getattr(fw, "f64", False))
     L = lib64() if is64 else lib()
     dt = np.float64 if is64 else np.float32
@@ -258,7 +261,8 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     ddep = _f(dL_dout_depth).reshape(H * W)
     dalp = _f(dL_dout_alpha).reshape(H * W)
     color_ptr = colors_precomp if colors_precomp is not None else fw.rgb    # rasterizer_impl.cu:397
-    L.oracle_render_backward(C.c_int(P), C.c_int(W), C.c_int(H), _p(fw.ranges), _p(fw.point_list), _p(bg),
+    (L.oracle_render_backward_f32acc if f32_accumulators else L.oracle_render_backward)(
+                             C.c_int(P), C.c_int(W), C.c_int(H), _p(fw.ranges), _p(fw.point_list), _p(bg),
                              _p(fw.means2D), _p(fw.conic_opacity), _p(np.ascontiguousarray(color_ptr)), _p(fw.depths),
                              _p(fw.final_T), _p(fw.n_contrib), _p(dpix), _p(ddep), _p(dalp),
                              _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors))

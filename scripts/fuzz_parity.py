@@ -36,7 +36,7 @@ for seed in range(first, first + n_cases):
         fw, t, e = tp._check_forward(d, dev, max_fragile=2e-2)
         if t.R > 0:
             g = tp._check_backward(d, dev, fw, t, e, zero_depth=bool(seed & 1), tol=2e-2, cos_gap=1e-3)
-            # the block masks must be conservative: with culling off the decisions and every gradient are bit-identical
+            # the block masks must be conservative: with culling off the decisions and every gradient equals up to rounding
             L.moss_raster_debug_set_cull(0)
             try:
                 t0 = hp.hip_forward(d, dev)
@@ -48,7 +48,8 @@ for seed in range(first, first + n_cases):
                 assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), "culling changed the image"
             for k, v in vars(g).items():
                 if v is not None and torch.is_tensor(v):
-                    assert torch.equal(v, getattr(g0, k)), f"culling changed {k}"
+                    v0 = getattr(g0, k)                      # (segments are cut every 64 HITS: the unculled run cuts elsewhere -> rounding only)
+                    assert float((v - v0).abs().max()) <= 1e-5 * float(v0.abs().max()) + 1e-30, f"culling changed {k}"
     except Exception as ex:                                      # keep going: report every failing seed
         bad += 1
         failures.append({"seed": seed, "P": s.P, "W": s.camera.W, "H": s.camera.H, "mode": mode, "degree": degree, "colors": colors,

@@ -47,11 +47,12 @@ def oracle_forward(d):
                           c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
 
 
-def oracle_backward(d, fw, dc, dd, da):
+def oracle_backward(d, fw, dc, dd, da, f32_accumulators=False):
     c = d.cam
     return oracle.backward(fw, d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), _np(d.scales), _np(d.rotations),
                            d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(), c.tanfovx,
-                           c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
+                           c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms),
+                           f32_accumulators=f32_accumulators)
 
 
 def _np(t):
@@ -196,3 +197,27 @@ def scaled_err(a, b, scale):
     dead = float(np.abs(a - b)[~pos].max()) if (~pos).any() else 0.0
     live = float((np.abs(a - b)[pos] / s[pos]).max()) if pos.any() else 0.0
     return live, dead
+
+
+U32 = 2.0 ** -24      # unit roundoff of float32
+
+
+def adjudication_excess(got, refs32, ref64, scale, factor=2.0):
+    """The float64 adjudication of one gradient tensor, element by element, in units of the element's contribution mass:
+
+        |got - f64|  <=  factor * E32 * mass  +  excess * mass
+
+    E32 = the worst distance from float64, in mass units, of the float32 restatements in ``refs32`` on this tensor: the oracle with
+    double accumulators (the centre of the reference's distribution) and the oracle with FLOAT32 accumulators added in loop order
+    (``f32_accumulators=True``: one of the orders the reference's atomicAdd can take, i.e. the reference's arithmetic including the
+    rounding of its atomics -- what an image-covering Gaussian with 10^4 contributing pixels actually gets).  Returns
+    (largest excess, E32, largest |got - f64| / mass); elements without mass must agree exactly (asserted)."""
+    a = np.asarray(got, dtype=np.float64); b64 = np.asarray(ref64, dtype=np.float64)
+    s = np.asarray(scale, dtype=np.float64).reshape(a.shape)
+    pos = s > 0
+    assert not np.abs(a - b64)[~pos].any(), "an element that nothing contributes to is not exactly zero"
+    if not pos.any():
+        return 0.0, 0.0, 0.0
+    e32 = max(float((np.abs(np.asarray(r, dtype=np.float64) - b64)[pos] / s[pos]).max()) for r in refs32)
+    err = np.abs(a - b64)[pos] / s[pos]
+    return float(err.max() - factor * e32), e32, float(err.max())
