@@ -35,7 +35,7 @@ namespace moss {
 
 namespace {
 
-constexpr int NPART = 12;           // 9 partial gradients padded to 12 floats (48 B) per (wave, entry)
+constexpr int NPART = GRAD_REC_FLOATS;   // 9 partial gradients per (instance, block) record, padded (common.h)
 
 struct PairEval { float power, G, alpha; };
 

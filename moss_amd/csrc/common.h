@@ -72,6 +72,9 @@ struct GeomView {
 constexpr int HEADER_WORDS = 32;
 constexpr int LIGHT_TILE_LOG2 = 7;     // tiles with fewer than 2^7 entries are "light": blended one pixel per lane ([7] = heavy tiles)
 constexpr int NUM_XCD_QUEUES = 8;
+// One gradient record per (instance, 4x4 block): 9 values, padded to GRAD_REC_FLOATS.  16 (one 64-byte cache line per record: the
+// per-Gaussian gather touches ONE line per record) or 12 (48 bytes: three of four records straddle two lines; measured: same 35 us).
+constexpr int GRAD_REC_FLOATS = 12;
 // Depth segments of the backward blend (blend.hip): while it blends a heavy 4x4 block front to back, the forward kernel cuts the
 // block's hit list every SEG_HITS hits and leaves, per cut, a descriptor {tile, block, first position, end position} plus the pixel
 // state AT THE END of the piece (T and the five running sums, 16 pixels x 6 floats).  The backward kernel then processes every
@@ -184,7 +187,7 @@ struct BinView {
     {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
         b.slabs = blend_subgroups();
-        b.slab_stride_floats = align_up(3 * n * 16) / 4;
+        b.slab_stride_floats = align_up(GRAD_REC_FLOATS * n * 4) / 4;
         b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n); b.inst_tile = carve<uint32_t>(p, n);
         b.inst_mask = carve<uint32_t>(p, n);
         b.inst_bmask = carve<uint16_t>(p, n);

@@ -418,17 +418,6 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 // order -> bitwise reproducible; then conic->cov2D->cov3D/mean (backward.cu:144-274), projection of the 2-D mean
 // gradient (:370-387), SH (:20-139) and scale/rotation (:278-341).  Writes every output element exactly once.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv)   // auxiliary.h:107-117
-{
-    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-    float3 r;
-    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
-    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
-    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
-    return r;
-}
-
 // STAGE_SH (requires M == 16, shs and dL_dsh given): the block's SH records are read from HBM with coalesced loads into LDS and
 // the dL_dsh records leave the same way.  Per thread a record is 48 floats at a 192-byte stride, i.e. every one of the 48 loads
 // and 48 stores of a wave would touch 64 different cache lines; through LDS (row stride 49 words: conflict-free) the global side
@@ -553,7 +542,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                             const bool any = bits[k] != 0u;
                             const uint32_t sl = any ? (uint32_t)(__ffs((int)bits[k]) - 1) : 0u;
                             bits[k] &= bits[k] - 1u;                               // (0 stays 0)
-                            const uint32_t o = any ? sl * slab_bytes + pp[kb + k] * 48u : OOB;
+                            const uint32_t o = any ? sl * slab_bytes + pp[kb + k] * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
                             rr[k][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
                             rr[k][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 16u : OOB, 0, 0);
                             rr[k][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 32u : OOB, 0, 0);
@@ -581,7 +570,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             // only the slabs flagged in the instance's mask, ascending
             for (uint32_t mbits = inst_mask[pos]; mbits != 0u; mbits &= mbits - 1u) {
                 const int sl = __ffs((int)mbits) - 1;
-                const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)pos;
+                const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)pos;
                 const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
                 gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
@@ -627,7 +616,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                         for (int j = 0; j < 4; j++) {
                             qd.w[j] = m ? 1.0f : 0.0f;
                             if (m) { sl = __ffs((int)m) - 1; m &= m - 1u; }
-                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)p[i];
+                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
                             qd.r[j][0] = rec[0]; qd.r[j][1] = rec[1]; qd.r[j][2] = rec[2];
                         }
                         mk[i] = m;                                               // what is left for the clean-up loop
@@ -658,7 +647,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                     for (int i = 0; i < IPL; i++) {
                         for (uint32_t mbits = mk[i]; mbits != 0u; mbits &= mbits - 1u) {
                             const int sl = __ffs((int)mbits) - 1;
-                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + 3 * (size_t)p[i];
+                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
                             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                             acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
                             acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
@@ -696,196 +685,187 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                           : ((M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr);
 
     if (visible) {
-        float view[16], proj[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) { view[i] = viewmatrix[i]; proj[i] = projmatrix[i]; }
+        // ================= per-Gaussian backward, in matrix form =================================================================
+        // What is differentiated is the reference's forward (forward.cu:74-113, 118-152, 20-71, 196-237) with the conventions its
+        // backward fixes (backward.cu:144-396): 1/(det^2 + 1e-7) in the inverse, no gradient through a clamped t.x/t.z, the SH clamp
+        // flags, the quaternion used as given.  The expressions are this file's own: every step is a small matrix identity.
+        //
+        // (1) conic K = inverse(S2), S2 = [[a b][b c]] the dilated 2-D covariance.  The blend kernels deliver G = dL/dK as a full
+        //     symmetric matrix [[gA gB][gB gC]] (gB per off-diagonal entry).  d(inverse):  dL/dS2 = -K G K = -(adj G adj) / det^2 with
+        //     adj = [[c -b][-b a]]; the reference regularises 1/det^2 as 1/(det^2 + 1e-7) (backward.cu:203) -- kept.
+        // (2) S2 = A S3 A^T + 0.3 I with A = J Rv (2x3): dL/dS3 = A^T dS2 A (the six-vector doubles the off-diagonals, each
+        //     appearing twice in the matrix), dL/dA = 2 dS2 A S3.
+        // (3) A = J Rv: dL/dJ = dL/dA Rv^T; J = [[fx/tz 0 -fx tx/tz^2][0 fy/tz -fy ty/tz^2]] so, written with J's own entries,
+        //     dJ00/dtz = -J00/tz, dJ02/dtx = -J00/tz, dJ02/dtz = -2 J02/tz (same for the y row); dL/dmean = Rv^T dL/dt.
+        const float Rv[3][3] = { { viewmatrix[0], viewmatrix[4], viewmatrix[8] }, { viewmatrix[1], viewmatrix[5], viewmatrix[9] },
+                                 { viewmatrix[2], viewmatrix[6], viewmatrix[10] } };            // t = Rv p + (view[12..14])
         const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
-        float cov3D[6];
-        const float* csrc = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
+        const float* c6 = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
+        const float S3[3][3] = { { c6[0], c6[1], c6[2] }, { c6[1], c6[3], c6[4] }, { c6[2], c6[4], c6[5] } };
+        float t[3];
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov3D[i] = csrc[i];
-
-        // ---- computeCov2DCUDA, backward.cu:144-274
-        const Cov2DSetup cs = cov2d_setup(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view);
+        for (int r = 0; r < 3; r++) t[r] = Rv[r][0] * mean.x + Rv[r][1] * mean.y + Rv[r][2] * mean.z + viewmatrix[12 + r];
         const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float x_grad_mul = cs.txtz < -limx || cs.txtz > limx ? 0 : 1;
-        const float y_grad_mul = cs.tytz < -limy || cs.tytz > limy ? 0 : 1;
-        const M3& T = cs.T; const M3& V = cs.Vrk; const M3& Wm = cs.W;
-        M3 cov2D = m3_mul(m3_mul(m3_t(T), m3_t(V)), T);
-        const float a = cov2D.m[0][0] += 0.3f;
-        const float b = cov2D.m[0][1];
-        const float c = cov2D.m[1][1] += 0.3f;
-        const float denom = a * c - b * b;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        const float3 dcon = make_float3(gca, gcb, gcc);
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-c * c * dcon.x + 2 * b * c * dcon.y + (denom - a * c) * dcon.z);
-            dL_dc = denom2inv * (-a * a * dcon.z + 2 * a * b * dcon.y + (denom - a * c) * dcon.x);
-            dL_db = denom2inv * 2 * (b * c * dcon.x - (denom + 2 * b * b) * dcon.y + a * b * dcon.z);
-            dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
-            dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
-            dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
-            dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
-            dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
-            dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+        const float rx = t[0] / t[2], ry = t[1] / t[2];
+        const bool x_free = !(rx < -limx || rx > limx), y_free = !(ry < -limy || ry > limy);     // forward.cu:82-87 clamp inactive
+        const float tx = fminf(limx, fmaxf(-limx, rx)) * t[2], ty = fminf(limy, fmaxf(-limy, ry)) * t[2];
+        const float itz = 1.0f / t[2];
+        const float J00 = h_x * itz, J11 = h_y * itz, J02 = -(h_x * tx) * (itz * itz), J12 = -(h_y * ty) * (itz * itz);
+        float A[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { A[0][k] = J00 * Rv[0][k] + J02 * Rv[2][k]; A[1][k] = J11 * Rv[1][k] + J12 * Rv[2][k]; }
+        float AS[2][3];                                                                          // A S3
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) AS[i][k] = A[i][0] * S3[0][k] + A[i][1] * S3[1][k] + A[i][2] * S3[2][k];
+        const float a2 = AS[0][0] * A[0][0] + AS[0][1] * A[0][1] + AS[0][2] * A[0][2] + 0.3f;
+        const float b2 = AS[0][0] * A[1][0] + AS[0][1] * A[1][1] + AS[0][2] * A[1][2];
+        const float c2 = AS[1][0] * A[1][0] + AS[1][1] * A[1][1] + AS[1][2] * A[1][2] + 0.3f;
+        const float det = a2 * c2 - b2 * b2;
+        const float w = 1.0f / (det * det + 0.0000001f);
+        // (1)  dS2 = -w adj G adj
+        const float u0 = c2 * gca - b2 * gcb, u1 = c2 * gcb - b2 * gcc;           // rows of adj G
+        const float v0 = a2 * gcb - b2 * gca, v1 = a2 * gcc - b2 * gcb;
+        float d2[2][2];
+        d2[0][0] = -w * (u0 * c2 - u1 * b2);
+        d2[0][1] = -w * (u1 * a2 - u0 * b2);
+        d2[1][1] = -w * (v1 * a2 - v0 * b2);
+        d2[1][0] = d2[0][1];
+        if (w == 0.0f) { d2[0][0] = 0.f; d2[0][1] = 0.f; d2[1][0] = 0.f; d2[1][1] = 0.f; }   // (denom2inv == 0 case of backward.cu:205)
+        // (2)  dS3 = A^T dS2 A,  dA = 2 dS2 (A S3)
+        float DA[2][3];                                                                          // dS2 A
+#pragma unroll
+        for (int k = 0; k < 3; k++) { DA[0][k] = d2[0][0] * A[0][k] + d2[0][1] * A[1][k]; DA[1][k] = d2[1][0] * A[0][k] + d2[1][1] * A[1][k]; }
+        {
+            const float f00 = A[0][0] * DA[0][0] + A[1][0] * DA[1][0], f11 = A[0][1] * DA[0][1] + A[1][1] * DA[1][1],
+                        f22 = A[0][2] * DA[0][2] + A[1][2] * DA[1][2];
+            const float f01 = A[0][0] * DA[0][1] + A[1][0] * DA[1][1], f02 = A[0][0] * DA[0][2] + A[1][0] * DA[1][2],
+                        f12 = A[0][1] * DA[0][2] + A[1][1] * DA[1][2];
+            dcov[0] = f00; dcov[3] = f11; dcov[5] = f22; dcov[1] = 2.0f * f01; dcov[2] = 2.0f * f02; dcov[4] = 2.0f * f12;
         }
-        const float dL_dT00 = 2 * (T.m[0][0] * V.m[0][0] + T.m[0][1] * V.m[0][1] + T.m[0][2] * V.m[0][2]) * dL_da +
-            (T.m[1][0] * V.m[0][0] + T.m[1][1] * V.m[0][1] + T.m[1][2] * V.m[0][2]) * dL_db;
-        const float dL_dT01 = 2 * (T.m[0][0] * V.m[1][0] + T.m[0][1] * V.m[1][1] + T.m[0][2] * V.m[1][2]) * dL_da +
-            (T.m[1][0] * V.m[1][0] + T.m[1][1] * V.m[1][1] + T.m[1][2] * V.m[1][2]) * dL_db;
-        const float dL_dT02 = 2 * (T.m[0][0] * V.m[2][0] + T.m[0][1] * V.m[2][1] + T.m[0][2] * V.m[2][2]) * dL_da +
-            (T.m[1][0] * V.m[2][0] + T.m[1][1] * V.m[2][1] + T.m[1][2] * V.m[2][2]) * dL_db;
-        const float dL_dT10 = 2 * (T.m[1][0] * V.m[0][0] + T.m[1][1] * V.m[0][1] + T.m[1][2] * V.m[0][2]) * dL_dc +
-            (T.m[0][0] * V.m[0][0] + T.m[0][1] * V.m[0][1] + T.m[0][2] * V.m[0][2]) * dL_db;
-        const float dL_dT11 = 2 * (T.m[1][0] * V.m[1][0] + T.m[1][1] * V.m[1][1] + T.m[1][2] * V.m[1][2]) * dL_dc +
-            (T.m[0][0] * V.m[1][0] + T.m[0][1] * V.m[1][1] + T.m[0][2] * V.m[1][2]) * dL_db;
-        const float dL_dT12 = 2 * (T.m[1][0] * V.m[2][0] + T.m[1][1] * V.m[2][1] + T.m[1][2] * V.m[2][2]) * dL_dc +
-            (T.m[0][0] * V.m[2][0] + T.m[0][1] * V.m[2][1] + T.m[0][2] * V.m[2][2]) * dL_db;
-        const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
-        const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
-        const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
-        const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
-        const float tz = 1.f / cs.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * cs.t.x) * tz3 * dL_dJ02 + (2 * h_y * cs.t.y) * tz3 * dL_dJ12;
-        dmean[0] = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;       // transformVec4x3Transpose
-        dmean[1] = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
-        dmean[2] = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+        float gA[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { gA[0][k] = 2.0f * (d2[0][0] * AS[0][k] + d2[0][1] * AS[1][k]); gA[1][k] = 2.0f * (d2[1][0] * AS[0][k] + d2[1][1] * AS[1][k]); }
+        // (3)  dJ = dA Rv^T (only the four non-zero entries of J), then t, then the mean
+        const float dJ00 = gA[0][0] * Rv[0][0] + gA[0][1] * Rv[0][1] + gA[0][2] * Rv[0][2];
+        const float dJ02 = gA[0][0] * Rv[2][0] + gA[0][1] * Rv[2][1] + gA[0][2] * Rv[2][2];
+        const float dJ11 = gA[1][0] * Rv[1][0] + gA[1][1] * Rv[1][1] + gA[1][2] * Rv[1][2];
+        const float dJ12 = gA[1][0] * Rv[2][0] + gA[1][1] * Rv[2][1] + gA[1][2] * Rv[2][2];
+        float dt[3];
+        dt[0] = x_free ? -(J00 * itz) * dJ02 : 0.0f;
+        dt[1] = y_free ? -(J11 * itz) * dJ12 : 0.0f;
+        dt[2] = -itz * (J00 * dJ00 + J11 * dJ11 + 2.0f * (J02 * dJ02 + J12 * dJ12));
+#pragma unroll
+        for (int k = 0; k < 3; k++) dmean[k] = Rv[0][k] * dt[0] + Rv[1][k] * dt[1] + Rv[2][k] * dt[2];
 
-        // ---- preprocessCUDA backward, backward.cu:370-387
-        const float4 m_hom = xform4x4(mean, proj);
-        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * gmx + (proj[1] * m_w - proj[3] * mul2) * gmy;
-        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * gmx + (proj[5] * m_w - proj[7] * mul2) * gmy;
-        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * gmx + (proj[9] * m_w - proj[11] * mul2) * gmy;
+        // (4) screen position: ndc = (P p)_{xy} / ((P p)_w + 1e-7); the gradient the blend delivers (gmx, gmy) is w.r.t. ndc
+        //     (backward.cu:370-387): d ndc_x / dp = (row_x - ndc_x row_w) / w'.   P's row k is projmatrix[4 c + k].
+        {
+            const float hx = projmatrix[0] * mean.x + projmatrix[4] * mean.y + projmatrix[8] * mean.z + projmatrix[12];
+            const float hy = projmatrix[1] * mean.x + projmatrix[5] * mean.y + projmatrix[9] * mean.z + projmatrix[13];
+            const float hw = projmatrix[3] * mean.x + projmatrix[7] * mean.y + projmatrix[11] * mean.z + projmatrix[15];
+            const float iw = 1.0f / (hw + 0.0000001f);
+            const float nx = hx * iw, ny = hy * iw;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dmean[k] += iw * ((projmatrix[4 * k] - nx * projmatrix[4 * k + 3]) * gmx + (projmatrix[4 * k + 1] - ny * projmatrix[4 * k + 3]) * gmy);
+        }
 
         PSTAMP(3);
-        // ---- SH backward, backward.cu:20-139
+        // (5) colour = max(0, 0.5 + sum_k b_k(n) sh_k), n = (mean - campos)/|.| (forward.cu:20-71).  dL/dsh_k = b_k(n) g (g = colour
+        //     gradient, zero in a clamped channel), and with s_k = sh_k . g the direction gets  sum_k s_k grad b_k(n), pushed through
+        //     the normalisation: (I - n n^T) / |v|.
         if (shs != nullptr) {
             const float* sh = STAGE_SH ? &s_sh[threadIdx.x * SH_ROW] : shs + (size_t)idx * M * 3;
-            const float3 dir_orig = make_float3(mean.x - cam_pos[0], mean.y - cam_pos[1], mean.z - cam_pos[2]);
-            const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-            const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+            const float vx = mean.x - cam_pos[0], vy = mean.y - cam_pos[1], vz = mean.z - cam_pos[2];
+            const float vlen = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float x = vx / vlen, y = vy / vlen, z = vz / vlen;
             const uint8_t cl = g.clamped[idx];
-            const float dRGB[3] = { (cl & 1) ? 0.0f : gcol.x, (cl & 2) ? 0.0f : gcol.y, (cl & 4) ? 0.0f : gcol.z };
-            float ddir[3] = { 0, 0, 0 };
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-#define SH(k) sh[3 * (k) + ch]
-#define DSH(k) dsh[3 * (k) + ch]
-                float dx_ = 0, dy_ = 0, dz_ = 0;
-                const float gch = dRGB[ch];
-                DSH(0) = SH_C0 * gch;
-                if (D > 0) {
-                    DSH(1) = (-SH_C1 * y) * gch;
-                    DSH(2) = (SH_C1 * z) * gch;
-                    DSH(3) = (-SH_C1 * x) * gch;
-                    dx_ = -SH_C1 * SH(3);
-                    dy_ = -SH_C1 * SH(1);
-                    dz_ = SH_C1 * SH(2);
-                    if (D > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z;
-                        const float xy = x * y, yz = y * z, xz = x * z;
-                        DSH(4) = (SH_C2[0] * xy) * gch;
-                        DSH(5) = (SH_C2[1] * yz) * gch;
-                        DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * gch;
-                        DSH(7) = (SH_C2[3] * xz) * gch;
-                        DSH(8) = (SH_C2[4] * (xx - yy)) * gch;
-                        dx_ += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
-                        dy_ += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
-                        dz_ += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
-                        if (D > 2) {
-                            DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * gch;
-                            DSH(10) = (SH_C3[1] * xy * z) * gch;
-                            DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * gch;
-                            DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * gch;
-                            DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * gch;
-                            DSH(14) = (SH_C3[5] * z * (xx - yy)) * gch;
-                            DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * gch;
-                            dx_ += (SH_C3[0] * SH(9) * 3.f * 2.f * xy +
-                                    SH_C3[1] * SH(10) * yz +
-                                    SH_C3[2] * SH(11) * -2.f * xy +
-                                    SH_C3[3] * SH(12) * -3.f * 2.f * xz +
-                                    SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-                                    SH_C3[5] * SH(14) * 2.f * xz +
-                                    SH_C3[6] * SH(15) * 3.f * (xx - yy));
-                            dy_ += (SH_C3[0] * SH(9) * 3.f * (xx - yy) +
-                                    SH_C3[1] * SH(10) * xz +
-                                    SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
-                                    SH_C3[3] * SH(12) * -3.f * 2.f * yz +
-                                    SH_C3[4] * SH(13) * -2.f * xy +
-                                    SH_C3[5] * SH(14) * -2.f * yz +
-                                    SH_C3[6] * SH(15) * -3.f * 2.f * xy);
-                            dz_ += (SH_C3[1] * SH(10) * xy +
-                                    SH_C3[2] * SH(11) * 4.f * 2.f * yz +
-                                    SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
-                                    SH_C3[4] * SH(13) * 4.f * 2.f * xz +
-                                    SH_C3[5] * SH(14) * (xx - yy));
-                        }
-                    }
-                }
-                const int used = (D + 1) * (D + 1);
-                for (int k = used; k < M; k++) DSH(k) = 0.0f;      // coefficients above the active degree get no gradient
-#undef SH
-#undef DSH
-                ddir[0] += dx_ * gch; ddir[1] += dy_ * gch; ddir[2] += dz_ * gch;
+            const float gc[3] = { (cl & 1) ? 0.0f : gcol.x, (cl & 2) ? 0.0f : gcol.y, (cl & 4) ? 0.0f : gcol.z };
+            float basis[16], gbx[16], gby[16], gbz[16];
+            const int used = (D + 1) * (D + 1);
+            basis[0] = SH_C0; gbx[0] = 0.f; gby[0] = 0.f; gbz[0] = 0.f;
+            if (D > 0) {
+                basis[1] = -SH_C1 * y; gbx[1] = 0.f;    gby[1] = -SH_C1; gbz[1] = 0.f;
+                basis[2] = SH_C1 * z;  gbx[2] = 0.f;    gby[2] = 0.f;    gbz[2] = SH_C1;
+                basis[3] = -SH_C1 * x; gbx[3] = -SH_C1; gby[3] = 0.f;    gbz[3] = 0.f;
             }
-            const float3 dm = dnormvdv(dir_orig, make_float3(ddir[0], ddir[1], ddir[2]));
-            dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                basis[4] = SH_C2[0] * (x * y);            gbx[4] = SH_C2[0] * y;          gby[4] = SH_C2[0] * x;          gbz[4] = 0.f;
+                basis[5] = SH_C2[1] * (y * z);            gbx[5] = 0.f;                   gby[5] = SH_C2[1] * z;          gbz[5] = SH_C2[1] * y;
+                basis[6] = SH_C2[2] * (2.f * zz - xx - yy); gbx[6] = SH_C2[2] * (-2.f * x); gby[6] = SH_C2[2] * (-2.f * y); gbz[6] = SH_C2[2] * (4.f * z);
+                basis[7] = SH_C2[3] * (x * z);            gbx[7] = SH_C2[3] * z;          gby[7] = 0.f;                   gbz[7] = SH_C2[3] * x;
+                basis[8] = SH_C2[4] * (xx - yy);          gbx[8] = SH_C2[4] * (2.f * x);  gby[8] = SH_C2[4] * (-2.f * y); gbz[8] = 0.f;
+                if (D > 2) {
+                    const float xy = x * y, yz = y * z, xz = x * z;
+                    basis[9] = SH_C3[0] * (y * (3.f * xx - yy));            gbx[9] = SH_C3[0] * (6.f * xy);              gby[9] = SH_C3[0] * (3.f * (xx - yy));           gbz[9] = 0.f;
+                    basis[10] = SH_C3[1] * (xy * z);                        gbx[10] = SH_C3[1] * yz;                     gby[10] = SH_C3[1] * xz;                          gbz[10] = SH_C3[1] * xy;
+                    basis[11] = SH_C3[2] * (y * (4.f * zz - xx - yy));      gbx[11] = SH_C3[2] * (-2.f * xy);            gby[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy);   gbz[11] = SH_C3[2] * (8.f * yz);
+                    basis[12] = SH_C3[3] * (z * (2.f * zz - 3.f * xx - 3.f * yy)); gbx[12] = SH_C3[3] * (-6.f * xz);     gby[12] = SH_C3[3] * (-6.f * yz);                 gbz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                    basis[13] = SH_C3[4] * (x * (4.f * zz - xx - yy));      gbx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); gby[13] = SH_C3[4] * (-2.f * xy);             gbz[13] = SH_C3[4] * (8.f * xz);
+                    basis[14] = SH_C3[5] * (z * (xx - yy));                 gbx[14] = SH_C3[5] * (2.f * xz);             gby[14] = SH_C3[5] * (-2.f * yz);                 gbz[14] = SH_C3[5] * (xx - yy);
+                    basis[15] = SH_C3[6] * (x * (xx - 3.f * yy));           gbx[15] = SH_C3[6] * (3.f * (xx - yy));      gby[15] = SH_C3[6] * (-6.f * xy);                 gbz[15] = 0.f;
+                }
+            }
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < used) {
+                    const float sk = sh[3 * k] * gc[0] + sh[3 * k + 1] * gc[1] + sh[3 * k + 2] * gc[2];
+                    dsh[3 * k] = basis[k] * gc[0]; dsh[3 * k + 1] = basis[k] * gc[1]; dsh[3 * k + 2] = basis[k] * gc[2];
+                    ddx += gbx[k] * sk; ddy += gby[k] * sk; ddz += gbz[k] * sk;
+                }
+            }
+            for (int k = used; k < M; k++) { dsh[3 * k] = 0.0f; dsh[3 * k + 1] = 0.0f; dsh[3 * k + 2] = 0.0f; }   // above the active degree
+            const float nd = x * ddx + y * ddy + z * ddz, il = 1.0f / vlen;
+            dmean[0] += (ddx - x * nd) * il; dmean[1] += (ddy - y * nd) * il; dmean[2] += (ddz - z * nd) * il;
         }
 
         PSTAMP(4);
-        // ---- scale / rotation backward, backward.cu:278-341
+        // (6) S3 = L L^T, L = R(q) diag(mod s) with the quaternion as given (forward.cu:118-152; with a transform: S3 = T (L L^T) T^T,
+        //     pulled back first).  dL/dL = 2 dS3 L (dS3 the symmetric matrix: off-diagonals are half the six-vector's entries);
+        //     dL/d(mod s_k) = sum_i dL_ik R_ik;  G = dL/dR, G_ik = dL_ik s_k;  and for R(q) = I + 2 [..] with q = (r, v):
+        //       dq_r = 2 v . a,   dq_v = 2 (Soff v + r a) - 4 v * (tr G - diag G),   a = (G21-G12, G02-G20, G10-G01), Soff = offdiag(G + G^T).
         if (scales != nullptr) {
             float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
             float qr[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
             const float q_raw[4] = { qr[0], qr[1], qr[2], qr[3] };
             activate_scale_rot(raw, scr, qr);                    // raw mode: exp / normalize as in the forward
-            const float r = qr[0], x = qr[1], y = qr[2], z = qr[3];
-            const M3 R = quat_to_R(r, x, y, z);
-            const float s[3] = { scale_modifier * scr[0], scale_modifier * scr[1], scale_modifier * scr[2] };
-            M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
-            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
-            const M3 Mm = m3_mul(S, R);
-            // with a transform the stored covariance is T Sigma T^T: pull dL_dcov3D back to the untransformed Sigma (and emit dL_dT)
-            float dc6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
+            float d6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
             if (transforms != nullptr) {
                 float Tm[9], pre[6], d6_pre[6];
 #pragma unroll
                 for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
                 cov3d_from_scale_rot(scr, scale_modifier, qr, pre);
-                transform_cov3d_bw(Tm, pre, dc6, d6_pre, dtf);
+                transform_cov3d_bw(Tm, pre, d6, d6_pre, dtf);
 #pragma unroll
-                for (int i = 0; i < 6; i++) dc6[i] = d6_pre[i];
+                for (int i = 0; i < 6; i++) d6[i] = d6_pre[i];
             }
-            const M3 dSigma = m3_cols(dc6[0], 0.5f * dc6[1], 0.5f * dc6[2],
-                                      0.5f * dc6[1], dc6[3], 0.5f * dc6[4],
-                                      0.5f * dc6[2], 0.5f * dc6[4], dc6[5]);
-            M3 M2;
+            const float qw = qr[0], qx = qr[1], qy = qr[2], qz = qr[3];
+            const float R[3][3] = { { 1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy) },
+                                    { 2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx) },
+                                    { 2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy) } };
+            const float sm[3] = { scale_modifier * scr[0], scale_modifier * scr[1], scale_modifier * scr[2] };
+            const float D3[3][3] = { { d6[0], 0.5f * d6[1], 0.5f * d6[2] }, { 0.5f * d6[1], d6[3], 0.5f * d6[4] }, { 0.5f * d6[2], 0.5f * d6[4], d6[5] } };
+            float G[3][3];
 #pragma unroll
-            for (int cc = 0; cc < 3; cc++)
+            for (int k = 0; k < 3; k++) {
+                float col[3];                                    // column k of dL/dL = 2 dS3 L
 #pragma unroll
-                for (int rr = 0; rr < 3; rr++) M2.m[cc][rr] = 2.0f * Mm.m[cc][rr];
-            const M3 dL_dM = m3_mul(M2, dSigma);
-            const M3 Rt = m3_t(R);
-            M3 dMt = m3_t(dL_dM);
+                for (int i = 0; i < 3; i++) col[i] = 2.0f * sm[k] * (D3[i][0] * R[0][k] + D3[i][1] * R[1][k] + D3[i][2] * R[2][k]);
+                dscale[k] = col[0] * R[0][k] + col[1] * R[1][k] + col[2] * R[2][k];      // w.r.t. mod * s, reported as is (backward.cu:322-325: no factor mod)
 #pragma unroll
-            for (int k = 0; k < 3; k++)
-                dscale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++) dMt.m[k][rr] *= s[k];
-#define DM(c_, r_) dMt.m[c_][r_]
-            drot[0] = 2 * z * (DM(0,1) - DM(1,0)) + 2 * y * (DM(2,0) - DM(0,2)) + 2 * x * (DM(1,2) - DM(2,1));
-            drot[1] = 2 * y * (DM(1,0) + DM(0,1)) + 2 * z * (DM(2,0) + DM(0,2)) + 2 * r * (DM(1,2) - DM(2,1)) - 4 * x * (DM(2,2) + DM(1,1));
-            drot[2] = 2 * x * (DM(1,0) + DM(0,1)) + 2 * r * (DM(2,0) - DM(0,2)) + 2 * z * (DM(1,2) + DM(2,1)) - 4 * y * (DM(2,2) + DM(0,0));
-            drot[3] = 2 * r * (DM(0,1) - DM(1,0)) + 2 * x * (DM(2,0) + DM(0,2)) + 2 * y * (DM(1,2) + DM(2,1)) - 4 * z * (DM(1,1) + DM(0,0));
-#undef DM
+                for (int i = 0; i < 3; i++) G[i][k] = col[i] * sm[k];
+            }
+            const float a0 = G[2][1] - G[1][2], a1 = G[0][2] - G[2][0], a2q = G[1][0] - G[0][1];
+            const float s01 = G[0][1] + G[1][0], s02 = G[0][2] + G[2][0], s12 = G[1][2] + G[2][1];
+            const float trG = G[0][0] + G[1][1] + G[2][2];
+            drot[0] = 2.0f * (qx * a0 + qy * a1 + qz * a2q);
+            drot[1] = 2.0f * (qy * s01 + qz * s02 + qw * a0) - 4.0f * qx * (trG - G[0][0]);
+            drot[2] = 2.0f * (qx * s01 + qz * s12 + qw * a1) - 4.0f * qy * (trG - G[1][1]);
+            drot[3] = 2.0f * (qx * s02 + qy * s12 + qw * a2q) - 4.0f * qz * (trG - G[2][2]);
             // raw mode: chain through the getters (same expressions as csrc/activations.hip)
             if (raw & RAW_SCALE) {
 #pragma unroll

@@ -6,7 +6,7 @@ from tests import helpers as hp
 from fuzz_scenes import random_scene
 dev = torch.device("cuda:0")
 names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dtransforms"]
-for seed in [275,612,673,1519,1698,1701,1816,2178,2457,2510,2755,3235]:
+for seed in [int(x) for x in sys.argv[1:]]:
     s, mode, degree, colors = random_scene(seed)
     d = hp.inputs_of(s, mode, degree=degree, colors=colors, bg=s.bg.tolist())
     fw = hp.oracle_forward(d); fw64 = hp.oracle_forward64(d, fw)
@@ -21,7 +21,7 @@ for seed in [275,612,673,1519,1698,1701,1816,2178,2457,2510,2755,3235]:
         a = getattr(g, n).cpu().numpy()
         ex, e32, eh = hp.adjudication_excess(a, (getattr(ref, n), getattr(refa, n)), getattr(ref64, n), sc[n], 2.0)
         rh = hp.rel_err(a, getattr(ref64, n)); ro = max(hp.rel_err(getattr(ref, n), getattr(ref64, n)), hp.rel_err(getattr(refa, n), getattr(ref64, n)))
-        if ex > 2e-5 or rh > 2*ro + 2e-5:
+        if ex > 2e-5 or rh > 2*ro + 2e-5 or True:
             # which gaussian
             s_ = np.asarray(sc[n]).reshape(a.shape); err = np.abs(a - getattr(ref64, n)) / np.where(s_ > 0, s_, 1)
             gi = np.unravel_index(np.argmax(err), err.shape)[0]

@@ -299,8 +299,14 @@ def test_fuzz_outliers_adjudicated_by_float64(gpu, hip_lib, seed):
     ref_f32acc = hp.oracle_backward(d, fw, dc, dd, da, f32_accumulators=True)
     scales = hp.oracle_gradient_scales(d, fw, dc, dd, da)
     got = {n: getattr(g, n).cpu().numpy() for n in _names(d)}
-    # whole-tensor bars as in the sweep that found them (2e-2 of the largest value); the per-Gaussian bar is the ADJUDICATED one
-    tp.check_gradients(got, {n: getattr(ref, n) for n in _names(d)}, scales, tol=2e-2, cos_gap=1e-4, per_gaussian=float("inf"))
+    # whole-tensor bar as in the sweep that found them (2e-2 of the largest value against the float32 oracle) -- unless the oracle
+    # itself is the one that is off: since the per-Gaussian backward is written in matrix form (round 2) the kernels are CLOSER to
+    # float64 than the reference's expressions on the worst-conditioned Gaussians (seed 1891: 1.3e-3 against the oracle's 2.8e-2)
+    for n in _names(d):
+        if got[n].size:
+            assert np.isfinite(got[n]).all(), n
+            r32, r64, o64 = hp.rel_err(got[n], getattr(ref, n)), hp.rel_err(got[n], getattr(ref64, n)), hp.rel_err(getattr(ref, n), getattr(ref64, n))
+            assert r32 <= 2e-2 or r64 <= o64, (n, r32, r64, o64)
     e = hp.hip_export(d, t, gpu)
     ok = m.numpy().astype(bool)
     np.testing.assert_array_equal(e.n_contrib[ok.reshape(-1)], fw.n_contrib[ok.reshape(-1)])
