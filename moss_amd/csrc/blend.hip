@@ -313,15 +313,17 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
 // trips = 8k+ cycles of blending, which covers the DMA latency), issues their DMAs, then blends the previous round's records.  Fetching them into registers
 // inside the trip loop (first version of this scheme) made every trip wait on L2: 640 instead of 520 cycles per trip.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LCAP = 1024;                       // per-wave list of hit positions (forward kernel)
+// Per-wave LDS of a heavy item: the list of hit positions (LCAP) and the record ring (RCAP slots of 48 bytes; a multiple of the
+// 64-slot DMA batch).  A scan round ends once it has found ROUND_HITS new hits (<= ROUND_HITS + 63 with its last group); the ring
+// holds the hits of two rounds + 3 carried + one batch of slack: 2 x 87 + 3 + 64 = 241 <= 256.
+// Round 1 ran the forward with 1024 / 512 / 64 (28 KB per wave, ONE workgroup per CU: "co-resident waves only slow the heaviest
+// item down").  Measured in round 2 with the work queues fixed (common.h): 13 KB per wave and TWO workgroups per CU take the
+// forward kernel from 57 to 48 us -- the second wave fills the issue slots the first leaves between its dependent instructions, and
+// with twice the waves every heavy block of the frame starts at once.  Same sizes for the backward kernel (whose items are short
+// since the forward cuts the lists into depth segments: up to three workgroups per CU).
+constexpr int LCAP = 256, RCAP = 256, ROUND_HITS = 24;
 constexpr int CHAPTER = 8;                       // 64-entry groups of block masks turned into hit masks at a time (512 entries)
-constexpr int ROUND_HITS = 64;                   // a scan round ends once it has found this many new hits (<= 127 with its last group)
-constexpr int RCAP = 512;                        // per-wave record ring (slots; a multiple of the 64-slot DMA batch): the hits of
-                                                 // two rounds (<= 2 x 128 + 3 carried) plus one batch of slack
-// The backward kernel's items are short since the forward cuts the lists into depth segments, and it wants SEVERAL waves per SIMD
-// (an item starts with a chain of dependent loads that only another wave's arithmetic can hide): a quarter of the forward's LDS.
-// Rounds of >= 24 new hits (<= 87 with their last group): two rounds + 3 carried + one batch of slack = 241 <= 256 slots.
-constexpr int LCAP_BWD = 256, RCAP_BWD = 256, ROUND_HITS_BWD = 24;
+constexpr int LCAP_BWD = LCAP, RCAP_BWD = RCAP, ROUND_HITS_BWD = ROUND_HITS;
 template <int RC, int LC>
 struct HeavyLdsT { float4 a[RC], b[RC], c[RC]; uint32_t lst[LC]; static constexpr int RMASK = RC - 1, LMASK = LC - 1; };
 typedef HeavyLdsT<RCAP, LCAP> HeavyLds;
@@ -812,7 +814,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
         const uint32_t share = seg_cap / (uint32_t)max(q_waves, 1);
         const size_t first = (size_t)qx * seg_cap + (size_t)my_rank * share;
         se.desc = seg_desc + first; se.state = seg_state + first * SEG_STATE_FLOATS;
-        se.cap = (seg_hits > 0 && q_waves <= MAX_FWD_QUEUE_WAVES) ? share : 0u;
+        se.cap = (seg_hits > 0 && q_waves <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) ? share : 0u;
         se.count = 0u; se.seg_hits = seg_hits > 0 ? seg_hits : (1 << 30);
         se.cut_sums = s_cut_sums[wv]; se.cut_pos = s_cut_pos[wv];
     }
@@ -860,7 +862,8 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
                            const uint32_t* __restrict__ tail_start, const uint32_t* __restrict__ seg_counts, int fwd_grid)
 {
     __shared__ HeavyLdsBwd s_heavy[4];                       // per wave: 13 KB; a light item uses its first 3 KB as the record ring
-    __shared__ uint32_t s_prefix[MAX_FWD_QUEUE_WAVES];       // inclusive prefix sums of the forward waves' segment counts (this XCD's region)
+    __shared__ uint16_t s_prefix[MAX_FWD_QUEUE_WAVES];       // inclusive prefix sums of the forward waves' segment counts (this XCD's region;
+                                                             // 16 bits: the forward cuts nothing when a region has more than 65535 slots)
     static_assert(sizeof(HeavyLdsBwd) >= 64 * 3 * sizeof(float4), "the light path's ring lives inside the heavy path's LDS");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(&s_heavy[wv]);
@@ -885,7 +888,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
         const int fq = min(NUM_XCD_QUEUES, fwd_grid);
         const int f_waves = qx < fq ? 4 * ((fwd_grid - qx + fq - 1) / fq) : 0;              // forward waves that fed this region
         uint32_t total = 0u;
-        if (f_waves > 0 && f_waves <= MAX_FWD_QUEUE_WAVES) {
+        if (f_waves > 0 && f_waves <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) {
             const uint32_t* cnt = seg_counts + (size_t)qx * MAX_FWD_QUEUE_WAVES;
             uint32_t carry = 0u;
             for (int b0 = 0; b0 < f_waves; b0 += 64) {
@@ -893,7 +896,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)v, d); if (lane >= d) v += y; }
                 v += carry;
-                if (b0 + lane < f_waves) s_prefix[b0 + lane] = v;
+                if (b0 + lane < f_waves) s_prefix[b0 + lane] = (uint16_t)v;
                 carry = (uint32_t)__shfl((int)v, 63);
             }
             total = carry;
@@ -906,8 +909,8 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
             const unsigned long long tp0 = WSTAMP();
             // flat index -> (forward wave, slot in its range): first wave whose inclusive prefix exceeds i
             int lo_w = 0, hi_w = f_waves - 1;
-            while (lo_w < hi_w) { const int mid = (lo_w + hi_w) >> 1; if (s_prefix[mid] <= i) lo_w = mid + 1; else hi_w = mid; }
-            const uint32_t before = lo_w > 0 ? s_prefix[lo_w - 1] : 0u;
+            while (lo_w < hi_w) { const int mid = (lo_w + hi_w) >> 1; if ((uint32_t)s_prefix[mid] <= i) lo_w = mid + 1; else hi_w = mid; }
+            const uint32_t before = lo_w > 0 ? (uint32_t)s_prefix[lo_w - 1] : 0u;
             const size_t slot_idx = (size_t)qx * seg_cap + (size_t)lo_w * share + (i - before);
             const uint4 d = seg_desc[slot_idx];
             const unsigned long long tp1 = WSTAMP();
@@ -958,20 +961,32 @@ int env_int(const char* name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
-// resident workgroups of the persistent blend kernels: a fixed number per CU (dynamic balancing does the rest)
-int persistent_workgroups()
+int device_cus()
 {
     static const int n = [] {
         int dev = 0; hipDeviceProp_t prop;
         int cus = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
-        // wave kernels: ONE wave per SIMD.  The kernel's duration is the instruction stream of its heaviest waves, and a SIMD issues
-        // one wave-instruction per 4 cycles however many waves it hosts: co-resident waves only slow the heavy ones down
-        // (measured 67 / 81 / 91 us forward for 1 / 2 / 3 workgroups per CU).
-        return cus * env_int("MOSS_BLEND_WGS_PER_CU", 1);
+        return cus;
     }();
     return n;
+}
+
+// Resident workgroups of the persistent blend kernels: a fixed number per CU (dynamic balancing does the rest), never more than fit
+// together -- a wave's FIRST work item is its rank in its queue (no atomic), so a workgroup that only started once another one had
+// left would sit on its items until then (measured: +10 us when 4 were launched where 3 fit).
+template <typename K>
+int resident_wgs_per_cu(K kernel, const char* env, int dflt, int cap)
+{
+    int occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
+    return std::max(1, std::min(std::min(occ, cap), env_int(env, dflt)));
+}
+int forward_grid(int T)
+{
+    static const int per_cu = resident_wgs_per_cu(blend_forward_wave_kernel, "MOSS_BLEND_WGS_PER_CU", 2, 2);
+    return min(4 * T, device_cus() * per_cu);
 }
 
 }  // anonymous namespace
@@ -990,7 +1005,7 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     static const int env_flags = env_int("MOSS_BLEND_CULL", 1);
     const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
     const int T = fp.gx * fp.gy;
-    const int wgs = min(4 * T, persistent_workgroups());               // 4 independent waves per workgroup, 16 items per tile
+    const int wgs = forward_grid(T);                                   // 4 independent waves per workgroup, 16 items per tile
     // hits per depth segment of the backward (0 = never cut: every block is ONE backward item, the round-1 behaviour)
     static const int seg_hits_env = [] { const int v = env_int("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
@@ -1009,20 +1024,14 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     static const int dbg = env_int("MOSS_BWD_DEBUG", 0) & (16 | 32 | 64);
     const int flags = (g_cull_override >= 0 ? g_cull_override : env_flags) | dbg;
     const int T = fp.gx * fp.gy;
-    // Workgroups per CU: 52.5 KB of LDS each, so up to three fit; never more than are RESIDENT together (a wave's first work item is
-    // its rank in the queue: a workgroup that only starts when another one has left would sit on its items until then).
-    static const int bwd_wgs_per_cu = [] {
-        int occ = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, blend_backward_wave_kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
-        return std::max(1, std::min(occ, env_int("MOSS_BWD_WGS_PER_CU", 3)));
-    }();
-    const int wgs = min(4 * T, persistent_workgroups() * bwd_wgs_per_cu);
+    static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel, "MOSS_BWD_WGS_PER_CU", 3, 3);   // 52.5 KB of LDS each
+    const int wgs = min(4 * T, device_cus() * bwd_wgs_per_cu);
     // the queue heads are zero here: cleared by the forward, rewound after each backward (preprocess_backward_kernel)
     MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
                        im.queues + (size_t)Q_BWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
                        dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
                        flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
-                       min(4 * T, persistent_workgroups()) /* the forward kernel's grid */);
+                       forward_grid(T) /* the forward kernel's grid */);
 }
 
 }  // namespace moss

@@ -9,7 +9,7 @@ d = hp.inputs_of(scenes.config3(), "scale_rot")
 L = _lib.lib()
 L.moss_raster_debug_set_bwd_stamps.argtypes = [ctypes.c_void_p]
 dc, dd, da = hp.image_grads(d.H, d.W)
-nw = 256 * 3 * 4
+nw = 256 * 4 * 4
 buf = torch.zeros(nw * 16, dtype=torch.int64, device=dev)
 t = hp.hip_forward(d, dev)
 for _ in range(3): hp.hip_backward(d, t, dc, dd, da, dev)
