@@ -108,7 +108,7 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
 // with ONE returning global atomic (after counting its own instances in LDS) and hands the slots out with LDS atomics.
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ keys, uint32_t* __restrict__ inst_tile, int lds_hist, const uint32_t* __restrict__ header)
+               uint64_t* __restrict__ keys, int lds_hist, const uint32_t* __restrict__ header)
 {
     extern __shared__ uint32_t s_mem[];
     if (header[0] == 0u) return;                       // nothing rendered (or capacity overflow: see scan_kernel)
@@ -163,9 +163,23 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
             if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
             else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
             keys[pos] = k;
-            inst_tile[pos] = (uint32_t)t;
         });
     }
+}
+
+// Which tile owns sort chunk c: the tile t with chunk_base[t] <= c < chunk_base[t] + ceil(n_t / CHUNK).  Every thread of the workgroup
+// tests the tiles tid, tid + blockDim, ... -- two independent loads each, ONE memory round trip for the workgroup (a binary search by
+// thread 0 was ten DEPENDENT loads, ~6 us, with 1023 threads waiting at the barrier behind it).  Ends with a barrier.
+__device__ __forceinline__ void find_chunk_tile(int T, uint32_t c, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base,
+                                                int* s_tile)
+{
+    for (int t = (int)threadIdx.x; t < T; t += (int)blockDim.x) {
+        const uint32_t cb = chunk_base[t];
+        const uint2 rg = ranges[t];
+        const uint32_t nch = (rg.y - rg.x + CHUNK - 1) / CHUNK;
+        if (cb <= c && c < cb + nch) *s_tile = t;
+    }
+    __syncthreads();
 }
 
 // Stage A of the sort: one workgroup per CHUNK of a tile's bucket (a tile of n entries has ceil(n/CHUNK) chunks), sorted and
@@ -183,12 +197,7 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
     const uint32_t c = blockIdx.x;
     if (c >= header[4]) return;                        // the grid is an upper bound when R is not known on the host
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {                 // last tile whose chunk_base <= c (tiles without entries share their successor's base)
-        int lo = 0, hi = T;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_base[mid] <= c) lo = mid; else hi = mid; }
-        s_tile = lo;
-    }
-    __syncthreads();
+    find_chunk_tile(T, c, ranges, chunk_base, &s_tile);
     const int tile = s_tile;
     const uint2 rg = ranges[tile];
     const uint32_t first = rg.x + (c - chunk_base[tile]) * CHUNK;
@@ -221,39 +230,49 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
     if (tid < n) gk[tid] = key;
 }
 
-// Stage B: one thread per instance.  Its final rank inside the tile = its rank inside its own (sorted) chunk + the number
-// of smaller keys in each of the tile's other chunks (binary search; keys (depth_bits, id) are unique).  The same thread
-// then emits everything that is per-instance: the sorted id, the 48-byte record the blend kernels stream, and the
-// Gaussian -> instance back-pointer used by the backward gather.
-__global__ void __launch_bounds__(256)
-merge_gather_kernel(const uint32_t* __restrict__ header, int gx, GeomView g, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
-                    const uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
+// Stage B: one workgroup per chunk again, one thread per instance.  An instance's final rank inside its tile = its rank inside its own
+// (sorted) chunk + the number of smaller keys in each of the tile's OTHER chunks (keys (depth_bits, id) are unique).  The other
+// chunks are brought into LDS one after the other (one coalesced 8-byte load per thread) and searched there: ten LDS reads per
+// chunk instead of ten dependent global loads (round 1: 20-40 dependent L2 round trips per instance of a 3-5 chunk tile were most of
+// this kernel's 18 us).  The same thread then emits everything that is per-instance: the sorted id, the 48-byte record the blend
+// kernels stream, the block mask, and the Gaussian -> instance back-pointer used by the backward gather.
+__global__ void __launch_bounds__(1024)
+merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView g, const uint2* __restrict__ ranges,
+                    const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
+                    uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
                     float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask)
 {
-    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), instances are in tile order, and
-    // neighbouring tiles gather the same Gaussians' 64-byte records: XCD k takes the k-th contiguous eighth of the instance blocks
-    // (counted from the device-side R, the grid is only an upper bound), so a Gaussian's record is fetched into one or two L2s
-    // instead of all eight.
-    const int n_blocks = ((int)header[0] + 255) / 256;
-    const int per_xcd = n_blocks / 8, extra = n_blocks % 8, xcd = (int)blockIdx.x % 8, nth = (int)blockIdx.x / 8;
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[CHUNK];
+    __shared__ int s_tile;
+    // XCD-aware chunk order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), chunks are in tile order, and neighbouring
+    // tiles gather the same Gaussians' 64-byte records: XCD k takes the k-th contiguous eighth of the chunks (counted from the
+    // device-side total, the grid is only an upper bound), so a Gaussian's record is fetched into one or two L2s instead of all eight.
+    const int n_chunks = (int)header[4];
+    const int per_xcd = n_chunks / 8, extra = n_chunks % 8, xcd = (int)blockIdx.x % 8, nth = (int)blockIdx.x / 8;
     if (nth >= per_xcd + (xcd < extra ? 1 : 0)) return;
-    const int i = (xcd * per_xcd + min(xcd, extra) + nth) * 256 + (int)threadIdx.x;
-    if (i >= (int)header[0]) return;
-    inst_mask[i] = 0u;                                        // no gradient record yet (set by the backward blend)
-    const uint32_t tile = inst_tile[i];
+    const uint32_t c = (uint32_t)(xcd * per_xcd + min(xcd, extra) + nth);
+    const uint32_t tid = threadIdx.x;
+    find_chunk_tile(T, c, ranges, chunk_base, &s_tile);
+    const uint32_t tile = (uint32_t)s_tile;
     const uint2 rg = ranges[tile];
-    const uint64_t key = keys[i];
-    const uint32_t local = (uint32_t)i - rg.x, own = local / CHUNK, n = rg.y - rg.x;
-    uint32_t rank = local % CHUNK;
-    const uint32_t nch = (n + CHUNK - 1) / CHUNK;
-    for (uint32_t c = 0; c < nch; c++) {
-        if (c == own) continue;
-        const uint64_t* seg = keys + rg.x + c * CHUNK;
-        uint32_t lo = 0, hi = min((uint32_t)CHUNK, n - c * CHUNK);        // count of keys < key in this sorted chunk
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seg[mid] < key) lo = mid + 1; else hi = mid; }
+    const uint32_t n = rg.y - rg.x, nch = (n + CHUNK - 1) / CHUNK, own = c - chunk_base[tile];
+    const uint32_t first = rg.x + own * CHUNK, n_own = min((uint32_t)CHUNK, rg.y - first);
+    const bool mine = tid < n_own;
+    const uint64_t key = mine ? keys[first + tid] : ~0ull;
+    uint32_t rank = tid;                                      // rank inside the own (sorted) chunk
+    for (uint32_t oc = 0; oc < nch; oc++) {                   // (wave-uniform trip count)
+        if (oc == own) continue;
+        const uint32_t ofirst = rg.x + oc * CHUNK, on = min((uint32_t)CHUNK, rg.y - ofirst);
+        __syncthreads();                                      // the previous chunk's readers are done
+        if (tid < on) s_keys[tid] = keys[ofirst + tid];
+        __syncthreads();
+        uint32_t lo = 0, hi = on;                             // count of keys < key in this sorted chunk
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_keys[mid] < key) lo = mid + 1; else hi = mid; }
         rank += lo;
     }
+    if (!mine) return;
     const uint32_t pos = rg.x + rank;
+    inst_mask[pos] = 0u;                                      // no gradient record yet (set by the backward blend)
     const uint32_t id = (uint32_t)key;
     point_list[pos] = id;
     float4* rec = inst_rec + 3 * (size_t)pos;
@@ -395,7 +414,7 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
-                       b.inst_tile, lds_hist, im.header);
+                       lds_hist, im.header);
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s)
@@ -405,7 +424,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) return;
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
-    hipLaunchKernelGGL(merge_gather_kernel, dim3((R + 255) / 256), dim3(256), 0, s, im.header, fp.gx, g, im.ranges, b.keys, b.inst_tile,
+    hipLaunchKernelGGL(merge_gather_kernel, dim3(total_chunks), dim3(CHUNK), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask);
 }
 

@@ -16,7 +16,7 @@
 //     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [6]=instances needed [16..31]=work-queue heads of the forward/backward blend
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
-//     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id); inst_tile u32[R] tile of a slot
+//     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id)
 //     inst_pos   u32[R]   for Gaussian g, its k-th tile (row-major inside its rect): position in point_list
 //     inst_rec   48 B * R  the three records of every instance in sorted order (written by the tile sort)
 //     scratch    48 B * R * slabs  forward: 64-bit sort keys (depth<<32|id) in the first 8R bytes;
@@ -172,7 +172,7 @@ extern int g_cull_override;            // -1 = MOSS_BLEND_CULL decides; 0 / 1 = 
 int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
 struct BinView {
-    uint32_t* point_list; uint32_t* inst_pos; uint32_t* inst_tile;
+    uint32_t* point_list; uint32_t* inst_pos;
     uint32_t* inst_mask;     // per instance (sorted order): bit b set <=> slab b holds a record for it
     uint16_t* inst_bmask;    // per instance (sorted order): bit b set <=> its alpha >= 1/255 bounding box touches 4x4 block b of its tile
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
@@ -187,7 +187,7 @@ struct BinView {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
         b.slabs = blend_subgroups();
         b.slab_stride_floats = align_up(GRAD_REC_FLOATS * n * 4) / 4;
-        b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n); b.inst_tile = carve<uint32_t>(p, n);
+        b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n);
         b.inst_mask = carve<uint32_t>(p, n);
         b.inst_bmask = carve<uint16_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);
