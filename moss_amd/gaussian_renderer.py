@@ -135,9 +135,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
 class RenderOutput(dict):
     """The reference's result dict (gaussian_renderer/__init__.py:125-136).  ``visibility_filter`` (= ``radii > 0``) is computed
-    the first time it is asked for: MOSS reads it only on densification steps (train_ZJU.py:172-174), and a minimal kernel costs
-    4-5 us of a 0.33 ms step.  ``out["visibility_filter"]``, ``out.get(..)`` and ``"visibility_filter" in out`` all work;
-    ``keys()`` / ``items()`` list it once it exists."""
+    the first time it is asked for (a minimal kernel costs 4-5 us of a 0.3 ms step).  MOSS itself asks for it in EVERY iteration
+    (train_ZJU.py:101, and uses it at :172-174 while it densifies), so its training loop pays that launch every step -- bench.py's
+    `callers.dropin_*` variants do, the headline step (which has no use for the mask) does not.  ``out["visibility_filter"]``,
+    ``out.get(..)`` and ``"visibility_filter" in out`` all work; ``keys()`` / ``items()`` list it once it exists."""
     _LAZY = "visibility_filter"
 
     def __missing__(self, key):

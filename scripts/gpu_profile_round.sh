@@ -1,7 +1,10 @@
 # Round profile set: (1) rocprofv3 kernel trace + stats of the default bench command, (2) PMC passes (separate runs, counters only)
-# over the eager-launch form of the same bench step.  Outputs under gpurun_out/r01_final/ ; copy the summaries into profiles/.
+# over the eager-launch form of the same bench step.  usage: bash scripts/gpu_profile_round.sh <tag>   (e.g. r02_final)
+# Outputs under gpurun_out/<tag>/ ; copy the summaries into profiles/ (pmc_stage_summary.json -> profiles/pmc_latest.json: it is
+# stamped with the sha256 of moss_amd/csrc/, and bench.py reports `traffic` only while that stamp matches the checkout).
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r01_final; rm -rf $OUT; mkdir -p $OUT/pmc; cd /tmp
+TAG=${1:-r02_final}
+OUT=$PWD/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT/pmc; cd /tmp
 # the bench line as the driver sees it (no profiler attached), then the same command under rocprofv3 (whose tool perturbs the
 # bench's own kernel-attached events by ~10 %: its line is kept beside the kernel statistics for reference only)
 python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_plain_stdout.log 2>&1
@@ -16,7 +19,7 @@ pmc p2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INS
 pmc p3 FETCH_SIZE
 pmc p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 cd $GRAFT_REPO_ROOT
-python3 scripts/summarize_pmc.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_hbm_bytes.txt 2>&1
+python3 scripts/summarize_pmc.py $OUT/pmc $OUT/pmc_summary.json $OUT/pmc_stage_summary.json > $OUT/pmc_hbm_bytes.txt 2>&1
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$OUT/bench_kernel_stats.csv")))

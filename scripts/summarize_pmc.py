@@ -45,6 +45,11 @@ if stage_out:
             st[s] = {"hbm_bytes_per_launch": sum(p["hbm_bytes_per_launch"] for p in present),
                      "hbm_bytes_raw": sum(p["hbm_bytes_raw"] for p in present), "kernels": [k for k in ks if k in res],
                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), eager-launch bench.py --graph 0 --steps 30 --warmup 10"}
+    # stamp: the kernel sources these counters were measured on (bench.py emits `traffic` only while this matches the checkout)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    st["csrc_sha256"] = bench.csrc_sha256()
     json.dump(st, open(stage_out, "w"), indent=1, sort_keys=True)
 for k, c in sorted(res.items()):
     print(k.ljust(30), {n: (round(v) if isinstance(v, float) else v) for n, v in c.items()})
