@@ -141,7 +141,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
-                    old[u] = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)c[u], rs_cur, c[u] ? (uint32_t)i * 4u : 0xfffffffcu /* out of range AND dword-aligned: a misaligned atomic faults before the range check */, 0, 0);
+                    old[u] = lds_hist == 2 ? 0u : (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)c[u], rs_cur, c[u] ? (uint32_t)i * 4u : 0xfffffffcu /* out of range AND dword-aligned: a misaligned atomic faults before the range check */, 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -408,7 +408,7 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
-    const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
+    const int lds_hist = (T <= MAX_LDS_TILES) ? (((env_int("MOSS_EXPERIMENT", 0) & 2) != 0) ? 2 : 1) : 0;   // (2: timing experiment, no reservation atomics)
     static const int per_thread = env_int("MOSS_SCATTER_ITEMS", 2);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;

@@ -407,7 +407,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
         __syncthreads();
         for (int i = threadIdx.x; i < T; i += blockDim.x) {
             const uint32_t v = s_hist[i];
-            if (v) atomicAdd(&tile_count[i], v);
+            if (v && !(raw & 0x100)) atomicAdd(&tile_count[i], v);        // (0x100: timing experiment, MOSS_EXPERIMENT=1 -- wrong counts)
         }
     }
 }
@@ -968,7 +968,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh,
-                       transforms, fp.raw);
+                       transforms, fp.raw | ((env_int("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0));
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,

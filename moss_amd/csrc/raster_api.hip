@@ -4,6 +4,7 @@
 #include "common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -180,6 +181,10 @@ static int forward_impl(
     if (R > 0) {
         { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, s); }
         STAGE_CHECK("scatter");
+        {   // timing experiment (scripts/exp_atomics.py): with the scatter's reservation atomics off the keys are garbage -- stop here
+            static const bool stop = getenv("MOSS_EXPERIMENT") && (atoi(getenv("MOSS_EXPERIMENT")) & 2);
+            if (stop) return R;
+        }
         { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s); }
         STAGE_CHECK("tile_sort");
     }

@@ -30,5 +30,5 @@ for r in rows[:24]:
 PY
 cat $OUT/pmc_hbm_bytes.txt | tail -20
 cut -c1-400 $OUT/bench_line.json
-rm -f $OUT/bench_kernel_trace.csv $OUT/pmc/*counter_collection.csv.bak
+rm -f $OUT/bench_kernel_trace.csv $OUT/pmc/*counter_collection.csv.bak $OUT/pmc/*counter_collection.csv   # (raw counter dumps are hundreds of MB: gpurun merges <= 64 MiB back)
 ls -la $OUT $OUT/pmc | head -40
