@@ -418,6 +418,256 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 // order -> bitwise reproducible; then conic->cov2D->cov3D/mean (backward.cu:144-274), projection of the 2-D mean
 // gradient (:370-387), SH (:20-139) and scale/rotation (:278-341).  Writes every output element exactly once.
 // ---------------------------------------------------------------------------------------------------------
+// ---- steps (1)-(4) of the per-Gaussian backward: conic gradient -> dL/dcov3D (six-vector) and dL/dmean (covariance and
+// screen-position paths).  gca/gcb/gcc = dL/dconic (A, B per off-diagonal entry, C), gmx/gmy = dL/dmean2D in NDC units.
+__device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb, float gcc, float gmx, float gmy,
+                                                  float tan_fovx, float tan_fovy, float h_x, float h_y,
+                                                  const float* __restrict__ means3D, const float* __restrict__ cov3D_precomp, const GeomView& g,
+                                                  const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+                                                  float3& mean, float* dmean, float* dcov)
+{
+    // ================= per-Gaussian backward, in matrix form =================================================================
+    // What is differentiated is the reference's forward (forward.cu:74-113, 118-152, 20-71, 196-237) with the conventions its
+    // backward fixes (backward.cu:144-396): 1/(det^2 + 1e-7) in the inverse, no gradient through a clamped t.x/t.z, the SH clamp
+    // flags, the quaternion used as given.  The expressions are this file's own: every step is a small matrix identity.
+    //
+    // (1) conic K = inverse(S2), S2 = [[a b][b c]] the dilated 2-D covariance.  The blend kernels deliver G = dL/dK as a full
+    //     symmetric matrix [[gA gB][gB gC]] (gB per off-diagonal entry).  d(inverse):  dL/dS2 = -K G K = -(adj G adj) / det^2 with
+    //     adj = [[c -b][-b a]]; the reference regularises 1/det^2 as 1/(det^2 + 1e-7) (backward.cu:203) -- kept.
+    // (2) S2 = A S3 A^T + 0.3 I with A = J Rv (2x3): dL/dS3 = A^T dS2 A (the six-vector doubles the off-diagonals, each
+    //     appearing twice in the matrix), dL/dA = 2 dS2 A S3.
+    // (3) A = J Rv: dL/dJ = dL/dA Rv^T; J = [[fx/tz 0 -fx tx/tz^2][0 fy/tz -fy ty/tz^2]] so, written with J's own entries,
+    //     dJ00/dtz = -J00/tz, dJ02/dtx = -J00/tz, dJ02/dtz = -2 J02/tz (same for the y row); dL/dmean = Rv^T dL/dt.
+    const float Rv[3][3] = { { viewmatrix[0], viewmatrix[4], viewmatrix[8] }, { viewmatrix[1], viewmatrix[5], viewmatrix[9] },
+                             { viewmatrix[2], viewmatrix[6], viewmatrix[10] } };            // t = Rv p + (view[12..14])
+    mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    const float* c6 = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
+    const float S3[3][3] = { { c6[0], c6[1], c6[2] }, { c6[1], c6[3], c6[4] }, { c6[2], c6[4], c6[5] } };
+    float t[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) t[r] = Rv[r][0] * mean.x + Rv[r][1] * mean.y + Rv[r][2] * mean.z + viewmatrix[12 + r];
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const float rx = t[0] / t[2], ry = t[1] / t[2];
+    const bool x_free = !(rx < -limx || rx > limx), y_free = !(ry < -limy || ry > limy);     // forward.cu:82-87 clamp inactive
+    const float tx = fminf(limx, fmaxf(-limx, rx)) * t[2], ty = fminf(limy, fmaxf(-limy, ry)) * t[2];
+    const float itz = 1.0f / t[2];
+    const float J00 = h_x * itz, J11 = h_y * itz, J02 = -(h_x * tx) * (itz * itz), J12 = -(h_y * ty) * (itz * itz);
+    float A[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A[0][k] = J00 * Rv[0][k] + J02 * Rv[2][k]; A[1][k] = J11 * Rv[1][k] + J12 * Rv[2][k]; }
+    float AS[2][3];                                                                          // A S3
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) AS[i][k] = A[i][0] * S3[0][k] + A[i][1] * S3[1][k] + A[i][2] * S3[2][k];
+    const float a2 = AS[0][0] * A[0][0] + AS[0][1] * A[0][1] + AS[0][2] * A[0][2] + 0.3f;
+    const float b2 = AS[0][0] * A[1][0] + AS[0][1] * A[1][1] + AS[0][2] * A[1][2];
+    const float c2 = AS[1][0] * A[1][0] + AS[1][1] * A[1][1] + AS[1][2] * A[1][2] + 0.3f;
+    const float det = a2 * c2 - b2 * b2;
+    const float w = 1.0f / (det * det + 0.0000001f);
+    // (1)  dS2 = -w adj G adj
+    const float u0 = c2 * gca - b2 * gcb, u1 = c2 * gcb - b2 * gcc;           // rows of adj G
+    const float v0 = a2 * gcb - b2 * gca, v1 = a2 * gcc - b2 * gcb;
+    float d2[2][2];
+    d2[0][0] = -w * (u0 * c2 - u1 * b2);
+    d2[0][1] = -w * (u1 * a2 - u0 * b2);
+    d2[1][1] = -w * (v1 * a2 - v0 * b2);
+    d2[1][0] = d2[0][1];
+    if (w == 0.0f) { d2[0][0] = 0.f; d2[0][1] = 0.f; d2[1][0] = 0.f; d2[1][1] = 0.f; }   // (denom2inv == 0 case of backward.cu:205)
+    // (2)  dS3 = A^T dS2 A,  dA = 2 dS2 (A S3)
+    float DA[2][3];                                                                          // dS2 A
+#pragma unroll
+    for (int k = 0; k < 3; k++) { DA[0][k] = d2[0][0] * A[0][k] + d2[0][1] * A[1][k]; DA[1][k] = d2[1][0] * A[0][k] + d2[1][1] * A[1][k]; }
+    {
+        const float f00 = A[0][0] * DA[0][0] + A[1][0] * DA[1][0], f11 = A[0][1] * DA[0][1] + A[1][1] * DA[1][1],
+                    f22 = A[0][2] * DA[0][2] + A[1][2] * DA[1][2];
+        const float f01 = A[0][0] * DA[0][1] + A[1][0] * DA[1][1], f02 = A[0][0] * DA[0][2] + A[1][0] * DA[1][2],
+                    f12 = A[0][1] * DA[0][2] + A[1][1] * DA[1][2];
+        dcov[0] = f00; dcov[3] = f11; dcov[5] = f22; dcov[1] = 2.0f * f01; dcov[2] = 2.0f * f02; dcov[4] = 2.0f * f12;
+    }
+    float gA[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gA[0][k] = 2.0f * (d2[0][0] * AS[0][k] + d2[0][1] * AS[1][k]); gA[1][k] = 2.0f * (d2[1][0] * AS[0][k] + d2[1][1] * AS[1][k]); }
+    // (3)  dJ = dA Rv^T (only the four non-zero entries of J), then t, then the mean
+    const float dJ00 = gA[0][0] * Rv[0][0] + gA[0][1] * Rv[0][1] + gA[0][2] * Rv[0][2];
+    const float dJ02 = gA[0][0] * Rv[2][0] + gA[0][1] * Rv[2][1] + gA[0][2] * Rv[2][2];
+    const float dJ11 = gA[1][0] * Rv[1][0] + gA[1][1] * Rv[1][1] + gA[1][2] * Rv[1][2];
+    const float dJ12 = gA[1][0] * Rv[2][0] + gA[1][1] * Rv[2][1] + gA[1][2] * Rv[2][2];
+    float dt[3];
+    dt[0] = x_free ? -(J00 * itz) * dJ02 : 0.0f;
+    dt[1] = y_free ? -(J11 * itz) * dJ12 : 0.0f;
+    dt[2] = -itz * (J00 * dJ00 + J11 * dJ11 + 2.0f * (J02 * dJ02 + J12 * dJ12));
+#pragma unroll
+    for (int k = 0; k < 3; k++) dmean[k] = Rv[0][k] * dt[0] + Rv[1][k] * dt[1] + Rv[2][k] * dt[2];
+
+    // (4) screen position: ndc = (P p)_{xy} / ((P p)_w + 1e-7); the gradient the blend delivers (gmx, gmy) is w.r.t. ndc
+    //     (backward.cu:370-387): d ndc_x / dp = (row_x - ndc_x row_w) / w'.   P's row k is projmatrix[4 c + k].
+    {
+        const float hx = projmatrix[0] * mean.x + projmatrix[4] * mean.y + projmatrix[8] * mean.z + projmatrix[12];
+        const float hy = projmatrix[1] * mean.x + projmatrix[5] * mean.y + projmatrix[9] * mean.z + projmatrix[13];
+        const float hw = projmatrix[3] * mean.x + projmatrix[7] * mean.y + projmatrix[11] * mean.z + projmatrix[15];
+        const float iw = 1.0f / (hw + 0.0000001f);
+        const float nx = hx * iw, ny = hy * iw;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            dmean[k] += iw * ((projmatrix[4 * k] - nx * projmatrix[4 * k + 3]) * gmx + (projmatrix[4 * k + 1] - ny * projmatrix[4 * k + 3]) * gmy);
+    }
+
+}
+
+// ---- step (6): dL/dcov3D -> dL/dscale, dL/drot (and dL/dtransforms), chained through the raw-parameter getters if asked
+__device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, float scale_modifier, int raw,
+                                                   const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                   const float* __restrict__ transforms, float* dscale, float* drot, float* dtf)
+{
+    // (6) S3 = L L^T, L = R(q) diag(mod s) with the quaternion as given (forward.cu:118-152; with a transform: S3 = T (L L^T) T^T,
+    //     pulled back first).  dL/dL = 2 dS3 L (dS3 the symmetric matrix: off-diagonals are half the six-vector's entries);
+    //     dL/d(mod s_k) = sum_i dL_ik R_ik;  G = dL/dR, G_ik = dL_ik s_k;  and for R(q) = I + 2 [..] with q = (r, v):
+    //       dq_r = 2 v . a,   dq_v = 2 (Soff v + r a) - 4 v * (tr G - diag G),   a = (G21-G12, G02-G20, G10-G01), Soff = offdiag(G + G^T).
+    if (scales != nullptr) {
+        float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
+        float qr[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
+        const float q_raw[4] = { qr[0], qr[1], qr[2], qr[3] };
+        activate_scale_rot(raw, scr, qr);                    // raw mode: exp / normalize as in the forward
+        float d6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
+        if (transforms != nullptr) {
+            float Tm[9], pre[6], d6_pre[6];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+            cov3d_from_scale_rot(scr, scale_modifier, qr, pre);
+            transform_cov3d_bw(Tm, pre, d6, d6_pre, dtf);
+#pragma unroll
+            for (int i = 0; i < 6; i++) d6[i] = d6_pre[i];
+        }
+        const float qw = qr[0], qx = qr[1], qy = qr[2], qz = qr[3];
+        const float R[3][3] = { { 1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy) },
+                                { 2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx) },
+                                { 2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy) } };
+        const float sm[3] = { scale_modifier * scr[0], scale_modifier * scr[1], scale_modifier * scr[2] };
+        const float D3[3][3] = { { d6[0], 0.5f * d6[1], 0.5f * d6[2] }, { 0.5f * d6[1], d6[3], 0.5f * d6[4] }, { 0.5f * d6[2], 0.5f * d6[4], d6[5] } };
+        float G[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float col[3];                                    // column k of dL/dL = 2 dS3 L
+#pragma unroll
+            for (int i = 0; i < 3; i++) col[i] = 2.0f * sm[k] * (D3[i][0] * R[0][k] + D3[i][1] * R[1][k] + D3[i][2] * R[2][k]);
+            dscale[k] = col[0] * R[0][k] + col[1] * R[1][k] + col[2] * R[2][k];      // w.r.t. mod * s, reported as is (backward.cu:322-325: no factor mod)
+#pragma unroll
+            for (int i = 0; i < 3; i++) G[i][k] = col[i] * sm[k];
+        }
+        const float a0 = G[2][1] - G[1][2], a1 = G[0][2] - G[2][0], a2q = G[1][0] - G[0][1];
+        const float s01 = G[0][1] + G[1][0], s02 = G[0][2] + G[2][0], s12 = G[1][2] + G[2][1];
+        const float trG = G[0][0] + G[1][1] + G[2][2];
+        drot[0] = 2.0f * (qx * a0 + qy * a1 + qz * a2q);
+        drot[1] = 2.0f * (qy * s01 + qz * s02 + qw * a0) - 4.0f * qx * (trG - G[0][0]);
+        drot[2] = 2.0f * (qx * s01 + qz * s12 + qw * a1) - 4.0f * qy * (trG - G[1][1]);
+        drot[3] = 2.0f * (qx * s02 + qy * s12 + qw * a2q) - 4.0f * qz * (trG - G[2][2]);
+        // raw mode: chain through the getters (same expressions as csrc/activations.hip)
+        if (raw & RAW_SCALE) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dscale[k] *= scr[k];                                  // d exp(v) = exp(v)
+        }
+        if (raw & RAW_ROTATION) normalize_backward(q_raw, qr, drot);
+    }
+}
+
+// A Gaussian that covers much of the image owns up to gx*gy instances x 16 records -- a serial sum of thousands of 48-byte gathers
+// for one lane -- so those (`is_big`) are summed by the 64 lanes of the wave together, one Gaussian at a time (lane-strided partial
+// sums, then a fixed butterfly): still a fixed order, hence bitwise reproducible.  The owner's lane receives sums[0..8] =
+// {colour r, g, b, mean2D x, y, conic A, B, C, opacity}.  Must be called with the whole wave converged.
+__device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t n_inst, const uint32_t* __restrict__ inst_pos,
+                                            const uint32_t* __restrict__ inst_mask, const float4* __restrict__ inst_grad,
+                                            size_t slab_stride_f4, float* sums)
+    {
+        unsigned long long big = __ballot(is_big);
+        const int lane = (int)(threadIdx.x & 63u);
+        while (big) {
+            const int src = __ffsll(big) - 1;
+            big &= big - 1;
+            const uint32_t boff = __shfl(off, src), bn = __shfl(n_inst, src);
+            float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            {
+                // Sparse records.  A Gaussian that covers the image owns ~1000 instances with up to 4 (light tiles) or 16 (heavy
+                // tiles) flagged records each, found through two levels of indirection (inst_pos -> inst_mask -> record): walked
+                // naively that is thousands of DEPENDENT loads for one wave (measured: +90 us per frame with ~50 such Gaussians).
+                // So: 16 instances per lane at a time, their positions and masks fetched together, then the first four flagged
+                // records of every instance with unconditional loads in straight-line code (the next instance's loads are
+                // issued before this one's are summed); further records (only heavy tiles have them) in a clean-up loop.
+                constexpr int IPL = 16;                                          // instances per lane per round
+                for (uint32_t c0 = 0; c0 < bn; c0 += 64u * IPL) {
+                    uint32_t p[IPL], mk[IPL];
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
+                        p[i] = inst_pos[boff + min(k, bn - 1u)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
+                        const uint32_t m = inst_mask[p[i]];
+                        mk[i] = k < bn ? m : 0u;
+                    }
+                    struct Quad { float4 r[4][3]; float w[4]; };
+                    auto fetch = [&](int i) {
+                        Quad qd;
+                        uint32_t m = mk[i];
+                        int sl = m ? __ffs((int)m) - 1 : 0;                      // no flagged record: slab 0 is read and ignored
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            qd.w[j] = m ? 1.0f : 0.0f;
+                            if (m) { sl = __ffs((int)m) - 1; m &= m - 1u; }
+                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
+                            qd.r[j][0] = rec[0]; qd.r[j][1] = rec[1]; qd.r[j][2] = rec[2];
+                        }
+                        mk[i] = m;                                               // what is left for the clean-up loop
+                        return qd;
+                    };
+                    auto add = [&](const Quad& qd) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            // unflagged slots may hold anything (never written): select, do not multiply
+                            const bool on = qd.w[j] != 0.0f;
+                            acc[0] += on ? qd.r[j][0].x : 0.f; acc[1] += on ? qd.r[j][0].y : 0.f; acc[2] += on ? qd.r[j][0].z : 0.f;
+                            acc[3] += on ? qd.r[j][0].w : 0.f; acc[4] += on ? qd.r[j][1].x : 0.f; acc[5] += on ? qd.r[j][1].y : 0.f;
+                            acc[6] += on ? qd.r[j][1].z : 0.f; acc[7] += on ? qd.r[j][1].w : 0.f; acc[8] += on ? qd.r[j][2].x : 0.f;
+                        }
+                    };
+                    const int rounds = (int)min((uint32_t)IPL, (bn - c0 + 63u) / 64u);     // wave-uniform: rounds with any instance
+                    Quad cur = fetch(0);
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        if (i < rounds) {
+                            Quad nxt = cur;
+                            if (i + 1 < rounds) nxt = fetch(i + 1);
+                            add(cur);
+                            cur = nxt;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < IPL; i++) {
+                        for (uint32_t mbits = mk[i]; mbits != 0u; mbits &= mbits - 1u) {
+                            const int sl = __ffs((int)mbits) - 1;
+                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
+                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                            acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
+                            acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
+                            acc[8] += r2.x;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d);
+            }
+            if (lane == src) {
+#pragma unroll
+                for (int q = 0; q < 9; q++) sums[q] = acc[q];
+            }
+        }
+    }
+
 // STAGE_SH (requires M == 16, shs and dL_dsh given): the block's SH records are read from HBM with coalesced loads into LDS and
 // the dL_dsh records leave the same way.  Per thread a record is 48 floats at a 192-byte stride, i.e. every one of the 48 loads
 // and 48 stores of a wave would touch 64 different cache lines; through LDS (row stride 49 words: conflict-free) the global side
@@ -579,93 +829,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     {
-        unsigned long long big = __ballot(visible && n_inst > COOP_INST);
-        const int lane = (int)(threadIdx.x & 63u);
-        while (big) {
-            const int src = __ffsll(big) - 1;
-            big &= big - 1;
-            const uint32_t boff = __shfl(off, src), bn = __shfl(n_inst, src);
-            float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            {
-                // Sparse records.  A Gaussian that covers the image owns ~1000 instances with up to 4 (light tiles) or 16 (heavy
-                // tiles) flagged records each, found through two levels of indirection (inst_pos -> inst_mask -> record): walked
-                // naively that is thousands of DEPENDENT loads for one wave (measured: +90 us per frame with ~50 such Gaussians).
-                // So: 16 instances per lane at a time, their positions and masks fetched together, then the first four flagged
-                // records of every instance with unconditional loads in straight-line code (the next instance's loads are
-                // issued before this one's are summed); further records (only heavy tiles have them) in a clean-up loop.
-                constexpr int IPL = 16;                                          // instances per lane per round
-                for (uint32_t c0 = 0; c0 < bn; c0 += 64u * IPL) {
-                    uint32_t p[IPL], mk[IPL];
-#pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
-                        p[i] = inst_pos[boff + min(k, bn - 1u)];
-                    }
-#pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
-                        const uint32_t m = inst_mask[p[i]];
-                        mk[i] = k < bn ? m : 0u;
-                    }
-                    struct Quad { float4 r[4][3]; float w[4]; };
-                    auto fetch = [&](int i) {
-                        Quad qd;
-                        uint32_t m = mk[i];
-                        int sl = m ? __ffs((int)m) - 1 : 0;                      // no flagged record: slab 0 is read and ignored
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            qd.w[j] = m ? 1.0f : 0.0f;
-                            if (m) { sl = __ffs((int)m) - 1; m &= m - 1u; }
-                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
-                            qd.r[j][0] = rec[0]; qd.r[j][1] = rec[1]; qd.r[j][2] = rec[2];
-                        }
-                        mk[i] = m;                                               // what is left for the clean-up loop
-                        return qd;
-                    };
-                    auto add = [&](const Quad& qd) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            // unflagged slots may hold anything (never written): select, do not multiply
-                            const bool on = qd.w[j] != 0.0f;
-                            acc[0] += on ? qd.r[j][0].x : 0.f; acc[1] += on ? qd.r[j][0].y : 0.f; acc[2] += on ? qd.r[j][0].z : 0.f;
-                            acc[3] += on ? qd.r[j][0].w : 0.f; acc[4] += on ? qd.r[j][1].x : 0.f; acc[5] += on ? qd.r[j][1].y : 0.f;
-                            acc[6] += on ? qd.r[j][1].z : 0.f; acc[7] += on ? qd.r[j][1].w : 0.f; acc[8] += on ? qd.r[j][2].x : 0.f;
-                        }
-                    };
-                    const int rounds = (int)min((uint32_t)IPL, (bn - c0 + 63u) / 64u);     // wave-uniform: rounds with any instance
-                    Quad cur = fetch(0);
-#pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        if (i < rounds) {
-                            Quad nxt = cur;
-                            if (i + 1 < rounds) nxt = fetch(i + 1);
-                            add(cur);
-                            cur = nxt;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        for (uint32_t mbits = mk[i]; mbits != 0u; mbits &= mbits - 1u) {
-                            const int sl = __ffs((int)mbits) - 1;
-                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
-                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                            acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
-                            acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
-                            acc[8] += r2.x;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 9; q++) {
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d);
-            }
-            if (lane == src) {
-                gcol.x = acc[0]; gcol.y = acc[1]; gcol.z = acc[2]; gmx = acc[3];
-                gmy = acc[4]; gca = acc[5]; gcb = acc[6]; gcc = acc[7]; gop = acc[8];
-            }
-        }
+        float sums[9] = { gcol.x, gcol.y, gcol.z, gmx, gmy, gca, gcb, gcc, gop };
+        coop_gather(visible && n_inst > COOP_INST, off, n_inst, inst_pos, inst_mask, inst_grad, slab_stride_f4, sums);
+        gcol.x = sums[0]; gcol.y = sums[1]; gcol.z = sums[2]; gmx = sums[3]; gmy = sums[4]; gca = sums[5]; gcb = sums[6]; gcc = sums[7]; gop = sums[8];
     }
     PSTAMP(12);
     PSTAMP(1);
@@ -685,92 +851,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                           : ((M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr);
 
     if (visible) {
-        // ================= per-Gaussian backward, in matrix form =================================================================
-        // What is differentiated is the reference's forward (forward.cu:74-113, 118-152, 20-71, 196-237) with the conventions its
-        // backward fixes (backward.cu:144-396): 1/(det^2 + 1e-7) in the inverse, no gradient through a clamped t.x/t.z, the SH clamp
-        // flags, the quaternion used as given.  The expressions are this file's own: every step is a small matrix identity.
-        //
-        // (1) conic K = inverse(S2), S2 = [[a b][b c]] the dilated 2-D covariance.  The blend kernels deliver G = dL/dK as a full
-        //     symmetric matrix [[gA gB][gB gC]] (gB per off-diagonal entry).  d(inverse):  dL/dS2 = -K G K = -(adj G adj) / det^2 with
-        //     adj = [[c -b][-b a]]; the reference regularises 1/det^2 as 1/(det^2 + 1e-7) (backward.cu:203) -- kept.
-        // (2) S2 = A S3 A^T + 0.3 I with A = J Rv (2x3): dL/dS3 = A^T dS2 A (the six-vector doubles the off-diagonals, each
-        //     appearing twice in the matrix), dL/dA = 2 dS2 A S3.
-        // (3) A = J Rv: dL/dJ = dL/dA Rv^T; J = [[fx/tz 0 -fx tx/tz^2][0 fy/tz -fy ty/tz^2]] so, written with J's own entries,
-        //     dJ00/dtz = -J00/tz, dJ02/dtx = -J00/tz, dJ02/dtz = -2 J02/tz (same for the y row); dL/dmean = Rv^T dL/dt.
-        const float Rv[3][3] = { { viewmatrix[0], viewmatrix[4], viewmatrix[8] }, { viewmatrix[1], viewmatrix[5], viewmatrix[9] },
-                                 { viewmatrix[2], viewmatrix[6], viewmatrix[10] } };            // t = Rv p + (view[12..14])
-        const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
-        const float* c6 = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
-        const float S3[3][3] = { { c6[0], c6[1], c6[2] }, { c6[1], c6[3], c6[4] }, { c6[2], c6[4], c6[5] } };
-        float t[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) t[r] = Rv[r][0] * mean.x + Rv[r][1] * mean.y + Rv[r][2] * mean.z + viewmatrix[12 + r];
-        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float rx = t[0] / t[2], ry = t[1] / t[2];
-        const bool x_free = !(rx < -limx || rx > limx), y_free = !(ry < -limy || ry > limy);     // forward.cu:82-87 clamp inactive
-        const float tx = fminf(limx, fmaxf(-limx, rx)) * t[2], ty = fminf(limy, fmaxf(-limy, ry)) * t[2];
-        const float itz = 1.0f / t[2];
-        const float J00 = h_x * itz, J11 = h_y * itz, J02 = -(h_x * tx) * (itz * itz), J12 = -(h_y * ty) * (itz * itz);
-        float A[2][3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { A[0][k] = J00 * Rv[0][k] + J02 * Rv[2][k]; A[1][k] = J11 * Rv[1][k] + J12 * Rv[2][k]; }
-        float AS[2][3];                                                                          // A S3
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) AS[i][k] = A[i][0] * S3[0][k] + A[i][1] * S3[1][k] + A[i][2] * S3[2][k];
-        const float a2 = AS[0][0] * A[0][0] + AS[0][1] * A[0][1] + AS[0][2] * A[0][2] + 0.3f;
-        const float b2 = AS[0][0] * A[1][0] + AS[0][1] * A[1][1] + AS[0][2] * A[1][2];
-        const float c2 = AS[1][0] * A[1][0] + AS[1][1] * A[1][1] + AS[1][2] * A[1][2] + 0.3f;
-        const float det = a2 * c2 - b2 * b2;
-        const float w = 1.0f / (det * det + 0.0000001f);
-        // (1)  dS2 = -w adj G adj
-        const float u0 = c2 * gca - b2 * gcb, u1 = c2 * gcb - b2 * gcc;           // rows of adj G
-        const float v0 = a2 * gcb - b2 * gca, v1 = a2 * gcc - b2 * gcb;
-        float d2[2][2];
-        d2[0][0] = -w * (u0 * c2 - u1 * b2);
-        d2[0][1] = -w * (u1 * a2 - u0 * b2);
-        d2[1][1] = -w * (v1 * a2 - v0 * b2);
-        d2[1][0] = d2[0][1];
-        if (w == 0.0f) { d2[0][0] = 0.f; d2[0][1] = 0.f; d2[1][0] = 0.f; d2[1][1] = 0.f; }   // (denom2inv == 0 case of backward.cu:205)
-        // (2)  dS3 = A^T dS2 A,  dA = 2 dS2 (A S3)
-        float DA[2][3];                                                                          // dS2 A
-#pragma unroll
-        for (int k = 0; k < 3; k++) { DA[0][k] = d2[0][0] * A[0][k] + d2[0][1] * A[1][k]; DA[1][k] = d2[1][0] * A[0][k] + d2[1][1] * A[1][k]; }
-        {
-            const float f00 = A[0][0] * DA[0][0] + A[1][0] * DA[1][0], f11 = A[0][1] * DA[0][1] + A[1][1] * DA[1][1],
-                        f22 = A[0][2] * DA[0][2] + A[1][2] * DA[1][2];
-            const float f01 = A[0][0] * DA[0][1] + A[1][0] * DA[1][1], f02 = A[0][0] * DA[0][2] + A[1][0] * DA[1][2],
-                        f12 = A[0][1] * DA[0][2] + A[1][1] * DA[1][2];
-            dcov[0] = f00; dcov[3] = f11; dcov[5] = f22; dcov[1] = 2.0f * f01; dcov[2] = 2.0f * f02; dcov[4] = 2.0f * f12;
-        }
-        float gA[2][3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { gA[0][k] = 2.0f * (d2[0][0] * AS[0][k] + d2[0][1] * AS[1][k]); gA[1][k] = 2.0f * (d2[1][0] * AS[0][k] + d2[1][1] * AS[1][k]); }
-        // (3)  dJ = dA Rv^T (only the four non-zero entries of J), then t, then the mean
-        const float dJ00 = gA[0][0] * Rv[0][0] + gA[0][1] * Rv[0][1] + gA[0][2] * Rv[0][2];
-        const float dJ02 = gA[0][0] * Rv[2][0] + gA[0][1] * Rv[2][1] + gA[0][2] * Rv[2][2];
-        const float dJ11 = gA[1][0] * Rv[1][0] + gA[1][1] * Rv[1][1] + gA[1][2] * Rv[1][2];
-        const float dJ12 = gA[1][0] * Rv[2][0] + gA[1][1] * Rv[2][1] + gA[1][2] * Rv[2][2];
-        float dt[3];
-        dt[0] = x_free ? -(J00 * itz) * dJ02 : 0.0f;
-        dt[1] = y_free ? -(J11 * itz) * dJ12 : 0.0f;
-        dt[2] = -itz * (J00 * dJ00 + J11 * dJ11 + 2.0f * (J02 * dJ02 + J12 * dJ12));
-#pragma unroll
-        for (int k = 0; k < 3; k++) dmean[k] = Rv[0][k] * dt[0] + Rv[1][k] * dt[1] + Rv[2][k] * dt[2];
-
-        // (4) screen position: ndc = (P p)_{xy} / ((P p)_w + 1e-7); the gradient the blend delivers (gmx, gmy) is w.r.t. ndc
-        //     (backward.cu:370-387): d ndc_x / dp = (row_x - ndc_x row_w) / w'.   P's row k is projmatrix[4 c + k].
-        {
-            const float hx = projmatrix[0] * mean.x + projmatrix[4] * mean.y + projmatrix[8] * mean.z + projmatrix[12];
-            const float hy = projmatrix[1] * mean.x + projmatrix[5] * mean.y + projmatrix[9] * mean.z + projmatrix[13];
-            const float hw = projmatrix[3] * mean.x + projmatrix[7] * mean.y + projmatrix[11] * mean.z + projmatrix[15];
-            const float iw = 1.0f / (hw + 0.0000001f);
-            const float nx = hx * iw, ny = hy * iw;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                dmean[k] += iw * ((projmatrix[4 * k] - nx * projmatrix[4 * k + 3]) * gmx + (projmatrix[4 * k + 1] - ny * projmatrix[4 * k + 3]) * gmy);
-        }
+        float3 mean;
+        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, means3D, cov3D_precomp, g, viewmatrix, projmatrix, mean, dmean, dcov);
 
         PSTAMP(3);
         // (5) colour = max(0, 0.5 + sum_k b_k(n) sh_k), n = (mean - campos)/|.| (forward.cu:20-71).  dL/dsh_k = b_k(n) g (g = colour
@@ -823,56 +905,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             dmean[0] += (ddx - x * nd) * il; dmean[1] += (ddy - y * nd) * il; dmean[2] += (ddz - z * nd) * il;
         }
 
+
         PSTAMP(4);
-        // (6) S3 = L L^T, L = R(q) diag(mod s) with the quaternion as given (forward.cu:118-152; with a transform: S3 = T (L L^T) T^T,
-        //     pulled back first).  dL/dL = 2 dS3 L (dS3 the symmetric matrix: off-diagonals are half the six-vector's entries);
-        //     dL/d(mod s_k) = sum_i dL_ik R_ik;  G = dL/dR, G_ik = dL_ik s_k;  and for R(q) = I + 2 [..] with q = (r, v):
-        //       dq_r = 2 v . a,   dq_v = 2 (Soff v + r a) - 4 v * (tr G - diag G),   a = (G21-G12, G02-G20, G10-G01), Soff = offdiag(G + G^T).
-        if (scales != nullptr) {
-            float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
-            float qr[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
-            const float q_raw[4] = { qr[0], qr[1], qr[2], qr[3] };
-            activate_scale_rot(raw, scr, qr);                    // raw mode: exp / normalize as in the forward
-            float d6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
-            if (transforms != nullptr) {
-                float Tm[9], pre[6], d6_pre[6];
-#pragma unroll
-                for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
-                cov3d_from_scale_rot(scr, scale_modifier, qr, pre);
-                transform_cov3d_bw(Tm, pre, d6, d6_pre, dtf);
-#pragma unroll
-                for (int i = 0; i < 6; i++) d6[i] = d6_pre[i];
-            }
-            const float qw = qr[0], qx = qr[1], qy = qr[2], qz = qr[3];
-            const float R[3][3] = { { 1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy) },
-                                    { 2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx) },
-                                    { 2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy) } };
-            const float sm[3] = { scale_modifier * scr[0], scale_modifier * scr[1], scale_modifier * scr[2] };
-            const float D3[3][3] = { { d6[0], 0.5f * d6[1], 0.5f * d6[2] }, { 0.5f * d6[1], d6[3], 0.5f * d6[4] }, { 0.5f * d6[2], 0.5f * d6[4], d6[5] } };
-            float G[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float col[3];                                    // column k of dL/dL = 2 dS3 L
-#pragma unroll
-                for (int i = 0; i < 3; i++) col[i] = 2.0f * sm[k] * (D3[i][0] * R[0][k] + D3[i][1] * R[1][k] + D3[i][2] * R[2][k]);
-                dscale[k] = col[0] * R[0][k] + col[1] * R[1][k] + col[2] * R[2][k];      // w.r.t. mod * s, reported as is (backward.cu:322-325: no factor mod)
-#pragma unroll
-                for (int i = 0; i < 3; i++) G[i][k] = col[i] * sm[k];
-            }
-            const float a0 = G[2][1] - G[1][2], a1 = G[0][2] - G[2][0], a2q = G[1][0] - G[0][1];
-            const float s01 = G[0][1] + G[1][0], s02 = G[0][2] + G[2][0], s12 = G[1][2] + G[2][1];
-            const float trG = G[0][0] + G[1][1] + G[2][2];
-            drot[0] = 2.0f * (qx * a0 + qy * a1 + qz * a2q);
-            drot[1] = 2.0f * (qy * s01 + qz * s02 + qw * a0) - 4.0f * qx * (trG - G[0][0]);
-            drot[2] = 2.0f * (qx * s01 + qz * s12 + qw * a1) - 4.0f * qy * (trG - G[1][1]);
-            drot[3] = 2.0f * (qx * s02 + qy * s12 + qw * a2q) - 4.0f * qz * (trG - G[2][2]);
-            // raw mode: chain through the getters (same expressions as csrc/activations.hip)
-            if (raw & RAW_SCALE) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) dscale[k] *= scr[k];                                  // d exp(v) = exp(v)
-            }
-            if (raw & RAW_ROTATION) normalize_backward(q_raw, qr, drot);
-        }
+        scale_rot_backward(idx, dcov, scale_modifier, raw, scales, rotations, transforms, dscale, drot, dtf);
     } else if (dsh != nullptr) {
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
     }
