@@ -364,14 +364,127 @@ struct SegEmit {
 };
 constexpr int MAX_CUTS = 16;     // cuts per block (a block with more than MAX_CUTS * SEG_HITS blended hits keeps the rest as its own item)
 
-__device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
-                                                   const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
-                                                   HeavyLds* L, const float* __restrict__ bg_color, float* __restrict__ out_color,
-                                                   float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
-                                                   unsigned long long* stamp_out, SegEmit& se, uint32_t* __restrict__ tail_start)
+// ---- wave PAIRS (forward kernel).  Round 2's stamps: the forward kernel lasts exactly as long as its longest item, and 32k of that
+// item's 102k cycles are NOT blending -- scanning block masks, issuing the record DMAs and waiting for them to land, all in the same
+// wave that then blends.  So a heavy item is now worked on by TWO waves of a workgroup: the SCANNER scans the masks, keeps the hit
+// list and has the hits' records copied into the pair's LDS ring; the BLENDER does nothing but trips.  They talk through a few LDS
+// words (no s_barrier: a workgroup barrier would tie the other pair in):
+//   scanner -> blender   post_seq / post_*   "item #seq is (tile, block, range)" or "no more heavy items"
+//                        ready               list entries whose records have LANDED in the ring (bit 31: the list is complete)
+//   blender -> scanner   consumed            list entries it is done with (ring slots below may be overwritten)
+//                        stop_seq            "every pixel of item #seq is finished: stop scanning"
+//                        fin_seq             "item #seq is written out: the ring is yours"
+// Every spin loop is bounded by the other wave's progress: the blender needs >= 4 landed entries (or the complete list) to run a
+// trip and the scanner always has room for them (RCAP >> 4 + one batch); the scanner needs ring room, which every trip frees.
+struct PairCtl {
+    uint32_t post_seq, post_kind, post_tile, post_blk, post_rank, rg_x, rg_y;
+    uint32_t ready, consumed, stop_seq, fin_seq, pad;
+};
+constexpr int PAIR_RCAP = 256, PAIR_LCAP = 256;           // ring slots / list entries per pair (powers of two, multiples of the 64-slot DMA batch)
+constexpr int PAIR_FIRST_HITS = 12, PAIR_ROUND_HITS = 24; // hits the scanner collects before it requests their records (first / later rounds)
+typedef HeavyLdsT<PAIR_RCAP, PAIR_LCAP> PairRing;
+
+// (explicit LDS address space: through a generic pointer a volatile access becomes a FLAT load with system-scope cache bits)
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p)
 {
-    constexpr int LMASK = HeavyLds::LMASK, RMASK = HeavyLds::RMASK;
+    const uint32_t v = *(const volatile lds_u32_t*)p;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32_t*)p = v; }
+
+// s_setprio takes an immediate
+__device__ __forceinline__ void set_wave_prio(int p)
+{
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+// issue priority of an item by the length of its tile's list: the longest items set the kernel's duration
+__device__ __forceinline__ int prio_of_length(uint32_t n) { return n >= 2048u ? 3 : n >= 1024u ? 2 : n >= 512u ? 1 : 0; }
+
+// SCANNER of a heavy item: block masks -> hit list -> record DMAs -> `ready`.  nx = the first chapter of masks (requested by the
+// caller before it waited for the blender to release the ring).
+__device__ __forceinline__ void heavy_forward_scan(int blk, int lane, const uint2 rg, const float4* __restrict__ inst_rec,
+                                                   const uint16_t* __restrict__ inst_bmask, PairRing* L, PairCtl* ctl, uint32_t seq,
+                                                   int flags, uint32_t (&nx)[CHAPTER])
+{
+    constexpr int LMASK = PairRing::LMASK;
+    const int n = (int)(rg.y - rg.x);
+    const uint16_t* const bm = inst_bmask + rg.x;
+    const float4* const recs = inst_rec + 3 * (size_t)rg.x;
+    const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;     // culling switched off (diagnostics): every entry is a hit
+    // list entries: [0, F) requested by DMA (and landed once `ready` says so), [F, nlist) found but not requested yet
+    int scan_pos = 0, nlist = 0, F = 0, grp = CHAPTER;
+    bool scan_done = n <= 0, stop = false;
+    int c_seen = 0;                                          // a lower bound of what the blender has consumed
+    uint32_t vb_lo = 0u, vb_hi = 0u;                         // lane k: the hit mask of the current chapter's group k
+    for (;;) {
+        int new_hits = 0;
+        const int target = F == 0 ? PAIR_FIRST_HITS : PAIR_ROUND_HITS;
+        while (!scan_done && new_hits < target) {
+            // Room: a group adds up to 64 entries and the DMA re-copies whole 64-slot batches, so ring slots up to entry nlist + 126
+            // are written -- the entries that lived there (index - RCAP) must be consumed.
+            if (nlist + 128 - PAIR_RCAP > c_seen) {
+                c_seen = (int)lds_peek(&ctl->consumed);
+                stop = lds_peek(&ctl->stop_seq) == seq;
+                if (stop) break;
+                if (nlist + 128 - PAIR_RCAP > c_seen) {
+                    if (new_hits > 0) break;                 // hand over what there is first
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+            }
+            if (grp == CHAPTER) {
+                // A new chapter: the 8 hit masks of its 64-entry groups are formed at once from the masks that were in flight (8
+                // independent ballots) and parked in lane k of a VGPR pair; the chapter after it is requested.
+                unsigned long long bl = 0ull;
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) {
+                    const int idx = scan_pos + 64 * k + lane;
+                    const unsigned long long b = __ballot(idx < n && (((nx[k] | all_hit) >> blk) & 1u) != 0u);
+                    bl = lane == k ? b : bl;
+                }
+                vb_lo = (uint32_t)bl; vb_hi = (uint32_t)(bl >> 32);
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(scan_pos + 64 * (CHAPTER + k) + lane, n - 1)];
+                grp = 0;
+            }
+            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vb_hi, grp) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)vb_lo, grp);
+            grp++;
+            if (m != 0ull) {
+                const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(scan_pos + lane);
+                const int c = __popcll(m);
+                nlist += c; new_hits += c;
+            }
+            scan_pos += 64;
+            scan_done = scan_pos >= n;
+        }
+        if (!stop) stop = lds_peek(&ctl->stop_seq) == seq;
+        if (stop) break;
+        __builtin_amdgcn_wave_barrier();
+        if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
+        __builtin_amdgcn_s_waitcnt(0);                       // the records (and the list) are in LDS
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_poke(&ctl->ready, (uint32_t)F | (scan_done ? 0x80000000u : 0u));
+        if (scan_done) break;
+    }
+    __builtin_amdgcn_s_waitcnt(0);                           // no DMA may still be writing the ring when the next item starts
+}
+
+// BLENDER of a heavy item: trips over the landed entries, cuts, and the block's outputs.
+__device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
+                                                    PairRing* L, PairCtl* ctl, uint32_t seq, const float* __restrict__ bg_color,
+                                                    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
+                                                    unsigned long long* stamp_out, SegEmit& se, uint32_t* __restrict__ tail_start)
+{
+    constexpr int LMASK = PairRing::LMASK, RMASK = PairRing::RMASK;
     const int slot = lane & 3, pl = lane >> 2, gbase = lane & ~3;
     const uint32_t below_mask = (1u << slot) - 1u;
     const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
@@ -379,12 +492,9 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
     const bool inside = px < W && py < H;
     const float pixx = (float)px, pixy = (float)py;
     const int n = (int)(rg.y - rg.x);
-    const uint16_t* const bm = inst_bmask + rg.x;
-    const float4* const recs = inst_rec + 3 * (size_t)rg.x;
-    const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;     // culling switched off (diagnostics): every entry is a hit
 #define STAMP() (stamp_out ? __builtin_amdgcn_s_memtime() : 0ull)
     const unsigned long long t_begin = STAMP();
-    unsigned long long d_trip = 0, n_rounds = 0, n_trips = 0;
+    unsigned long long d_trip = 0, d_starve = 0, n_rounds = 0, n_trips = 0, t_first = 0;
 
     float T = 1.0f, T_stop = -1.0f;
     float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
@@ -452,58 +562,26 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
         if (last_valid != 0) emit_cut((int)__int_as_float(last_pos1));
     };
 
-    // list entries: [0, C) blended, [C, F) records requested by DMA, [F, nlist) found by the scan but not requested yet
-    int scan_pos = 0, nlist = 0, C = 0, F = 0, grp = CHAPTER;
-    bool scan_done = false;
-    uint32_t nx[CHAPTER];                                    // the next chapter of masks, in flight
-    uint32_t vb_lo = 0u, vb_hi = 0u;                         // lane k: the hit mask of the current chapter's group k
-#pragma unroll
-    for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(64 * k + lane, n - 1)];
+    int C = 0;                                               // list entries [0, C) are blended
+    if (finished) lds_poke(&ctl->stop_seq, seq);
     while (!finished) {
-        __builtin_amdgcn_s_waitcnt(0);                       // every DMA issued so far has landed (they had a round of blending to do so)
-        __builtin_amdgcn_wave_barrier();
-        const int ready = F;                                 // records of [C, ready) are in the ring
-        const bool final_round = scan_done;                  // nothing new can come: blend everything that is left
-        n_rounds++;
-        // ---- scan 64-entry groups until this round has found ROUND_HITS new hits (or the list ends)
-        int new_hits = 0;
-        while (!scan_done && new_hits < ROUND_HITS) {
-            if (grp == CHAPTER) {
-                // A new chapter: the 8 hit masks of its 64-entry groups are formed at once from the masks that were in flight (8
-                // independent ballots, no per-group LDS read -> ballot -> branch chain) and parked in lane k of a VGPR pair;
-                // the chapter after it is requested.
-                unsigned long long bl = 0ull;
-#pragma unroll
-                for (int k = 0; k < CHAPTER; k++) {
-                    const int idx = scan_pos + 64 * k + lane;
-                    const unsigned long long b = __ballot(idx < n && (((nx[k] | all_hit) >> blk) & 1u) != 0u);
-                    bl = lane == k ? b : bl;
-                }
-                vb_lo = (uint32_t)bl; vb_hi = (uint32_t)(bl >> 32);
-#pragma unroll
-                for (int k = 0; k < CHAPTER; k++) nx[k] = bm[min(scan_pos + 64 * (CHAPTER + k) + lane, n - 1)];
-                grp = 0;
-            }
-            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)vb_hi, grp) << 32) |
-                                         (uint32_t)__builtin_amdgcn_readlane((int)vb_lo, grp);
-            grp++;
-            if (m != 0ull) {
-                const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(scan_pos + lane);
-                const int c = __popcll(m);
-                nlist += c; new_hits += c;
-            }
-            scan_pos += 64;
-            scan_done = scan_pos >= n;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- request the new hits' records; they land while the previous round's are blended below
-        if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
-        // ---- blend the complete groups of 4 among [C, ready) (in the final round: all of it)
+        const unsigned long long t_poll = STAMP();
+        const uint32_t r = lds_peek(&ctl->ready);
+        const bool final_round = (r >> 31) != 0u;            // the list is complete: blend everything that is left
+        const int ready = (int)(r & 0x7fffffffu);            // records of [C, ready) are in the ring
         const int avail = ready - C;
         const int ntrip = (avail >> 2) + ((final_round && (avail & 3) != 0) ? 1 : 0);
-        if (ntrip > 0 && !(flags & 2)) {
+        if (ntrip == 0) {
+            if (final_round) break;
+            __builtin_amdgcn_s_sleep(2);
+            d_starve += STAMP() - t_poll;
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        n_rounds++;
+        if (!(flags & 2)) {
             const unsigned long long t4 = STAMP();
+            if (t_first == 0) t_first = t4 - t_begin;
             n_trips += ntrip;
             auto get = [&](int t) -> Fetched {
                 const int li = C + 4 * t + slot;
@@ -522,14 +600,16 @@ __device__ __forceinline__ void heavy_forward_item(int W, int H, int gx, int til
                 if (trip(f1)) { finished = true; break; }
                 maybe_cut(f1, C + 4 * (t + 2), final_round && t + 2 >= ntrip);
             }
-            C += 4 * ntrip;
             d_trip += STAMP() - t4;
         }
+        C += 4 * ntrip;
+        if (finished) { lds_poke(&ctl->stop_seq, seq); break; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // (the ring reads above are complete before the slots are given back)
+        lds_poke(&ctl->consumed, (uint32_t)min(C, ready));
         if (final_round) break;
     }
-    __builtin_amdgcn_s_waitcnt(0);                           // no DMA may still be writing this wave's LDS when the next item starts
     if (stamp_out && lane == 0) {
-        stamp_out[0] = STAMP() - t_begin; stamp_out[1] = (unsigned long long)n; stamp_out[2] = 0; stamp_out[3] = 0; stamp_out[4] = 0;
+        stamp_out[0] = STAMP() - t_begin; stamp_out[1] = (unsigned long long)n; stamp_out[2] = d_starve; stamp_out[3] = t_first; stamp_out[4] = 0;
         stamp_out[5] = d_trip; stamp_out[6] = n_rounds; stamp_out[7] = n_trips;
     }
 #undef STAMP
@@ -795,44 +875,118 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
                           float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
                           unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */,
                           uint4* __restrict__ seg_desc, float* __restrict__ seg_state, uint32_t seg_cap, int seg_hits,
-                          uint32_t* __restrict__ tail_start, uint32_t* __restrict__ seg_counts)
+                          uint32_t* __restrict__ tail_start, uint32_t* __restrict__ seg_counts, int role_swap, int prio_mode)
 {
-    __shared__ HeavyLds s_heavy[4];                         // heavy path: per-wave hit list and record ring (28 KB each); a light item
-    __shared__ float s_cut_sums[4][MAX_CUTS * 16 * 6];      // uses the first 3 KB as its record ring.  Per wave: the cuts of the current block
-    __shared__ uint2 s_cut_pos[4][MAX_CUTS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(&s_heavy[wv]);
+    // Two wave PAIRS per workgroup (see PairCtl): per pair a record ring + hit list, the cuts of the block being blended, and the
+    // control words.  A light item uses 3 KB of the pair's ring per wave as its record ring.
+    __shared__ PairRing s_ring[FWD_PAIRS_PER_WG];
+    __shared__ float s_cut_sums[FWD_PAIRS_PER_WG][MAX_CUTS * 16 * 6];
+    __shared__ uint2 s_cut_pos[FWD_PAIRS_PER_WG][MAX_CUTS];
+    __shared__ PairCtl s_ctl[FWD_PAIRS_PER_WG];
+    static_assert(sizeof(PairRing) >= 2 * 64 * 3 * sizeof(float4), "the light path's rings live inside the pair's ring");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pair = wv >> 1;
+    // Which wave of the pair blends: the waves of a workgroup sit on SIMD 0..3 in order, and a CU hosts several workgroups -- the roles
+    // are swapped between them so that a SIMD gets blenders (busy) and scanners (mostly waiting) in equal numbers.
+    const bool is_scanner = (((wv ^ role_swap ^ (int)((blockIdx.x >> 3) / 32u)) & 1) == 0);
+    if (threadIdx.x < FWD_PAIRS_PER_WG * (int)(sizeof(PairCtl) / 4)) reinterpret_cast<uint32_t*>(s_ctl)[threadIdx.x] = 0u;
+    __syncthreads();                                         // (the only workgroup barrier of the kernel)
+    PairRing* const L = &s_ring[pair];
+    PairCtl* const ctl = &s_ctl[pair];
+    float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(reinterpret_cast<char*>(L) + (size_t)(wv & 1) * 64 * 3 * sizeof(float4));
     const int n_work = (int)header[5];                       // tile_order lists the tiles that own instances first
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
-    const int q_waves = 4 * (((int)gridDim.x - qx + nq - 1) / nq);     // waves that pull from this queue
-    const int my_rank = ((int)blockIdx.x / nq) * 4 + wv;               // this wave's rank among them
-    // this wave's private slot range: region of its XCD, q_waves equal shares
-    SegEmit se;
-    {
-        const uint32_t share = seg_cap / (uint32_t)max(q_waves, 1);
-        const size_t first = (size_t)qx * seg_cap + (size_t)my_rank * share;
-        se.desc = seg_desc + first; se.state = seg_state + first * SEG_STATE_FLOATS;
-        se.cap = (seg_hits > 0 && q_waves <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) ? share : 0u;
-        se.count = 0u; se.seg_hits = seg_hits > 0 ? seg_hits : (1 << 30);
-        se.cut_sums = s_cut_sums[wv]; se.cut_pos = s_cut_pos[wv];
+    const int q_pairs = FWD_PAIRS_PER_WG * (((int)gridDim.x - qx + nq - 1) / nq);     // pairs that pull from this queue
+    const int my_rank = ((int)blockIdx.x / nq) * FWD_PAIRS_PER_WG + pair;             // this pair's rank among them
+    uint32_t* const my_head = queue_head + (size_t)qx * QLINE_WORDS;
+    // queue index -> item.  Of a queue's tiles the first hx are heavy (16 block items each), the rest light (4 quadrant items each).
+    auto decode = [&](int qi) -> WaveItem {
+        WaveItem it;
+        it.heavy = qi < WAVE_BLOCKS * hx;
+        const int k = it.heavy ? (qi >> 4) : hx + ((qi - WAVE_BLOCKS * hx) >> 2);
+        it.sub = it.heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
+        it.rank = k * nq + qx;
+        it.valid = it.rank < n_work;
+        it.tile = it.valid ? (int)tile_order[it.rank] : 0;
+        return it;
+    };
+    auto pop = [&]() -> int {
+        int qi = 0;
+        if (lane == 0) qi = (int)atomicAdd(my_head, 1u) + q_pairs;
+        return __builtin_amdgcn_readfirstlane(qi);
+    };
+    int light_qi = -1;                                       // scanner: the first light item it drew (the blender draws its own)
+    if (is_scanner) {
+        // ---- heavy phase, scanner: draws the pair's items.  The FIRST item is the pair's rank in its queue (no atomic: with one
+        // returning atomic per wave at kernel start the last wave waited 2-12 us for its first item, see common.h).
+        uint32_t seq = 0u;
+        int qi = my_rank;
+        for (;;) {
+            const WaveItem it = decode(qi);
+            const uint2 rg = it.valid ? ranges[it.tile] : make_uint2(0u, 0u);
+            const bool heavy = it.valid && it.heavy;
+            uint32_t nx[CHAPTER];
+            if (heavy) {                                     // the first chapter of block masks: requested before the wait below
+                const int n = (int)(rg.y - rg.x);
+                const uint16_t* const bm = inst_bmask + rg.x;
+#pragma unroll
+                for (int k = 0; k < CHAPTER; k++) nx[k] = bm[max(min(64 * k + lane, n - 1), 0)];
+            }
+            while (lds_peek(&ctl->fin_seq) != seq) __builtin_amdgcn_s_sleep(2);       // the blender is done with the previous item
+            seq++;
+            if (lane == 0) {
+                lds_poke(&ctl->ready, 0u); lds_poke(&ctl->consumed, 0u);
+                lds_poke(&ctl->post_kind, heavy ? 1u : 0u); lds_poke(&ctl->post_tile, (uint32_t)it.tile);
+                lds_poke(&ctl->post_blk, (uint32_t)it.sub); lds_poke(&ctl->post_rank, (uint32_t)it.rank);
+                lds_poke(&ctl->rg_x, rg.x); lds_poke(&ctl->rg_y, rg.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_poke(&ctl->post_seq, seq);
+            if (!heavy) { light_qi = it.valid ? qi : -1; break; }
+            if (prio_mode == 2) set_wave_prio(prio_of_length(rg.y - rg.x));
+            else if (prio_mode == 3) set_wave_prio(min(3, prio_of_length(rg.y - rg.x) + 1));
+            heavy_forward_scan(it.sub, lane, rg, inst_rec, inst_bmask, L, ctl, seq, flags, nx);
+            qi = pop();
+        }
+    } else {
+        // ---- heavy phase, blender: this pair's slot range for depth segments (region of its XCD, q_pairs equal shares)
+        SegEmit se;
+        {
+            const uint32_t share = seg_cap / (uint32_t)max(q_pairs, 1);
+            const size_t first = (size_t)qx * seg_cap + (size_t)my_rank * share;
+            se.desc = seg_desc + first; se.state = seg_state + first * SEG_STATE_FLOATS;
+            se.cap = (seg_hits > 0 && q_pairs <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) ? share : 0u;
+            se.count = 0u; se.seg_hits = seg_hits > 0 ? seg_hits : (1 << 30);
+            se.cut_sums = s_cut_sums[pair]; se.cut_pos = s_cut_pos[pair];
+        }
+        uint32_t seq = 0u;
+        for (;;) {
+            seq++;
+            while (lds_peek(&ctl->post_seq) != seq) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lds_peek(&ctl->post_kind) == 0u) break;
+            const int tile = (int)lds_peek(&ctl->post_tile), blk = (int)lds_peek(&ctl->post_blk), rank = (int)lds_peek(&ctl->post_rank);
+            const uint2 rg = make_uint2(lds_peek(&ctl->rg_x), lds_peek(&ctl->rg_y));
+            if (prio_mode != 0) set_wave_prio(prio_of_length(rg.y - rg.x));
+            heavy_forward_blend(W, H, gx, tile, blk, lane, rg, L, ctl, seq, bg_color, out_color, out_depth, out_alpha, final_T, n_contrib,
+                                flags, stamps ? stamps + (size_t)(rank * WAVE_BLOCKS + blk) * 8 : nullptr, se, tail_start);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_poke(&ctl->fin_seq, seq);
+        }
+        // how many of its slots this pair filled (EVERY pair writes its count: the backward kernel sums them per region)
+        if (lane == 0 && my_rank < MAX_FWD_QUEUE_WAVES) seg_counts[(size_t)qx * MAX_FWD_QUEUE_WAVES + my_rank] = se.count;
     }
-    int first_rank = my_rank;
+    if (prio_mode != 0) set_wave_prio(0);
+    // ---- light phase: every wave on its own (queue indices only grow: once a pair has drawn a light item, heavy ones are gone)
     for (;;) {
-        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, tile_order, first_rank, q_waves);
-        first_rank = -1;
+        const int qi = light_qi >= 0 ? light_qi : pop();
+        light_qi = -1;
+        const WaveItem it = decode(qi);
         if (!it.valid) break;
-        if (it.heavy)
-            heavy_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, out_color,
-                               out_depth, out_alpha, final_T, n_contrib, flags,
-                               stamps ? stamps + (size_t)(it.rank * WAVE_BLOCKS + it.sub) * 8 : nullptr, se, tail_start);
-        else
-            light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, flags);
+        light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
+                           out_alpha, final_T, n_contrib, flags);
     }
-    // how many of its slots this wave filled (EVERY wave writes its count: the backward kernel sums them per region)
-    if (lane == 0 && my_rank < MAX_FWD_QUEUE_WAVES) seg_counts[(size_t)qx * MAX_FWD_QUEUE_WAVES + my_rank] = se.count;
 
     // Tiles without instances get the background only (forward.cu:374-382 with an empty range); done after the queue so that
     // the heavy items start immediately.
@@ -886,7 +1040,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
         // The forward waves of this XCD filled private slot ranges; their counts give every segment of the region a flat index.  Each
         // wave builds the prefix table itself (all four waves of the workgroup write the same values: no barrier needed).
         const int fq = min(NUM_XCD_QUEUES, fwd_grid);
-        const int f_waves = qx < fq ? 4 * ((fwd_grid - qx + fq - 1) / fq) : 0;              // forward waves that fed this region
+        const int f_waves = qx < fq ? FWD_PAIRS_PER_WG * ((fwd_grid - qx + fq - 1) / fq) : 0;   // forward pairs (blender waves) that fed this region
         uint32_t total = 0u;
         if (f_waves > 0 && f_waves <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) {
             const uint32_t* cnt = seg_counts + (size_t)qx * MAX_FWD_QUEUE_WAVES;
@@ -985,7 +1139,7 @@ int resident_wgs_per_cu(K kernel, const char* env, int dflt, int cap)
 }
 int forward_grid(int T)
 {
-    static const int per_cu = resident_wgs_per_cu(blend_forward_wave_kernel, "MOSS_BLEND_WGS_PER_CU", 2, 2);
+    static const int per_cu = resident_wgs_per_cu(blend_forward_wave_kernel, "MOSS_BLEND_WGS_PER_CU", 4, 4);
     return min(4 * T, device_cus() * per_cu);
 }
 
@@ -1009,9 +1163,11 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     // hits per depth segment of the backward (0 = never cut: every block is ONE backward item, the round-1 behaviour)
     static const int seg_hits_env = [] { const int v = env_int("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
+    static const int role_swap = env_int("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = env_int("MOSS_FWD_PRIO", 0);
     MOSS_LAUNCH_TIMED(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                        im.queues + (size_t)Q_FWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
-                       im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts);
+                       im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
+                       role_swap, prio_mode);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,

@@ -86,7 +86,8 @@ constexpr int GRAD_REC_FLOATS = 12;
 // segment slots handed out by the forward, Q_SEG_HEAD + xcd = segment pop heads of the backward.
 constexpr int QLINE_WORDS = 64;
 constexpr int Q_FWD = 0, Q_BWD = 8, Q_SEG_ALLOC = 16, Q_SEG_HEAD = 24, Q_LINES = 32;
-constexpr int MAX_FWD_QUEUE_WAVES = 256;    // forward waves per XCD region the segment bookkeeping supports (MI355X, one workgroup per CU: 128); more = no cuts
+constexpr int FWD_PAIRS_PER_WG = 2;         // the forward blend works in wave PAIRS (scanner + blender, blend.hip): two per 256-thread workgroup
+constexpr int MAX_FWD_QUEUE_WAVES = 256;    // forward pairs (= blender waves, the ones that cut) per XCD region the segment bookkeeping supports; more = no cuts
 constexpr int SEG_STATE_FLOATS = 16 * 6;      // per segment and pixel of the block: T at the segment's far end + the five sums
                                               // (r, g, b, depth, weight) of everything the pixel blends BEHIND it
 inline size_t seg_region_cap(int R) { return (size_t)(R > 0 ? R : 0) / 128 + 4096; }   // slots per XCD region (shared equally by its forward waves)

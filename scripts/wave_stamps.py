@@ -1,4 +1,5 @@
-"""Per-item breakdown of the wave-autonomous forward blend kernel (s_memtime stamps, diagnostics build path)."""
+"""Per-item breakdown of the forward blend kernel as its BLENDER waves see it (s_memtime stamps): cycles in trips, cycles starved
+(waiting for the pair's scanner), cycles until the first trip."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,11 +19,11 @@ L.moss_raster_debug_set_stamps(None)
 s = buf.cpu().numpy().reshape(-1, 8)
 work = s[s[:, 6] > 0]
 order = np.argsort(-work[:, 0])[:12]
-print("  total cycles   n entries  steps  trips  trip cycles   (cull+wait = total - trips)")
+print("  blender cycles  n entries  rounds  trips(scheduled)  trip cycles  starved  first trip after")
 for i in order:
     w = work[i]
-    print(f"{w[0]:10d} {w[1]:10d} {w[6]:6d} {w[7]:6d} {w[5]:10d}   per-trip {w[5]/max(w[7],1):.0f}  per-step(non-trip) {(w[0]-w[5])/max(w[6],1):.0f}")
+    print(f"{w[0]:10d} {w[1]:10d} {w[6]:6d} {w[7]:6d} {w[5]:10d} {w[2]:8d} {w[3]:8d}   per-trip {w[5]/max(w[7],1):.0f}")
 tc = work[:, 0].astype(np.float64)
 print("items with work:", len(work), "sum cycles", int(tc.sum()), "longest", int(tc.max()), "sum/3072 waves", int(tc.sum() / 3072))
 print("percentiles 50/90/99/100:", np.percentile(tc, [50, 90, 99, 100]).astype(int))
-print("total steps", int(work[:, 6].sum()), "total trips", int(work[:, 7].sum()), "trip share", round(work[:, 5].sum() / tc.sum(), 3))
+print("total rounds", int(work[:, 6].sum()), "scheduled trips", int(work[:, 7].sum()), "trip share", round(work[:, 5].sum() / tc.sum(), 3), "starved share", round(work[:, 2].sum() / tc.sum(), 3))
