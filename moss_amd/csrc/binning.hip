@@ -23,9 +23,15 @@ namespace moss {
 
 namespace {
 
-// Exclusive scan of one value per thread across a 1024-thread block; returns this thread's offset, `total` = sum.
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave /* >= 16 */, uint32_t& total)
+constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort_kernel
+
+// The scan's outputs for one block of `NT` threads (NT a multiple of 64, <= 1024): see scan_kernel.  Shared by scan_kernel (its own
+// launch: synchronous mode, where the host sizes the binning buffer from R before anything else can run) and by the LAST block of
+// scatter_kernel (asynchronous mode: the scan rides along with the scatter instead of costing a 5 us launch of its own).
+template <int NT>
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t* s_wave /* >= NT/64 */, uint32_t& total)
 {
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t x = v;
 #pragma unroll
@@ -36,43 +42,29 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave
     __syncthreads();                 // s_wave may still be read from a previous call
     if (lane == 63) s_wave[w] = x;
     __syncthreads();
-    if (w == 0) {
-        uint32_t t = lane < 16 ? s_wave[lane] : 0u;
+    uint32_t base = 0u, tot = 0u;
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const uint32_t y = __shfl_up(t, d);
-            if (lane >= d) t += y;
-        }
-        if (lane < 16) s_wave[lane] = t;
-    }
-    __syncthreads();
-    const uint32_t base = w ? s_wave[w - 1] : 0u;
-    total = s_wave[15];
+    for (int i = 0; i < NW; i++) { const uint32_t t = s_wave[i]; if (i < w) base += t; tot += t; }
+    total = tot;
     return base + x - v;
 }
 
-constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort_kernel
-
-// One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram, chunk_base[t] = number
-// of sort chunks in front of tile t; header[0] = R (num_rendered), header[1] = longest tile list, header[4] = total chunks.
-// (The per-Gaussian offsets are produced by the preprocess kernel.)
-__global__ void __launch_bounds__(1024)
-scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
-            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2)
+template <int NT>
+__device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
+                                             uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
+                                             uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
+                                             uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */)
 {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t s_bucket[34];
     const int tid = threadIdx.x;
-    if (tid == 0) s_max = 0;
+    if (tid == 0) *s_max = 0;
     if (tid < 34) s_bucket[tid] = 0;
-    const int chunk = (T + 1023) / 1024;
+    const int chunk = (T + NT - 1) / NT;
     const int b = tid * chunk, e = min(T, b + chunk);
     uint32_t sum = 0, mx = 0, nch = 0;
     for (int i = b; i < e; i++) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); nch += (v + CHUNK - 1) / CHUNK; }
     uint32_t total, total_chunks;
-    uint32_t off = block_scan_1024(sum, s_wave, total);
-    uint32_t coff = block_scan_1024(nch, s_wave, total_chunks);
+    uint32_t off = block_scan<NT>(sum, s_wave, total);
+    uint32_t coff = block_scan<NT>(nch, s_wave, total_chunks);
     // Asynchronous mode (no host read-back): the binning buffer was sized for `capacity` instances before R was known.
     // If this frame needs more, render NOTHING (all ranges empty, no queued work) and raise the overflow flag: the
     // following kernels stay inside the buffer and the host reports the error at its next check.
@@ -83,7 +75,7 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
         chunk_base[i] = coff; coff += (v + CHUNK - 1) / CHUNK;
     }
     if (overflow) { sum = 0; mx = 0; off = 0; coff = 0; }
-    if (mx) atomicMax(&s_max, mx);
+    if (mx) atomicMax(s_max, mx);
     // tile_order: tiles grouped by floor(log2(list length)), longest class first, empty tiles last.  The blend kernels
     // pull (tile, quadrant) work items in this order from an atomic queue (longest-processing-time-first balancing).
     for (int i = b; i < e; i++) { const uint32_t v = overflow ? 0u : tile_count[i]; atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u); }
@@ -91,7 +83,7 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
     if (tid == 0) {
         uint32_t acc = 0;
         for (int k = 0; k < 33; k++) { const uint32_t c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
-        header[0] = overflow ? 0u : total; header[1] = s_max; header[4] = overflow ? 0u : total_chunks;
+        header[0] = overflow ? 0u : total; header[1] = *s_max; header[4] = overflow ? 0u : total_chunks;
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
         header[6] = total;                             // instances this frame needs (for the host's capacity policy)
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
@@ -104,24 +96,70 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
     }
 }
 
+// One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram, chunk_base[t] = number
+// of sort chunks in front of tile t; header[0] = R (num_rendered), header[1] = longest tile list, header[4] = total chunks.
+// (The per-Gaussian offsets are produced by the preprocess kernel.)
+__global__ void __launch_bounds__(1024)
+scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
+            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bucket[34];
+    scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket);
+}
+
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
 // with ONE returning global atomic (after counting its own instances in LDS) and hands the slots out with LDS atomics.
+// fold_scan (asynchronous forward, histogram in LDS): there is no scan kernel in front of this one.  Every block turns the tile
+// histogram into the tiles' start offsets ITSELF (T <= 8192 counts: one coalesced read and a block scan, overlapped with its
+// instance counting), and one extra block at the end of the grid writes what the later kernels need (ranges, chunk bases, tile order,
+// header) -- the scan costs no launch of its own (5.5 us) and no memory round trip between the two kernels.
 __global__ void __launch_bounds__(256)
-scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ keys, int lds_hist, const uint32_t* __restrict__ header)
+scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
+               uint64_t* __restrict__ keys, int lds_hist, uint32_t* __restrict__ header, int fold_scan,
+               const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
+               uint32_t capacity, int light_log2)
 {
     extern __shared__ uint32_t s_mem[];
-    if (header[0] == 0u) return;                       // nothing rendered (or capacity overflow: see scan_kernel)
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bucket[34];
+    int n_blocks = (int)gridDim.x;                     // blocks that scatter
+    if (fold_scan) {
+        n_blocks--;
+        if ((int)blockIdx.x == n_blocks) {
+            scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket);
+            return;
+        }
+    } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
     uint32_t* s_cnt = s_mem;
     uint32_t* s_base = s_mem + T;
     if (lds_hist) {
+        // (fold_scan) this thread's share of the histogram: requested now, summed after the counting pass
+        const int per = (T + 255) / 256, tb = (int)threadIdx.x * per, te = min(T, tb + per);
+        uint32_t cnt4[4] = { 0u, 0u, 0u, 0u };
+        if (fold_scan && per <= 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) cnt4[u] = tile_count[min(tb + u, T - 1)];
+        }
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
-        for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {      // whole waves stay converged
+        for (int base = blockIdx.x * blockDim.x; base < P; base += n_blocks * blockDim.x) {      // whole waves stay converged
             const int idx = base + (int)threadIdx.x;
             const float4 gd = g.geo[4 * (size_t)min(idx, P - 1) + 3];
             const uint2 r = idx < P ? make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y)) : make_uint2(0u, 0u);
             wave_for_each_tile(r, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
+        }
+        if (fold_scan) {
+            uint32_t sum = 0u;
+            if (per <= 4) { for (int u = 0; u < 4; u++) sum += tb + u < te ? cnt4[u] : 0u; }
+            else for (int i = tb; i < te; i++) sum += tile_count[i];
+            uint32_t total;
+            uint32_t off = block_scan<256>(sum, s_wave, total);      // (its barriers also end the counting pass)
+            if (total == 0u || total > capacity) return;             // nothing rendered / capacity overflow (flag: the scan block)
+            if (per <= 4) { for (int u = 0; u < 4; u++) if (tb + u < te) { s_base[tb + u] = off; off += cnt4[u]; } }
+            else for (int i = tb; i < te; i++) { s_base[i] = off; off += tile_count[i]; }
         }
         __syncthreads();
         // One returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket.  Four tiles per thread at a
@@ -136,7 +174,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
                 for (int u = 0; u < 4; u++) {
                     const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
                     c[u] = i < T ? s_cnt[i] : 0u;
-                    start[u] = ranges[min(i, T - 1)].x;
+                    start[u] = fold_scan ? s_base[min(i, T - 1)] : ranges[min(i, T - 1)].x;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -152,7 +190,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
         }
         __syncthreads();
     }
-    for (int base = blockIdx.x * blockDim.x; base < P; base += gridDim.x * blockDim.x) {
+    for (int base = blockIdx.x * blockDim.x; base < P; base += n_blocks * blockDim.x) {
         const int idx = base + (int)threadIdx.x;
         const float4 gd = g.geo[4 * (size_t)min(idx, P - 1) + 3];
         const uint2 r = idx < P ? make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y)) : make_uint2(0u, 0u);
@@ -169,15 +207,28 @@ scatter_kernel(int P, int gx, int T, GeomView g, const uint2* __restrict__ range
 
 // Which tile owns sort chunk c: the tile t with chunk_base[t] <= c < chunk_base[t] + ceil(n_t / CHUNK).  Every thread of the workgroup
 // tests the tiles tid, tid + blockDim, ... -- two independent loads each, ONE memory round trip for the workgroup (a binary search by
-// thread 0 was ten DEPENDENT loads, ~6 us, with 1023 threads waiting at the barrier behind it).  Ends with a barrier.
-__device__ __forceinline__ void find_chunk_tile(int T, uint32_t c, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base,
-                                                int* s_tile)
+// thread 0 was ten DEPENDENT loads, ~6 us, with 1023 threads waiting at the barrier behind it).  The finder also leaves the tile's
+// range and chunk base in LDS, and the device-side chunk count (header[4]) is loaded in the same round trip: the prologue of a sort
+// workgroup is ONE round trip, not four (header -> lookup -> range of the tile -> keys were 4 x ~2 us of its ~12).  Ends with a barrier.
+struct ChunkOwner { int tile; uint32_t start, end, cbase, n_chunks, c; };
+// `chunk_of(n_chunks)` maps this workgroup's turn to a chunk index (or ~0u: nothing to do); it is evaluated AFTER the tile loads
+// have been issued, so the header word and the tile table arrive in the same round trip.
+template <typename F>
+__device__ __forceinline__ void find_chunk_tile(int T, F&& chunk_of, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base,
+                                                const uint32_t* __restrict__ header, ChunkOwner* s_own)
 {
-    for (int t = (int)threadIdx.x; t < T; t += (int)blockDim.x) {
-        const uint32_t cb = chunk_base[t];
-        const uint2 rg = ranges[t];
+    int t = (int)threadIdx.x;
+    uint32_t cb = chunk_base[min(t, T - 1)];
+    uint2 rg = ranges[min(t, T - 1)];
+    const uint32_t n_chunks = header[4];
+    const uint32_t c = chunk_of(n_chunks);
+    if (threadIdx.x == 0) { s_own->n_chunks = n_chunks; s_own->c = c; }
+    for (;;) {
         const uint32_t nch = (rg.y - rg.x + CHUNK - 1) / CHUNK;
-        if (cb <= c && c < cb + nch) *s_tile = t;
+        if (t < T && cb <= c && c < cb + nch) { s_own->tile = t; s_own->start = rg.x; s_own->end = rg.y; s_own->cbase = cb; }
+        t += (int)blockDim.x;
+        if (t >= T) break;
+        cb = chunk_base[t]; rg = ranges[t];
     }
     __syncthreads();
 }
@@ -188,89 +239,145 @@ __device__ __forceinline__ void find_chunk_tile(int T, uint32_t c, const uint2* 
 // same wave (two ds_bpermute, no barrier): 45 of the 55 stages of a full chunk; only j >= 64 goes through LDS with barriers
 // (the all-LDS version spent ~800 cycles per stage on barriers with 16 waves).  Threads past n hold the maximum key, and the
 // network stops at the padded size, so short chunks run few stages.
+// The grid is bounded (launch_tile_sort) and a workgroup loops over the chunks c = blockIdx.x, blockIdx.x + gridDim.x, ...: the
+// host-side chunk count is only an upper bound when R stays on the device, and a thousand empty 1024-thread workgroups are not free.
 __global__ void __launch_bounds__(1024)
 chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
-                  const uint32_t* __restrict__ header)
+                  const uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[CHUNK];
-    __shared__ int s_tile;
-    const uint32_t c = blockIdx.x;
-    if (c >= header[4]) return;                        // the grid is an upper bound when R is not known on the host
+    __shared__ ChunkOwner s_own;
     const uint32_t tid = threadIdx.x;
-    find_chunk_tile(T, c, ranges, chunk_base, &s_tile);
-    const int tile = s_tile;
-    const uint2 rg = ranges[tile];
-    const uint32_t first = rg.x + (c - chunk_base[tile]) * CHUNK;
-    const uint32_t n = min((uint32_t)CHUNK, rg.y - first);
-    uint64_t* gk = keys + first;
-    uint32_t npad = 64;                                // at least one wave's worth: the intra-wave stages need no branches
-    while (npad < n) npad <<= 1;
-    if (tid >= npad) return;                           // whole waves only (npad is a multiple of 64); the barriers below count the
-                                                       // waves that are still alive
-    uint64_t key = tid < n ? gk[tid] : ~0ull;
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
-        const bool up = (tid & k) == 0u;
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            uint64_t other;
-            if (j >= 64u) {                            // cross-wave partner through LDS
-                s_keys[tid] = key;
-                __syncthreads();
-                other = s_keys[tid ^ j];
-                __syncthreads();
-            } else {
-                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j);
-                other = ((uint64_t)hi << 32) | lo;
-            }
-            const bool lower = (tid & j) == 0u;
-            const bool take_min = lower == up;
-            const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
-            key = take_min ? mn : mx;
+#define KSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
+    KSTAMP(0);
+    for (uint32_t c = blockIdx.x;; c += gridDim.x) {
+        find_chunk_tile(T, [&](uint32_t) { return c; }, ranges, chunk_base, header, &s_own);
+        const uint32_t n_chunks = s_own.n_chunks;
+        if (c >= n_chunks) return;
+        KSTAMP(1);
+        const uint32_t first = s_own.start + (c - s_own.cbase) * CHUNK;
+        const uint32_t n = min((uint32_t)CHUNK, s_own.end - first);
+        uint64_t* gk = keys + first;
+        uint32_t npad = 64;                                // at least one wave's worth: the intra-wave stages need no branches
+        while (npad < n) npad <<= 1;
+        const bool last_turn = c + gridDim.x >= n_chunks;  // (no further lookup just to find that out: it is a memory round trip)
+        if (tid >= npad) {
+            // whole waves (npad is a multiple of 64) with nothing to sort.  On the workgroup's last turn they leave -- the barriers
+            // below count the waves that are still alive (gfx9 s_barrier semantics; 16-wave barriers are what a short chunk's network
+            // would otherwise pay) -- on earlier turns they only keep the barrier count: two per cross-wave stage.
+            if (last_turn) return;
+            for (uint32_t k = 128; k <= npad; k <<= 1)
+                for (uint32_t j = k >> 1; j >= 64u; j >>= 1) { __syncthreads(); __syncthreads(); }
+            __syncthreads();
+            continue;
         }
+        uint64_t key = tid < n ? gk[tid] : ~0ull;
+        if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = key ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = n; }
+        for (uint32_t k = 2; k <= npad; k <<= 1) {
+            const bool up = (tid & k) == 0u;
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                uint64_t other;
+                if (j >= 64u) {                            // cross-wave partner through LDS
+                    s_keys[tid] = key;
+                    __syncthreads();
+                    other = s_keys[tid ^ j];
+                    __syncthreads();
+                } else {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j);
+                    other = ((uint64_t)hi << 32) | lo;
+                }
+                const bool lower = (tid & j) == 0u;
+                const bool take_min = lower == up;
+                const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+                key = take_min ? mn : mx;
+            }
+        }
+        KSTAMP(3);
+        if (tid < n) gk[tid] = key;
+        KSTAMP(4);
+        if (last_turn) return;
+        __syncthreads();                                   // s_own is rewritten by the next round's lookup
     }
-    if (tid < n) gk[tid] = key;
 }
 
 // Stage B: one workgroup per chunk again, one thread per instance.  An instance's final rank inside its tile = its rank inside its own
 // (sorted) chunk + the number of smaller keys in each of the tile's OTHER chunks (keys (depth_bits, id) are unique).  The other
-// chunks are brought into LDS one after the other (one coalesced 8-byte load per thread) and searched there: ten LDS reads per
-// chunk instead of ten dependent global loads (round 1: 20-40 dependent L2 round trips per instance of a 3-5 chunk tile were most of
-// this kernel's 18 us).  The same thread then emits everything that is per-instance: the sorted id, the 48-byte record the blend
-// kernels stream, the block mask, and the Gaussian -> instance back-pointer used by the backward gather.
+// chunks are brought into LDS TOGETHER (up to MERGE_OC at a time: one coalesced 8-byte load per thread and chunk, all in flight at
+// once) and searched there side by side -- independent binary searches whose LDS reads overlap.  (Round 1 searched in global memory:
+// 20-40 dependent L2 round trips per instance; round 2 brought the chunks into LDS one after the other: a load round trip and two
+// barriers per sibling chunk, 4 x ~2.5 us for a five-chunk tile.)  The same thread then emits everything that is per-instance: the
+// sorted id, the 48-byte record the blend kernels stream, the block mask, and the Gaussian -> instance back-pointer used by the
+// backward gather.
+constexpr int MERGE_OC = 6;                                // sibling chunks searched per round (48 KB of LDS)
 __global__ void __launch_bounds__(1024)
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView g, const uint2* __restrict__ ranges,
                     const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
-                    float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask)
+                    float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask,
+                    unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup (after the sort's), else NULL */)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t s_keys[CHUNK];
-    __shared__ int s_tile;
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[MERGE_OC][CHUNK];
+    __shared__ ChunkOwner s_own;
+    const uint32_t tid = threadIdx.x;
+    KSTAMP(0);
+    for (uint32_t it = blockIdx.x;; it += gridDim.x) {
     // XCD-aware chunk order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), chunks are in tile order, and neighbouring
     // tiles gather the same Gaussians' 64-byte records: XCD k takes the k-th contiguous eighth of the chunks (counted from the
-    // device-side total, the grid is only an upper bound), so a Gaussian's record is fetched into one or two L2s instead of all eight.
-    const int n_chunks = (int)header[4];
-    const int per_xcd = n_chunks / 8, extra = n_chunks % 8, xcd = (int)blockIdx.x % 8, nth = (int)blockIdx.x / 8;
-    if (nth >= per_xcd + (xcd < extra ? 1 : 0)) return;
-    const uint32_t c = (uint32_t)(xcd * per_xcd + min(xcd, extra) + nth);
-    const uint32_t tid = threadIdx.x;
-    find_chunk_tile(T, c, ranges, chunk_base, &s_tile);
-    const uint32_t tile = (uint32_t)s_tile;
-    const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x, nch = (n + CHUNK - 1) / CHUNK, own = c - chunk_base[tile];
+    // device-side total), so a Gaussian's record is fetched into one or two L2s instead of all eight.
+    const uint32_t NONE = 0xffffffffu;
+    find_chunk_tile(T, [&](uint32_t n_chunks) -> uint32_t {
+        const int per_xcd = (int)n_chunks / 8, extra = (int)n_chunks % 8, xcd = (int)it % 8, nth = (int)it / 8;
+        return nth < per_xcd + (xcd < extra ? 1 : 0) ? (uint32_t)(xcd * per_xcd + min(xcd, extra) + nth) : NONE;
+    }, ranges, chunk_base, header, &s_own);
+    const uint32_t c = s_own.c;
+    if (c == NONE) return;                                    // (turns only grow: later ones are past this XCD's share as well)
+    KSTAMP(1);
+    const bool last_turn = (it + gridDim.x) / 8 >= s_own.n_chunks / 8 + ((it % 8) < s_own.n_chunks % 8 ? 1u : 0u);
+    const uint32_t tile = (uint32_t)s_own.tile;
+    const uint2 rg = make_uint2(s_own.start, s_own.end);
+    const uint32_t n = rg.y - rg.x, nch = (n + CHUNK - 1) / CHUNK, own = c - s_own.cbase;
     const uint32_t first = rg.x + own * CHUNK, n_own = min((uint32_t)CHUNK, rg.y - first);
     const bool mine = tid < n_own;
-    const uint64_t key = mine ? keys[first + tid] : ~0ull;
+    const uint64_t key_ld = keys[min(first + tid, rg.y - 1u)];
+    const uint64_t key = mine ? key_ld : ~0ull;
     uint32_t rank = tid;                                      // rank inside the own (sorted) chunk
-    for (uint32_t oc = 0; oc < nch; oc++) {                   // (wave-uniform trip count)
-        if (oc == own) continue;
-        const uint32_t ofirst = rg.x + oc * CHUNK, on = min((uint32_t)CHUNK, rg.y - ofirst);
-        __syncthreads();                                      // the previous chunk's readers are done
-        if (tid < on) s_keys[tid] = keys[ofirst + tid];
+    for (uint32_t s0 = 0; s0 + 1 < nch; s0 += MERGE_OC) {     // (wave-uniform trip count) siblings s0 .. s0 + MERGE_OC - 1 of nch - 1
+        uint32_t on[MERGE_OC];
+        uint64_t v[MERGE_OC];
+#pragma unroll
+        for (int q = 0; q < MERGE_OC; q++) {
+            const uint32_t si = s0 + (uint32_t)q;             // sibling index: the tile's chunks without the own one
+            const uint32_t oc = si + (si >= own ? 1u : 0u);
+            const uint32_t ofirst = rg.x + oc * CHUNK;
+            on[q] = si + 1 < nch ? min((uint32_t)CHUNK, rg.y - ofirst) : 0u;
+            v[q] = keys[on[q] ? min(ofirst + tid, rg.y - 1u) : first];       // (unconditional, clamped: the six loads are in flight together)
+        }
+        __syncthreads();                                      // the previous group's readers are done
+#pragma unroll
+        for (int q = 0; q < MERGE_OC; q++) if (tid < on[q]) s_keys[q][tid] = v[q];
         __syncthreads();
-        uint32_t lo = 0, hi = on;                             // count of keys < key in this sorted chunk
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_keys[mid] < key) lo = mid + 1; else hi = mid; }
-        rank += lo;
+        const int ns = (int)min((uint32_t)MERGE_OC, nch - 1u - s0);      // siblings in this group (wave-uniform)
+        uint32_t lo[MERGE_OC], hi[MERGE_OC];
+#pragma unroll
+        for (int q = 0; q < MERGE_OC; q++) { lo[q] = 0u; hi[q] = on[q]; }
+        for (int step = 0; step < 11; step++) {               // 2^10 keys: eleven halvings; the siblings' searches run side by side
+#pragma unroll
+            for (int q = 0; q < MERGE_OC; q++) {
+                if (q < ns) {                                 // (scalar branch: absent siblings cost nothing)
+                    // branch-free halving: a finished search (lo == hi) re-reads a valid slot and keeps its bounds
+                    const uint32_t mid = min((lo[q] + hi[q]) >> 1, (uint32_t)CHUNK - 1u);
+                    const bool less = s_keys[q][mid] < key && lo[q] < hi[q];
+                    const bool open = lo[q] < hi[q];
+                    lo[q] = less ? mid + 1u : lo[q];
+                    hi[q] = (open && !less) ? mid : hi[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MERGE_OC; q++) rank += q < ns ? lo[q] : 0u;     // keys < key in that sorted chunk
     }
-    if (!mine) return;
+    if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = rank + 1u ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = nch; }
+    if (mine) {
     const uint32_t pos = rg.x + rank;
     inst_mask[pos] = 0u;                                      // no gradient record yet (set by the backward blend)
     const uint32_t id = (uint32_t)key;
@@ -278,6 +385,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     float4* rec = inst_rec + 3 * (size_t)pos;
     const float4* gsrc = g.geo + 4 * (size_t)id;                  // the Gaussian's one 64-byte record
     const float4 ga = gsrc[0], gb = gsrc[1], gd = gsrc[3];
+    if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 3] = ga.x == 12345.678f ? 1ull : __builtin_amdgcn_s_memtime();
     rec[0] = ga; rec[1] = gb; rec[2] = gsrc[2];
     const uint2 r = make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y));
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
@@ -338,6 +446,12 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     }
     const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     inst_pos[__float_as_uint(gd.z) + k] = pos;
+    }   // mine
+    KSTAMP(4);
+#undef KSTAMP
+    if (last_turn) return;
+    __syncthreads();                                          // s_own / s_keys are rewritten by the next round
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -396,16 +510,29 @@ void launch_zero_floats(float* ptr, size_t n, hipStream_t s)
     hipLaunchKernelGGL(zero_floats_kernel, dim3(blocks), dim3(256), 0, s, ptr, n);
 }
 
+static int light_log2_knob()
+{
+    static const int v = std::max(0, std::min(31, env_int("MOSS_LIGHT_LOG2", LIGHT_TILE_LOG2)));
+    return v;
+}
+
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s)
 {
     (void)P; (void)g;
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
-    static const int light_log2 = std::max(0, std::min(31, env_int("MOSS_LIGHT_LOG2", LIGHT_TILE_LOG2)));
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header, cap, light_log2);
+                       im.header, cap, light_log2_knob());
 }
 
-void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
+// The scan can ride along with the scatter (no launch of its own) when the tile histogram fits the scatter's LDS and nobody has to
+// read R back before the binning buffer exists (asynchronous forward).
+bool scatter_folds_scan(const FrameParams& fp)
+{
+    static const int on = env_int("MOSS_FOLD_SCAN", 1);
+    return on && fp.gx * fp.gy <= MAX_LDS_TILES;
+}
+
+void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? (((env_int("MOSS_EXPERIMENT", 0) & 2) != 0) ? 2 : 1) : 0;   // (2: timing experiment, no reservation atomics)
@@ -413,8 +540,10 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
-    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
-                       lds_hist, im.header);
+    const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
+    const int fold = (fold_scan && lds_hist) ? 1 : 0;
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks + fold), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
+                       lds_hist, im.header, fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob());
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s)
@@ -423,9 +552,16 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
     // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) return;
-    hipLaunchKernelGGL(chunk_sort_kernel, dim3(total_chunks), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header);
-    hipLaunchKernelGGL(merge_gather_kernel, dim3(total_chunks), dim3(CHUNK), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
-                       b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask);
+    // at most two 1024-thread workgroups per CU in flight; the workgroups loop over the chunks
+    static const int max_grid = std::max(8, env_int("MOSS_SORT_GRID", 512));
+    const int grid = std::min(total_chunks, max_grid);
+    // diagnostics (scripts/sort_stamps.py): the stamp buffer's words [131072, 131072 + 16384) -- behind the forward blend's item stamps
+    static const int stamps_on = env_int("MOSS_SORT_STAMPS", 0);
+    unsigned long long* const sort_stamps = (stamps_on && g_stamps) ? g_stamps + 131072 : nullptr;
+    hipLaunchKernelGGL(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
+                       sort_stamps);
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((grid + 7) / 8 * 8), dim3(CHUNK), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
+                       b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
 }
 
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

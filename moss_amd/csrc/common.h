@@ -236,7 +236,8 @@ void launch_mark_visible(int P, const float* means3D, const float* view16_dev, u
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header
-void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);  // duplicateWithKeys
+bool scatter_folds_scan(const FrameParams& fp);                                                // asynchronous forward: no scan launch, see binning.hip
+void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s);  // duplicateWithKeys (+ the scan)
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s);
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
                            uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);

@@ -154,8 +154,12 @@ static int forward_impl(
     { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
       launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, g, im, radii, s); }
     STAGE_CHECK("preprocess");
-    { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, capacity, s); }
-    STAGE_CHECK("scan");
+    // Asynchronous forward: the scan rides along with the scatter kernel (no launch of its own).
+    const bool fold_scan = capacity > 0 && scatter_folds_scan(fp);
+    if (!fold_scan) {
+        { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, capacity, s); }
+        STAGE_CHECK("scan");
+    }
 
     int R, total_chunks;
     if (capacity < 0) {
@@ -179,7 +183,7 @@ static int forward_impl(
     BinView b = BinView::at(bin_ptr, R);
 
     if (R > 0) {
-        { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, s); }
+        { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, fold_scan, capacity, s); }
         STAGE_CHECK("scatter");
         {   // timing experiment (scripts/exp_atomics.py): with the scatter's reservation atomics off the keys are garbage -- stop here
             static const bool stop = getenv("MOSS_EXPERIMENT") && (atoi(getenv("MOSS_EXPERIMENT")) & 2);

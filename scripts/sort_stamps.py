@@ -1,0 +1,32 @@
+"""Phase stamps of the two tile-sort kernels (thread 0 of every workgroup, s_memtime): lookup, key load, network / searches, gather, stores."""
+import ctypes, os, sys
+os.environ["MOSS_SORT_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from moss_amd import scenes, _lib
+from tests import helpers as hp
+dev = torch.device("cuda:0")
+d = hp.inputs_of(scenes.config3(), "scale_rot")
+L = _lib.lib()
+L.moss_raster_debug_set_stamps.argtypes = [ctypes.c_void_p]
+buf = torch.zeros(131072 + 16384 + 64, dtype=torch.int64, device=dev)
+for _ in range(3): hp.hip_forward(d, dev)
+torch.cuda.synchronize()
+L.moss_raster_debug_set_stamps(buf.data_ptr())
+hp.hip_forward(d, dev); torch.cuda.synchronize()
+L.moss_raster_debug_set_stamps(None)
+s = buf.cpu().numpy()[131072:]
+for name, off in (("chunk_sort [lookup, key load, network, store]", 0), ("merge_gather [lookup, keys+searches, gather, emit]", 8 * 1024)):
+    w = s[off: off + 8 * 1024].reshape(-1, 8).astype(np.float64)
+    w = w[(w[:, 0] > 0) & (w[:, 4] > 0)]
+    # the clocks of the 8 XCDs are not synchronised: spans per XCD (workgroup index % 8)
+    ph = np.diff(w[:, :5], axis=1)
+    print(name, "workgroups", len(w), "mean cycles per phase", ph.mean(0).astype(int), "p95", np.percentile(ph, 95, axis=0).astype(int), "total mean", int((w[:, 4] - w[:, 0]).mean()), "max", int((w[:, 4] - w[:, 0]).max()))
+    idx = np.nonzero((s[off: off + 8 * 1024].reshape(-1, 8)[:, 0] > 0) & (s[off: off + 8 * 1024].reshape(-1, 8)[:, 4] > 0))[0]
+    for x in range(8):
+        m = idx % 8 == x
+        if m.any():
+            print("   xcd", x, "workgroups", int(m.sum()), "first start -> last end", int(w[m, 4].max() - w[m, 0].min()), "start spread", int(w[m, 0].max() - w[m, 0].min()))
+    big = w[:, 6] >= (1024 if off == 0 else 3)
+    if big.any():
+        print("   full chunks / tiles of >= 3 chunks:", int(big.sum()), "mean phases", np.diff(w[big, :5], axis=1).mean(0).astype(int))
