@@ -233,19 +233,67 @@ __device__ __forceinline__ void find_chunk_tile(int T, F&& chunk_of, const uint2
     __syncthreads();
 }
 
+// ---- the chunk sort's compare-exchange network.  Thread tid holds one 64-bit key in registers; the partner of step j is tid ^ j.
+// For j < 64 the partner is in the same wave and is reached WITHOUT LDS: quad permutes (j = 1, 2), half-row mirror + quad reverse
+// (j = 4: i ^ 7 ^ 3), row rotation by 8 (j = 8), v_permlane16_swap / v_permlane32_swap (j = 16, 32).  (Round 2's stamps: the
+// ds_bpermute version of this network was 21k of a full chunk's 25k cycles -- 380 cycles per step with the LDS round trip inside.)
+// Steps with j >= 64 go through LDS, double-buffered: ONE barrier per step.
+#define MOSS_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (ctrl), 0xf, 0xf, true))
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane)
+{
+    if constexpr (J == 1) return MOSS_DPP(v, 0xB1);                               // quad_perm:[1,0,3,2]
+    else if constexpr (J == 2) return MOSS_DPP(v, 0x4E);                          // quad_perm:[2,3,0,1]
+    else if constexpr (J == 4) { const uint32_t m = MOSS_DPP(v, 0x141); return MOSS_DPP(m, 0x1B); }   // row_half_mirror, quad_perm:[3,2,1,0]
+    else if constexpr (J == 8) return MOSS_DPP(v, 0x128);                         // row_ror:8
+    else if constexpr (J == 16) {
+        // swaps the odd rows of the first operand with the even rows of the second: r[0] = {v0, v0, v2, v2}, r[1] = {v1, v1, v3, v3}
+        auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16u) ? r[0] : r[1];
+    } else {
+        static_assert(J == 32, "intra-wave partner distance");
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);            // r[0] = {lower, lower}, r[1] = {upper, upper}
+        return (lane & 32u) ? r[0] : r[1];
+    }
+}
+#undef MOSS_DPP
+
+template <int K, int J>
+__device__ __forceinline__ void network_steps(uint64_t& key, uint32_t tid, uint64_t (*s_buf)[CHUNK], int& p)
+{
+    uint64_t other;
+    if constexpr (J >= 64) {
+        s_buf[p][tid] = key;
+        __syncthreads();
+        other = s_buf[p][tid ^ J];
+        p ^= 1;                                            // the next cross-wave step writes the other buffer: no second barrier
+    } else {
+        const uint32_t lo = lane_xor<J>((uint32_t)key, tid), hi = lane_xor<J>((uint32_t)(key >> 32), tid);
+        other = ((uint64_t)hi << 32) | lo;
+    }
+    const bool take_min = ((tid & (uint32_t)J) == 0u) == ((tid & (uint32_t)K) == 0u);     // lower partner of an ascending run
+    const bool lt = key < other;
+    key = (lt == take_min) ? key : other;
+    if constexpr (J > 1) network_steps<K, J / 2>(key, tid, s_buf, p);
+}
+template <int K>
+__device__ __forceinline__ void network_phases(uint64_t& key, uint32_t tid, uint32_t npad, uint64_t (*s_buf)[CHUNK], int& p)
+{
+    if constexpr (K > 2) network_phases<K / 2>(key, tid, npad, s_buf, p);
+    if ((uint32_t)K <= npad) network_steps<K, K / 2>(key, tid, s_buf, p);          // (wave-uniform)
+}
+
 // Stage A of the sort: one workgroup per CHUNK of a tile's bucket (a tile of n entries has ceil(n/CHUNK) chunks), sorted and
 // written back in place.  Every workgroup has at most 1024 keys, so there is no long-tile tail here.
-// One key per thread, in REGISTERS: a bitonic network whose compare-exchange partner is tid ^ j.  For j < 64 the partner is in the
-// same wave (two ds_bpermute, no barrier): 45 of the 55 stages of a full chunk; only j >= 64 goes through LDS with barriers
-// (the all-LDS version spent ~800 cycles per stage on barriers with 16 waves).  Threads past n hold the maximum key, and the
-// network stops at the padded size, so short chunks run few stages.
+// One key per thread, in REGISTERS: a bitonic network (above).  Threads past n hold the maximum key, and the network stops at the
+// padded size, so short chunks run few steps.
 // The grid is bounded (launch_tile_sort) and a workgroup loops over the chunks c = blockIdx.x, blockIdx.x + gridDim.x, ...: the
 // host-side chunk count is only an upper bound when R stays on the device, and a thousand empty 1024-thread workgroups are not free.
 __global__ void __launch_bounds__(1024)
 chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
                   const uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t s_keys[CHUNK];
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[2][CHUNK];
     __shared__ ChunkOwner s_own;
     const uint32_t tid = threadIdx.x;
 #define KSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
@@ -258,40 +306,23 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
         const uint32_t first = s_own.start + (c - s_own.cbase) * CHUNK;
         const uint32_t n = min((uint32_t)CHUNK, s_own.end - first);
         uint64_t* gk = keys + first;
-        uint32_t npad = 64;                                // at least one wave's worth: the intra-wave stages need no branches
+        uint32_t npad = 64;                                // at least one wave's worth: the intra-wave steps need no branches
         while (npad < n) npad <<= 1;
         const bool last_turn = c + gridDim.x >= n_chunks;  // (no further lookup just to find that out: it is a memory round trip)
         if (tid >= npad) {
             // whole waves (npad is a multiple of 64) with nothing to sort.  On the workgroup's last turn they leave -- the barriers
             // below count the waves that are still alive (gfx9 s_barrier semantics; 16-wave barriers are what a short chunk's network
-            // would otherwise pay) -- on earlier turns they only keep the barrier count: two per cross-wave stage.
+            // would otherwise pay) -- on earlier turns they only keep the barrier count: one per cross-wave step.
             if (last_turn) return;
             for (uint32_t k = 128; k <= npad; k <<= 1)
-                for (uint32_t j = k >> 1; j >= 64u; j >>= 1) { __syncthreads(); __syncthreads(); }
+                for (uint32_t j = k >> 1; j >= 64u; j >>= 1) __syncthreads();
             __syncthreads();
             continue;
         }
         uint64_t key = tid < n ? gk[tid] : ~0ull;
         if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = key ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = n; }
-        for (uint32_t k = 2; k <= npad; k <<= 1) {
-            const bool up = (tid & k) == 0u;
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                uint64_t other;
-                if (j >= 64u) {                            // cross-wave partner through LDS
-                    s_keys[tid] = key;
-                    __syncthreads();
-                    other = s_keys[tid ^ j];
-                    __syncthreads();
-                } else {
-                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j);
-                    other = ((uint64_t)hi << 32) | lo;
-                }
-                const bool lower = (tid & j) == 0u;
-                const bool take_min = lower == up;
-                const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
-                key = take_min ? mn : mx;
-            }
-        }
+        int p = 0;
+        network_phases<CHUNK>(key, tid, npad, s_keys, p);
         KSTAMP(3);
         if (tid < n) gk[tid] = key;
         KSTAMP(4);
