@@ -321,9 +321,13 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
 // forward kernel from 57 to 48 us -- the second wave fills the issue slots the first leaves between its dependent instructions, and
 // with twice the waves every heavy block of the frame starts at once.  Same sizes for the backward kernel (whose items are short
 // since the forward cuts the lists into depth segments: up to three workgroups per CU).
-constexpr int LCAP = 256, RCAP = 256, ROUND_HITS = 24;
+constexpr int LCAP = 256, RCAP = 256;
 constexpr int CHAPTER = 8;                       // 64-entry groups of block masks turned into hit masks at a time (512 entries)
-constexpr int LCAP_BWD = LCAP, RCAP_BWD = RCAP, ROUND_HITS_BWD = ROUND_HITS;
+// Backward: 128 ring slots = two 64-slot DMA batches, 6.6 KB per wave -- a wave collects the hits of up to two batches, has their
+// records copied, waits, and runs their trips (no scan / DMA / blend pipeline inside an item: with four or five waves per SIMD the
+// other waves cover the DMA round trip).  The small footprint is what lets EVERY depth segment of the frame start in the first round
+// (round 2 of this kernel: 3072 resident waves for 3498 segments -- 426 waves ran a second full segment while the rest idled).
+constexpr int LCAP_BWD = 128, RCAP_BWD = 128;
 template <int RC, int LC>
 struct HeavyLdsT { float4 a[RC], b[RC], c[RC]; uint32_t lst[LC]; static constexpr int RMASK = RC - 1, LMASK = LC - 1; };
 typedef HeavyLdsT<RCAP, LCAP> HeavyLds;
@@ -668,7 +672,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     // the list ends for these pixels (end = the largest n_contrib), so every pixel starts from (T_final, Q = 0), exactly the
     // reference's start (backward.cu:440-447).  seg_state != NULL: a depth segment cut by the forward kernel (end = hi_limit) -- the
     // pixels still alive at its far end start from the state the forward left there (see below).
-    constexpr int LMASK = HeavyLdsBwd::LMASK, RMASK = HeavyLdsBwd::RMASK, ROUND_HITS = ROUND_HITS_BWD;
+    constexpr int LMASK = HeavyLdsBwd::LMASK, RMASK = HeavyLdsBwd::RMASK;
     const int slot = lane & 3, pl = lane >> 2;
     // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
     const int row = lane >> 4, rh = row >> 1, rp = row & 1;
@@ -775,21 +779,19 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         }
     };
 
-    // back to front: scan offset o <-> list position n_eff-1-o.  Same pipeline as the forward kernel.
+    // back to front: scan offset o <-> list position n_eff-1-o.  Rounds of (scan -> record DMAs -> wait -> trips); list entries
+    // [0, C) are blended, [C, nlist) found.  At most two DMA batches (entries 64q .. 64q+63 -> ring slots (64q & RMASK) + lane) are
+    // alive at a time: a round scans while nlist + 64 <= 64 * ((C >> 6) + 2).
     int scan_off = 0, nlist = 0, C = 0, F = 0, grp = CHAPTER;
-    bool scan_done = false;
+    bool scan_done = n_eff - lo <= 0;
     uint32_t nx[CHAPTER];
     uint32_t vb_lo = 0u, vb_hi = 0u;
 #pragma unroll
     for (int k = 0; k < CHAPTER; k++) nx[k] = bm[max(n_eff - 1 - (64 * k + lane), 0)];
     for (;;) {
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        const int ready = F;
-        const bool final_round = scan_done;
-        int new_hits = 0;
-        while (!scan_done && new_hits < ROUND_HITS) {
-            if (grp == CHAPTER) {                            // (see the forward kernel)
+        const int limit = 64 * ((C >> 6) + 2);
+        while (!scan_done && nlist + 64 <= limit) {
+            if (grp == CHAPTER) {                            // (see the forward kernel's scanner)
                 unsigned long long bl = 0ull;
 #pragma unroll
                 for (int k = 0; k < CHAPTER; k++) {
@@ -808,22 +810,23 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
             if (m != 0ull) {
                 const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(n_eff - 1 - (scan_off + lane));
-                const int c = __popcll(m);
-                nlist += c; new_hits += c;
+                nlist += __popcll(m);
             }
             scan_off += 64;
             scan_done = scan_off >= n_eff - lo;
         }
         __builtin_amdgcn_wave_barrier();
         if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
-        const int avail = ready - C;
-        const int ntrip = (avail >> 2) + ((final_round && (avail & 3) != 0) ? 1 : 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int avail = nlist - C;
+        const int ntrip = (avail >> 2) + ((scan_done && (avail & 3) != 0) ? 1 : 0);
         if (ntrip > 0 && !(flags & 2)) {
             auto get = [&](int t) -> Fetched {
                 const int li = C + 4 * t + slot;
                 Fetched f;
                 f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];
-                f.pos1 = (float)(L->lst[li & LMASK] + 1u); f.valid = li < ready ? 1.0f : 0.0f;
+                f.pos1 = (float)(L->lst[li & LMASK] + 1u); f.valid = li < nlist ? 1.0f : 0.0f;
                 return f;
             };
             Fetched f0 = get(0);
@@ -834,11 +837,10 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
                 f0 = get(t + 2);
                 trip(f1);
             }
-            C += 4 * ntrip;
         }
-        if (final_round) break;
+        C += 4 * ntrip;
+        if (scan_done) break;
     }
-    __builtin_amdgcn_s_waitcnt(0);
 }
 
 // Work-item decode shared by both kernels.  One queue per XCD (workgroups are dealt round-robin to the 8 XCDs, so blockIdx % 8
@@ -1004,7 +1006,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)      // (four waves per SIMD: at most 128 VGPRs)
 blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
                            uint32_t* __restrict__ queue_head, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
                            const uint16_t* __restrict__ inst_bmask,
@@ -1015,7 +1017,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
                            const uint4* __restrict__ seg_desc, const float* __restrict__ seg_state, uint32_t seg_cap,
                            const uint32_t* __restrict__ tail_start, const uint32_t* __restrict__ seg_counts, int fwd_grid)
 {
-    __shared__ HeavyLdsBwd s_heavy[4];                       // per wave: 13 KB; a light item uses its first 3 KB as the record ring
+    __shared__ HeavyLdsBwd s_heavy[4];                       // per wave: 6.6 KB; a light item uses its first 3 KB as the record ring
     __shared__ uint16_t s_prefix[MAX_FWD_QUEUE_WAVES];       // inclusive prefix sums of the forward waves' segment counts (this XCD's region;
                                                              // 16 bits: the forward cuts nothing when a region has more than 65535 slots)
     static_assert(sizeof(HeavyLdsBwd) >= 64 * 3 * sizeof(float4), "the light path's ring lives inside the heavy path's LDS");
@@ -1030,7 +1032,8 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
     const int q_waves = 4 * (((int)gridDim.x - qx + nq - 1) / nq);
     int first_rank = ((int)blockIdx.x / nq) * 4 + wv;
 #define WSTAMP() (wstamps ? __builtin_amdgcn_s_memtime() : 0ull)
-    const unsigned long long t_start = WSTAMP();
+#define RSTAMP() (wstamps ? __builtin_amdgcn_s_memrealtime() : 0ull)     /* 100 MHz, the same clock on every CU (s_memtime is not) */
+    const unsigned long long t_start = RSTAMP();
     unsigned long long n_seg = 0, c_seg = 0, c_pop = 0, n_tail = 0, c_tail = 0, c_tailpop = 0;
     // ---- 1. the depth segments the forward kernel cut on this XCD (pieces of SEG_HITS hits of the heavy tiles' lists; the records of
     // those tiles are in this L2).  A wave's first segment is its rank among the queue's waves, later ones come from the region's pop head
@@ -1080,7 +1083,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
             i = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
         }
     }
-    const unsigned long long t_phase1 = WSTAMP();
+    const unsigned long long t_phase1 = RSTAMP();
     // ---- 2. every block's own item: the part of its list behind the last cut (the whole list if it was never cut)
     for (;;) {
         const unsigned long long tq0 = WSTAMP();
@@ -1101,10 +1104,11 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
     }
     if (wstamps && lane == 0) {
         unsigned long long* w = wstamps + ((size_t)blockIdx.x * 4 + wv) * 16;
-        w[0] = t_start; w[1] = t_phase1; w[2] = WSTAMP(); w[3] = n_seg; w[4] = c_seg; w[5] = c_pop; w[6] = 0; w[7] = n_tail;
+        w[0] = t_start; w[1] = t_phase1; w[2] = RSTAMP(); w[3] = n_seg; w[4] = c_seg; w[5] = c_pop; w[6] = 0; w[7] = n_tail;
         w[8] = c_tail; w[9] = c_tailpop; w[10] = (unsigned long long)qx;
     }
 #undef WSTAMP
+#undef RSTAMP
     // (the queue heads of this kernel are rewound by the per-Gaussian backward kernel that follows it on the stream -- a counter that
     // every wave increments on its way out was 1024 serialised atomics at the very end of the kernel)
 }
@@ -1180,7 +1184,7 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     static const int dbg = env_int("MOSS_BWD_DEBUG", 0) & (16 | 32 | 64);
     const int flags = (g_cull_override >= 0 ? g_cull_override : env_flags) | dbg;
     const int T = fp.gx * fp.gy;
-    static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel, "MOSS_BWD_WGS_PER_CU", 3, 3);   // 52.5 KB of LDS each
+    static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel, "MOSS_BWD_WGS_PER_CU", 4, 5);   // 27 KB of LDS each
     const int wgs = min(4 * T, device_cus() * bwd_wgs_per_cu);
     // the queue heads are zero here: cleared by the forward, rewound after each backward (preprocess_backward_kernel)
     MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,

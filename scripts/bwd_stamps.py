@@ -9,7 +9,7 @@ d = hp.inputs_of(scenes.config3(), "scale_rot")
 L = _lib.lib()
 L.moss_raster_debug_set_bwd_stamps.argtypes = [ctypes.c_void_p]
 dc, dd, da = hp.image_grads(d.H, d.W)
-nw = 256 * 4 * 4
+nw = 256 * 4 * 6
 buf = torch.zeros(nw * 16, dtype=torch.int64, device=dev)
 t = hp.hip_forward(d, dev)
 for _ in range(3): hp.hip_backward(d, t, dc, dd, da, dev)
@@ -19,10 +19,13 @@ hp.hip_backward(d, t, dc, dd, da, dev); torch.cuda.synchronize()
 L.moss_raster_debug_set_bwd_stamps(None)
 s = buf.cpu().numpy().reshape(-1, 16).astype(np.float64)
 s = s[s[:, 0] > 0]
-t0 = s[:, 0].min()
-print("waves", len(s), "kernel span (cycles of s_memtime)", s[:, 2].max() - t0, "start spread", s[:, 0].max() - t0)
-print("phase1 end: min/mean/max", (s[:, 1] - t0).min(), (s[:, 1] - t0).mean(), (s[:, 1] - t0).max())
-print("end: min/mean/max", (s[:, 2] - t0).min(), (s[:, 2] - t0).mean(), (s[:, 2] - t0).max())
+t0 = s[:, 0].min()      # w[0..2] are s_memrealtime ticks (100 MHz, one clock for the whole device); the item costs are s_memtime cycles
+us = lambda v: np.round((v - t0) / 100.0, 2)
+print("waves", len(s), "| kernel span", us(s[:, 2].max()), "us | wave starts: first 0, median", us(np.median(s[:, 0])), "last", us(s[:, 0].max()))
+print("segment phase ends: min/median/p90/max", us(s[:, 1].min()), us(np.median(s[:, 1])), us(np.percentile(s[:, 1], 90)), us(s[:, 1].max()))
+print("wave ends: min/median/p90/max", us(s[:, 2].min()), us(np.median(s[:, 2])), us(np.percentile(s[:, 2], 90)), us(s[:, 2].max()))
+hist, edges = np.histogram((s[:, 2] - t0) / 100.0, bins=12)
+print("wave end histogram (us):", [(round(float(e), 1), int(h)) for e, h in zip(edges[:-1], hist)])
 print("segments per wave: mean %.2f max %d total %d; invalid slots popped total %d" % (s[:, 3].mean(), s[:, 3].max(), s[:, 3].sum(), s[:, 6].sum()))
 print("cycles per segment item: mean %.0f; pop wait per pop: %.0f; share of phase 1 spent in items %.2f, in pops %.2f" % (
     s[:, 4].sum() / max(s[:, 3].sum(), 1), s[:, 5].sum() / max((s[:, 3] + s[:, 6] + 8).sum(), 1),
@@ -31,4 +34,7 @@ print("tail items per wave: mean %.2f max %d; cycles per tail item %.0f; pop wai
     s[:, 7].mean(), s[:, 7].max(), s[:, 8].sum() / max(s[:, 7].sum(), 1), s[:, 9].sum() / max((s[:, 7] + 1).sum(), 1)))
 for q in range(8):
     m = s[:, 10] == q
-    print(" xcd", q, "waves", int(m.sum()), "segments", int(s[m, 3].sum()), "phase1 end mean", int((s[m, 1] - t0).mean()), "end mean", int((s[m, 2] - t0).mean()))
+    if not m.any(): continue
+    x = s[m]
+    print(" xcd", q, "waves", int(m.sum()), "segments", int(x[:, 3].sum()), "tails", int(x[:, 7].sum()), "| segment phase end median/max", us(np.median(x[:, 1])), us(x[:, 1].max()),
+          "| end median/max", us(np.median(x[:, 2])), us(x[:, 2].max()))
