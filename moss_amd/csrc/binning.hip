@@ -289,7 +289,10 @@ __device__ __forceinline__ void network_phases(uint64_t& key, uint32_t tid, uint
 // padded size, so short chunks run few steps.
 // The grid is bounded (launch_tile_sort) and a workgroup loops over the chunks c = blockIdx.x, blockIdx.x + gridDim.x, ...: the
 // host-side chunk count is only an upper bound when R stays on the device, and a thousand empty 1024-thread workgroups are not free.
-__global__ void __launch_bounds__(1024)
+// (80 SGPRs: the CU admits waves per SIMD by the scalar file too -- 800 per SIMD in blocks of 16 + 16 -- and TWO 1024-thread workgroups,
+// eight waves per SIMD, only fit up to 80; with the 106 the unrolled network asked for, 84 of cfg3's 340 chunks waited for a first-round
+// workgroup to leave: scripts/sort_stamps.py, starts at 6.4 us)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
 chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
                   const uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */)
 {
@@ -297,7 +300,8 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
     __shared__ ChunkOwner s_own;
     const uint32_t tid = threadIdx.x;
 #define KSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
-    KSTAMP(0);
+#define RSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()   /* 100 MHz, device-wide */
+    KSTAMP(0); RSTAMP(5);
     for (uint32_t c = blockIdx.x;; c += gridDim.x) {
         find_chunk_tile(T, [&](uint32_t) { return c; }, ranges, chunk_base, header, &s_own);
         const uint32_t n_chunks = s_own.n_chunks;
@@ -325,7 +329,7 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
         network_phases<CHUNK>(key, tid, npad, s_keys, p);
         KSTAMP(3);
         if (tid < n) gk[tid] = key;
-        KSTAMP(4);
+        KSTAMP(4); RSTAMP(7);
         if (last_turn) return;
         __syncthreads();                                   // s_own is rewritten by the next round's lookup
     }
@@ -340,7 +344,7 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
 // sorted id, the 48-byte record the blend kernels stream, the block mask, and the Gaussian -> instance back-pointer used by the
 // backward gather.
 constexpr int MERGE_OC = 6;                                // sibling chunks searched per round (48 KB of LDS)
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))     // (two workgroups per CU: see chunk_sort_kernel)
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView g, const uint2* __restrict__ ranges,
                     const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
@@ -350,7 +354,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[MERGE_OC][CHUNK];
     __shared__ ChunkOwner s_own;
     const uint32_t tid = threadIdx.x;
-    KSTAMP(0);
+    KSTAMP(0); RSTAMP(5);
     for (uint32_t it = blockIdx.x;; it += gridDim.x) {
     // XCD-aware chunk order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), chunks are in tile order, and neighbouring
     // tiles gather the same Gaussians' 64-byte records: XCD k takes the k-th contiguous eighth of the chunks (counted from the
@@ -417,7 +421,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     const float4* gsrc = g.geo + 4 * (size_t)id;                  // the Gaussian's one 64-byte record
     const float4 ga = gsrc[0], gb = gsrc[1], gd = gsrc[3];
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 3] = ga.x == 12345.678f ? 1ull : __builtin_amdgcn_s_memtime();
-    rec[0] = ga; rec[1] = gb; rec[2] = gsrc[2];
+    rec[0] = ga; rec[1] = gb; rec[2] = gsrc[2];       // (non-temporal or write-through stores here: +3 / +7 us -- the write-back at the kernel's end is cheaper)
     const uint2 r = make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y));
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
     const int tx = (int)tile % gx, ty = (int)tile / gx;
@@ -478,8 +482,9 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     inst_pos[__float_as_uint(gd.z) + k] = pos;
     }   // mine
-    KSTAMP(4);
+    KSTAMP(4); RSTAMP(7);
 #undef KSTAMP
+#undef RSTAMP
     if (last_turn) return;
     __syncthreads();                                          // s_own / s_keys are rewritten by the next round
     }

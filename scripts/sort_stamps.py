@@ -22,11 +22,9 @@ for name, off in (("chunk_sort [lookup, key load, network, store]", 0), ("merge_
     # the clocks of the 8 XCDs are not synchronised: spans per XCD (workgroup index % 8)
     ph = np.diff(w[:, :5], axis=1)
     print(name, "workgroups", len(w), "mean cycles per phase", ph.mean(0).astype(int), "p95", np.percentile(ph, 95, axis=0).astype(int), "total mean", int((w[:, 4] - w[:, 0]).mean()), "max", int((w[:, 4] - w[:, 0]).max()))
-    idx = np.nonzero((s[off: off + 8 * 1024].reshape(-1, 8)[:, 0] > 0) & (s[off: off + 8 * 1024].reshape(-1, 8)[:, 4] > 0))[0]
-    for x in range(8):
-        m = idx % 8 == x
-        if m.any():
-            print("   xcd", x, "workgroups", int(m.sum()), "first start -> last end", int(w[m, 4].max() - w[m, 0].min()), "start spread", int(w[m, 0].max() - w[m, 0].min()))
+    t0 = w[:, 5].min()
+    print("   realtime (us): workgroup starts median %.2f last %.2f | ends median %.2f p90 %.2f last %.2f" % (
+        np.median(w[:, 5] - t0) / 100, (w[:, 5].max() - t0) / 100, np.median(w[:, 7] - t0) / 100, np.percentile(w[:, 7] - t0, 90) / 100, (w[:, 7].max() - t0) / 100))
     big = w[:, 6] >= (1024 if off == 0 else 3)
     if big.any():
         print("   full chunks / tiles of >= 3 chunks:", int(big.sum()), "mean phases", np.diff(w[big, :5], axis=1).mean(0).astype(int))
