@@ -201,10 +201,12 @@ int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_a
                     int num_segments, const long long* segment_end, const float* segment_lr,
                     const int* segment_period, const int* segment_split, const float* segment_lr2,
                     float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
-/* Same update with the step counter kept on the device: `step_state` is 288 zero-initialised device bytes ([0] = int step,
- * advanced by one per call by the update kernel itself; [3] and [4..67] = its two-level block-completion counters; [68..71] =
- * the bias corrections of the current / next step, double-buffered by step parity).  n must be > 0.  Nothing in the call depends on a host-side
+/* Same update with the step counter kept on the device: `step_state` is MOSS_ADAMW_STATE_BYTES (9216) zero-initialised device bytes
+ * (32-bit words: [0] = int step, advanced by one per call by the update kernel itself; [8..11] = the bias corrections of the
+ * current / next step, double-buffered by step parity; [64] and [128 + 64 g], g < 32 = its two-level block-completion counters,
+ * each on a 256-byte line of its own).  n must be > 0.  Nothing in the call depends on a host-side
  * counter, so a captured hipGraph of a training step replays correctly. */
+#define MOSS_ADAMW_STATE_BYTES 9216
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
                             const int* segment_period, const int* segment_split, const float* segment_lr2,

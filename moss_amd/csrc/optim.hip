@@ -11,7 +11,7 @@ namespace {
 
 struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; float lr2[8]; };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))   // (eight waves per SIMD: the scalar file admits six at 106 SGPRs)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
              Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
              const float* __restrict__ step_state)
@@ -26,14 +26,14 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             bc1 = (float)(1.0 - pow((double)beta1, 1.0));
             bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, 1.0));
         } else {                                             // cached by the previous step (slot = parity of the step)
-            bc1 = step_state[68 + 2 * (t_dev & 1)]; bc2_sqrt = step_state[69 + 2 * (t_dev & 1)];
+            bc1 = step_state[8 + 2 * (t_dev & 1)]; bc2_sqrt = step_state[9 + 2 * (t_dev & 1)];
         }
         // the NEXT step's corrections go to the other slot, computed by one thread at the START of this launch (two double pow()
         // at the end of the last block were a 3-5 us serial tail); nobody reads that slot during this launch
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             float* sf = const_cast<float*>(step_state);
-            sf[68 + 2 * ((t_dev + 1) & 1)] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));
-            sf[69 + 2 * ((t_dev + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
+            sf[8 + 2 * ((t_dev + 1) & 1)] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));
+            sf[9 + 2 * ((t_dev + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
         }
     }
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
@@ -102,15 +102,18 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     }
     if (step_state && threadIdx.x == 0) {
         int* st = reinterpret_cast<int*>(const_cast<float*>(step_state));
-        // two-level completion count: 64 group counters (words 4..67), then one global counter (word 3), so that no address sees
-        // more than gridDim/64 + 64 atomics (4096 same-address atomics cost +34 us, see profiles/r01_notes.md)
-        const int grp = (int)(blockIdx.x & 63u);
-        const int grp_size = ((int)gridDim.x - grp + 63) / 64;                    // blocks with this group id
-        const int n_groups = min((int)gridDim.x, 64);
-        if (atomicAdd(&st[4 + grp], 1) == grp_size - 1) {
-            st[4 + grp] = 0;
-            if (atomicAdd(&st[3], 1) == n_groups - 1) {
-                st[0] = t_dev; st[3] = 0;
+        // Two-level completion count, EVERY counter on a 256-byte line of its own: 32 group counters (words 128 + 64 g), then one
+        // global counter (word 64).  Atomics on words of ONE cache line execute one after the other for the whole device (~11 ns
+        // each, profiles/r02_notes.md finding 1): round 2 kept 64 group counters in two lines, so the 4096 blocks' atomics were a
+        // ~6 us tail of this kernel (26 us with a host-side step count, 32 us with the device-side one).
+        constexpr int NGROUPS = 32;
+        const int grp = (int)(blockIdx.x % (unsigned)NGROUPS);
+        const int grp_size = ((int)gridDim.x - grp + NGROUPS - 1) / NGROUPS;      // blocks with this group id
+        const int n_groups = min((int)gridDim.x, NGROUPS);
+        if (atomicAdd(&st[128 + 64 * grp], 1) == grp_size - 1) {
+            st[128 + 64 * grp] = 0;
+            if (atomicAdd(&st[64], 1) == n_groups - 1) {
+                st[0] = t_dev; st[64] = 0;
             }
         }
     }
@@ -128,7 +131,8 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
         segs.period[i] = pat ? segment_period[i] : 0; segs.split[i] = pat ? segment_split[i] : 0; segs.lr2[i] = pat ? segment_lr2[i] : 0.f;
     }
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    static const long long max_blocks = [] { const char* v = getenv("MOSS_ADAMW_BLOCKS"); return (long long)((v && *v) ? atoi(v) : 2048); }();
+    if (blocks > max_blocks) blocks = max_blocks;            // (2048: eight 256-thread blocks per CU, all resident at once)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
                        segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state);

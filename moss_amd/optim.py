@@ -49,7 +49,7 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.t = 0
-        self.step_state = torch.zeros(72, dtype=torch.int32, device=dev) if capturable else None
+        self.step_state = torch.zeros(2304, dtype=torch.int32, device=dev) if capturable else None     # csrc/optim.hip: counters on lines of their own
 
     def snapshot(self):
         """Copies of everything a step changes (parameters, both moments, step counters)."""
