@@ -6,7 +6,7 @@
 //
 // The reference runs five depthwise 11x11 convolutions + ~20 elementwise kernels forward and their autograd mirror
 // backward (measured here with MIOpen: 8 x 178 us + ~60 launches per step).  Here: two launches.
-//   pass 1: per 16x16 tile and channel, x and y tiles (+5 px halo) go to LDS once, the five windowed moments
+//   pass 1: per 32x32 tile and channel, x and y tiles (+5 px halo) go to LDS once, the five windowed moments
 //           (E[x], E[y], E[x^2], E[y^2], E[xy]) are formed separably (horizontal then vertical 11-tap), SSIM and its partial
 //           derivatives w.r.t. the three x-dependent moments are evaluated per pixel; the derivative maps are written
 //           (3 floats per pixel-channel) and the block's loss sums go to a partials array (fixed-order => deterministic);
@@ -20,9 +20,12 @@ namespace moss {
 
 namespace {
 
-constexpr int LT = 16;              // tile edge
+constexpr int LT = 32;              // tile edge: 32 x 32 outputs per 256-thread workgroup
 constexpr int HALO = 5;             // window 11
-constexpr int LP = LT + 2 * HALO;   // 26
+constexpr int LP = LT + 2 * HALO;   // 42
+constexpr int SEG = 8;              // outputs per thread in the horizontal pass (a run of 8 in one row: 18 inputs)
+constexpr int VR = 4;               // outputs per thread in the vertical pass (4 consecutive rows of one column: 14 inputs)
+static_assert(LT % SEG == 0 && (LT / SEG) * LP <= 256 && LT * (LT / VR) == 256, "work split of a 256-thread workgroup");
 
 struct Win { float g[11]; };
 
@@ -48,6 +51,12 @@ __device__ __forceinline__ TileId xcd_tile()
     return id;
 }
 
+// Both passes are separable 11-tap filters through LDS with SLIDING WINDOWS in registers (round 2: one output per thread and pass,
+// 11 LDS reads per output and moment, products recomputed per tap -- 7.8 wave-instructions per pixel-channel, 30 % of the wave
+// cycles waiting on LDS).  Horizontal: a thread owns a run of SEG outputs of one row, walks its SEG + 10 inputs once and adds each
+// into the outputs whose window holds it.  Vertical: a thread owns VR consecutive rows of one column.  32 x 32 tiles: the halo costs
+// 1.7x instead of 2.6x.
+
 __global__ void __launch_bounds__(256)
 ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Win win,
                   float* __restrict__ dmap /* [3][C][H][W] */, float* __restrict__ partials /* [blocks][2] */,
@@ -66,61 +75,98 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     const float* xc = img + (size_t)c * H * W;
     const float* yc = gt + (size_t)c * H * W;
 
-    for (int i = tid; i < LP * LP; i += 256) {
-        const int r = i / LP, q = i % LP;
-        s_x[r][q] = ld0(xc, x0 + q - HALO, y0 + r - HALO, W, H);
-        s_y[r][q] = ld0(yc, x0 + q - HALO, y0 + r - HALO, W, H);
-    }
-    __syncthreads();
-    for (int i = tid; i < LP * LT; i += 256) {          // horizontal 11-tap for the 5 moments
-        // lanes run down a column (r fastest): consecutive lanes are LP + 1 = 27 words apart, an odd stride, so the 11-tap reads
-        // below hit distinct LDS banks (row-major lanes put rows r and r + 1 of a half-wave on the same banks: PMC showed
-        // 30% of this kernel's wave-cycles waiting on LDS with 2.6M bank-conflict cycles)
-        const int r = i % LP, q = i / LP;
-        float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+    {
+        // the tile + halo: all loads first (clamped addresses, no branch: they are in flight together), then the LDS stores
+        constexpr int NLD = (LP * LP + 255) / 256;
+        float vx[NLD], vy[NLD];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float a = s_x[r][q + k], b = s_y[r][q + k], w = win.g[k];
-            m1 = __fmaf_rn(w, a, m1); m2 = __fmaf_rn(w, b, m2);
-            xx = __fmaf_rn(w, a * a, xx); yy = __fmaf_rn(w, b * b, yy); xy = __fmaf_rn(w, a * b, xy);
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + 256 * k, r = i / LP, q = i % LP;
+            const size_t o = (size_t)min(max(y0 + r - HALO, 0), H - 1) * W + min(max(x0 + q - HALO, 0), W - 1);
+            vx[k] = xc[o]; vy[k] = yc[o];
         }
-        s_h[0][r][q] = m1; s_h[1][r][q] = m2; s_h[2][r][q] = xx; s_h[3][r][q] = yy; s_h[4][r][q] = xy;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + 256 * k, r = i / LP, q = i % LP;
+            const int gx_ = x0 + q - HALO, gy_ = y0 + r - HALO;
+            const bool in = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
+            if (i < LP * LP) { s_x[r][q] = in ? vx[k] : 0.0f; s_y[r][q] = in ? vy[k] : 0.0f; }
+        }
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4;
-    const int px = x0 + lx, py = y0 + ly;
+    if (tid < (LT / SEG) * LP) {                         // horizontal 11-tap for the 5 moments: rows run along the lanes (odd row
+        const int r = tid % LP, q0 = (tid / LP) * SEG;   // stride: conflict-free LDS reads), a thread owns columns q0 .. q0 + SEG - 1
+        float acc[SEG][5];
+#pragma unroll
+        for (int j = 0; j < SEG; j++) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; acc[j][4] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < SEG + 10; i++) {
+            const float a = s_x[r][q0 + i], b = s_y[r][q0 + i];
+            const float aa = a * a, bb = b * b, ab = a * b;
+#pragma unroll
+            for (int j = 0; j < SEG; j++) {
+                if (i - j >= 0 && i - j <= 10) {
+                    const float w = win.g[i - j];
+                    acc[j][0] = __fmaf_rn(w, a, acc[j][0]); acc[j][1] = __fmaf_rn(w, b, acc[j][1]);
+                    acc[j][2] = __fmaf_rn(w, aa, acc[j][2]); acc[j][3] = __fmaf_rn(w, bb, acc[j][3]); acc[j][4] = __fmaf_rn(w, ab, acc[j][4]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SEG; j++) {
+#pragma unroll
+            for (int m = 0; m < 5; m++) s_h[m][r][q0 + j] = acc[j][m];
+        }
+    }
+    __syncthreads();
+    const int lx = tid % LT, ly0 = (tid / LT) * VR;      // vertical: column lx, rows ly0 .. ly0 + VR - 1
+    float mo[VR][5];
+#pragma unroll
+    for (int j = 0; j < VR; j++) { mo[j][0] = 0.f; mo[j][1] = 0.f; mo[j][2] = 0.f; mo[j][3] = 0.f; mo[j][4] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < VR + 10; i++) {
+        float v[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) v[m] = s_h[m][ly0 + i][lx];
+#pragma unroll
+        for (int j = 0; j < VR; j++) {
+            if (i - j >= 0 && i - j <= 10) {
+                const float w = win.g[i - j];
+#pragma unroll
+                for (int m = 0; m < 5; m++) mo[j][m] = __fmaf_rn(w, v[m], mo[j][m]);
+            }
+        }
+    }
     float ssim_v = 0.f, l1_v = 0.f, mask_v = 0.f;
-    if (px < W && py < H) {
-        float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+    const int px = x0 + lx;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.g[k];
-            mu1 = __fmaf_rn(w, s_h[0][ly + k][lx], mu1); mu2 = __fmaf_rn(w, s_h[1][ly + k][lx], mu2);
-            exx = __fmaf_rn(w, s_h[2][ly + k][lx], exx); eyy = __fmaf_rn(w, s_h[3][ly + k][lx], eyy);
-            exy = __fmaf_rn(w, s_h[4][ly + k][lx], exy);
-        }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-        const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
-        const float inv = 1.0f / (b1 * b2);
-        const float S = a1 * a2 * inv;
-        // partial derivatives of S w.r.t. (mu1 | sigma1^2 | sigma12), then total derivatives w.r.t. the three filtered
-        // moments E[x], E[x^2], E[xy] (sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2)
-        const float dS_ds1 = -S / b2;
-        const float dS_ds12 = 2.f * a1 * inv;
-        const float dS_dmu1 = 2.f * mu2 * a2 * inv - S * 2.f * mu1 / b1 + dS_ds1 * (-2.f * mu1) + dS_ds12 * (-mu2);
-        const size_t o = ((size_t)c * H + py) * W + px, plane3 = (size_t)C * H * W;
-        dmap[o] = dS_dmu1; dmap[plane3 + o] = dS_ds1; dmap[2 * plane3 + o] = dS_ds12;
-        ssim_v = S;
-        l1_v = fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
-        // the alpha-vs-mask L2 term rides on channel 0's tiles; it is computed HERE (not in pass 2, where its gradient would
-        // fit just as well) so that everything pass 2's closing fold reads was written by an earlier kernel
-        if (c == 0 && alpha != nullptr) {
-            const size_t oa = (size_t)py * W + px;
-            const float da = alpha[oa] - mask[oa];
-            mask_v = da * da;
-            dL_dalpha[oa] = lambda_mask * 2.f * da / ((float)H * (float)W);
+    for (int j = 0; j < VR; j++) {
+        const int ly = ly0 + j, py = y0 + ly;
+        if (px < W && py < H) {
+            const float mu1 = mo[j][0], mu2 = mo[j][1], exx = mo[j][2], eyy = mo[j][3], exy = mo[j][4];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+            const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
+            const float inv = 1.0f / (b1 * b2);
+            const float S = a1 * a2 * inv;
+            // partial derivatives of S w.r.t. (mu1 | sigma1^2 | sigma12), then total derivatives w.r.t. the three filtered
+            // moments E[x], E[x^2], E[xy] (sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2)
+            const float dS_ds1 = -S / b2;
+            const float dS_ds12 = 2.f * a1 * inv;
+            const float dS_dmu1 = 2.f * mu2 * a2 * inv - S * 2.f * mu1 / b1 + dS_ds1 * (-2.f * mu1) + dS_ds12 * (-mu2);
+            const size_t o = ((size_t)c * H + py) * W + px, plane3 = (size_t)C * H * W;
+            dmap[o] = dS_dmu1; dmap[plane3 + o] = dS_ds1; dmap[2 * plane3 + o] = dS_ds12;
+            ssim_v += S;
+            l1_v += fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
+            // the alpha-vs-mask L2 term rides on channel 0's tiles; it is computed HERE (not in pass 2, where its gradient would
+            // fit just as well) so that everything pass 2's closing fold reads was written by an earlier kernel
+            if (c == 0 && alpha != nullptr) {
+                const size_t oa = (size_t)py * W + px;
+                const float da = alpha[oa] - mask[oa];
+                mask_v += da * da;
+                dL_dalpha[oa] = lambda_mask * 2.f * da / ((float)H * (float)W);
+            }
         }
     }
 #pragma unroll
@@ -153,36 +199,71 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     const size_t plane3 = (size_t)C * H * W;
     const float N = (float)C * (float)H * (float)W;
 
-    for (int i = tid; i < 3 * LP * LP; i += 256) {
-        const int m = i / (LP * LP), j = i % (LP * LP);
-        const int r = j / LP, q = j % LP;
-        s_d[m][r][q] = ld0(dmap + m * plane3 + (size_t)c * H * W, x0 + q - HALO, y0 + r - HALO, W, H);
-    }
-    __syncthreads();
-    for (int i = tid; i < 3 * LP * LT; i += 256) {
-        const int m = i / (LP * LT), j = i % (LP * LT);
-        const int r = j % LP, q = j / LP;                    // column-major lanes: conflict-free LDS reads (see pass 1)
-        float acc = 0.f;
+    {
+        constexpr int NLD = (LP * LP + 255) / 256;
+        float v[3][NLD];
 #pragma unroll
-        for (int k = 0; k < 11; k++) acc = __fmaf_rn(win.g[k], s_d[m][r][q + k], acc);
-        s_h[m][r][q] = acc;
-    }
-    __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4;
-    const int px = x0 + lx, py = y0 + ly;
-    if (px < W && py < H) {
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.g[k];
-            f0 = __fmaf_rn(w, s_h[0][ly + k][lx], f0); f1 = __fmaf_rn(w, s_h[1][ly + k][lx], f1); f2 = __fmaf_rn(w, s_h[2][ly + k][lx], f2);
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + 256 * k, r = i / LP, q = i % LP;
+            const size_t o = (size_t)c * H * W + (size_t)min(max(y0 + r - HALO, 0), H - 1) * W + min(max(x0 + q - HALO, 0), W - 1);
+            v[0][k] = dmap[o]; v[1][k] = dmap[plane3 + o]; v[2][k] = dmap[2 * plane3 + o];
         }
-        const size_t o = ((size_t)c * H + py) * W + px;
-        const float x = img[o], y = gt[o];
-        const float dssim = f0 + 2.f * x * f1 + y * f2;                    // d(sum SSIM)/dx
-        const float d = x - y;
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dL_dimg[o] = sgn / N - lambda_dssim * dssim / N;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + 256 * k, r = i / LP, q = i % LP;
+            const int gx_ = x0 + q - HALO, gy_ = y0 + r - HALO;
+            const bool in = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
+            if (i < LP * LP) { s_d[0][r][q] = in ? v[0][k] : 0.0f; s_d[1][r][q] = in ? v[1][k] : 0.0f; s_d[2][r][q] = in ? v[2][k] : 0.0f; }
+        }
+    }
+    __syncthreads();
+    if (tid < (LT / SEG) * LP) {                         // horizontal pass of the three derivative maps (see pass 1)
+        const int r = tid % LP, q0 = (tid / LP) * SEG;
+        float acc[SEG][3];
+#pragma unroll
+        for (int j = 0; j < SEG; j++) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < SEG + 10; i++) {
+            const float v0 = s_d[0][r][q0 + i], v1 = s_d[1][r][q0 + i], v2 = s_d[2][r][q0 + i];
+#pragma unroll
+            for (int j = 0; j < SEG; j++) {
+                if (i - j >= 0 && i - j <= 10) {
+                    const float w = win.g[i - j];
+                    acc[j][0] = __fmaf_rn(w, v0, acc[j][0]); acc[j][1] = __fmaf_rn(w, v1, acc[j][1]); acc[j][2] = __fmaf_rn(w, v2, acc[j][2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SEG; j++) { s_h[0][r][q0 + j] = acc[j][0]; s_h[1][r][q0 + j] = acc[j][1]; s_h[2][r][q0 + j] = acc[j][2]; }
+    }
+    __syncthreads();
+    const int lx = tid % LT, ly0 = (tid / LT) * VR;
+    float f[VR][3];
+#pragma unroll
+    for (int j = 0; j < VR; j++) { f[j][0] = 0.f; f[j][1] = 0.f; f[j][2] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < VR + 10; i++) {
+        const float v0 = s_h[0][ly0 + i][lx], v1 = s_h[1][ly0 + i][lx], v2 = s_h[2][ly0 + i][lx];
+#pragma unroll
+        for (int j = 0; j < VR; j++) {
+            if (i - j >= 0 && i - j <= 10) {
+                const float w = win.g[i - j];
+                f[j][0] = __fmaf_rn(w, v0, f[j][0]); f[j][1] = __fmaf_rn(w, v1, f[j][1]); f[j][2] = __fmaf_rn(w, v2, f[j][2]);
+            }
+        }
+    }
+    const int px = x0 + lx;
+#pragma unroll
+    for (int j = 0; j < VR; j++) {
+        const int py = y0 + ly0 + j;
+        if (px < W && py < H) {
+            const size_t o = ((size_t)c * H + py) * W + px;
+            const float x = img[o], y = gt[o];
+            const float dssim = f[j][0] + 2.f * x * f[j][1] + y * f[j][2];     // d(sum SSIM)/dx
+            const float d = x - y;
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            dL_dimg[o] = sgn / N - lambda_dssim * dssim / N;
+        }
     }
     // Block (0,0,0) folds pass 1's partials into the four loss terms (no separate "finish" launch: a minimal launch costs 4-5 us).
     // Everything it reads was written by pass 1, an earlier kernel -- which is why the mask term is computed there.
