@@ -53,7 +53,8 @@ template <int NT>
 __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
                                              uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
                                              uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
-                                             uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */)
+                                             uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */,
+                                             int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base)
 {
     const int tid = threadIdx.x;
     if (tid == 0) *s_max = 0;
@@ -94,6 +95,17 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         const uint32_t v = overflow ? 0u : tile_count[i];
         tile_order[atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u)] = (uint32_t)i;
     }
+    // where the inst_pos slot runs of every group of 256 Gaussians start (the preprocess kernel left group-relative run starts
+    // and the groups' totals): the reference's device-wide scan of tiles_touched, rasterizer_impl.cu:279, at 1/256 of its length
+    {
+        const int gchunk = (n_groups + NT - 1) / NT;
+        const int gb = tid * gchunk, ge = min(n_groups, gb + gchunk);
+        uint32_t gs = 0;
+        for (int i = gb; i < ge; i++) gs += group_tot[i];
+        uint32_t gtotal;
+        uint32_t goff = block_scan<NT>(gs, s_wave, gtotal);
+        for (int i = gb; i < ge; i++) { group_base[i] = goff; goff += group_tot[i]; }
+    }
 }
 
 // One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram, chunk_base[t] = number
@@ -101,12 +113,14 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
 // (The per-Gaussian offsets are produced by the preprocess kernel.)
 __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
-            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2)
+            uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
+            int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_bucket[34];
-    scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket);
+    scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
+                       n_groups, group_tot, group_base);
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
@@ -129,7 +143,8 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
     if (fold_scan) {
         n_blocks--;
         if ((int)blockIdx.x == n_blocks) {
-            scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket);
+            scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
+                              (P + 255) / 256, g.group_tot, g.group_base);
             return;
         }
     } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
@@ -480,7 +495,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         inst_bmask[pos] = (uint16_t)bmask;
     }
     const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-    inst_pos[__float_as_uint(gd.z) + k] = pos;
+    inst_pos[g.group_base[id >> 8] + __float_as_uint(gd.z) + k] = pos;
     }   // mine
     KSTAMP(4); RSTAMP(7);
 #undef KSTAMP
@@ -554,10 +569,9 @@ static int light_log2_knob()
 
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s)
 {
-    (void)P; (void)g;
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header, cap, light_log2_knob());
+                       im.header, cap, light_log2_knob(), (P + 255) / 256, g.group_tot, g.group_base);
 }
 
 // The scan can ride along with the scatter (no launch of its own) when the tile histogram fits the scatter's LDS and nobody has to

@@ -49,7 +49,8 @@ inline T* carve(char*& p, size_t count)
 
 struct GeomView {
     float4* geo;             // 4 float4 per Gaussian, see the layout comment at the top of this file
-    uint32_t* tiles_touched; uint32_t* point_offsets;
+    uint32_t* tiles_touched; uint32_t* point_offsets;    // point_offsets: start of the Gaussian's slot run RELATIVE to its group of 256
+    uint32_t* group_tot; uint32_t* group_base;           // per group of 256 consecutive Gaussians: instances, and where its runs start
     int* radius;
     uint8_t* clamped;
     float* cov3D;
@@ -58,6 +59,7 @@ struct GeomView {
         GeomView g; char* p = base; size_t n = (size_t)P;
         g.geo = carve<float4>(p, 4 * n);
         g.tiles_touched = carve<uint32_t>(p, n); g.point_offsets = carve<uint32_t>(p, n);
+        g.group_tot = carve<uint32_t>(p, (n + 255) / 256); g.group_base = carve<uint32_t>(p, (n + 255) / 256);
         g.radius = carve<int>(p, n);
         g.clamped = carve<uint8_t>(p, n);
         g.cov3D = carve<float>(p, 6 * n);
@@ -235,7 +237,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view16_dev, u
 
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
-void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header, group bases
 bool scatter_folds_scan(const FrameParams& fp);                                                // asynchronous forward: no scan launch, see binning.hip
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s);  // duplicateWithKeys (+ the scan)
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s);

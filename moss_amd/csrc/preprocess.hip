@@ -205,11 +205,13 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                           GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header,
-                          int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms, int raw)
+                          int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms, int raw,
+                          unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */)
 {
+#define FSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+    FSTAMP(0);
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_blockbase;
     const int T = gx * gy;
     if (lds_hist) {
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
@@ -243,9 +245,33 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             }
             __syncthreads();
         }
+        // Every per-Gaussian input is requested HERE, unconditionally (clamped index), before anything is waited for: read where
+        // they are used -- means, then (behind the frustum test) scales / rotations, then (behind the covariance and colour math) the
+        // opacity -- each was a memory round trip of its own on this kernel's critical path (~2 us each at 1.5 waves per SIMD).
+        const size_t ic = (size_t)min(idx, P - 1);
+        const float3 p_ld = make_float3(means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2]);
+        const float opa_ld = opacities[ic];
+        float cov_ld[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, sc_ld[3] = { 0.f, 0.f, 0.f }, q_ld[4] = { 0.f, 0.f, 0.f, 0.f };
+        float tm_ld[9] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (cov3D_precomp != nullptr) {                      // (kernel-uniform branches)
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov_ld[i] = cov3D_precomp[6 * ic + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) sc_ld[i] = scales[3 * ic + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) q_ld[i] = rotations[4 * ic + i];
+            if (transforms != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) tm_ld[i] = transforms[9 * ic + i];
+            }
+        }
+        float3 col_ld = make_float3(0.f, 0.f, 0.f);
+        if (colors_precomp != nullptr) col_ld = make_float3(colors_precomp[3 * ic], colors_precomp[3 * ic + 1], colors_precomp[3 * ic + 2]);
+        FSTAMP(1);
         int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
         if (idx < P) do {
-            const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+            const float3 p_orig = p_ld;
             const float3 p_view = xform4x3(p_orig, view);
             if (p_view.z <= 0.2f) {                                   // in_frustum, auxiliary.h:154
                 if (prefiltered) atomicOr(&header[2], ERRFLAG_PREFILTERED);
@@ -258,16 +284,16 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             float cov3D[6];
             if (cov3D_precomp != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+                for (int i = 0; i < 6; i++) cov3D[i] = cov_ld[i];
             } else {
-                float sc[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
-                float q[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
+                float sc[3] = { sc_ld[0], sc_ld[1], sc_ld[2] };
+                float q[4] = { q_ld[0], q_ld[1], q_ld[2], q_ld[3] };
                 activate_scale_rot(raw, sc, q);
                 cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
                 if (transforms != nullptr) {
                     float Tm[9], pre[6];
 #pragma unroll
-                    for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+                    for (int i = 0; i < 9; i++) Tm[i] = tm_ld[i];
 #pragma unroll
                     for (int i = 0; i < 6; i++) pre[i] = cov3D[i];
                     transform_cov3d(Tm, pre, cov3D);
@@ -342,13 +368,13 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                 }
                 rgb = make_float3(res[0], res[1], res[2]);
             } else {
-                rgb = make_float3(colors_precomp[3 * (size_t)idx], colors_precomp[3 * (size_t)idx + 1], colors_precomp[3 * (size_t)idx + 2]);
+                rgb = col_ld;
             }
 
             // Conservative extent of the region where this Gaussian can reach alpha >= 1/255 (power >= -tau,
             // tau = ln(255*opacity)): half-widths sqrt(2*tau*cov_xx), sqrt(2*tau*cov_yy) of the ellipse's bounding box,
             // widened by 1e-4 relative + 0.01 px against rounding.  Used only to SKIP work in the blend kernels.
-            const float opa = (raw & RAW_OPACITY) ? sigmoid_act(opacities[idx]) : opacities[idx];
+            const float opa = (raw & RAW_OPACITY) ? sigmoid_act(opa_ld) : opa_ld;
             float hx = __builtin_huge_valf(), hy = __builtin_huge_valf();
             if (opa == opa) {
                 if (!(opa > 0.0f)) { hx = -1.0f; hy = -1.0f; }
@@ -372,26 +398,26 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             out_rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
 
         } while (0);
+        FSTAMP(2);
         // per-tile histogram of the (Gaussian, tile) instances; large rectangles are walked by the whole wave
         wave_for_each_tile(out_rect, gx, 0ull, [&](int t, uint64_t) {
             if (lds_hist) atomicAdd(&s_hist[t], 1u);
             else atomicAdd(&tile_count[t], 1u);
         });
-        // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos.  The runs only have to
-        // be disjoint, not ordered by index, so a block-level prefix sum plus ONE returning atomic per block replaces the
-        // device-wide scan of the reference (rasterizer_impl.cu:279).
+        // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos (the reference: a device-wide inclusive
+        // scan, rasterizer_impl.cu:279).  Here: the run's start RELATIVE to the block's group of 256 Gaussians (a block prefix sum) and
+        // the group's total; the scan block that rides along with the scatter kernel turns the totals into group bases.  (Round 1-2
+        // reserved the group's slots with ONE returning atomic per block on a header word: 391 atomics on one address, 11 ns each --
+        // the last block got its answer 4.5 us after the first: the tail of this kernel, scripts/sort_stamps.py.)
         uint32_t incl = out_tiles;
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         if (lane == 63) s_wsum[wv] = incl;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            s_blockbase = tot ? atomicAdd(&header[3], tot) : 0u;
-        }
-        __syncthreads();
-        uint32_t wbase = s_blockbase;
+        if (threadIdx.x == 0 && (it * gridDim.x + blockIdx.x) * blockDim.x < (unsigned)P)
+            g.group_tot[it * gridDim.x + blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t wbase = 0u;
         for (int w = 0; w < wv; w++) wbase += s_wsum[w];
         if (idx < P) {
             g.radius[idx] = out_radius;
@@ -402,6 +428,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             if (radii_out) radii_out[idx] = out_radius;
         }
         __syncthreads();
+        FSTAMP(4);
     }
     if (lds_hist) {
         __syncthreads();
@@ -410,6 +437,8 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             if (v && !(raw & 0x100)) atomicAdd(&tile_count[i], v);        // (0x100: timing experiment, MOSS_EXPERIMENT=1 -- wrong counts)
         }
     }
+    FSTAMP(5);
+#undef FSTAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -716,7 +745,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
         for (int j = 0; j < 12; j++) shv[j] = src[min(base4 + threadIdx.x + (size_t)j * blockDim.x, total4 - 1)];
     }
-    const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc], hdr_flags = header[2];
+    const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc] + g.group_base[idc >> 8], hdr_flags = header[2];
     if (STAGE_SH) {
         // into LDS right away (row stride 49: conflict-free rows): the SH loads are the oldest outstanding ones, so this waits for
         // them only, and their 48 registers are free during the gather (holding them across it spilled to scratch)
@@ -1003,7 +1032,8 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh,
-                       transforms, fp.raw | ((env_int("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0));
+                       transforms, fp.raw | ((env_int("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0),
+                       (g_stamps && env_int("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr);
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,

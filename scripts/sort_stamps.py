@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 d = hp.inputs_of(scenes.config3(), "scale_rot")
 L = _lib.lib()
 L.moss_raster_debug_set_stamps.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(131072 + 16384 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(131072 + 32768 + 8 * 4096 + 64, dtype=torch.int64, device=dev)
 for _ in range(3): hp.hip_forward(d, dev)
 torch.cuda.synchronize()
 L.moss_raster_debug_set_stamps(buf.data_ptr())
@@ -28,3 +28,10 @@ for name, off in (("chunk_sort [lookup, key load, network, store]", 0), ("merge_
     big = w[:, 6] >= (1024 if off == 0 else 3)
     if big.any():
         print("   full chunks / tiles of >= 3 chunks:", int(big.sum()), "mean phases", np.diff(w[big, :5], axis=1).mean(0).astype(int))
+
+w = s[32768: 32768 + 8 * 4096].reshape(-1, 8).astype(np.float64)
+w = w[w[:, 0] > 0]
+t0 = w[:, 0].min()
+print("preprocess_forward blocks", len(w), "(realtime us, relative to the first block's start)")
+for i, name in ((0, "start"), (1, "loads issued + SH staged"), (2, "geometry done + stored"), (4, "histogram + slot runs"), (5, "flushed, end")):
+    print("   %-28s median %6.2f  p90 %6.2f  max %6.2f" % (name, np.median(w[:, i] - t0) / 100, np.percentile(w[:, i] - t0, 90) / 100, (w[:, i].max() - t0) / 100))
