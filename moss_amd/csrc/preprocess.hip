@@ -727,10 +727,14 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         const int line = threadIdx.x < NUM_XCD_QUEUES ? Q_BWD + (int)threadIdx.x : Q_SEG_HEAD + (int)threadIdx.x - NUM_XCD_QUEUES;
         queues[(size_t)line * QLINE_WORDS] = 0u;
     }
-    extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then the same for dL_dsh out
+    extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then dL_dsh out (in place)
 #define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
-    PSTAMP(0);
-    float* const s_dsh = s_sh + blockDim.x * SH_ROW;
+#define PRSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime()
+    PSTAMP(0); PRSTAMP(13);
+    // dL_dsh leaves through the SAME rows the SH record came in by: a thread reads coefficient k of its row and then writes its
+    // gradient there.  (A second set of rows made this kernel's LDS 25 KB per 64-thread block: SIX blocks per CU, 1536 resident for
+    // cfg3's 1563 -- the 27 left over started when the first ones ended, 18 us in, and ran alone: scripts/prebwd_stamps.py.)
+    float* const s_dsh = s_sh;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
     // All first-level loads are issued together and unconditionally (clamped indices): the 12 SH float4 of this thread's share of
@@ -968,8 +972,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
         }
     }
-    PSTAMP(6);
+    PSTAMP(6); PRSTAMP(14);
 #undef PSTAMP
+#undef PRSTAMP
 }
 
 __global__ void __launch_bounds__(256)
@@ -1050,7 +1055,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
 #define LAUNCH_PB(STAGE)                                                                                                        \
     MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
-                       (STAGE) ? 2 * (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
+                       (STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \

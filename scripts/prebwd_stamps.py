@@ -10,7 +10,7 @@ dc, dd, da = hp.image_grads(d.H, d.W)
 dc, dd, da = dc.to(dev), dd.to(dev), da.to(dev)
 L = _lib.lib()
 L.moss_raster_debug_set_stamps.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(16 * 1024 * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(16 * 2048 * 16, dtype=torch.int64, device=dev)
 for _ in range(3):
     t = hp.hip_forward(d, dev); hp.hip_backward(d, t, dc, dd, da, dev)
 t = hp.hip_forward(d, dev)
@@ -19,7 +19,7 @@ L.moss_raster_debug_set_stamps(buf.data_ptr())
 hp.hip_backward(d, t, dc, dd, da, dev); torch.cuda.synchronize()
 L.moss_raster_debug_set_stamps(None)
 s = buf.cpu().numpy().reshape(-1, 16)
-nb = (100000 + 127) // 128
+nb = (100000 + 63) // 64
 s = s[:nb]
 t0 = s[:, 0].min()
 ph = np.diff(s[:, :7], axis=1)
@@ -28,3 +28,8 @@ print("mean cycles per phase [gather+SHload, barrier, pre-SH math+writes, SH, sc
 f = s[:, [0, 8, 9, 10, 11, 12, 1]]
 print("fine phase 1 [first-level loads, pos loads, mask loads, record batches, coop loop, SH->LDS]:", np.diff(f, axis=1).mean(0).astype(int))
 print("p90:", np.percentile(ph, 90, axis=0).astype(int), " block total mean", int((s[:, 6] - s[:, 0]).mean()), "max", int((s[:, 6] - s[:, 0]).max()))
+
+r0 = s[:, 13].min()
+print("realtime (us): block starts median %.2f p90 %.2f last %.2f | block ends median %.2f p90 %.2f last %.2f" % (
+    np.median(s[:, 13] - r0) / 100, np.percentile(s[:, 13] - r0, 90) / 100, (s[:, 13].max() - r0) / 100,
+    np.median(s[:, 14] - r0) / 100, np.percentile(s[:, 14] - r0, 90) / 100, (s[:, 14].max() - r0) / 100))
