@@ -362,7 +362,7 @@ constexpr int MERGE_OC = 6;                                // sibling chunks sea
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))     // (two workgroups per CU: see chunk_sort_kernel)
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView g, const uint2* __restrict__ ranges,
                     const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
-                    uint32_t* __restrict__ point_list, uint32_t* __restrict__ inst_pos,
+                    uint32_t* __restrict__ point_list,
                     float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask,
                     unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup (after the sort's), else NULL */)
 {
@@ -429,17 +429,22 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = rank + 1u ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = nch; }
     if (mine) {
     const uint32_t pos = rg.x + rank;
-    inst_mask[pos] = 0u;                                      // no gradient record yet (set by the backward blend)
     const uint32_t id = (uint32_t)key;
     point_list[pos] = id;
     float4* rec = inst_rec + 3 * (size_t)pos;
     const float4* gsrc = g.geo + 4 * (size_t)id;                  // the Gaussian's one 64-byte record
     const float4 ga = gsrc[0], gb = gsrc[1], gd = gsrc[3];
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 3] = ga.x == 12345.678f ? 1ull : __builtin_amdgcn_s_memtime();
-    rec[0] = ga; rec[1] = gb; rec[2] = gsrc[2];       // (non-temporal or write-through stores here: +3 / +7 us -- the write-back at the kernel's end is cheaper)
     const uint2 r = make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y));
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
     const int tx = (int)tile % gx, ty = (int)tile / gx;
+    // the instance's SLOT: its place in its Gaussian's run (group base + run start + index of this tile in the rectangle).  The
+    // backward blend files its gradient records and mask bits under it, so that the per-Gaussian gather walks [run, run + n) directly;
+    // it travels in the record's third word (the cull half-width, which only this kernel reads -- from the geometry record).
+    const uint32_t slot = g.group_base[id >> 8] + __float_as_uint(gd.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    inst_mask[slot] = 0u;                                     // no gradient record yet (set by the backward blend)
+    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(slot), ga.w); rec[1] = gb; rec[2] = gsrc[2];
+    // (non-temporal or write-through stores here: +3 / +7 us -- the write-back at the kernel's end is cheaper)
     {
         // which 4x4 pixel blocks of this tile the entry's alpha >= 1/255 bounding box {x, y, hx, hy} touches (pixel centres are
         // integers; block b spans [bx0, bx0+3] x [by0, by0+3]); NaN extents give no bit, infinite ones every bit.  The blend
@@ -494,8 +499,6 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         }
         inst_bmask[pos] = (uint16_t)bmask;
     }
-    const uint32_t k = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-    inst_pos[g.group_base[id >> 8] + __float_as_uint(gd.z) + k] = pos;
     }   // mine
     KSTAMP(4); RSTAMP(7);
 #undef KSTAMP
@@ -611,7 +614,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
                        sort_stamps);
     hipLaunchKernelGGL(merge_gather_kernel, dim3((grid + 7) / 8 * 8), dim3(CHUNK), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
-                       b.point_list, b.inst_pos, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
+                       b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
 }
 
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

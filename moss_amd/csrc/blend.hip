@@ -220,8 +220,10 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    float* const my_grad = inst_grad + (size_t)q * slab_stride + (size_t)rg.x * NPART;     // light tiles use slabs / mask bits 0..3
-    uint32_t* const my_mask = inst_mask + rg.x;
+    // records and mask words are addressed by the instance's SLOT (its place in its Gaussian's run, carried in the record's third
+    // word): the per-Gaussian gather then needs no position table
+    float* const my_grad = inst_grad + (size_t)q * slab_stride;                             // light tiles use slabs / mask bits 0..3
+    uint32_t* const my_mask = inst_mask;
     const uint32_t q_bit = 1u << q;
     const int row = lane >> 4;
     float T = T_final, Q = 0.0f;
@@ -244,7 +246,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
             // up to four entries per round; the 4 x 9 partial gradients are summed over the 64 pixels by ONE reduce-scatter:
             // fold32 pairs entries (0,2) and (1,3), fold16 pairs those, after which row r of the wave holds entry r's values
             float v[4][9];
-            int pos4[4];
+            int pos4[4]; uint32_t slot4[4];
             bool any4[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -276,7 +278,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 v[k][4] = dL_dG * dG_ddely * ddely_dy;
                 v[k][5] = hdG * gdx * dx; v[k][6] = hdG * gdx * dy; v[k][7] = hdG * gdy * dy;
                 v[k][8] = G * dL_dopa;
-                pos4[k] = pos;
+                pos4[k] = pos; slot4[k] = __float_as_uint(a.z);
                 any4[k] = __ballot(al > 0.0f) != 0ull;
             }
             if (any4[0] || any4[1] || any4[2] || any4[3]) {
@@ -284,7 +286,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
 #pragma unroll
                 for (int j = 0; j < 9; j++)
                     tot[j] = row_sum16(fold16(fold32(v[0][j], v[2][j]), fold32(v[1][j], v[3][j])));   // row r: entry r
-                const int my_pos = row == 0 ? pos4[0] : row == 1 ? pos4[1] : row == 2 ? pos4[2] : pos4[3];
+                const uint32_t my_pos = row == 0 ? slot4[0] : row == 1 ? slot4[1] : row == 2 ? slot4[2] : slot4[3];
                 const bool my_any = row == 0 ? any4[0] : row == 1 ? any4[1] : row == 2 ? any4[2] : any4[3];
                 if ((lane & 15) == 0 && my_any) {
                     float4* dst = reinterpret_cast<float4*>(my_grad + (size_t)my_pos * NPART);
@@ -704,8 +706,8 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         if (dL_dalphas) gpa = dL_dalphas[pix_id];
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
-    float* const my_grad = inst_grad + (size_t)blk * slab_stride + (size_t)rg.x * NPART;   // this block's slab of the tile's records
-    uint32_t* const my_mask = inst_mask + rg.x;
+    float* const my_grad = inst_grad + (size_t)blk * slab_stride;   // this block's slab, addressed by the instance's slot (see the light path)
+    uint32_t* const my_mask = inst_mask;
     const uint32_t blk_bit = 1u << blk;
     const uint16_t* const bm = inst_bmask + rg.x;
     const float4* const recs = inst_rec + 3 * (size_t)rg.x;
@@ -772,9 +774,10 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
             // an entry leaves a record (and its block bit) only if one of the block's pixels blended it
             const bool slot_any = ((contrib >> slot) & 0x1111111111111111ull) != 0ull;
             if (writer && slot_any) {
-                float* dst = my_grad + (size_t)pos * NPART;
+                const uint32_t gslot = __float_as_uint(f.a.z);
+                float* dst = my_grad + (size_t)gslot * NPART;
                 dst[m0] = s0; dst[m1] = s1;
-                if (row == 0) { dst[8] = s2; atomicOr(&my_mask[pos], blk_bit); }
+                if (row == 0) { dst[8] = s2; atomicOr(&my_mask[gslot], blk_bit); }
             }
         }
     };

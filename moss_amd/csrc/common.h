@@ -175,8 +175,8 @@ extern int g_cull_override;            // -1 = MOSS_BLEND_CULL decides; 0 / 1 = 
 int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
 struct BinView {
-    uint32_t* point_list; uint32_t* inst_pos;
-    uint32_t* inst_mask;     // per instance (sorted order): bit b set <=> slab b holds a record for it
+    uint32_t* point_list;
+    uint32_t* inst_mask;     // per instance, by SLOT (Gaussian-major: the run of Gaussian g's instances): bit b set <=> slab b holds a record for it
     uint16_t* inst_bmask;    // per instance (sorted order): bit b set <=> its alpha >= 1/255 bounding box touches 4x4 block b of its tile
     uint64_t* keys;          // aliases inst_grad (dead after the sort)
     float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
@@ -190,7 +190,7 @@ struct BinView {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
         b.slabs = blend_subgroups();
         b.slab_stride_floats = align_up(GRAD_REC_FLOATS * n * 4) / 4;
-        b.point_list = carve<uint32_t>(p, n); b.inst_pos = carve<uint32_t>(p, n);
+        b.point_list = carve<uint32_t>(p, n);
         b.inst_mask = carve<uint32_t>(p, n);
         b.inst_bmask = carve<uint16_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);

@@ -604,7 +604,7 @@ __device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, f
 // for one lane -- so those (`is_big`) are summed by the 64 lanes of the wave together, one Gaussian at a time (lane-strided partial
 // sums, then a fixed butterfly): still a fixed order, hence bitwise reproducible.  The owner's lane receives sums[0..8] =
 // {colour r, g, b, mean2D x, y, conic A, B, C, opacity}.  Must be called with the whole wave converged.
-__device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t n_inst, const uint32_t* __restrict__ inst_pos,
+__device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t n_inst,
                                             const uint32_t* __restrict__ inst_mask, const float4* __restrict__ inst_grad,
                                             size_t slab_stride_f4, float* sums)
     {
@@ -617,7 +617,7 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
             float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
             {
                 // Sparse records.  A Gaussian that covers the image owns ~1000 instances with up to 4 (light tiles) or 16 (heavy
-                // tiles) flagged records each, found through two levels of indirection (inst_pos -> inst_mask -> record): walked
+                // tiles) flagged records each, found through the mask words (inst_mask -> record): walked
                 // naively that is thousands of DEPENDENT loads for one wave (measured: +90 us per frame with ~50 such Gaussians).
                 // So: 16 instances per lane at a time, their positions and masks fetched together, then the first four flagged
                 // records of every instance with unconditional loads in straight-line code (the next instance's loads are
@@ -628,7 +628,7 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
 #pragma unroll
                     for (int i = 0; i < IPL; i++) {
                         const uint32_t k = c0 + 64u * i + (uint32_t)lane;
-                        p[i] = inst_pos[boff + min(k, bn - 1u)];
+                        p[i] = boff + min(k, bn - 1u);                              // the instance's slot: records and masks are filed under it
                     }
 #pragma unroll
                     for (int i = 0; i < IPL; i++) {
@@ -710,7 +710,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ scales, const float* __restrict__ rotations,
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                            const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
-                           GeomView g, const uint32_t* __restrict__ inst_pos, const float4* __restrict__ inst_grad,
+                           GeomView g, const float4* __restrict__ inst_grad,
                            int slabs, size_t slab_stride_f4, const uint32_t* __restrict__ inst_mask, const uint32_t* __restrict__ header,
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
@@ -797,14 +797,14 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         // 104 unconditional global loads per lane cost 51k cycles per wave; predicated ones were each waited for at their join).
         typedef float v4f __attribute__((ext_vector_type(4)));
         constexpr uint32_t OOB = 0xffffffffu, RSRC3 = 0x00020000u;
-        const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc((void*)inst_pos, 0, 0xffffff00u, RSRC3);
         const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)inst_mask, 0, 0xffffff00u, RSRC3);
         const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)inst_grad, 0, 0xffffff00u, RSRC3);
         const uint32_t slab_bytes = (uint32_t)(slab_stride_f4 * 16);
+        // (records and mask words are filed under the instance's SLOT = run start + k: no position table between the Gaussian and
+        // its records -- round 2 went Gaussian -> inst_pos -> inst_mask -> record, one more dependent round trip)
         uint32_t pp[COOP_INST], mm[COOP_INST];
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++)
-            pp[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_pos, (mine && (uint32_t)k < n_inst) ? (off + k) * 4u : OOB, 0, 0);
+        for (int k = 0; k < (int)COOP_INST; k++) pp[k] = off + (uint32_t)k;
         PSTAMP(9);
 #pragma unroll
         for (int k = 0; k < (int)COOP_INST; k++)
@@ -849,7 +849,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     }
     if (visible && n_inst <= COOP_INST) {
         for (uint32_t k = k_first; k < n_inst; k++) {
-            const uint32_t pos = inst_pos[off + k];
+            const uint32_t pos = off + k;
             // only the slabs flagged in the instance's mask, ascending
             for (uint32_t mbits = inst_mask[pos]; mbits != 0u; mbits &= mbits - 1u) {
                 const int sl = __ffs((int)mbits) - 1;
@@ -863,7 +863,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     }
     {
         float sums[9] = { gcol.x, gcol.y, gcol.z, gmx, gmy, gca, gcb, gcc, gop };
-        coop_gather(visible && n_inst > COOP_INST, off, n_inst, inst_pos, inst_mask, inst_grad, slab_stride_f4, sums);
+        coop_gather(visible && n_inst > COOP_INST, off, n_inst, inst_mask, inst_grad, slab_stride_f4, sums);
         gcol.x = sums[0]; gcol.y = sums[1]; gcol.z = sums[2]; gmx = sums[3]; gmy = sums[4]; gca = sums[5]; gcb = sums[6]; gcc = sums[7]; gop = sums[8];
     }
     PSTAMP(12);
@@ -1058,7 +1058,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        (STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
-                       g, b.inst_pos, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
+                       g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw, g_stamps, queues)
     if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
