@@ -703,6 +703,8 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
 // is 12 fully coalesced 16-byte accesses per lane.
 // Gradient records are sparse: slab b of an instance holds a record only if bit b of its inst_mask is set (blend.hip).
 constexpr int SH_ROW = 49;
+constexpr int GATHER_CAP = 512;                          // records of a wave gathered per pass (8 rows of 64)
+constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
 template <bool STAGE_SH>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float scale_modifier,
@@ -810,38 +812,90 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         for (int k = 0; k < (int)COOP_INST; k++)
             mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_inst) ? pp[k] * 4u : OOB, 0, 0);
         PSTAMP(10);
+        // ---- wave-balanced gather.  A lane owns 3-5 flagged records on average but some own 30+: fetched lane by lane (round 2: four
+        // instances x two records per round trip) the wave made 4-6 dependent round trips for its busiest lane -- 17k of a block's 41k
+        // cycles.  Here the wave's records are put in ONE list (lane i's records at list positions base_i .. base_i + c_i - 1, in the
+        // fixed order instance, slab), every lane fetches the records at positions lane, lane + 64, ... whoever owns them -- all
+        // requested before any is waited for -- and a segmented scan over each row of 64 hands every owner its sum.  The order of the
+        // additions is fixed by the list: bitwise reproducible.
+        {
+            uint32_t* const w_desc = reinterpret_cast<uint32_t*>(s_sh + (STAGE_SH ? blockDim.x * SH_ROW : 0)) + (threadIdx.x >> 6) * GATHER_WORDS;
+            float* const w_row = reinterpret_cast<float*>(w_desc + GATHER_CAP);          // [64][9]: a row's scanned values
+            const int lane = (int)(threadIdx.x & 63u);
+            uint32_t cnt = 0u;
 #pragma unroll
-        for (int kb = 0; kb < (int)COOP_INST; kb += 4) {
-            if ((uint32_t)kb < wmax) {                       // wave-uniform
-                uint32_t bits[4] = { mm[kb], mm[kb + 1], mm[kb + 2], mm[kb + 3] };
-                // rounds of (4 instances x their next 2 flagged records); almost always one round, an instance whose box covers
-                // a whole heavy tile has up to 16 records = 8 rounds.  The order (round, instance, slab) is fixed.
-                do {
-                    v4f rr[4][2][3];
+            for (int k = 0; k < (int)COOP_INST; k++) cnt += (uint32_t)__popc(mm[k]);
+            uint32_t incl = cnt;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
+            const uint32_t base = incl - cnt, W = (uint32_t)__shfl((int)incl, 63);
+            for (uint32_t w0 = 0u; w0 < W; w0 += (uint32_t)GATHER_CAP) {                 // (one pass unless the wave owns > GATHER_CAP records)
+                const uint32_t w1 = min(W, w0 + (uint32_t)GATHER_CAP);
+                // 1. every lane files its records' descriptors {head of the lane's run << 31 | slab << 27 | slot}
+                __builtin_amdgcn_wave_barrier();
+                {
+                    uint32_t j = base;
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const bool any = bits[k] != 0u;
-                            const uint32_t sl = any ? (uint32_t)(__ffs((int)bits[k]) - 1) : 0u;
-                            bits[k] &= bits[k] - 1u;                               // (0 stays 0)
-                            const uint32_t o = any ? sl * slab_bytes + pp[kb + k] * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
-                            rr[k][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
-                            rr[k][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 16u : OOB, 0, 0);
-                            rr[k][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 32u : OOB, 0, 0);
+                    for (int k = 0; k < (int)COOP_INST; k++) {
+                        if ((uint32_t)k < wmax) {                                        // wave-uniform
+                            uint32_t bits = mm[k];
+                            while (__ballot(bits != 0u) != 0ull) {
+                                if (bits != 0u) {
+                                    const uint32_t sl = (uint32_t)(__ffs((int)bits) - 1);
+                                    bits &= bits - 1u;
+                                    if (j >= w0 && j < w1) w_desc[j - w0] = (j == base ? 0x80000000u : 0u) | (sl << 27) | pp[k];
+                                    j++;
+                                }
+                            }
                         }
                     }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // 2. row r of the list = positions w0 + 64 r + lane: all rows requested together
+                constexpr int ROWS = GATHER_CAP / 64;
+                const int nrows = (int)((w1 - w0 + 63u) / 64u);
+                v4f ra[ROWS], rb[ROWS]; float rc[ROWS]; uint32_t dsc[ROWS];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                for (int r = 0; r < ROWS; r++) {
+                    const uint32_t w = w0 + 64u * (uint32_t)r + (uint32_t)lane;
+                    const bool on = w < w1;
+                    dsc[r] = on ? w_desc[w - w0] : 0x80000000u;
+                    const uint32_t o = on ? ((dsc[r] >> 27) & 15u) * slab_bytes + (dsc[r] & 0x07ffffffu) * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
+                    ra[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
+                    rb[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, on ? o + 16u : OOB, 0, 0);
+                    rc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rec, on ? o + 32u : OOB, 0, 0));
+                }
+                // 3. per row: segmented inclusive scan (a lane's run starts at its head flag; a row starts a segment of its own), then
+                //    every owner whose run reaches into the row takes the value at the run's last position in it
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            // (slots not loaded are exact zeros: adding them changes nothing)
-                            gcol.x += rr[k][j][0].x; gcol.y += rr[k][j][0].y; gcol.z += rr[k][j][0].z; gmx += rr[k][j][0].w;
-                            gmy += rr[k][j][1].x; gca += rr[k][j][1].y; gcb += rr[k][j][1].z; gcc += rr[k][j][1].w;
-                            gop += rr[k][j][2].x;
+                for (int r = 0; r < ROWS; r++) {
+                    if (r < nrows) {                                                     // wave-uniform
+                        float v[9] = { ra[r].x, ra[r].y, ra[r].z, ra[r].w, rb[r].x, rb[r].y, rb[r].z, rb[r].w, rc[r] };
+                        uint32_t f = (dsc[r] >> 31) | (lane == 0 ? 1u : 0u);
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t fu = (uint32_t)__shfl_up((int)f, d);
+                            float t[9];
+#pragma unroll
+                            for (int q = 0; q < 9; q++) t[q] = __shfl_up(v[q], d);
+                            const bool take = lane >= d && f == 0u;
+#pragma unroll
+                            for (int q = 0; q < 9; q++) v[q] += take ? t[q] : 0.0f;
+                            f |= lane >= d ? fu : 0u;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int q = 0; q < 9; q++) w_row[lane * 9 + q] = v[q];
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t row0 = w0 + 64u * (uint32_t)r, row1 = min(w1, row0 + 64u);
+                        const uint32_t lo = max(base, row0), hi = min(base + cnt, row1);
+                        if (lo < hi) {                                                   // this lane's run reaches into the row
+                            const float* e = w_row + (hi - 1u - row0) * 9u;
+                            gcol.x += e[0]; gcol.y += e[1]; gcol.z += e[2]; gmx += e[3];
+                            gmy += e[4]; gca += e[5]; gcb += e[6]; gcc += e[7]; gop += e[8];
                         }
                     }
-                } while (__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u) != 0ull);
+                }
             }
         }
         k_first = COOP_INST;                                 // nothing left for the serial loop
@@ -1055,7 +1109,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
 #define LAUNCH_PB(STAGE)                                                                                                        \
     MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
-                       (STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0, s,                                               \
+                       ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
