@@ -472,13 +472,16 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         const float A = gb.x, B = gb.y, C = gb.z, opa = gb.w;
         const float det = A * C - B * B;
         if (bmask != 0u && ga.z < 3.0e38f && ga.w < 3.0e38f && A > 0.0f && C > 0.0f && det > 0.0f && opa > 0.0f) {
-            const float K = 2.0f * (logf(255.0f * opa) + 1.0e-3f) / 0.9999f;
+            // (v_log / v_sqrt / v_rcp, ~1 ulp each: this file is compiled with correctly rounded division and square root, ~15
+            // instructions apiece, and the eleven roots and four quotients below were 40 % of this kernel's instructions.  The
+            // margins -- 1e-3 on tau, `slack` on every interval end -- are four orders of magnitude above those errors.)
+            const float K = 2.0f * (__logf(255.0f * opa) + 1.0e-3f) * (1.0f / 0.9999f);
             uint32_t keep = 0u;
             if (K >= 0.0f) {
-                const float inv_det = 1.0f / det, invA = 1.0f / A;
+                const float inv_det = __builtin_amdgcn_rcpf(det), invA = __builtin_amdgcn_rcpf(A);
                 const float aK = A * K;
-                const float Ymax = sqrtf(aK * inv_det);                   // |dy| on the ellipse
-                const float X_R = sqrtf(C * K * inv_det), Y_R = -B * X_R / C;     // its rightmost point
+                const float Ymax = __builtin_amdgcn_sqrtf(aK * inv_det);                   // |dy| on the ellipse
+                const float X_R = __builtin_amdgcn_sqrtf(C * K * inv_det), Y_R = -B * X_R * __builtin_amdgcn_rcpf(C);     // its rightmost point
                 const float slack = 1.0e-3f + 1.0e-5f * (fabsf(ga.x) + X_R);      // rounding of the roots / divisions, in pixels
                 const float bx_first = (float)(tx * TILE) - ga.x, by_first = (float)(ty * TILE) - ga.y;
 #pragma unroll
@@ -486,8 +489,8 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
                     const float y0 = by_first + (float)(4 * by), y1 = y0 + 3.0f;
                     if (y0 > Ymax + slack || y1 < -Ymax - slack) continue;            // the strip misses the ellipse
                     const float yr = fminf(fmaxf(Y_R, y0), y1), yl = fminf(fmaxf(-Y_R, y0), y1);
-                    const float xr = (-B * yr + sqrtf(fmaxf(aK - det * yr * yr, 0.0f))) * invA + slack;
-                    const float xl = (-B * yl - sqrtf(fmaxf(aK - det * yl * yl, 0.0f))) * invA - slack;
+                    const float xr = (-B * yr + __builtin_amdgcn_sqrtf(fmaxf(aK - det * yr * yr, 0.0f))) * invA + slack;
+                    const float xl = (-B * yl - __builtin_amdgcn_sqrtf(fmaxf(aK - det * yl * yl, 0.0f))) * invA - slack;
 #pragma unroll
                     for (int bx = 0; bx < 4; bx++) {
                         const float x0 = bx_first + (float)(4 * bx);

@@ -703,7 +703,7 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
 // is 12 fully coalesced 16-byte accesses per lane.
 // Gradient records are sparse: slab b of an instance holds a record only if bit b of its inst_mask is set (blend.hip).
 constexpr int SH_ROW = 49;
-constexpr int GATHER_CAP = 512;                          // records of a wave gathered per pass (8 rows of 64)
+constexpr int GATHER_CAP = 320;                          // records of a wave gathered per pass (8 rows of 64)
 constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
 template <bool STAGE_SH>
 __global__ void __launch_bounds__(256)

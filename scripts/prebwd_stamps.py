@@ -27,6 +27,8 @@ print("blocks", nb, " kernel span (cycles):", int(s[:, 6].max() - t0), " block s
 print("mean cycles per phase [gather+SHload, barrier, pre-SH math+writes, SH, scale/rot, tail writes, copy-out]:", ph.mean(0).astype(int))
 f = s[:, [0, 8, 9, 10, 11, 12, 1]]
 print("fine phase 1 [first-level loads, pos loads, mask loads, record batches, coop loop, SH->LDS]:", np.diff(f, axis=1).mean(0).astype(int))
+f2 = s[:, [10, 7, 15, 11]]
+print("balanced gather [count + file descriptors, request + wait for the records, scans + hand-over]:", np.diff(f2, axis=1).mean(0).astype(int))
 print("p90:", np.percentile(ph, 90, axis=0).astype(int), " block total mean", int((s[:, 6] - s[:, 0]).mean()), "max", int((s[:, 6] - s[:, 0]).max()))
 
 r0 = s[:, 13].min()
