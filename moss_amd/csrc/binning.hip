@@ -160,11 +160,14 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         }
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
-        for (int base = blockIdx.x * blockDim.x; base < P; base += n_blocks * blockDim.x) {      // whole waves stay converged
-            const int idx = base + (int)threadIdx.x;
-            const float4 gd = g.geo[4 * (size_t)min(idx, P - 1) + 3];
-            const uint2 r = idx < P ? make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y)) : make_uint2(0u, 0u);
-            wave_for_each_tile(r, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
+        // (two Gaussians per thread per trip, both rectangles requested before the first is walked: one memory round trip per trip)
+        for (int base = blockIdx.x * blockDim.x; base < P; base += 2 * n_blocks * blockDim.x) {  // whole waves stay converged
+            const int idx0 = base + (int)threadIdx.x, idx1 = idx0 + n_blocks * (int)blockDim.x;
+            const float4 gd0 = g.geo[4 * (size_t)min(idx0, P - 1) + 3], gd1 = g.geo[4 * (size_t)min(idx1, P - 1) + 3];
+            const uint2 r0 = idx0 < P ? make_uint2(__float_as_uint(gd0.x), __float_as_uint(gd0.y)) : make_uint2(0u, 0u);
+            const uint2 r1 = idx1 < P ? make_uint2(__float_as_uint(gd1.x), __float_as_uint(gd1.y)) : make_uint2(0u, 0u);
+            wave_for_each_tile(r0, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
+            wave_for_each_tile(r1, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
         }
         if (fold_scan) {
             uint32_t sum = 0u;
@@ -205,18 +208,31 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         }
         __syncthreads();
     }
-    for (int base = blockIdx.x * blockDim.x; base < P; base += n_blocks * blockDim.x) {
-        const int idx = base + (int)threadIdx.x;
-        const float4 gd = g.geo[4 * (size_t)min(idx, P - 1) + 3];
-        const uint2 r = idx < P ? make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y)) : make_uint2(0u, 0u);
-        const bool any = idx < P && (r.y & 0xffffu) > (r.x & 0xffffu) && (r.y >> 16) > (r.x >> 16);
-        const uint64_t key = any ? (((uint64_t)__float_as_uint(g.geo[4 * (size_t)idx + 2].w) << 32) | (uint32_t)idx) : 0ull;
-        wave_for_each_tile(r, gx, key, [&](int t, uint64_t k) {
-            uint32_t pos;
-            if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-            else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
-            keys[pos] = k;
-        });
+    for (int base = blockIdx.x * blockDim.x; base < P; base += 2 * n_blocks * blockDim.x) {
+        // (rectangle and depth of both Gaussians of the trip requested together, unconditionally)
+        int idx[2]; uint2 r[2]; uint64_t key[2];
+        float4 gd[2]; float dep[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            idx[u] = base + (int)threadIdx.x + u * n_blocks * (int)blockDim.x;
+            const size_t ic = (size_t)min(idx[u], P - 1);
+            gd[u] = g.geo[4 * ic + 3]; dep[u] = g.geo[4 * ic + 2].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            r[u] = idx[u] < P ? make_uint2(__float_as_uint(gd[u].x), __float_as_uint(gd[u].y)) : make_uint2(0u, 0u);
+            const bool any = idx[u] < P && (r[u].y & 0xffffu) > (r[u].x & 0xffffu) && (r[u].y >> 16) > (r[u].x >> 16);
+            key[u] = any ? (((uint64_t)__float_as_uint(dep[u]) << 32) | (uint32_t)idx[u]) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            wave_for_each_tile(r[u], gx, key[u], [&](int t, uint64_t k) {
+                uint32_t pos;
+                if (lds_hist) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+                else pos = ranges[t].x + atomicAdd(&tile_cursor[t], 1u);
+                keys[pos] = k;
+            });
+        }
     }
 }
 
