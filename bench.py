@@ -466,6 +466,10 @@ def main(argv=None):
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"))
     all_b = dict(fwd_b); all_b.update(bwd_b)
+    if stage_ms.get("scan", 0.0) == 0.0:
+        # asynchronous forward: the scan rides along with the scatter kernel (no launch of its own) -- its bytes count there
+        all_b["scatter"] += all_b.pop("scan")
+        stage_ms.pop("scan", None)
     dom_bytes = all_b[dominant]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     total_bytes = sum(all_b.values())

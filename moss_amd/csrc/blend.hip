@@ -1087,11 +1087,14 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
         }
     }
     const unsigned long long t_phase1 = RSTAMP();
-    // ---- 2. every block's own item: the part of its list behind the last cut (the whole list if it was never cut)
+    // ---- 2. every block's own item: the part of its list behind the last cut (the whole list if it was never cut).  ALL of them
+    // are drawn from the queue (LPT order) when a wave gets here, none by rank: with 4096 waves for ~3500 segments and ~2400 block
+    // items a static deal gave wave r segment r AND block item r -- the waves whose segment ended last (35 us) then still had a block
+    // item of their own to do; drawn dynamically, the waves without a segment and the early finishers take the long ones first.
+    (void)first_rank;
     for (;;) {
         const unsigned long long tq0 = WSTAMP();
-        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, tile_order, first_rank, q_waves);
-        first_rank = -1;
+        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, tile_order, -1, 0);
         const unsigned long long tq1 = WSTAMP();
         c_tailpop += tq1 - tq0;
         if (!it.valid) break;

@@ -325,3 +325,29 @@ def test_fuzz_outliers_adjudicated_by_float64(gpu, hip_lib, seed):
         assert excess <= ADJ_FLOOR, (n, e_hip, e_orc, excess)
         assert r_hip <= ADJ_FACTOR_OUTLIERS * r_orc + 2e-5, (n, r_hip, r_orc)
     _note(f"fuzz{seed}", {"grads_vs_f64 (scaled hip, scaled float32 restatements, excess, relmax hip, relmax restatements)": adj})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [320, 1400])
+def test_many_gradient_records_per_gaussian(gpu, hip_lib, P):
+    """Wide, faint Gaussians: every one reaches ~9 tiles and nearly every 4x4 block of them without saturating a pixel, so a wave of
+    the per-Gaussian backward owns thousands of gradient records (P=320: light tiles, up to 4 quadrant records per instance; P=1400:
+    heavy tiles, up to 16 block records per instance) -- the wave-balanced gather (csrc/preprocess.hip) runs many passes of its
+    record list and every row is a mixture of long runs.  Checked against the oracle like every other configuration, plus run-to-run
+    bitwise reproducibility."""
+    s = scenes.config1(P=P, seed=77)
+    g = torch.Generator().manual_seed(123)
+    s.scales = torch.exp(np.log(0.11) + 0.15 * torch.randn(P, 3, generator=g))
+    s.opacities = 0.01 + 0.05 * torch.rand(P, 1, generator=g)
+    s.cov3D_precomp = scenes.covariance_precomp(s.scales, s.rotations, 1.0, s.transforms)
+    d = hp.inputs_of(s, "scale_rot")
+    fw, t, e = tp._check_forward(d, gpu)
+    tiles = e.tiles_touched.astype(np.int64)
+    assert tiles[tiles > 0].mean() > 6.0                      # the scene does what it is meant to do
+    g1 = tp._check_backward(d, gpu, fw, t, e)
+    dc, dd, da = hp.image_grads(d.H, d.W)
+    a = hp.hip_backward(d, t, dc, dd, da, gpu)
+    b = hp.hip_backward(d, t, dc, dd, da, gpu)
+    for k, v in vars(a).items():
+        if torch.is_tensor(v) and v.numel() > 0:
+            assert torch.equal(v, getattr(b, k)), k
