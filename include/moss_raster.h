@@ -103,6 +103,18 @@ int moss_raster_forward_async(
     float tan_fovx, float tan_fovy, int prefiltered,
     float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream);
 
+/*
+ * Frame state (optional; no counterpart in the reference, which memsets its buffers in every forward): a caller-owned device block of
+ * moss_raster_frame_state_bytes(width, height) bytes, zero-initialised ONCE.  moss_raster_frame_state(ptr) makes the NEXT
+ * moss_raster_forward* call of the calling host thread keep the per-frame counters its kernels add to (tile histogram, tile cursors,
+ * error flags) in that block instead of in the image buffer; the forward returns the block all-zero again (its sort kernel re-zeroes
+ * it; error paths clean it too), so no clear kernel runs in front of the preprocess kernel -- one launch less per frame (4 us inside a
+ * captured graph).  One block per concurrent user (stream); the same block serves every call of that user, also across image sizes
+ * up to the one it was sized for.
+ */
+size_t moss_raster_frame_state_bytes(int width, int height);
+int moss_raster_frame_state(char* frame_state);
+
 /* Enqueue (on `stream`) a copy of the forward's 8 status words from the image buffer to pinned host memory:
  * [0] instances rendered  [1] longest tile list  [2] flags: bit0 prefiltered-point culled, bit1 capacity overflow
  * [4] sort chunks  [5] non-empty tiles  [6] instances the frame needed. */

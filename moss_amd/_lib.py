@@ -34,6 +34,10 @@ def _declare(lib):
     lib.moss_raster_image_bytes.argtypes = [_i, _i]
     lib.moss_raster_binning_bytes.restype = C.c_size_t
     lib.moss_raster_binning_bytes.argtypes = [_i]
+    lib.moss_raster_frame_state_bytes.restype = C.c_size_t
+    lib.moss_raster_frame_state_bytes.argtypes = [_i, _i]
+    lib.moss_raster_frame_state.restype = _i
+    lib.moss_raster_frame_state.argtypes = [_p]
     lib.moss_raster_forward.restype = _i
     lib.moss_raster_forward.argtypes = [
         ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p,          # geometry / binning / image allocators

@@ -54,9 +54,14 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
                                              uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
                                              uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
                                              uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */,
-                                             int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base)
+                                             int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
+                                             uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues)
 {
     const int tid = threadIdx.x;
+    // every header word is WRITTEN here and the queue words are zeroed (the blend kernels pop from them): nothing in the image
+    // buffer needs a clear in front of the forward when the counters kernels add to live in the caller's frame state
+    if (tid < Q_LINES) queues[(size_t)tid * QLINE_WORDS] = 0u;
+    if (tid >= 8 && tid < HEADER_WORDS) header[tid] = 0u;
     if (tid == 0) *s_max = 0;
     if (tid < 34) s_bucket[tid] = 0;
     const int chunk = (T + NT - 1) / NT;
@@ -88,7 +93,9 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
         header[6] = total;                             // instances this frame needs (for the host's capacity policy)
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
-        if (overflow) atomicOr(&header[2], ERRFLAG_OVERFLOW);
+        header[3] = 0u;
+        header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u);       // (the preprocess kernel's flags: it finished before this one)
+        if (flags_acc != header + 2) *flags_acc = 0u;                       // frame state: zero again for the next forward
     }
     __syncthreads();
     for (int i = b; i < e; i++) {
@@ -114,13 +121,14 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
 __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
             uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
-            int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base)
+            int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
+            uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_bucket[34];
     scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                       n_groups, group_tot, group_base);
+                       n_groups, group_tot, group_base, flags_acc, queues);
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ keys, int lds_hist, uint32_t* __restrict__ header, int fold_scan,
                const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
-               uint32_t capacity, int light_log2)
+               uint32_t capacity, int light_log2, uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues)
 {
     extern __shared__ uint32_t s_mem[];
     __shared__ uint32_t s_wave[4];
@@ -144,7 +152,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         n_blocks--;
         if ((int)blockIdx.x == n_blocks) {
             scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                              (P + 255) / 256, g.group_tot, g.group_base);
+                              (P + 255) / 256, g.group_tot, g.group_base, flags_acc, queues);
             return;
         }
     } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
@@ -325,9 +333,13 @@ __device__ __forceinline__ void network_phases(uint64_t& key, uint32_t tid, uint
 // workgroup to leave: scripts/sort_stamps.py, starts at 6.4 us)
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
 chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
-                  const uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */)
+                  const uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */,
+                  uint4* __restrict__ frame_state, uint32_t frame_state_n16)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[2][CHUNK];
+    // the caller's frame state (tile histogram, cursors, flag word) is dead once the scatter kernel has ended: all-zero again for the
+    // next forward (every workgroup of the grid takes a slice, before anything can make it leave)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frame_state_n16; i += gridDim.x * blockDim.x) frame_state[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ ChunkOwner s_own;
     const uint32_t tid = threadIdx.x;
 #define KSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
@@ -593,7 +605,7 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 {
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header, cap, light_log2_knob(), (P + 255) / 256, g.group_tot, g.group_base);
+                       im.header, cap, light_log2_knob(), (P + 255) / 256, g.group_tot, g.group_base, im.flags_acc, im.queues);
 }
 
 // The scan can ride along with the scatter (no launch of its own) when the tile histogram fits the scatter's LDS and nobody has to
@@ -615,15 +627,19 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
     const int fold = (fold_scan && lds_hist) ? 1 : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks + fold), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
-                       lds_hist, im.header, fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob());
+                       lds_hist, im.header, fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob(), im.flags_acc, im.queues);
 }
 
-void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s)
+void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
+                      char* frame_state, size_t frame_state_bytes)
 {
     const int T = fp.gx * fp.gy;
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
     // themselves with the device-side values in the header
-    if (R <= 0 || total_chunks <= 0) return;
+    if (R <= 0 || total_chunks <= 0) {
+        if (frame_state) launch_clear(frame_state, frame_state_bytes, s);
+        return;
+    }
     // at most two 1024-thread workgroups per CU in flight; the workgroups loop over the chunks
     static const int max_grid = std::max(8, env_int("MOSS_SORT_GRID", 512));
     const int grid = std::min(total_chunks, max_grid);
@@ -631,7 +647,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     static const int stamps_on = env_int("MOSS_SORT_STAMPS", 0);
     unsigned long long* const sort_stamps = (stamps_on && g_stamps) ? g_stamps + 131072 : nullptr;
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
-                       sort_stamps);
+                       sort_stamps, reinterpret_cast<uint4*>(frame_state), (uint32_t)(frame_state ? frame_state_bytes / 16 : 0));
     hipLaunchKernelGGL(merge_gather_kernel, dim3((grid + 7) / 8 * 8), dim3(CHUNK), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
 }

@@ -98,6 +98,7 @@ struct ImageView {
     uint32_t* queues;        // Q_LINES cache lines of QLINE_WORDS words, one counter each (cleared with the header)
     uint32_t* tile_count; uint32_t* tile_cursor; uint2* ranges; uint32_t* chunk_base; uint32_t* tile_order;
     float* final_T; uint32_t* n_contrib;
+    uint32_t* flags_acc;     // where the preprocess kernel ORs its error flags: &header[2], or the caller's frame state (below)
     uint32_t* tail_start;    // per (tile, 4x4 block): list position where the part of the block's list NOT covered by depth segments begins
     uint32_t* seg_counts;    // [NUM_XCD_QUEUES][MAX_FWD_QUEUE_WAVES]: segments each forward wave left in its slot range
     static ImageView at(char* base, int W, int H)
@@ -105,6 +106,7 @@ struct ImageView {
         ImageView v; char* p = base;
         size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
         v.header = carve<uint32_t>(p, HEADER_WORDS);
+        v.flags_acc = v.header + 2;
         v.queues = carve<uint32_t>(p, (size_t)Q_LINES * QLINE_WORDS);
         v.tile_count = carve<uint32_t>(p, T); v.tile_cursor = carve<uint32_t>(p, T);
         v.ranges = carve<uint2>(p, T); v.chunk_base = carve<uint32_t>(p, T); v.tile_order = carve<uint32_t>(p, T);
@@ -120,6 +122,21 @@ struct ImageView {
     }
     // header + queues + tile_count + tile_cursor are contiguous (each carved at 16-byte granularity or coarser): one clear covers them
     size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
+    // FRAME STATE (moss_raster_frame_state): a caller-owned block that is all-zero between forward calls.  With it the per-frame
+    // counters that kernels ADD to -- the tile histogram, the tile cursors, the error-flag word -- live there instead of in this
+    // buffer, and nothing has to be zeroed before the preprocess kernel: the scan block writes every header word and zeroes the
+    // queue words, the sort kernel re-zeroes the frame state for the next forward.  (The clear was a 4 us launch of 20 waves.)
+    static size_t frame_state_bytes(int W, int H)
+    {
+        const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        return 256 + align_up(2 * T * sizeof(uint32_t));
+    }
+    void use_frame_state(char* fs, int W, int H)
+    {
+        const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        flags_acc = reinterpret_cast<uint32_t*>(fs);
+        tile_count = reinterpret_cast<uint32_t*>(fs + 256); tile_cursor = tile_count + T;
+    }
 };
 
 #if defined(__HIPCC__)
@@ -240,7 +257,8 @@ void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header, group bases
 bool scatter_folds_scan(const FrameParams& fp);                                                // asynchronous forward: no scan launch, see binning.hip
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s);  // duplicateWithKeys (+ the scan)
-void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s);
+void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
+                      char* frame_state = nullptr, size_t frame_state_bytes = 0);   // (re-zeroes the frame state, if any)
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
                            uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);
 void launch_export_geometry(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,

@@ -204,7 +204,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
                           const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
-                          GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header,
+                          GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header /* the error-flag word */,
                           int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms, int raw,
                           unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */)
 {
@@ -274,7 +274,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             const float3 p_orig = p_ld;
             const float3 p_view = xform4x3(p_orig, view);
             if (p_view.z <= 0.2f) {                                   // in_frustum, auxiliary.h:154
-                if (prefiltered) atomicOr(&header[2], ERRFLAG_PREFILTERED);
+                if (prefiltered) atomicOr(header, ERRFLAG_PREFILTERED);
                 break;
             }
             const float4 p_hom = xform4x4(p_orig, proj);
@@ -1090,7 +1090,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     MOSS_LAUNCH_TIMED(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
-                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.header, radii_out, lds_hist, stage_sh,
+                       cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.flags_acc, radii_out, lds_hist, stage_sh,
                        transforms, fp.raw | ((env_int("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0),
                        (g_stamps && env_int("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr);
 }

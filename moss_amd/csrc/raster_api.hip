@@ -87,6 +87,9 @@ struct Pinned {
 };
 thread_local Pinned g_pinned;
 
+// moss_raster_frame_state: the block the NEXT forward call of this host thread takes its per-frame counters from (consumed by it)
+thread_local char* g_next_frame_state = nullptr;
+
 FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float tan_fovy, float scale_modifier, int prefiltered,
                         const float* view, const float* proj, const float* campos, const float* bg)
 {
@@ -150,7 +153,15 @@ static int forward_impl(
     fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;     // scales / rotations are not read with a precomputed covariance
     const int T = fp.gx * fp.gy;
 
-    launch_clear(im.header, im.clear_bytes(), s);                        // header + tile histogram + tile cursors
+    // The counters kernels ADD to (tile histogram, tile cursors, error flags) must be zero here.  With the caller's frame state
+    // (moss_raster_frame_state: all-zero between calls, re-zeroed by the sort kernel) nothing is launched for that; without it, a clear.
+    char* const frame_state = g_next_frame_state;
+    g_next_frame_state = nullptr;
+    const size_t fs_bytes = ImageView::frame_state_bytes(width, height);
+    if (frame_state) im.use_frame_state(frame_state, width, height);
+    else launch_clear(im.header, im.clear_bytes(), s);                   // header + tile histogram + tile cursors
+    // (a forward that ends before its sort kernel has run leaves the frame state dirty: clean it on those paths)
+    auto abandon_frame_state = [&]() { if (frame_state) launch_clear(frame_state, fs_bytes, s); };
     { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
       launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, g, im, radii, s); }
     STAGE_CHECK("preprocess");
@@ -169,8 +180,10 @@ static int forward_impl(
         HIP_TRY(hipStreamSynchronize(s));
         R = (int)g_pinned.p[0];
         total_chunks = (int)g_pinned.p[4];
-        if (g_pinned.p[2] & ERRFLAG_PREFILTERED)
+        if (g_pinned.p[2] & ERRFLAG_PREFILTERED) {
+            abandon_frame_state();
             return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        }
     } else {
         // Asynchronous: no read-back.  Buffers and grids are sized for the caller's capacity; kernels bound themselves with the
         // device-side R; a frame that needs more renders nothing and sets the overflow flag (moss_raster_read_status).
@@ -179,7 +192,7 @@ static int forward_impl(
     }
 
     char* bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
-    if (!bin_ptr) return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL");
+    if (!bin_ptr) { abandon_frame_state(); return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL"); }
     BinView b = BinView::at(bin_ptr, R);
 
     if (R > 0) {
@@ -187,11 +200,11 @@ static int forward_impl(
         STAGE_CHECK("scatter");
         {   // timing experiment (scripts/exp_atomics.py): with the scatter's reservation atomics off the keys are garbage -- stop here
             static const bool stop = getenv("MOSS_EXPERIMENT") && (atoi(getenv("MOSS_EXPERIMENT")) & 2);
-            if (stop) return R;
+            if (stop) { abandon_frame_state(); return R; }
         }
-        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s); }
+        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes); }
         STAGE_CHECK("tile_sort");
-    }
+    } else abandon_frame_state();                                        // (nothing rendered: no sort kernel to re-zero it)
     { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }
     STAGE_CHECK("blend_forward");
     return R;
@@ -252,6 +265,9 @@ int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out 
     hipError_t e = hipMemcpyAsync(host_pinned_out, image_buffer, 32, hipMemcpyDeviceToHost, (hipStream_t)stream);
     return e == hipSuccess ? 0 : fail(MOSS_ERR_HIP, "status copy failed: %s", hipGetErrorString(e));
 }
+
+size_t moss_raster_frame_state_bytes(int width, int height) { return ImageView::frame_state_bytes(width, height); }
+int moss_raster_frame_state(char* frame_state) { g_next_frame_state = frame_state; return 0; }
 
 int moss_abi_version(void) { return MOSS_ABI_VERSION; }
 const char* moss_last_error(void) { return g_err; }

@@ -87,7 +87,8 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
                     const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
                     double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const torch::Tensor& sh,
                     int64_t degree, const torch::Tensor& campos, bool prefiltered, bool debug,
-                    const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, int64_t capacity)
+                    const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, int64_t capacity,
+                    const c10::optional<torch::Tensor>& frame_state)
 {
     TORCH_CHECK(means3D.ndimension() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");   // :57-59
     TORCH_CHECK(means3D.is_cuda(), "means3D must live on the GPU; this op has no CPU path");
@@ -132,6 +133,11 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     float *oc = reinterpret_cast<float*>(out_color.data_ptr()), *od = reinterpret_cast<float*>(out_depth.data_ptr()),
           *oa = reinterpret_cast<float*>(out_alpha.data_ptr());
     const int cap = use_async ? static_cast<int>(capacity) : -1;
+    if (frame_state.has_value() && frame_state->defined() && P > 0) {
+        TORCH_CHECK(frame_state->is_cuda() && frame_state->is_contiguous() && frame_state->scalar_type() == torch::kByte &&
+                    (size_t)frame_state->numel() >= moss_raster_frame_state_bytes(W, H), "frame_state: a zero-initialised byte tensor of moss_raster_frame_state_bytes on the GPU");
+        moss_raster_frame_state(reinterpret_cast<char*>(frame_state->data_ptr()));     // consumed by the forward call below
+    }
     int rc;
     if (raw_flags)
         rc = moss_raster_forward_raw(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
@@ -263,7 +269,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"),
           py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("image_height"), py::arg("image_width"), py::arg("sh"),
           py::arg("degree"), py::arg("campos"), py::arg("prefiltered"), py::arg("debug"), py::arg("transforms") = py::none(),
-          py::arg("raw_flags") = 0, py::arg("capacity") = -1);
+          py::arg("raw_flags") = 0, py::arg("capacity") = -1, py::arg("frame_state") = py::none());
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"),
           py::arg("colors"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
           py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"),

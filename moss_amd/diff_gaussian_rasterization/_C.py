@@ -47,6 +47,7 @@ class RasterContext:
         self.last_img_buffer = None  # image buffer (holds the status header) of the most recent asynchronous forward
         self.last_num_rendered = 0
         self.sinks = dict.fromkeys(_SINK_NAMES)
+        self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
 
     # ---- asynchronous forward -------------------------------------------------------------------------------------------------
     def set_async(self, enabled: bool, capacity: int = 0, margin: float = 2.0):
@@ -92,6 +93,15 @@ class RasterContext:
         if img_buffer is not None:
             self._request_status(img_buffer, img_buffer.device)
         self._consume_status(block=True)
+
+    def _frame_state(self, dev, width, height):
+        """The zero-initialised block of C ABI ``moss_raster_frame_state`` for this context (one per context: its forwards are ordered
+        on one stream); re-made when the device changes or a larger image comes along.  With it no clear kernel runs per forward."""
+        n = int(lib().moss_raster_frame_state_bytes(int(width), int(height)))
+        fs = self.frame_state
+        if fs is None or fs.device != dev or fs.numel() < n:
+            fs = self.frame_state = torch.zeros(n, dtype=torch.uint8, device=dev)
+        return fs
 
     # ---- gradient sinks ---------------------------------------------------------------------------------------------------------
     def set_grad_sink(self, sh=None, means3D=None, opacity=None, scales=None, rotations=None):
@@ -143,7 +153,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     res = ext().rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
                                     viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), sh,
                                     int(degree), campos, bool(prefiltered), bool(debug), transforms, int(raw_flags),
-                                    int(cx.capacity) if use_async else -1)
+                                    int(cx.capacity) if use_async else -1,
+                                    cx._frame_state(means3D.device, image_width, image_height) if use_async else None)
     rendered, img = res[0], res[7]
     if use_async:
         cx.last_img_buffer = img

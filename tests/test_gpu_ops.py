@@ -306,6 +306,10 @@ def test_async_forward_equals_sync_forward(gpu, hip_lib, async_mode, raw):
     for _ in range(2):
         got = _train_like_step(pc, cam, pipe, bg, w)          # asynchronous
     async_mode.check_async_status()
+    # the context's frame state (per-frame counters of the asynchronous forward, C ABI moss_raster_frame_state) was used -- no clear
+    # kernel ran -- and is all-zero again
+    fs = async_mode._C.ASYNC.frame_state
+    assert fs is not None and int(fs.count_nonzero()) == 0
     for a, b, c in zip(ref[:3], first[:3], got[:3]):
         assert torch.equal(a, b) and torch.equal(a, c)
     for a, c in zip(ref[3], got[3]):
@@ -334,6 +338,7 @@ def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode
         assert float(g.abs().max()) == 0.0
     with pytest.raises(RuntimeError, match="needed"):
         async_mode.check_async_status()
+    assert int(async_mode._C.ASYNC.frame_state.count_nonzero()) == 0      # the overflowed frame left its counters clean too
     assert async_mode._C.ASYNC.capacity > 2048
     got = _train_like_step(pc, cam, pipe, bg, w)               # the grown capacity fits
     async_mode.check_async_status()
