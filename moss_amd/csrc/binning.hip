@@ -387,7 +387,11 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
 // sorted id, the 48-byte record the blend kernels stream, the block mask, and the Gaussian -> instance back-pointer used by the
 // backward gather.
 constexpr int MERGE_OC = 6;                                // sibling chunks searched per round (48 KB of LDS)
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))     // (two workgroups per CU: see chunk_sort_kernel)
+// MERGE_THREADS threads = a PART of a chunk's instances per workgroup (512: two workgroups per chunk).  One 1024-thread workgroup per
+// chunk put two workgroups on 84 of the 256 CUs for cfg3's 340 chunks and one on the rest: the kernel ended with the double-loaded CUs
+// (workgroup ends 8 us median, 17 us last).  Halves spread 680 workgroups three to a CU at most; each loads the sibling chunks itself.
+constexpr int MERGE_THREADS = 512, MERGE_PARTS = CHUNK / MERGE_THREADS;
+__global__ void __launch_bounds__(MERGE_THREADS) __attribute__((amdgpu_num_sgpr(80)))     // (see chunk_sort_kernel)
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView g, const uint2* __restrict__ ranges,
                     const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ point_list,
@@ -403,36 +407,50 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     // tiles gather the same Gaussians' 64-byte records: XCD k takes the k-th contiguous eighth of the chunks (counted from the
     // device-side total), so a Gaussian's record is fetched into one or two L2s instead of all eight.
     const uint32_t NONE = 0xffffffffu;
+    // turn `it` = (chunk turn it / MERGE_PARTS on this XCD ... , part it % MERGE_PARTS)?  No: the XCD of a workgroup is blockIdx % 8, so
+    // the part index sits ABOVE the XCD digit: it = 8 * (MERGE_PARTS * nth + part) + xcd.
+    const uint32_t part = (it / 8u) % (uint32_t)MERGE_PARTS, nth_u = (it / 8u) / (uint32_t)MERGE_PARTS;
     find_chunk_tile(T, [&](uint32_t n_chunks) -> uint32_t {
-        const int per_xcd = (int)n_chunks / 8, extra = (int)n_chunks % 8, xcd = (int)it % 8, nth = (int)it / 8;
+        const int per_xcd = (int)n_chunks / 8, extra = (int)n_chunks % 8, xcd = (int)it % 8, nth = (int)nth_u;
         return nth < per_xcd + (xcd < extra ? 1 : 0) ? (uint32_t)(xcd * per_xcd + min(xcd, extra) + nth) : NONE;
     }, ranges, chunk_base, header, &s_own);
     const uint32_t c = s_own.c;
     if (c == NONE) return;                                    // (turns only grow: later ones are past this XCD's share as well)
     KSTAMP(1);
-    const bool last_turn = (it + gridDim.x) / 8 >= s_own.n_chunks / 8 + ((it % 8) < s_own.n_chunks % 8 ? 1u : 0u);
+    const bool last_turn = ((it + gridDim.x) / 8u) / (uint32_t)MERGE_PARTS >= s_own.n_chunks / 8 + ((it % 8) < s_own.n_chunks % 8 ? 1u : 0u);
     const uint32_t tile = (uint32_t)s_own.tile;
     const uint2 rg = make_uint2(s_own.start, s_own.end);
     const uint32_t n = rg.y - rg.x, nch = (n + CHUNK - 1) / CHUNK, own = c - s_own.cbase;
     const uint32_t first = rg.x + own * CHUNK, n_own = min((uint32_t)CHUNK, rg.y - first);
-    const bool mine = tid < n_own;
-    const uint64_t key_ld = keys[min(first + tid, rg.y - 1u)];
+    const uint32_t my = part * (uint32_t)MERGE_THREADS + tid; // this thread's instance of the chunk
+    const bool mine = my < n_own;
+    const uint64_t key_ld = keys[min(first + my, rg.y - 1u)];
     const uint64_t key = mine ? key_ld : ~0ull;
-    uint32_t rank = tid;                                      // rank inside the own (sorted) chunk
+    uint32_t rank = my;                                       // rank inside the own (sorted) chunk
+    if (part * (uint32_t)MERGE_THREADS >= n_own) {            // (a short chunk has no second part: wave-uniform)
+        if (last_turn) return;
+        __syncthreads();
+        continue;
+    }
     for (uint32_t s0 = 0; s0 + 1 < nch; s0 += MERGE_OC) {     // (wave-uniform trip count) siblings s0 .. s0 + MERGE_OC - 1 of nch - 1
         uint32_t on[MERGE_OC];
-        uint64_t v[MERGE_OC];
+        uint64_t v[MERGE_OC][MERGE_PARTS];
 #pragma unroll
         for (int q = 0; q < MERGE_OC; q++) {
             const uint32_t si = s0 + (uint32_t)q;             // sibling index: the tile's chunks without the own one
             const uint32_t oc = si + (si >= own ? 1u : 0u);
             const uint32_t ofirst = rg.x + oc * CHUNK;
             on[q] = si + 1 < nch ? min((uint32_t)CHUNK, rg.y - ofirst) : 0u;
-            v[q] = keys[on[q] ? min(ofirst + tid, rg.y - 1u) : first];       // (unconditional, clamped: the six loads are in flight together)
+#pragma unroll
+            for (int u = 0; u < MERGE_PARTS; u++)             // (unconditional, clamped: all loads are in flight together)
+                v[q][u] = keys[on[q] ? min(ofirst + (uint32_t)u * MERGE_THREADS + tid, rg.y - 1u) : first];
         }
         __syncthreads();                                      // the previous group's readers are done
 #pragma unroll
-        for (int q = 0; q < MERGE_OC; q++) if (tid < on[q]) s_keys[q][tid] = v[q];
+        for (int q = 0; q < MERGE_OC; q++) {
+#pragma unroll
+            for (int u = 0; u < MERGE_PARTS; u++) if ((uint32_t)u * MERGE_THREADS + tid < on[q]) s_keys[q][u * MERGE_THREADS + tid] = v[q][u];
+        }
         __syncthreads();
         const int ns = (int)min((uint32_t)MERGE_OC, nch - 1u - s0);      // siblings in this group (wave-uniform)
         uint32_t lo[MERGE_OC], hi[MERGE_OC];
@@ -648,7 +666,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     unsigned long long* const sort_stamps = (stamps_on && g_stamps) ? g_stamps + 131072 : nullptr;
     hipLaunchKernelGGL(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
                        sort_stamps, reinterpret_cast<uint4*>(frame_state), (uint32_t)(frame_state ? frame_state_bytes / 16 : 0));
-    hipLaunchKernelGGL(merge_gather_kernel, dim3((grid + 7) / 8 * 8), dim3(CHUNK), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
 }
 
