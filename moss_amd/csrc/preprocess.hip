@@ -812,6 +812,76 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         for (int k = 0; k < (int)COOP_INST; k++)
             mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_inst) ? pp[k] * 4u : OOB, 0, 0);
         PSTAMP(10);
+        // ---- two ways to fetch the flagged records, chosen per wave.  How many records each lane owns:
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int k = 0; k < (int)COOP_INST; k++) cnt += (uint32_t)__popc(mm[k]);
+        uint32_t incl = cnt;
+        uint32_t bmax = 0u;                                   // byte b: the most records one instance of batch b (instances 4b .. 4b+3) has
+#pragma unroll
+        for (int k = 0; k < (int)COOP_INST; k++) {
+            const uint32_t pc = (uint32_t)__popc(mm[k]), sh = 8u * (uint32_t)(k >> 2);
+            bmax = max(bmax & (0xffu << sh), pc << sh) | (bmax & ~(0xffu << sh));
+        }
+        {
+            const int lane_ = (int)(threadIdx.x & 63u);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane_ >= d) incl += y; }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {               // bytewise maximum over the wave
+                const uint32_t o = (uint32_t)__shfl_xor((int)bmax, d);
+                uint32_t r = 0u;
+#pragma unroll
+                for (int b = 0; b < 4; b++) r |= max(bmax & (0xffu << (8 * b)), o & (0xffu << (8 * b)));
+                bmax = r;
+            }
+        }
+        const uint32_t W_all = (uint32_t)__shfl((int)incl, 63);
+        // DIRECT (lane by lane: four instances x two records per round trip) makes sum over the batches of ceil(most records of one
+        // instance / 2) round trips of 2-4k cycles (few waves ... a busy memory system); BALANCED (below) a pass of ~20k cycles -- filing,
+        // one round of requests, the scans --
+        // per GATHER_CAP records of the wave, whoever owns them.  Balanced pays when the records are unevenly spread (cfg3: 5 per lane
+        // on average, 30 for the busiest: 24 vs 28 us); when every lane owns many (cfg2's wide Gaussians) it would be passes on end
+        // (61 vs 24 us).
+        const uint32_t passes = (W_all + (uint32_t)GATHER_CAP - 1u) / (uint32_t)GATHER_CAP;
+        const uint32_t direct_trips = ((bmax & 0xffu) + 1u) / 2u + (((bmax >> 8) & 0xffu) + 1u) / 2u + (((bmax >> 16) & 0xffu) + 1u) / 2u + ((bmax >> 24) + 1u) / 2u;
+        const bool balanced = (raw & 0x200) ? false : (raw & 0x400) ? true : (passes == 1u ? direct_trips >= 5u : passes * 8u < direct_trips);     // (0x200 / 0x400: diagnostics, MOSS_GATHER=1 / 2)
+        if (!balanced) {
+#pragma unroll
+        for (int kb = 0; kb < (int)COOP_INST; kb += 4) {
+            if ((uint32_t)kb < wmax) {                       // wave-uniform
+                uint32_t bits[4] = { mm[kb], mm[kb + 1], mm[kb + 2], mm[kb + 3] };
+                // rounds of (4 instances x their next 2 flagged records); almost always one round, an instance whose box covers
+                // a whole heavy tile has up to 16 records = 8 rounds.  The order (round, instance, slab) is fixed.
+                do {
+                    v4f rr[4][2][3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const bool any = bits[k] != 0u;
+                            const uint32_t sl = any ? (uint32_t)(__ffs((int)bits[k]) - 1) : 0u;
+                            bits[k] &= bits[k] - 1u;                               // (0 stays 0)
+                            const uint32_t o = any ? sl * slab_bytes + pp[kb + k] * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
+                            rr[k][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
+                            rr[k][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 16u : OOB, 0, 0);
+                            rr[k][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 32u : OOB, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            // (slots not loaded are exact zeros: adding them changes nothing)
+                            gcol.x += rr[k][j][0].x; gcol.y += rr[k][j][0].y; gcol.z += rr[k][j][0].z; gmx += rr[k][j][0].w;
+                            gmy += rr[k][j][1].x; gca += rr[k][j][1].y; gcb += rr[k][j][1].z; gcc += rr[k][j][1].w;
+                            gop += rr[k][j][2].x;
+                        }
+                    }
+                } while (__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u) != 0ull);
+            }
+        }
+        } else
         // ---- wave-balanced gather.  A lane owns 3-5 flagged records on average but some own 30+: fetched lane by lane (round 2: four
         // instances x two records per round trip) the wave made 4-6 dependent round trips for its busiest lane -- 17k of a block's 41k
         // cycles.  Here the wave's records are put in ONE list (lane i's records at list positions base_i .. base_i + c_i - 1, in the
@@ -822,13 +892,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             uint32_t* const w_desc = reinterpret_cast<uint32_t*>(s_sh + (STAGE_SH ? blockDim.x * SH_ROW : 0)) + (threadIdx.x >> 6) * GATHER_WORDS;
             float* const w_row = reinterpret_cast<float*>(w_desc + GATHER_CAP);          // [64][9]: a row's scanned values
             const int lane = (int)(threadIdx.x & 63u);
-            uint32_t cnt = 0u;
-#pragma unroll
-            for (int k = 0; k < (int)COOP_INST; k++) cnt += (uint32_t)__popc(mm[k]);
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
-            const uint32_t base = incl - cnt, W = (uint32_t)__shfl((int)incl, 63);
+            const uint32_t base = incl - cnt, W = W_all;
             for (uint32_t w0 = 0u; w0 < W; w0 += (uint32_t)GATHER_CAP) {                 // (one pass unless the wave owns > GATHER_CAP records)
                 const uint32_t w1 = min(W, w0 + (uint32_t)GATHER_CAP);
                 // 1. every lane files its records' descriptors {head of the lane's run << 31 | slab << 27 | slot}
@@ -1104,6 +1168,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
 {
     (void)colors_precomp;
     static const int threads = env_int("MOSS_PREBWD_THREADS", 64);
+    static const int gather_knob = env_int("MOSS_GATHER", 0) == 1 ? 0x200 : env_int("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     const int blocks = (fp.P + threads - 1) / threads;
     const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
@@ -1113,7 +1178,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw, g_stamps, queues)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob, g_stamps, queues)
     if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
 }
