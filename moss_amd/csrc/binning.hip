@@ -158,6 +158,13 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
     } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
     uint32_t* s_cnt = s_mem;
     uint32_t* s_base = s_mem + T;
+    // rectangle (geo[3]) and depth (geo[2].w) of the two Gaussians of a trip, requested together, unconditionally
+    auto fetch2 = [&](int base, float4& a, float4& b, float& da, float& db) {
+        const size_t i0 = (size_t)min(base + (int)threadIdx.x, P - 1), i1 = (size_t)min(base + (int)threadIdx.x + n_blocks * (int)blockDim.x, P - 1);
+        a = g.geo[4 * i0 + 3]; b = g.geo[4 * i1 + 3]; da = g.geo[4 * i0 + 2].w; db = g.geo[4 * i1 + 2].w;
+    };
+    float4 pre_gd[2]; float pre_dep[2];
+    fetch2((int)(blockIdx.x * blockDim.x), pre_gd[0], pre_gd[1], pre_dep[0], pre_dep[1]);
     if (lds_hist) {
         // (fold_scan) this thread's share of the histogram: requested now, summed after the counting pass
         const int per = (T + 255) / 256, tb = (int)threadIdx.x * per, te = min(T, tb + per);
@@ -168,10 +175,13 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         }
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
-        // (two Gaussians per thread per trip, both rectangles requested before the first is walked: one memory round trip per trip)
+        // (two Gaussians per thread per trip, both rectangles requested before the first is walked: one memory round trip per trip;
+        // the first trip's -- with the default grid the only one -- were requested at the top and serve the scatter pass as well)
         for (int base = blockIdx.x * blockDim.x; base < P; base += 2 * n_blocks * blockDim.x) {  // whole waves stay converged
+            float4 gd0, gd1; float d0_, d1_;
+            if (base == (int)(blockIdx.x * blockDim.x)) { gd0 = pre_gd[0]; gd1 = pre_gd[1]; }
+            else fetch2(base, gd0, gd1, d0_, d1_);
             const int idx0 = base + (int)threadIdx.x, idx1 = idx0 + n_blocks * (int)blockDim.x;
-            const float4 gd0 = g.geo[4 * (size_t)min(idx0, P - 1) + 3], gd1 = g.geo[4 * (size_t)min(idx1, P - 1) + 3];
             const uint2 r0 = idx0 < P ? make_uint2(__float_as_uint(gd0.x), __float_as_uint(gd0.y)) : make_uint2(0u, 0u);
             const uint2 r1 = idx1 < P ? make_uint2(__float_as_uint(gd1.x), __float_as_uint(gd1.y)) : make_uint2(0u, 0u);
             wave_for_each_tile(r0, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
@@ -217,15 +227,12 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         __syncthreads();
     }
     for (int base = blockIdx.x * blockDim.x; base < P; base += 2 * n_blocks * blockDim.x) {
-        // (rectangle and depth of both Gaussians of the trip requested together, unconditionally)
         int idx[2]; uint2 r[2]; uint64_t key[2];
         float4 gd[2]; float dep[2];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            idx[u] = base + (int)threadIdx.x + u * n_blocks * (int)blockDim.x;
-            const size_t ic = (size_t)min(idx[u], P - 1);
-            gd[u] = g.geo[4 * ic + 3]; dep[u] = g.geo[4 * ic + 2].w;
-        }
+        for (int u = 0; u < 2; u++) idx[u] = base + (int)threadIdx.x + u * n_blocks * (int)blockDim.x;
+        if (base == (int)(blockIdx.x * blockDim.x)) { gd[0] = pre_gd[0]; gd[1] = pre_gd[1]; dep[0] = pre_dep[0]; dep[1] = pre_dep[1]; }
+        else fetch2(base, gd[0], gd[1], dep[0], dep[1]);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             r[u] = idx[u] < P ? make_uint2(__float_as_uint(gd[u].x), __float_as_uint(gd[u].y)) : make_uint2(0u, 0u);
