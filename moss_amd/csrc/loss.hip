@@ -28,6 +28,7 @@ constexpr int VR = 4;               // outputs per thread in the vertical pass (
 static_assert(LT % SEG == 0 && (LT / SEG) * LP <= 256 && LT * (LT / VR) == 256, "work split of a 256-thread workgroup");
 
 struct Win { float g[11]; };
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float ld0(const float* __restrict__ p, int x, int y, int W, int H)
 {
@@ -96,44 +97,47 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __syncthreads();
     if (tid < (LT / SEG) * LP) {                         // horizontal 11-tap for the 5 moments: rows run along the lanes (odd row
         const int r = tid % LP, q0 = (tid / LP) * SEG;   // stride: conflict-free LDS reads), a thread owns columns q0 .. q0 + SEG - 1
-        float acc[SEG][5];
+        // (moments in pairs: v_pk_fma_f32 does two of the five accumulations per instruction)
+        v2f a01[SEG], a23[SEG]; float a4[SEG];
 #pragma unroll
-        for (int j = 0; j < SEG; j++) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; acc[j][4] = 0.f; }
+        for (int j = 0; j < SEG; j++) { a01[j] = v2f{0.f, 0.f}; a23[j] = v2f{0.f, 0.f}; a4[j] = 0.f; }
 #pragma unroll
         for (int i = 0; i < SEG + 10; i++) {
             const float a = s_x[r][q0 + i], b = s_y[r][q0 + i];
-            const float aa = a * a, bb = b * b, ab = a * b;
+            const v2f ab = v2f{a, b}, sq = ab * ab;
+            const float xy = a * b;
 #pragma unroll
             for (int j = 0; j < SEG; j++) {
                 if (i - j >= 0 && i - j <= 10) {
                     const float w = win.g[i - j];
-                    acc[j][0] = __fmaf_rn(w, a, acc[j][0]); acc[j][1] = __fmaf_rn(w, b, acc[j][1]);
-                    acc[j][2] = __fmaf_rn(w, aa, acc[j][2]); acc[j][3] = __fmaf_rn(w, bb, acc[j][3]); acc[j][4] = __fmaf_rn(w, ab, acc[j][4]);
+                    const v2f w2 = v2f{w, w};
+                    a01[j] = __builtin_elementwise_fma(w2, ab, a01[j]); a23[j] = __builtin_elementwise_fma(w2, sq, a23[j]);
+                    a4[j] = __fmaf_rn(w, xy, a4[j]);
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < SEG; j++) {
-#pragma unroll
-            for (int m = 0; m < 5; m++) s_h[m][r][q0 + j] = acc[j][m];
+            s_h[0][r][q0 + j] = a01[j].x; s_h[1][r][q0 + j] = a01[j].y; s_h[2][r][q0 + j] = a23[j].x; s_h[3][r][q0 + j] = a23[j].y;
+            s_h[4][r][q0 + j] = a4[j];
         }
     }
     __syncthreads();
     const int lx = tid % LT, ly0 = (tid / LT) * VR;      // vertical: column lx, rows ly0 .. ly0 + VR - 1
-    float mo[VR][5];
+    v2f m01[VR], m23[VR]; float m4[VR];
 #pragma unroll
-    for (int j = 0; j < VR; j++) { mo[j][0] = 0.f; mo[j][1] = 0.f; mo[j][2] = 0.f; mo[j][3] = 0.f; mo[j][4] = 0.f; }
+    for (int j = 0; j < VR; j++) { m01[j] = v2f{0.f, 0.f}; m23[j] = v2f{0.f, 0.f}; m4[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < VR + 10; i++) {
-        float v[5];
-#pragma unroll
-        for (int m = 0; m < 5; m++) v[m] = s_h[m][ly0 + i][lx];
+        const v2f v01 = v2f{s_h[0][ly0 + i][lx], s_h[1][ly0 + i][lx]}, v23 = v2f{s_h[2][ly0 + i][lx], s_h[3][ly0 + i][lx]};
+        const float v4 = s_h[4][ly0 + i][lx];
 #pragma unroll
         for (int j = 0; j < VR; j++) {
             if (i - j >= 0 && i - j <= 10) {
                 const float w = win.g[i - j];
-#pragma unroll
-                for (int m = 0; m < 5; m++) mo[j][m] = __fmaf_rn(w, v[m], mo[j][m]);
+                const v2f w2 = v2f{w, w};
+                m01[j] = __builtin_elementwise_fma(w2, v01, m01[j]); m23[j] = __builtin_elementwise_fma(w2, v23, m23[j]);
+                m4[j] = __fmaf_rn(w, v4, m4[j]);
             }
         }
     }
@@ -143,7 +147,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     for (int j = 0; j < VR; j++) {
         const int ly = ly0 + j, py = y0 + ly;
         if (px < W && py < H) {
-            const float mu1 = mo[j][0], mu2 = mo[j][1], exx = mo[j][2], eyy = mo[j][3], exy = mo[j][4];
+            const float mu1 = m01[j].x, mu2 = m01[j].y, exx = m23[j].x, eyy = m23[j].y, exy = m4[j];
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
             const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
