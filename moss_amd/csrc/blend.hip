@@ -512,6 +512,9 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     auto trip = [&](const Fetched& f) -> bool {
         const PairEval pe = eval_pair(f.a.x - pixx, f.a.y - pixy, f.b.x, f.b.y, f.b.z, f.b.w);
         const float al = pe.alpha * live * f.valid;                    // 0 for finished / outside pixels and padding slots
+        // none of the four entries reaches any live pixel (the block masks are conservative): nothing changes -- T, the sums, the
+        // stop flags -- so the rest of the trip is skipped (-1.6 us on the kernel, same-box A/B)
+        if (__ballot(al > 0.0f) == 0ull) return false;
         const float fm = 1.0f - al;
         // multiplied in list order: bit-identical to the serial loop
         float X = T * fm, Y;

@@ -223,36 +223,38 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __syncthreads();
     if (tid < (LT / SEG) * LP) {                         // horizontal pass of the three derivative maps (see pass 1)
         const int r = tid % LP, q0 = (tid / LP) * SEG;
-        float acc[SEG][3];
+        v2f a01[SEG]; float a2[SEG];
 #pragma unroll
-        for (int j = 0; j < SEG; j++) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
+        for (int j = 0; j < SEG; j++) { a01[j] = v2f{0.f, 0.f}; a2[j] = 0.f; }
 #pragma unroll
         for (int i = 0; i < SEG + 10; i++) {
-            const float v0 = s_d[0][r][q0 + i], v1 = s_d[1][r][q0 + i], v2 = s_d[2][r][q0 + i];
+            const v2f v01 = v2f{s_d[0][r][q0 + i], s_d[1][r][q0 + i]};
+            const float v2 = s_d[2][r][q0 + i];
 #pragma unroll
             for (int j = 0; j < SEG; j++) {
                 if (i - j >= 0 && i - j <= 10) {
                     const float w = win.g[i - j];
-                    acc[j][0] = __fmaf_rn(w, v0, acc[j][0]); acc[j][1] = __fmaf_rn(w, v1, acc[j][1]); acc[j][2] = __fmaf_rn(w, v2, acc[j][2]);
+                    a01[j] = __builtin_elementwise_fma(v2f{w, w}, v01, a01[j]); a2[j] = __fmaf_rn(w, v2, a2[j]);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < SEG; j++) { s_h[0][r][q0 + j] = acc[j][0]; s_h[1][r][q0 + j] = acc[j][1]; s_h[2][r][q0 + j] = acc[j][2]; }
+        for (int j = 0; j < SEG; j++) { s_h[0][r][q0 + j] = a01[j].x; s_h[1][r][q0 + j] = a01[j].y; s_h[2][r][q0 + j] = a2[j]; }
     }
     __syncthreads();
     const int lx = tid % LT, ly0 = (tid / LT) * VR;
-    float f[VR][3];
+    v2f f01[VR]; float f2[VR];
 #pragma unroll
-    for (int j = 0; j < VR; j++) { f[j][0] = 0.f; f[j][1] = 0.f; f[j][2] = 0.f; }
+    for (int j = 0; j < VR; j++) { f01[j] = v2f{0.f, 0.f}; f2[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < VR + 10; i++) {
-        const float v0 = s_h[0][ly0 + i][lx], v1 = s_h[1][ly0 + i][lx], v2 = s_h[2][ly0 + i][lx];
+        const v2f v01 = v2f{s_h[0][ly0 + i][lx], s_h[1][ly0 + i][lx]};
+        const float v2 = s_h[2][ly0 + i][lx];
 #pragma unroll
         for (int j = 0; j < VR; j++) {
             if (i - j >= 0 && i - j <= 10) {
                 const float w = win.g[i - j];
-                f[j][0] = __fmaf_rn(w, v0, f[j][0]); f[j][1] = __fmaf_rn(w, v1, f[j][1]); f[j][2] = __fmaf_rn(w, v2, f[j][2]);
+                f01[j] = __builtin_elementwise_fma(v2f{w, w}, v01, f01[j]); f2[j] = __fmaf_rn(w, v2, f2[j]);
             }
         }
     }
@@ -263,7 +265,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         if (px < W && py < H) {
             const size_t o = ((size_t)c * H + py) * W + px;
             const float x = img[o], y = gt[o];
-            const float dssim = f[j][0] + 2.f * x * f[j][1] + y * f[j][2];     // d(sum SSIM)/dx
+            const float dssim = f01[j].x + 2.f * x * f01[j].y + y * f2[j];     // d(sum SSIM)/dx
             const float d = x - y;
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             dL_dimg[o] = sgn / N - lambda_dssim * dssim / N;
