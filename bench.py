@@ -41,7 +41,8 @@ def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
         "preprocess_fwd": P * (12 + c + 4) + Pv * 12 * K + P * 8 + Pv * 43,
         "scan": 8 * P,
         "scatter": Pv * 24 + 12 * R,
-        "tile_sort": 24 * R + 8 * R + 8 * tiles,
+        "chunk_sort": 16 * R + 8 * tiles,                    # keys read + written in place
+        "merge_gather": 8 * R + 8 * R,                        # keys read, sorted ids + per-tile ranges written (24R + 8R + 8 tiles for the sort)
         "blend_fwd": 44 * R + 28 * N,
     }
     bwd = {

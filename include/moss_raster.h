@@ -381,10 +381,11 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
 #define MOSS_STAGE_PREPROCESS_FWD 0
 #define MOSS_STAGE_SCAN           1
 #define MOSS_STAGE_SCATTER        2
-#define MOSS_STAGE_TILE_SORT      3
+#define MOSS_STAGE_TILE_SORT      3   /* the chunk sort kernel */
 #define MOSS_STAGE_BLEND_FWD      4
 #define MOSS_STAGE_BLEND_BWD      5
 #define MOSS_STAGE_PREPROCESS_BWD 6
+#define MOSS_STAGE_MERGE_GATHER   7   /* the second kernel of the tile sort: rank merge + per-instance emit */
 #define MOSS_NUM_STAGES           8
 void moss_raster_profile_enable(uint32_t stage_mask);
 /* Diagnostics: register a device buffer of 8 x (4 * padded tile count) uint64; while set, the forward blend kernel stores per

@@ -174,7 +174,7 @@ def ext():
     return _ext
 
 
-STAGES = ["preprocess_fwd", "scan", "scatter", "tile_sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+STAGES = ["preprocess_fwd", "scan", "scatter", "chunk_sort", "blend_fwd", "blend_bwd", "preprocess_bwd", "merge_gather"]    # (every stage is ONE kernel)
 
 
 def profile_enable(stages=None):

@@ -656,13 +656,13 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
-                      char* frame_state, size_t frame_state_bytes)
+                      char* frame_state, size_t frame_state_bytes, int part)
 {
     const int T = fp.gx * fp.gy;
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
     // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) {
-        if (frame_state) launch_clear(frame_state, frame_state_bytes, s);
+        if (frame_state && part == 0) launch_clear(frame_state, frame_state_bytes, s);
         return;
     }
     // at most two 1024-thread workgroups per CU in flight; the workgroups loop over the chunks
@@ -671,9 +671,11 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // diagnostics (scripts/sort_stamps.py): the stamp buffer's words [131072, 131072 + 16384) -- behind the forward blend's item stamps
     static const int stamps_on = env_int("MOSS_SORT_STAMPS", 0);
     unsigned long long* const sort_stamps = (stamps_on && g_stamps) ? g_stamps + 131072 : nullptr;
-    hipLaunchKernelGGL(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
+    if (part == 0)
+    MOSS_LAUNCH_TIMED(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
                        sort_stamps, reinterpret_cast<uint4*>(frame_state), (uint32_t)(frame_state ? frame_state_bytes / 16 : 0));
-    hipLaunchKernelGGL(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
+    else
+    MOSS_LAUNCH_TIMED(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
 }
 

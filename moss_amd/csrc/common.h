@@ -258,7 +258,7 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 bool scatter_folds_scan(const FrameParams& fp);                                                // asynchronous forward: no scan launch, see binning.hip
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s);  // duplicateWithKeys (+ the scan)
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
-                      char* frame_state = nullptr, size_t frame_state_bytes = 0);   // (re-zeroes the frame state, if any)
+                      char* frame_state, size_t frame_state_bytes, int part);   // part 0: chunk sort (re-zeroes the frame state, if any), part 1: merge + emit
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
                            uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);
 void launch_export_geometry(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,

@@ -202,7 +202,8 @@ static int forward_impl(
             static const bool stop = getenv("MOSS_EXPERIMENT") && (atoi(getenv("MOSS_EXPERIMENT")) & 2);
             if (stop) { abandon_frame_state(); return R; }
         }
-        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes); }
+        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 0); }
+        { StageTimer tm(MOSS_STAGE_MERGE_GATHER, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 1); }
         STAGE_CHECK("tile_sort");
     } else abandon_frame_state();                                        // (nothing rendered: no sort kernel to re-zero it)
     { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }

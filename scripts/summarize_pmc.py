@@ -13,7 +13,7 @@ KERNELS = ["preprocess_forward_kernel", "preprocess_backward_kernel", "scan_kern
            "blend_backward_kernel", "clear_words_kernel", "ssim_pass1_kernel", "ssim_pass2_kernel", "loss_finish_kernel",
            "adamw_kernel", "adamw_tick_kernel", "activate_forward_kernel", "activate_backward_kernel", "mark_visible_kernel"]
 STAGES = {"preprocess_fwd": ["preprocess_forward_kernel"], "scan": ["scan_kernel"], "scatter": ["scatter_kernel"],
-          "tile_sort": ["chunk_sort_kernel", "merge_gather_kernel"], "blend_fwd": ["blend_forward_wave_kernel", "blend_forward_kernel"],
+          "chunk_sort": ["chunk_sort_kernel"], "merge_gather": ["merge_gather_kernel"], "blend_fwd": ["blend_forward_wave_kernel", "blend_forward_kernel"],
           "blend_bwd": ["blend_backward_wave_kernel", "blend_backward_kernel"], "preprocess_bwd": ["preprocess_backward_kernel"]}
 
 
