@@ -7,16 +7,18 @@
 // busiest wave) x 4 cycles while most SIMDs idle (measured: profiles/r01_notes.md).  The design therefore minimises the work
 // of the busiest WAVE, not the total work:
 //
-//   * a work item is ONE WAVE, there is no workgroup barrier anywhere (the first versions, one workgroup per tile quadrant
-//     with per-batch barriers, spent 38 % of their critical path waiting at those barriers; they are in the history of this
-//     file and in profiles/r01_notes.md);
+//   * a work item is ONE WAVE -- in the forward kernel a wave PAIR for heavy items: a scanner (block masks, hit list, record DMAs)
+//     and a blender (trips only), see PairCtl -- and there is no workgroup barrier anywhere (the first versions, one workgroup per
+//     tile quadrant with per-batch barriers, spent 38 % of their critical path waiting at those barriers; they are in the history
+//     of this file and in profiles/r01_notes.md);
 //   * heavy tiles (>= 128 entries): item = one 4x4 pixel block, lane = (pixel, slot), 4 consecutive list entries per trip; the
 //     order-dependent parts (transmittance T; the backward's suffix blend) are carried across the 4 slots of a pixel by a 3-step
 //     DPP chain that is bit-identical to the serial loop;
 //   * light tiles: item = one 8x8 quadrant, lane = pixel, entries one after the other;
 //   * the inner loops stay on the VECTOR unit: per-lane conditions are float selects, not lane-mask algebra -- the scalar unit
 //     is shared by every wave of a CU and was the measured bottleneck of the first version;
-//   * persistent workgroups of 4 independent waves (one per SIMD) pull items from per-XCD queues in LPT order.
+//   * persistent workgroups of 4 waves (one per SIMD; four workgroups per CU in both kernels) pull items from per-XCD queues in LPT
+//     order; the backward's long lists arrive cut into 64-hit depth segments (the forward leaves the state at every cut).
 //
 // Backward: the reference issues 9 global float atomics per (pixel, Gaussian) pair (backward.cu:538,574-584).  Here the 9
 // partial gradients of a trip's entries are summed over the wave's pixels by a reduce-scatter (v_permlane32_swap and

@@ -121,6 +121,10 @@ static int forward_impl(
 {
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
+    // (the frame state announced for THIS call is taken here, whatever happens below: a call that fails its argument checks must not
+    // leave it to the next one; untouched, the block is still all-zero)
+    char* const frame_state = g_next_frame_state;
+    g_next_frame_state = nullptr;
     if (P < 0 || width <= 0 || height <= 0) return fail(MOSS_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (!out_color || !out_depth || !out_alpha || !background) return fail(MOSS_ERR_INVALID_ARG, "null output/background pointer");
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(MOSS_ERR_INVALID_ARG, "null allocator callback");
@@ -155,8 +159,6 @@ static int forward_impl(
 
     // The counters kernels ADD to (tile histogram, tile cursors, error flags) must be zero here.  With the caller's frame state
     // (moss_raster_frame_state: all-zero between calls, re-zeroed by the sort kernel) nothing is launched for that; without it, a clear.
-    char* const frame_state = g_next_frame_state;
-    g_next_frame_state = nullptr;
     const size_t fs_bytes = ImageView::frame_state_bytes(width, height);
     if (frame_state) im.use_frame_state(frame_state, width, height);
     else launch_clear(im.header, im.clear_bytes(), s);                   // header + tile histogram + tile cursors
