@@ -72,7 +72,7 @@ struct GeomView {
 // instances, [6] instances needed, [7] heavy tiles (list length >= 2^LIGHT_TILE_LOG2; they come first in tile_order), [8]/[9] unused, [10] backward leaver count,
 // [16..23] / [24..31] per-XCD queue heads of the wave blend kernels (forward / backward)
 constexpr int HEADER_WORDS = 32;
-constexpr int LIGHT_TILE_LOG2 = 7;     // tiles with fewer than 2^7 entries are "light": blended one pixel per lane ([7] = heavy tiles)
+constexpr int LIGHT_TILE_LOG2 = 5;     // tiles with fewer than 2^5 entries are "light": blended one pixel per lane ([7] = heavy tiles)
 constexpr int NUM_XCD_QUEUES = 8;
 // One gradient record per (instance, 4x4 block): 9 values, padded to GRAD_REC_FLOATS.  16 (one 64-byte cache line per record: the
 // per-Gaussian gather touches ONE line per record) or 12 (48 bytes: three of four records straddle two lines; measured: same 35 us).
