@@ -432,16 +432,12 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     const uint32_t my = part * (uint32_t)MERGE_THREADS + tid; // this thread's instance of the chunk
     const bool mine = my < n_own;
     const uint64_t key_ld = keys[min(first + my, rg.y - 1u)];
-    const uint64_t key = mine ? key_ld : ~0ull;
     uint32_t rank = my;                                       // rank inside the own (sorted) chunk
-    if (part * (uint32_t)MERGE_THREADS >= n_own) {            // (a short chunk has no second part: wave-uniform)
-        if (last_turn) return;
-        __syncthreads();
-        continue;
-    }
-    for (uint32_t s0 = 0; s0 + 1 < nch; s0 += MERGE_OC) {     // (wave-uniform trip count) siblings s0 .. s0 + MERGE_OC - 1 of nch - 1
-        uint32_t on[MERGE_OC];
-        uint64_t v[MERGE_OC][MERGE_PARTS];
+    // Sibling group s0: chunks s0 .. s0 + MERGE_OC - 1 of the tile's nch - 1 OTHER chunks (unconditional, clamped loads: all in
+    // flight together).
+    uint32_t on[MERGE_OC];
+    uint64_t v[MERGE_OC][MERGE_PARTS];
+    auto load_group = [&](uint32_t s0) {
 #pragma unroll
         for (int q = 0; q < MERGE_OC; q++) {
             const uint32_t si = s0 + (uint32_t)q;             // sibling index: the tile's chunks without the own one
@@ -449,14 +445,38 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
             const uint32_t ofirst = rg.x + oc * CHUNK;
             on[q] = si + 1 < nch ? min((uint32_t)CHUNK, rg.y - ofirst) : 0u;
 #pragma unroll
-            for (int u = 0; u < MERGE_PARTS; u++)             // (unconditional, clamped: all loads are in flight together)
+            for (int u = 0; u < MERGE_PARTS; u++)
                 v[q][u] = keys[on[q] ? min(ofirst + (uint32_t)u * MERGE_THREADS + tid, rg.y - 1u) : first];
         }
+    };
+    if (part * (uint32_t)MERGE_THREADS >= n_own) {            // (a short chunk has no second part: wave-uniform)
+        if (last_turn) return;
+        __syncthreads();
+        continue;
+    }
+    // Request order = arrival order: the own key, the first group of siblings, and -- as soon as the key is there (its low word names
+    // the Gaussian) -- the Gaussian's 64-byte record and its group's slot base.  Those last loads stay in flight under the LDS fill
+    // and the searches; after the searches they were one more memory round trip on the critical path of every workgroup of a
+    // multi-chunk tile.  (A thread without an instance re-reads the record of the chunk's last key: a valid address.)
+    float4 ga, gb, gc, gd; uint32_t slot_base, id;
+    auto load_gaussian = [&]() {
+        id = (uint32_t)key_ld;
+        asm volatile("" : "+v"(id));                          // (opaque: otherwise the address arithmetic -- and with it the wait for
+                                                              // the key -- is hoisted in front of the siblings' loads)
+        const float4* const gsrc = g.geo + 4 * (size_t)id;    // the Gaussian's one 64-byte record
+        ga = gsrc[0]; gb = gsrc[1]; gc = gsrc[2]; gd = gsrc[3]; slot_base = g.group_base[id >> 8];
+    };
+    // the group's chunks into LDS, searched side by side
+    auto search_group = [&](uint32_t s0) {
+        uint32_t k_lo = (uint32_t)key_ld, k_hi = (uint32_t)(key_ld >> 32);
+        asm volatile("" : "+v"(k_lo), "+v"(k_hi));            // (opaque, like the id: the key is first NEEDED here, behind the requests)
+        const uint64_t key = mine ? (((uint64_t)k_hi << 32) | k_lo) : ~0ull;
         __syncthreads();                                      // the previous group's readers are done
 #pragma unroll
         for (int q = 0; q < MERGE_OC; q++) {
 #pragma unroll
-            for (int u = 0; u < MERGE_PARTS; u++) if ((uint32_t)u * MERGE_THREADS + tid < on[q]) s_keys[q][u * MERGE_THREADS + tid] = v[q][u];
+            for (int u = 0; u < MERGE_PARTS; u++) s_keys[q][u * MERGE_THREADS + tid] = v[q][u];   // (unconditional: slots past on[q] are never read for a decision, and a store
+                                                                                                  // inside a branch pulls its load in with it -- behind a wait for ALL loads)
         }
         __syncthreads();
         const int ns = (int)min((uint32_t)MERGE_OC, nch - 1u - s0);      // siblings in this group (wave-uniform)
@@ -478,15 +498,22 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         }
 #pragma unroll
         for (int q = 0; q < MERGE_OC; q++) rank += q < ns ? lo[q] : 0u;     // keys < key in that sorted chunk
+    };
+    if (nch > 1u) {                                           // (wave-uniform)
+        load_group(0u);
+        __builtin_amdgcn_sched_barrier(0);                    // (this order, in ONE basic block: left alone, the compiler requests the
+        load_gaussian();                                      // record first and sinks the siblings' loads behind the wait for the key)
+        __builtin_amdgcn_sched_barrier(0);
+        search_group(0u);
+    } else {
+        load_gaussian();
     }
+    for (uint32_t s0 = MERGE_OC; s0 + 1 < nch; s0 += MERGE_OC) { load_group(s0); search_group(s0); }   // tiles of more than 7 chunks
     if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = rank + 1u ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = nch; }
     if (mine) {
     const uint32_t pos = rg.x + rank;
-    const uint32_t id = (uint32_t)key;
     point_list[pos] = id;
     float4* rec = inst_rec + 3 * (size_t)pos;
-    const float4* gsrc = g.geo + 4 * (size_t)id;                  // the Gaussian's one 64-byte record
-    const float4 ga = gsrc[0], gb = gsrc[1], gd = gsrc[3];
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 3] = ga.x == 12345.678f ? 1ull : __builtin_amdgcn_s_memtime();
     const uint2 r = make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y));
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
@@ -494,9 +521,11 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     // the instance's SLOT: its place in its Gaussian's run (group base + run start + index of this tile in the rectangle).  The
     // backward blend files its gradient records and mask bits under it, so that the per-Gaussian gather walks [run, run + n) directly;
     // it travels in the record's third word (the cull half-width, which only this kernel reads -- from the geometry record).
-    const uint32_t slot = g.group_base[id >> 8] + __float_as_uint(gd.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    asm volatile("" :: "v"(gd.w));                            // (keeps the record's last register out of reuse while its load is in flight:
+                                                              // the allocator put the slot base there and waited for the load to do so)
+    const uint32_t slot = slot_base + __float_as_uint(gd.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     inst_mask[slot] = 0u;                                     // no gradient record yet (set by the backward blend)
-    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(slot), ga.w); rec[1] = gb; rec[2] = gsrc[2];
+    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(slot), ga.w); rec[1] = gb; rec[2] = gc;
     // (non-temporal or write-through stores here: +3 / +7 us -- the write-back at the kernel's end is cheaper)
     {
         // which 4x4 pixel blocks of this tile the entry's alpha >= 1/255 bounding box {x, y, hx, hy} touches (pixel centres are

@@ -11,7 +11,7 @@
 //     and a blender (trips only), see PairCtl -- and there is no workgroup barrier anywhere (the first versions, one workgroup per
 //     tile quadrant with per-batch barriers, spent 38 % of their critical path waiting at those barriers; they are in the history
 //     of this file and in profiles/r01_notes.md);
-//   * heavy tiles (>= 128 entries): item = one 4x4 pixel block, lane = (pixel, slot), 4 consecutive list entries per trip; the
+//   * heavy tiles (>= 2^LIGHT_TILE_LOG2 = 32 entries): item = one 4x4 pixel block, lane = (pixel, slot), 4 consecutive list entries per trip; the
 //     order-dependent parts (transmittance T; the backward's suffix blend) are carried across the 4 slots of a pixel by a 3-step
 //     DPP chain that is bit-identical to the serial loop;
 //   * light tiles: item = one 8x8 quadrant, lane = pixel, entries one after the other;
@@ -121,9 +121,12 @@ __device__ __forceinline__ Rec load_rec(const float4* __restrict__ inst_rec, int
 // ---------------------------------------------------------------------------------------------------------
 // LIGHT tiles (fewer than 2^LIGHT_TILE_LOG2 entries): one wave per 8x8 QUADRANT, lane = pixel, entries visited one after
 // the other exactly like the reference's loop.  Per (pixel, entry) pair this costs ~0.4 wave-instructions against ~1.3 for the
-// 4-slot layout of the heavy path (no cross-slot prefix, no stop-flag exchange), and a tile is 4 work items instead of 16.  A
-// background splat that covers the image puts ~50 entries into EVERY tile: the slot layout, built to shorten the critical path of
-// tiles with thousands of entries, spent most of the frame on those short lists.
+// 4-slot layout of the heavy path (no cross-slot prefix, no stop-flag exchange), and a tile is 4 work items instead of 16 -- but
+// the quadrant's wave visits every entry whose box touches any of its four blocks with all 64 lanes, where the heavy path's
+// block masks send an entry only to the blocks it reaches.  Measured (scripts/stage_times.py, MOSS_LIGHT_LOG2 = 3 ... 9): the
+// threshold was 128 entries until the backward blend got depth segments and dynamic block items; with those, 32 is where the
+// backward kernel stops gaining (bench scene 37.0 -> 33.6 us, configs[1] 38.4 -> 26.0 us, configs[4] 88 -> 80 us; 8-16 the
+// same, 256 and up twice as slow), the forward kernel does not care.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
                                                    const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,

@@ -11,7 +11,7 @@ d = hp.inputs_of(scene, "scale_rot")
 t = hp.hip_forward(d, dev)
 e = hp.hip_export(d, t, dev)
 n = (e.ranges[:, 1] - e.ranges[:, 0]).astype(np.int64)
-print(name, "P", d.P, "R", t.R, "tiles", len(n), "non-empty", int((n > 0).sum()), "heavy(>=128)", int((n >= 128).sum()))
+print(name, "P", d.P, "R", t.R, "tiles", len(n), "non-empty", int((n > 0).sum()), "heavy(>=32)", int((n >= 32).sum()), "of them >=128:", int((n >= 128).sum()))
 print("list length percentiles (non-empty) 10/50/90/99/100:", np.percentile(n[n > 0], [10, 50, 90, 99, 100]).astype(int))
 for c in (1024, 2048, 4096, 8192):
     nch = (n + c - 1) // c

@@ -144,14 +144,30 @@ def test_image_covering_gaussians(gpu, hip_lib):
 
 
 def test_heavy_tiles_on_a_ragged_image(gpu, hip_lib):
-    """Heavy tiles (>= 128 entries: block-mask scan + LDS-DMA path, 16 wave items per tile) on an image whose size is not a multiple
-    of the tile: partial tiles on the right and bottom edge, pixels outside the image inside 4x4 blocks."""
+    """Heavy tiles (lists of 32 entries or more: block-mask scan + LDS-DMA path, 16 wave items per tile; here hundreds of entries)
+    on an image whose size is not a multiple of the tile: partial tiles on the right and bottom edge, pixels outside the image
+    inside 4x4 blocks."""
     from tests.test_gpu_parity import _check_forward, _check_backward
     s = _stacked_scene(2500, W=70, H=50, spread=0.25, scale=0.12, seed=7)
     d = hp.inputs_of(s, "precomp")
     fw, t, e = _check_forward(d, gpu, max_fragile=3e-2)
     n = fw.ranges[:, 1] - fw.ranges[:, 0]
     assert (n >= 128).sum() >= 6 and n.max() < 2500            # several heavy tiles, including edge ones
+    _check_backward(d, gpu, fw, t, e)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_lists_on_both_sides_of_the_light_heavy_threshold(gpu, hip_lib, seed):
+    """Tiles with fewer than 32 entries are blended one pixel per lane (light path, 4 quadrant items), longer ones by wave pairs per
+    4x4 block (heavy path, 16 block items).  A blob that thins out towards the image border gives lists of every length from a few
+    entries to a few hundred in one frame -- including the 32..127 class that was light until the threshold moved -- so the class
+    boundary of the scan block (binning.hip: header[7]) and both blend paths are checked against the oracle together."""
+    from tests.test_gpu_parity import _check_forward, _check_backward
+    s = _stacked_scene(900, W=112, H=80, spread=0.55, scale=0.04, seed=seed)
+    d = hp.inputs_of(s, "precomp")
+    fw, t, e = _check_forward(d, gpu, max_fragile=3e-2)
+    n = np.asarray(fw.ranges[:, 1] - fw.ranges[:, 0])
+    assert ((n > 0) & (n < 32)).sum() >= 3 and ((n >= 32) & (n < 128)).sum() >= 3 and (n >= 128).sum() >= 1, sorted(n.tolist())
     _check_backward(d, gpu, fw, t, e)
 
 
