@@ -83,6 +83,10 @@ def parse_args(argv=None):
                          "other colours) through the same camera, mask = its alpha > 0.5 -- a masked person on black, like MOSS's "
                          "ZJU-MoCap frames; smooth = a full-frame smooth colour field (drives a few dozen Gaussians to cover the "
                          "whole image within ~250 steps, a regime real captures do not have)")
+    ap.add_argument("--order", default="as_generated", choices=["as_generated", "morton"],
+                    help="index order of the synthetic Gaussians: as generated (uncorrelated with position -- the default, and the "
+                         "least favourable) or re-indexed along a Morton curve (moss_amd.densify.spatial_order); a side experiment, "
+                         "named in config.workload when used")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
     ap.add_argument("--cpu-iters", type=int, default=20,
@@ -325,6 +329,12 @@ def main(argv=None):
     poses = scenes.look_at_ring(max(world, 8))
     maker = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[args.config]
     scene = maker()
+    if args.order == "morton":
+        from moss_amd.densify import spatial_order
+        perm = spatial_order(scene.means3D)
+        for k_, v_ in list(vars(scene).items()):
+            if torch.is_tensor(v_) and v_.dim() >= 1 and v_.shape[0] == scene.P:
+                setattr(scene, k_, v_[perm].contiguous())
     if world > 1:
         R_, t_ = poses[rank % len(poses)]
         c0 = scene.camera
@@ -493,7 +503,7 @@ def main(argv=None):
         "config": {"workload": f"BASELINE configs[2]: {P} Gaussians on a synthetic capsule body, {W}x{H}, SH degree 3, "
                                f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
                    if args.config == "cfg3" else args.config,
-                   "target": args.target, "input_mode": args.mode,
+                   "target": args.target, "input_mode": args.mode, "index_order": args.order,
                    "activations": "torch" if args.torch_activations else ("in_op" if h.pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                    "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
@@ -534,6 +544,8 @@ def main(argv=None):
         torch.cuda.empty_cache()
         result["callers"] = caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_transforms())
         result["value_dropin"] = result["callers"]["dropin_unchanged"].get("value")
+        if "spatial_order" in result["callers"]:
+            result["value_spatial_order"] = result["callers"]["spatial_order"].get("value")
         result["value_lbs_in_op"] = result["callers"]["lbs_in_op"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
@@ -551,7 +563,12 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
       dropin_fused_sides the same call pattern with the caller-side rows of SURVEY 8(f) switched to this repository's kernels: fused
                          L1+SSIM loss, DensifyStats, flat AdamW, fused activation kernels (still cov3D_precomp from Python, still
                          synchronous and eager)
-      lbs_in_op          the transforms applied inside the op (raw parameters, asynchronous forward, one hipGraph per step)"""
+      lbs_in_op          the transforms applied inside the op (raw parameters, asynchronous forward, one hipGraph per step)
+      spatial_order      the HEADLINE configuration on the same Gaussians re-indexed along a Morton curve (densify.spatial_order, what
+                         a caller would do whenever it rebuilds its tensors: densify / prune): the synthetic scene's own index order is
+                         uncorrelated with position -- the least favourable case for the per-tile counters and the gathers by
+                         Gaussian index; MOSS's order (SMPL mesh order + appended clones) lies between the two"""
+    import copy
     import torch
     res = {}
     specs = {
@@ -561,18 +578,35 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                                    fused_loss=True, caller_side="fused"),
         "lbs_in_op": dict(mode="lbs", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
     }
+    if args.order == "as_generated" and args.mode in ("scale_rot", "lbs") and args.forward == "async" and args.graph:
+        # (the pair is measured the same way -- same harness, same number of replays -- so that their RATIO is the effect of the order)
+        same = dict(mode=args.mode, activations=args.activations, torch_activations=args.torch_activations,
+                    torch_adamw=args.torch_adamw, forward="async", graph=1)
+        specs["as_generated_order"] = dict(same)
+        specs["spatial_order"] = dict(same)
     for name, kw in specs.items():
         try:
-            h = Harness(args, dev, 0, 1, scene, cam, gt, gt_mask, bg, lbs_T=lbs_T, **kw)
+            sc, T_ = scene, lbs_T
+            if name == "spatial_order":
+                from moss_amd.densify import spatial_order
+                perm = spatial_order(scene.means3D)
+                sc = copy.copy(scene)
+                for k_, v_ in list(vars(sc).items()):
+                    if torch.is_tensor(v_) and v_.dim() >= 1 and v_.shape[0] == scene.P:
+                        setattr(sc, k_, v_[perm].contiguous())
+                T_ = lbs_T[perm.to(lbs_T.device)].contiguous()
+            h = Harness(args, dev, 0, 1, sc, cam, gt, gt_mask, bg, lbs_T=T_ if kw["mode"] in ("lbs", "lbs_python") else None, **kw)
+            n_steps = 3 * steps if name in ("as_generated_order", "spatial_order") else steps
             for _ in range(warmup):
                 h.step()
             torch.cuda.synchronize(dev)
             if h.use_graph:
                 h.capture()
-            dt, _ = h.time_steps(steps)
+                h.time_steps(warmup)                         # (replays: clocks and caches as in the timed region)
+            dt, _ = h.time_steps(n_steps)
             if kw["forward"] == "async":
                 h.ctx.check_status()
-            res[name] = {"value": round(steps / dt, 2), "unit": "iters/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+            res[name] = {"value": round(n_steps / dt, 2), "unit": "iters/s", "ms_per_step": round(1e3 * dt / n_steps, 4), "steps": n_steps,
                          "launch": h.graph_note if h.use_graph else "eager launches", "forward": kw["forward"]}
             del h
         except Exception as e:                               # a side measurement must not take the headline down with it

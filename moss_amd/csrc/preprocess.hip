@@ -737,7 +737,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // gradient there.  (A second set of rows made this kernel's LDS 25 KB per 64-thread block: SIX blocks per CU, 1536 resident for
     // cfg3's 1563 -- the 27 left over started when the first ones ended, 18 us in, and ran alone: scripts/prebwd_stamps.py.)
     float* const s_dsh = s_sh;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // Which Gaussians a block takes: its rows r = 0 .. blockDim-1 are GROUPS of 16 consecutive Gaussians taken from blockDim/16 places
+    // spread over the index range (group q of block b = Gaussians 16 (q gridDim + b) ...).  With neighbouring indices being spatial
+    // neighbours (densify.spatial_order; MOSS's own order is partly so) a block of 64 CONSECUTIVE Gaussians is all-heavy or
+    // all-light -- the kernel then lasted as long as its block in the densest part of the image (bench frame, Morton order: 28.8 us
+    // against 25.0 in random order; interleaved: see profiles/r02_notes.md) -- while 16 consecutive ones still share their cache lines.
+    auto gaussian_of_row = [&](int r) -> int { return 16 * ((r >> 4) * (int)gridDim.x + (int)blockIdx.x) + (r & 15); };
+    const int idx = gaussian_of_row((int)threadIdx.x);
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
     // All first-level loads are issued together and unconditionally (clamped indices): the 12 SH float4 of this thread's share of
     // the block's records, tiles_touched, point_offsets, the header flags.  Stamps showed this phase -- 12 SH loads each waited
@@ -746,10 +752,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     const int idc = min(idx, P - 1);
     float4 shv[12];
     if (STAGE_SH) {
-        const size_t base4 = (size_t)blockIdx.x * blockDim.x * 12, total4 = (size_t)P * 12;     // in float4 units (48 floats = 12)
+        const size_t total4 = (size_t)P * 12;               // in float4 units (48 floats = 12)
         const float4* src = reinterpret_cast<const float4*>(shs);
 #pragma unroll
-        for (int j = 0; j < 12; j++) shv[j] = src[min(base4 + threadIdx.x + (size_t)j * blockDim.x, total4 - 1)];
+        for (int j = 0; j < 12; j++) {
+            const int f = (int)threadIdx.x + j * (int)blockDim.x;         // float4 f of the block's rows: row f / 12, part f % 12
+            shv[j] = src[min((size_t)gaussian_of_row(f / 12) * 12 + (size_t)(f % 12), total4 - 1)];
+        }
     }
     const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc] + g.group_base[idc >> 8], hdr_flags = header[2];
     if (STAGE_SH) {
@@ -1081,12 +1090,12 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     PSTAMP(5);
     if (STAGE_SH) {
         __syncthreads();                                     // every row now holds dL_dsh
-        const size_t base4 = (size_t)blockIdx.x * blockDim.x * 12, total4 = (size_t)P * 12;
         float4* dst = reinterpret_cast<float4*>(dL_dsh);
         for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
-            if (base4 + f < total4) {
+            const int gi = gaussian_of_row(f / 12);
+            if (gi < P) {
                 const float* r = &s_dsh[(f / 12) * SH_ROW + (f % 12) * 4];
-                dst[base4 + f] = make_float4(r[0], r[1], r[2], r[3]);
+                dst[(size_t)gi * 12 + (size_t)(f % 12)] = make_float4(r[0], r[1], r[2], r[3]);
             }
         }
     }
@@ -1167,7 +1176,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 const float* transforms, float* dL_dtransforms, hipStream_t s)
 {
     (void)colors_precomp;
-    static const int threads = env_int("MOSS_PREBWD_THREADS", 64);
+    static const int threads = std::max(16, env_int("MOSS_PREBWD_THREADS", 64) & ~15);    // (whole groups of 16 rows: gaussian_of_row)
     static const int gather_knob = env_int("MOSS_GATHER", 0) == 1 ? 0x200 : env_int("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     const int blocks = (fp.P + threads - 1) / threads;
     const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&

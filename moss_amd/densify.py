@@ -94,3 +94,26 @@ def cal_kl(xyz: torch.Tensor, rotation: torch.Tensor, scaling: torch.Tensor, knn
     from .knn_cuda import knn
     _, ids = knn(xyz.detach()[None], xyz.detach()[None], 2, knn_impl)
     return neighbour_kl(xyz, rotation, scaling, ids[0]), ids[0]
+
+
+def spatial_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """A permutation that lists the Gaussians along a 3-D Morton (Z-order) curve of their positions (`bits` per axis).
+
+    Nothing in the rasterizer depends on the index order of the Gaussians (ties in depth are broken by the index, as in the
+    reference's radix sort of (tile | depth) keys, rasterizer_impl.cu:330-337), but its memory traffic does: a block of 256
+    consecutive Gaussians adds to the histogram of every tile it touches (preprocess.hip), reserves a run in each of those tiles
+    (binning.hip: scatter) and its instances' records are gathered by Gaussian index (merge_gather, per-Gaussian backward).  MOSS
+    starts from the SMPL vertices in mesh order and appends clones and splits next to nothing in particular
+    (scene/gaussian_model.py: densification_postfix); re-indexing the set along a space-filling curve whenever it is rebuilt anyway
+    (densify / prune, every few hundred iterations) keeps index neighbours spatial neighbours.  Apply the returned permutation to
+    every per-Gaussian tensor AND to the optimizer state (`FlatAdamW.permute`)."""
+    with torch.no_grad():
+        p = xyz.detach().float()
+        lo = p.min(dim=0).values
+        span = (p.max(dim=0).values - lo).clamp_min(1e-12)
+        q = ((p - lo) / span * (2 ** bits - 1)).round().to(torch.int64).clamp_(0, 2 ** bits - 1)
+        code = torch.zeros(p.shape[0], dtype=torch.int64, device=p.device)
+        for b in range(bits):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        return torch.argsort(code, stable=True)

@@ -61,6 +61,21 @@ class FlatAdamW:
         if self.step_state is not None:
             self.step_state.copy_(snap[4])
 
+    def permute_rows(self, perm: torch.Tensor):
+        """Re-index the Gaussians: row i of every parameter whose leading dimension is len(perm) -- and of its two moments -- becomes
+        the old row perm[i] (e.g. ``moss_amd.densify.spatial_order(xyz)``).  The step count is shared and stays.  Not capturable:
+        call it between graph captures, where MOSS rebuilds its tensors anyway (densify / prune)."""
+        n_rows = int(perm.numel())
+        perm = perm.to(self.flat_params.device)
+        off = 0
+        with torch.no_grad():
+            for p, n in zip(self.bucket.params, self.bucket.sizes):
+                if p.dim() >= 1 and p.shape[0] == n_rows:
+                    for flat in (self.flat_params, self.exp_avg, self.exp_avg_sq):
+                        v = flat[off:off + n].view_as(p)
+                        v.copy_(v[perm].clone())
+                off += n
+
     def step(self):
         self.t += 1
         dev = self.flat_params.device

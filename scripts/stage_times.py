@@ -9,9 +9,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="cfg3")
 ap.add_argument("--mode", default="precomp")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--order", default="as_is", help="as_is | morton (Gaussians re-indexed along a 3-D Morton curve) | random")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 scene = {"cfg1": scenes.config1, "cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[args.config]()
+if args.order != "as_is":
+    from moss_amd.densify import spatial_order
+    perm = spatial_order(scene.means3D) if args.order == "morton" else torch.randperm(scene.P, generator=torch.Generator().manual_seed(1))
+    for k, v in list(vars(scene).items()):
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == scene.P:
+            setattr(scene, k, v[perm].contiguous())
 d = hp.inputs_of(scene, args.mode)
 dc, dd, da = hp.image_grads(d.H, d.W)
 dc, dd, da = dc.to(dev), dd.to(dev), da.to(dev)

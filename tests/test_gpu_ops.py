@@ -434,6 +434,40 @@ def test_flat_adamw_device_step_counter(gpu, hip_lib):
         assert hp.rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6
 
 
+def test_flat_adamw_rows_can_be_reindexed(gpu, hip_lib):
+    """densify.spatial_order + FlatAdamW.permute_rows: training on the re-indexed set is the same training (the parameters and both
+    moments move together), checked against an optimizer that never saw the permutation."""
+    from moss_amd.dist import GradBucket
+    from moss_amd.optim import FlatAdamW
+    from moss_amd.densify import spatial_order
+    torch.manual_seed(2)
+    P = 777
+    shapes, lrs = [(P, 3), (P, 15, 3), (P, 4)], [0.01, 0.002, 0.003]
+    init = [torch.randn(*s) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(gpu)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(gpu)) for t in init]
+    ba, bb = GradBucket(pa), GradBucket(pb)
+    oa = FlatAdamW([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], ba, eps=1e-15)
+    ob = FlatAdamW([{"params": [p], "lr": lr} for p, lr in zip(pb, lrs)], bb, eps=1e-15)
+    perm = None
+    for it in range(4):
+        if it == 2:
+            perm = spatial_order(pa[0].detach())
+            assert sorted(perm.tolist()) == list(range(P))
+            oa.permute_rows(perm)
+        ba.attach(); bb.attach()
+        for p, q, s_ in zip(pa, pb, shapes):
+            g = torch.randn(*s_, device=gpu)
+            q.grad.copy_(g)
+            p.grad.copy_(g if perm is None else g[perm])
+        oa.step(); ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p.detach(), q.detach()[perm])
+    # the curve keeps index neighbours close: mean distance between consecutive Gaussians well under that of a random order
+    step_len = lambda x: float((x[1:] - x[:-1]).norm(dim=1).mean())
+    assert step_len(pa[0].detach()) < 0.5 * step_len(pb[0].detach())
+
+
 # ---------------------------------------------------------------- fused parameter activations
 def _raw_params(P, K, gpu, seed=0):
     g = torch.Generator().manual_seed(seed)
