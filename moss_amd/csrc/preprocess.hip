@@ -742,7 +742,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // neighbours (densify.spatial_order; MOSS's own order is partly so) a block of 64 CONSECUTIVE Gaussians is all-heavy or
     // all-light -- the kernel then lasted as long as its block in the densest part of the image (bench frame, Morton order: 28.8 us
     // against 25.0 in random order; interleaved: see profiles/r02_notes.md) -- while 16 consecutive ones still share their cache lines.
-    auto gaussian_of_row = [&](int r) -> int { return 16 * ((r >> 4) * (int)gridDim.x + (int)blockIdx.x) + (r & 15); };
+    const int gl2 = (raw >> 12) & 7;                       // log2 of the group size (launch_preprocess_backward)
+    auto gaussian_of_row = [&](int r) -> int { return (((r >> gl2) * (int)gridDim.x + (int)blockIdx.x) << gl2) + (r & ((1 << gl2) - 1)); };
     const int idx = gaussian_of_row((int)threadIdx.x);
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
     // All first-level loads are issued together and unconditionally (clamped indices): the 12 SH float4 of this thread's share of
@@ -1140,6 +1141,16 @@ export_geometry_kernel(int P, GeomView g, float* depths, float* means2D, float* 
 
 }  // anonymous namespace
 
+static int device_cus()
+{
+    static const int n = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }();
+    return n;
+}
+
 static int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
@@ -1176,18 +1187,31 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 const float* transforms, float* dL_dtransforms, hipStream_t s)
 {
     (void)colors_precomp;
-    static const int threads = std::max(16, env_int("MOSS_PREBWD_THREADS", 64) & ~15);    // (whole groups of 16 rows: gaussian_of_row)
+    static const int threads = std::max(64, env_int("MOSS_PREBWD_THREADS", 64) & ~63);
+    // Rows of a block = groups of 2^gl2 consecutive Gaussians (gaussian_of_row); 6 = the block's 64 rows are consecutive.  Groups of 16
+    // from four places even the blocks out, which is what counts while every block of the grid is resident at once (the kernel then
+    // lasts as long as its heaviest block: bench frame in Morton order 29.3 -> 25.0 us); once the grid runs in several rounds the
+    // dispatcher does the balancing and the shared cache lines of 64 neighbours count for more (configs[4]: 81 us consecutive, 87-95
+    // in groups of 16) -- so: groups of 16 for a grid that fits, consecutive rows otherwise.
+    static const int gl2_env = env_int("MOSS_PREBWD_GROUP_LOG2", 0);
     static const int gather_knob = env_int("MOSS_GATHER", 0) == 1 ? 0x200 : env_int("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     const int blocks = (fp.P + threads - 1) / threads;
     const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
+    const size_t lds_bytes_staged = (size_t)threads * SH_ROW * sizeof(float) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4;
+    static const int resident_per_cu = [&] {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, preprocess_backward_kernel<true>, threads, lds_bytes_staged) != hipSuccess || occ < 1) occ = 1;
+        return occ;
+    }();
+    const int gl2 = gl2_env ? std::max(4, std::min(6, gl2_env)) : (blocks <= resident_per_cu * device_cus() ? 4 : 6);
 #define LAUNCH_PB(STAGE)                                                                                                        \
     MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
                        ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob, g_stamps, queues)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues)
     if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
 }
