@@ -363,6 +363,7 @@ def main(argv=None):
                 torch_activations=args.torch_activations, torch_adamw=args.torch_adamw, forward=args.forward, graph=args.graph,
                 lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None)
     opt, bucket, pc = h.opt, h.bucket, h.pc
+    pc.spatially_ordered = args.order == "morton"
 
     t_start = time.perf_counter()
 
@@ -596,6 +597,8 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                         setattr(sc, k_, v_[perm].contiguous())
                 T_ = lbs_T[perm.to(lbs_T.device)].contiguous()
             h = Harness(args, dev, 0, 1, sc, cam, gt, gt_mask, bg, lbs_T=T_ if kw["mode"] in ("lbs", "lbs_python") else None, **kw)
+            if name == "spatial_order":
+                h.pc.spatially_ordered = True                # what GaussianSet.reorder_spatially() leaves behind: render() hints the op
             n_steps = 3 * steps if name in ("as_generated_order", "spatial_order") else steps
             for _ in range(warmup):
                 h.step()

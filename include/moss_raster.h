@@ -303,10 +303,14 @@ int moss_raster_backward_tf(
  *   raw_flags: MOSS_RAW_OPACITY (opacities are logits) | MOSS_RAW_SCALE (scales are logarithms) | MOSS_RAW_ROTATION
  *   (rotations are not normalised; normalised as x / max(|x|, 1e-12) like torch.nn.functional.normalize).
  *   The backward needs the raw opacities again (the reference backward does not take opacities at all).
+ *   MOSS_HINT_SPATIAL_ORDER may be OR-ed in: "neighbours in index are neighbours in space" (the caller re-indexed its Gaussians along
+ *   a space-filling curve, e.g. moss_amd.densify.spatial_order).  It changes no result beyond the order of some float32 sums, only how the per-Gaussian backward deals
+ *   Gaussians to its workgroups (groups of 16 from places spread over the index range, so that no workgroup is all-heavy).
  */
 #define MOSS_RAW_OPACITY 1
 #define MOSS_RAW_SCALE 2
 #define MOSS_RAW_ROTATION 4
+#define MOSS_HINT_SPATIAL_ORDER 8
 int moss_raster_forward_raw(
     moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
     moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,

@@ -230,6 +230,7 @@ struct BinView {
 // `raw` bits of FrameParams (moss_raster_forward_raw / _backward_raw): the GaussianModel getters applied inside preprocess
 constexpr int RAW_OPACITY = 1;      // opacities are logits:            get_opacity  = sigmoid(_opacity)          (scene/gaussian_model.py:160-161)
 constexpr int RAW_SCALE = 2;        // scales are logarithms:           get_scaling  = exp(_scaling)              (:142-143)
+constexpr int HINT_SPATIAL_ORDER = 8; // (not a raw-parameter bit) index neighbours are spatial neighbours: include/moss_raster.h
 constexpr int RAW_ROTATION = 4;     // rotations are not normalised:    get_rotation = normalize(_rotation)       (:146-147)
 struct FrameParams {
     int P, D, M, W, H, gx, gy;

@@ -1188,11 +1188,12 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
 {
     (void)colors_precomp;
     static const int threads = std::max(64, env_int("MOSS_PREBWD_THREADS", 64) & ~63);
-    // Rows of a block = groups of 2^gl2 consecutive Gaussians (gaussian_of_row); 6 = the block's 64 rows are consecutive.  Groups of 16
-    // from four places even the blocks out, which is what counts while every block of the grid is resident at once (the kernel then
-    // lasts as long as its heaviest block: bench frame in Morton order 29.3 -> 25.0 us); once the grid runs in several rounds the
-    // dispatcher does the balancing and the shared cache lines of 64 neighbours count for more (configs[4]: 81 us consecutive, 87-95
-    // in groups of 16) -- so: groups of 16 for a grid that fits, consecutive rows otherwise.
+    // Rows of a block = groups of 2^gl2 consecutive Gaussians (gaussian_of_row); 6 = the block's 64 rows are consecutive: the default.
+    // When the caller says that index neighbours are spatial neighbours (MOSS_HINT_SPATIAL_ORDER) 64 consecutive Gaussians are all-heavy
+    // or all-light, and while every block of the grid is resident at once the kernel lasts as long as its heaviest block: then groups of
+    // 16 from four places (bench frame in Morton order 29.3 -> 25.0 us).  Not otherwise: in an order without locality the groups cost
+    // coalescing (stress case with image-covering Gaussians 91.5 -> 99.3 us), and once the grid runs in several rounds the dispatcher
+    // does the balancing while the shared cache lines of 64 neighbours count for more (configs[4]: 81 us consecutive, 87-95 in groups).
     static const int gl2_env = env_int("MOSS_PREBWD_GROUP_LOG2", 0);
     static const int gather_knob = env_int("MOSS_GATHER", 0) == 1 ? 0x200 : env_int("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     const int blocks = (fp.P + threads - 1) / threads;
@@ -1204,7 +1205,8 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, preprocess_backward_kernel<true>, threads, lds_bytes_staged) != hipSuccess || occ < 1) occ = 1;
         return occ;
     }();
-    const int gl2 = gl2_env ? std::max(4, std::min(6, gl2_env)) : (blocks <= resident_per_cu * device_cus() ? 4 : 6);
+    const int gl2 = gl2_env ? std::max(4, std::min(6, gl2_env))
+                            : (((fp.raw & HINT_SPATIAL_ORDER) && blocks <= resident_per_cu * device_cus()) ? 4 : 6);
 #define LAUNCH_PB(STAGE)                                                                                                        \
     MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
                        ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \

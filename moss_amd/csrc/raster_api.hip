@@ -372,7 +372,7 @@ int moss_raster_forward_raw(
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
     float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, void* stream)
 {
-    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (!scales || !rotations)) return fail(MOSS_ERR_INVALID_ARG, "scales and rotations are required");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
@@ -392,7 +392,7 @@ int moss_raster_backward_raw(
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, void* stream)
 {
-    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))
         return fail(MOSS_ERR_INVALID_ARG, "scales and rotations (and dL_dtransforms with transforms) are required");
     return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,

@@ -18,6 +18,7 @@ from .._lib import check, ext, lib
 NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/config.h:14
 
 RAW_OPACITY, RAW_SCALE, RAW_ROTATION = 1, 2, 4       # include/moss_raster.h MOSS_RAW_*
+HINT_SPATIAL_ORDER = 8                               # MOSS_HINT_SPATIAL_ORDER: OR-ed into raw_flags, changes no result
 
 last_num_rendered = 0   # num_rendered of the most recent forward call of ANY context (kept for callers that predate contexts)
 

@@ -39,6 +39,26 @@ class GaussianSet(nn.Module):
         self._rotation = nn.Parameter(scene.rotations.clone().to(dev))
         self._opacity = nn.Parameter(inverse_sigmoid(scene.opacities.clamp(1e-4, 1 - 1e-4)).to(dev))
 
+    spatially_ordered = False
+
+    def reorder_spatially(self, optimizer=None):
+        """Re-index the Gaussians along a Morton curve of their positions (moss_amd.densify.spatial_order) -- parameters in place and,
+        if given, the rows of a ``FlatAdamW``'s moments with them -- and remember that index neighbours are now spatial neighbours
+        (``render`` passes the hint to the op).  Results do not depend on the index order; the memory traffic of the binning and of the
+        per-Gaussian kernels does (profiles/r02_notes.md, finding 30).  Meant for the moments the set is rebuilt anyway (MOSS:
+        densify / prune, scene/gaussian_model.py:densification_postfix); not capturable.  Returns the permutation."""
+        from .densify import spatial_order
+        perm = spatial_order(self._xyz.detach())
+        if optimizer is not None and hasattr(optimizer, "permute_rows"):
+            optimizer.permute_rows(perm)                     # (the parameters live in its flat buffer: moved there)
+        else:
+            with torch.no_grad():
+                for p in self.parameters():
+                    if p.dim() >= 1 and p.shape[0] == perm.numel():
+                        p.copy_(p[perm].clone())
+        self.spatially_ordered = True
+        return perm
+
     # activations as in scene/gaussian_model.py:46-56,134-166
     @property
     def get_xyz(self):

@@ -65,6 +65,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     if (getattr(pipe, "raw_parameters_in_op", False) and not pipe.compute_cov3D_python
             and all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation"))):
         raw_flags = 7                                        # _C.RAW_OPACITY | _C.RAW_SCALE | _C.RAW_ROTATION
+        if getattr(pc, "spatially_ordered", False):          # (GaussianSet.reorder_spatially: index neighbours are spatial neighbours)
+            raw_flags |= 8                                   # _C.HINT_SPATIAL_ORDER
     elif getattr(pipe, "fused_activations", False):
         pc = pc.activate(getattr(pipe, "grad_bucket", None))
     xyz = pc.get_xyz

@@ -434,6 +434,43 @@ def test_flat_adamw_device_step_counter(gpu, hip_lib):
         assert hp.rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6
 
 
+def test_spatial_order_hint_changes_no_result(gpu, hip_lib):
+    """GaussianSet.reorder_spatially(): the rendered image is the same image, the gradients are the same gradients in the new order,
+    and the MOSS_HINT_SPATIAL_ORDER bit render() then passes (per-Gaussian backward: rows dealt in groups of 16) changes nothing but the
+    order of some float32 sums."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    s = scenes.config1(P=3000, W=160, H=96)
+    cam = camera_view(s.camera, gpu)
+    bg = torch.zeros(3, device=gpu)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True)
+    w = torch.rand(3, 96, 160, generator=torch.Generator().manual_seed(5)).to(gpu)
+
+    def grads(pc):
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, pipe, bg)
+        ((out["render"] * w).sum() + 0.3 * out["render_alpha"].sum()).backward()
+        return out["render"].detach().clone(), {n: p.grad.detach().clone() for n, p in pc.named_parameters()}
+
+    pc = GaussianSet(s, sh_degree=3, device=gpu, unified_features=True)
+    img0, g0 = grads(pc)
+    perm = pc.reorder_spatially()
+    assert pc.spatially_ordered and sorted(perm.tolist()) == list(range(3000))
+    img1, g1 = grads(pc)                                      # hinted
+    pc.spatially_ordered = False
+    img2, g2 = grads(pc)                                      # same order, no hint
+    # (not bit for bit: the wave-balanced gather adds a Gaussian's records in an order that depends on its wave-mates, and the hint
+    # changes who they are)
+    assert torch.equal(img1, img2)
+    for n in g1:
+        assert hp.rel_err(g1[n].cpu().numpy(), g2[n].cpu().numpy()) < 2e-6, n
+    assert float((img1 - img0).abs().max()) <= 2e-6           # (depth ties are broken by the index: none in this scene; sums re-ordered)
+    for n in g0:
+        assert hp.rel_err(g1[n].cpu().numpy(), g0[n][perm].cpu().numpy()) < 2e-5, n
+
+
 def test_flat_adamw_rows_can_be_reindexed(gpu, hip_lib):
     """densify.spatial_order + FlatAdamW.permute_rows: training on the re-indexed set is the same training (the parameters and both
     moments move together), checked against an optimizer that never saw the permutation."""
