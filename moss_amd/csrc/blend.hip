@@ -505,6 +505,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     const int n = (int)(rg.y - rg.x);
 #define STAMP() (stamp_out ? __builtin_amdgcn_s_memtime() : 0ull)
     const unsigned long long t_begin = STAMP();
+    const unsigned long long rt_begin = stamp_out ? __builtin_amdgcn_s_memrealtime() : 0ull;      // (100 MHz, one clock for the device)
     unsigned long long d_trip = 0, d_starve = 0, n_rounds = 0, n_trips = 0, t_first = 0;
 
     float T = 1.0f, T_stop = -1.0f;
@@ -623,8 +624,8 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         if (final_round) break;
     }
     if (stamp_out && lane == 0) {
-        stamp_out[0] = STAMP() - t_begin; stamp_out[1] = (unsigned long long)n; stamp_out[2] = d_starve; stamp_out[3] = t_first; stamp_out[4] = 0;
-        stamp_out[5] = d_trip; stamp_out[6] = n_rounds; stamp_out[7] = n_trips;
+        stamp_out[0] = STAMP() - t_begin; stamp_out[1] = (unsigned long long)n; stamp_out[2] = d_starve; stamp_out[3] = t_first; stamp_out[4] = rt_begin;
+        stamp_out[5] = d_trip; stamp_out[6] = n_rounds | (__builtin_amdgcn_s_memrealtime() << 16); stamp_out[7] = n_trips;     // (scripts/fwd_timeline.py)
     }
 #undef STAMP
 

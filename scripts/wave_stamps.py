@@ -17,6 +17,7 @@ L.moss_raster_debug_set_stamps(buf.data_ptr())
 hp.hip_forward(d, dev); torch.cuda.synchronize()
 L.moss_raster_debug_set_stamps(None)
 s = buf.cpu().numpy().reshape(-1, 8)
+s[:, 6] &= 0xffff                                           # (the upper bits carry the item's end on the realtime clock: fwd_timeline.py)
 work = s[s[:, 6] > 0]
 order = np.argsort(-work[:, 0])[:12]
 print("  blender cycles  n entries  rounds  trips(scheduled)  trip cycles  starved  first trip after")
