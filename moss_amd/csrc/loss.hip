@@ -142,6 +142,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         }
     }
     float ssim_v = 0.f, l1_v = 0.f, mask_v = 0.f;
+    const float inv_hw = 1.0f / ((float)H * (float)W);
     const int px = x0 + lx;
 #pragma unroll
     for (int j = 0; j < VR; j++) {
@@ -152,13 +153,15 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
             const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
             const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
-            const float inv = 1.0f / (b1 * b2);
+            // (hardware reciprocals, ~1 ulp: this file is compiled with correctly rounded division, ten instructions apiece, and the
+            // four quotients per pixel-channel were an eighth of this kernel's vector instructions; b1 >= C1, b2 ~ C2 + variances)
+            const float rb1 = __builtin_amdgcn_rcpf(b1), rb2 = __builtin_amdgcn_rcpf(b2), inv = rb1 * rb2;
             const float S = a1 * a2 * inv;
             // partial derivatives of S w.r.t. (mu1 | sigma1^2 | sigma12), then total derivatives w.r.t. the three filtered
             // moments E[x], E[x^2], E[xy] (sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2)
-            const float dS_ds1 = -S / b2;
+            const float dS_ds1 = -S * rb2;
             const float dS_ds12 = 2.f * a1 * inv;
-            const float dS_dmu1 = 2.f * mu2 * a2 * inv - S * 2.f * mu1 / b1 + dS_ds1 * (-2.f * mu1) + dS_ds12 * (-mu2);
+            const float dS_dmu1 = 2.f * mu2 * a2 * inv - S * 2.f * mu1 * rb1 + dS_ds1 * (-2.f * mu1) + dS_ds12 * (-mu2);
             const size_t o = ((size_t)c * H + py) * W + px, plane3 = (size_t)C * H * W;
             dmap[o] = dS_dmu1; dmap[plane3 + o] = dS_ds1; dmap[2 * plane3 + o] = dS_ds12;
             ssim_v += S;
@@ -169,7 +172,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
                 const size_t oa = (size_t)py * W + px;
                 const float da = alpha[oa] - mask[oa];
                 mask_v += da * da;
-                dL_dalpha[oa] = lambda_mask * 2.f * da / ((float)H * (float)W);
+                dL_dalpha[oa] = lambda_mask * 2.f * da * inv_hw;
             }
         }
     }
