@@ -343,13 +343,15 @@ typedef HeavyLdsT<RCAP_BWD, LCAP_BWD> HeavyLdsBwd;
 // Issue the DMA batches that cover list entries [from, to): batch q = entries 64q .. 64q+63 -> ring slots (64q & RMASK) + lane.
 // Lanes whose entry is not in the list yet copy the tile's first record (overwritten when the batch is re-issued with that
 // entry; never read before); lanes whose entry was fetched before re-copy the same record.
-template <typename LDS>
+// FPOS: the list holds (position + 1) as a FLOAT (the backward kernel: its trips compare positions as floats and never need the integer).
+template <bool FPOS = false, typename LDS>
 __device__ __forceinline__ void dma_records(LDS* L, const float4* __restrict__ recs, int from, int to, int nlist, int lane)
 {
     constexpr int LMASK = LDS::LMASK, RMASK = LDS::RMASK;
     for (int q = from >> 6; q <= (to - 1) >> 6; q++) {
         const int li = 64 * q + lane;
-        const uint32_t p = li < nlist ? L->lst[li & LMASK] : 0u;
+        const uint32_t v = L->lst[li & LMASK];
+        const uint32_t p = li < nlist ? (FPOS ? (uint32_t)__uint_as_float(v) - 1u : v) : 0u;
         const float4* r = recs + 3 * (size_t)p;
         const int base = (64 * q) & RMASK;
         __builtin_amdgcn_global_load_lds(r, &L->a[base], 16, 0, 0);
@@ -736,11 +738,13 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         Q = __fmaf_rn(s0.y, gpr, __fmaf_rn(s1.x, gpg, __fmaf_rn(s1.y, gpb, __fmaf_rn(s2.x, gpd, s2.y * gpa)))) / T;
     }
 
+    // (positions are compared as floats -- exact below 2^24 -- and a padding slot of the last trip carries a position behind every
+    // contributor: no integer conversion and no validity flag in the trip; this kernel is bound by vector-instruction issue)
+    const float last_contributor_f = (float)last_contributor;
     auto trip = [&](const Fetched& f) {
-        const int pos = (int)f.pos1 - 1;
         const float dx = f.a.x - pixx, dy = f.a.y - pixy;
         const PairEval pe = eval_pair(dx, dy, f.b.x, f.b.y, f.b.z, f.b.w);
-        const float al = (f.valid != 0.0f && pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514; 0 = pair skipped
+        const float al = (f.pos1 <= last_contributor_f) ? pe.alpha : 0.0f;   // position < last contributor (backward.cu:499-514); 0 = pair skipped
         const float G = (al > 0.0f) ? pe.G : 0.0f;
         // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
         const float mm = 1.0f - al;
@@ -821,14 +825,17 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
             grp++;
             if (m != 0ull) {
                 const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(n_eff - 1 - (scan_off + lane));
+                if ((m >> lane) & 1ull) L->lst[r & LMASK] = __float_as_uint((float)(n_eff - (scan_off + lane)));      // position + 1, as a float
                 nlist += __popcll(m);
             }
             scan_off += 64;
             scan_done = scan_off >= n_eff - lo;
         }
         __builtin_amdgcn_wave_barrier();
-        if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
+        if (nlist > F) { dma_records<true>(L, recs, F, nlist, nlist, lane); F = nlist; }
+        // the last trip's padding slots (list entries nlist .. next multiple of four: free, the list holds at most LCAP entries from C
+        // on): a position no pixel reaches; their ring slots hold the tile's first record (see dma_records)
+        if (scan_done && lane < ((C - nlist) & 3)) L->lst[(nlist + lane) & LMASK] = __float_as_uint(3.0e38f);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const int avail = nlist - C;
@@ -838,7 +845,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
                 const int li = C + 4 * t + slot;
                 Fetched f;
                 f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];
-                f.pos1 = (float)(L->lst[li & LMASK] + 1u); f.valid = li < nlist ? 1.0f : 0.0f;
+                f.pos1 = __uint_as_float(L->lst[li & LMASK]); f.valid = 1.0f;
                 return f;
             };
             Fetched f0 = get(0);
