@@ -36,6 +36,10 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             sf[9 + 2 * ((t_dev + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
         }
     }
+    // (once per thread, correctly rounded; per ELEMENT: a hardware square root and reciprocal, ~1 ulp each -- with this file's correctly
+    // rounded sqrt / divisions the update was ~40 vector instructions per element, ten million per step: as much issue time as the
+    // kernel's 165 MB are HBM time)
+    const float inv_bc1 = 1.0f / bc1, inv_bc2_sqrt = 1.0f / bc2_sqrt;
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
         const long long i = i4 * 4;
         float pv[4], gv[4], mv[4], vv[4];
@@ -89,8 +93,8 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             pv[k] *= 1.0f - lr * weight_decay;
             mv[k] = beta1 * mv[k] + (1.0f - beta1) * gv[k];
             vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
-            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
-            pv[k] -= (lr / bc1) * (mv[k] / denom);
+            const float denom = __builtin_amdgcn_sqrtf(vv[k]) * inv_bc2_sqrt + eps;
+            pv[k] -= (lr * inv_bc1) * (mv[k] * __builtin_amdgcn_rcpf(denom));
         }
         if (full) {
             reinterpret_cast<float4*>(p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
