@@ -102,6 +102,31 @@ def test_scene_generators_are_deterministic():
         np.testing.assert_allclose(np.linalg.norm(-R.T @ t), 3.0, atol=1e-12)       # camera centre on the ring
 
 
+def test_spatial_order_is_a_permutation_along_a_curve():
+    """densify.spatial_order (pure torch, any device): a permutation of the indices; consecutive Gaussians of the re-indexed set are
+    close in space (a Morton curve), which is all the rasterizer's memory traffic asks of it; deterministic; degenerate inputs
+    (all points equal, a single point) do not divide by zero."""
+    from moss_amd.densify import spatial_order
+    s = scenes.config2()
+    x = s.means3D
+    perm = spatial_order(x)
+    assert perm.dtype == torch.int64 and sorted(perm.tolist()) == list(range(x.shape[0]))
+    assert torch.equal(perm, spatial_order(x))
+    step = lambda y: float((y[1:] - y[:-1]).norm(dim=1).mean())
+    assert step(x[perm]) < 0.25 * step(x)                      # the generator's own order is uncorrelated with position
+    assert sorted(spatial_order(torch.zeros(5, 3)).tolist()) == [0, 1, 2, 3, 4]
+    assert spatial_order(torch.tensor([[1.0, 2.0, 3.0]])).tolist() == [0]
+
+
+def test_header_declares_the_spatial_order_hint():
+    """MOSS_HINT_SPATIAL_ORDER of include/moss_raster.h and its Python mirror are the same bit, distinct from the raw-parameter bits."""
+    from moss_amd.diff_gaussian_rasterization import _C
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "moss_raster.h")).read()
+    m = re.search(r"#define\s+MOSS_HINT_SPATIAL_ORDER\s+(\d+)", text)
+    assert m and int(m.group(1)) == _C.HINT_SPATIAL_ORDER == 8
+    assert _C.HINT_SPATIAL_ORDER & (_C.RAW_OPACITY | _C.RAW_SCALE | _C.RAW_ROTATION) == 0
+
+
 def test_shard_views():
     from moss_amd.dist import shard_views
     parts = [shard_views(10, r, 4) for r in range(4)]
