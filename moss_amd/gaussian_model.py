@@ -46,7 +46,9 @@ class GaussianSet(nn.Module):
         if given, the rows of a ``FlatAdamW``'s moments with them -- and remember that index neighbours are now spatial neighbours
         (``render`` passes the hint to the op).  Results do not depend on the index order; the memory traffic of the binning and of the
         per-Gaussian kernels does (profiles/r02_notes.md, finding 30).  Meant for the moments the set is rebuilt anyway (MOSS:
-        densify / prune, scene/gaussian_model.py:densification_postfix); not capturable.  Returns the permutation."""
+        densify / prune, scene/gaussian_model.py:densification_postfix); not capturable.  Returns the permutation: per-Gaussian state
+        kept OUTSIDE this module and the optimizer (``DensifyStats`` accumulators, an LBS transform table) must be indexed with it too --
+        MOSS resets its own accumulators at exactly these moments (densification_postfix)."""
         from .densify import spatial_order
         perm = spatial_order(self._xyz.detach())
         if optimizer is not None and hasattr(optimizer, "permute_rows"):
