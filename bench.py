@@ -87,6 +87,11 @@ def parse_args(argv=None):
                     help="index order of the synthetic Gaussians: as generated (uncorrelated with position -- the default, and the "
                          "least favourable) or re-indexed along a Morton curve (moss_amd.densify.spatial_order); a side experiment, "
                          "named in config.workload when used")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded"],
+                    help="N > 1 only. allreduce = one all-reduce (mean) of the flat gradient bucket, then the full AdamW on every rank; "
+                         "sharded = reduce-scatter, AdamW on the rank's 1/N of the parameters (moments memory and update time / N), "
+                         "all-gather of the updated parameters (moss_amd.dist.ShardedStep).  The other variant is measured after the "
+                         "timed region and reported beside the headline as `exchange_variants`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
     ap.add_argument("--cpu-iters", type=int, default=20,
@@ -140,7 +145,7 @@ class Harness:
     n_exchange = 0
 
     def __init__(self, args, dev, rank, world, scene, cam, gt, gt_mask, bg, *, mode, activations, torch_activations, torch_adamw,
-                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None):
+                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None, exchange="allreduce"):
         import torch
         from types import SimpleNamespace
         from moss_amd import dist as mdist
@@ -159,13 +164,19 @@ class Harness:
             raw_parameters_in_op=(not torch_activations and activations == "in_op" and unified and mode in ("scale_rot", "lbs")),
             raster_context=self.ctx)
         self.lbs_T = lbs_T
-        self.bucket = bucket = mdist.GradBucket(list(pc.parameters()))
+        self.exchange_kind = exchange if (world > 1 and not torch_adamw) else "allreduce"
+        self.bucket = bucket = mdist.GradBucket(list(pc.parameters()), world=world if self.exchange_kind == "sharded" else 1)
         pipe.grad_bucket = bucket
+        self.sharded = None
         if torch_adamw:
             self.opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15)          # scene/gaussian_model.py:226
         else:
             from moss_amd.optim import FlatAdamW
-            self.opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)     # same rule, one kernel over the bucket
+            # same rule, one kernel over the bucket (sharded: over this rank's 1/N of it, between a reduce-scatter and an all-gather)
+            self.opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True,
+                                 shard=(rank, world) if self.exchange_kind == "sharded" else None)
+            if self.exchange_kind == "sharded":
+                self.sharded = mdist.ShardedStep(bucket, self.opt, rank, world)
         self.use_graph = bool(graph) and forward == "async" and not torch_adamw and caller_side is None
         self.ctx.set_async(forward == "async")
         if unified:
@@ -225,26 +236,49 @@ class Harness:
         self.step = self.eager_step
         self.graphed = None
         self.graph_note = "eager launches"
-        self.t_allreduce = self.t_adamw = 0.0
+        self.t_phase = [0.0, 0.0, 0.0]       # allreduce: [all-reduce, AdamW, -]; sharded: [reduce-scatter, AdamW on the shard, all-gather]
         self._ev = None
         self._ev_pending = False
 
     def exchange(self):
-        """N > 1: ONE RCCL all-reduce of the flat gradient bucket (+ loss slot), then AdamW; both timed with event pairs."""
-        torch = self.torch
+        """N > 1, after the rank-local part of the step.  allreduce: ONE RCCL all-reduce (mean) of the flat gradient bucket (+ loss
+        block), then the full AdamW.  sharded: reduce-scatter, AdamW on this rank's shard, all-gather of the parameters
+        (moss_amd.dist.ShardedStep, spelled out here so that each phase sits between two events)."""
+        torch, mdist = self.torch, sys.modules["moss_amd.dist"]
         if self._ev is None:
-            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         if self._ev_pending:                                 # the previous step's pairs (long complete: no stall)
-            self._ev[2].synchronize()
-            self.t_allreduce += self._ev[0].elapsed_time(self._ev[1]); self.t_adamw += self._ev[1].elapsed_time(self._ev[2])
+            self._ev[3].synchronize()
+            for i in range(3):
+                self.t_phase[i] += self._ev[i].elapsed_time(self._ev[i + 1])
             self.n_exchange += 1
-        e0, e1, e2 = self._ev
-        e0.record()
-        self.bucket.all_reduce_mean(None, self.world)
-        e1.record()
-        self.opt.step()
-        e2.record()
+        e = self._ev
+        e[0].record()
+        if self.sharded is None:
+            self.bucket.all_reduce_mean(None, self.world)
+            e[1].record()
+            self.opt.step()
+            e[2].record(); e[3].record()
+        else:
+            sh, per = self.sharded, self.bucket.shard_len
+            mdist._reduce_scatter_mean(self.opt.grad_shard, self.bucket.flat, self.world)
+            e[1].record()
+            self.opt.step()
+            if sh.rank == sh.tail_rank:
+                sh.loss_terms.copy_(self.opt.grad_shard[sh.tail_off:sh.tail_off + 4])
+            e[2].record()
+            torch.distributed.all_gather_into_tensor(self.opt.flat_params, self.opt.flat_params[sh.rank * per:(sh.rank + 1) * per])
+            e[3].record()
         self._ev_pending = True
+
+    def exchange_report(self):
+        """{phase: ms per step} over the steps since the counters were reset."""
+        n = max(self.n_exchange, 1)
+        t = [round(x / n, 4) for x in self.t_phase]
+        if self.sharded is None:
+            return {"allreduce_ms": t[0], "adamw_ms": t[1], "bytes_reduced": int(self.bucket.flat.numel() * 4), "adamw_elements": int(self.opt.count)}
+        return {"reduce_scatter_ms": t[0], "adamw_ms": t[1], "all_gather_ms": t[2], "bytes_reduced": int(self.bucket.flat.numel() * 4),
+                "adamw_elements": int(self.opt.count)}
 
     def eager_step(self):
         out = self.compute()
@@ -272,7 +306,8 @@ class Harness:
             graph_step()
         self.torch.cuda.synchronize(self.dev)
         self.step = graph_step
-        self.graph_note = "one hipGraph replay per step" + (" + eager RCCL all-reduce and AdamW" if self.world > 1 else "")
+        self.graph_note = "one hipGraph replay per step" + ((" + eager RCCL all-reduce and AdamW" if self.sharded is None else
+                                                             " + eager RCCL reduce-scatter, AdamW on the rank's shard, all-gather") if self.world > 1 else "")
 
     def time_steps(self, n, barrier=None):
         torch = self.torch
@@ -361,7 +396,7 @@ def main(argv=None):
 
     h = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
                 torch_activations=args.torch_activations, torch_adamw=args.torch_adamw, forward=args.forward, graph=args.graph,
-                lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None)
+                lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=args.exchange)
     opt, bucket, pc = h.opt, h.bucket, h.pc
     pc.spatially_ordered = args.order == "morton"
 
@@ -408,7 +443,7 @@ def main(argv=None):
     # the timed region restore this snapshot and REPLAY THE SAME K ITERATIONS (the kernels are deterministic), so the per-kernel
     # durations they report belong to exactly the frames the timed region rendered.
     snap = opt.snapshot() if hasattr(opt, "snapshot") else None
-    h.t_allreduce = h.t_adamw = 0.0
+    h.t_phase = [0.0, 0.0, 0.0]
     h.n_exchange = 0
     note("entering timed region")
     # ---- timed region: EXACTLY K steps between barrier+sync pairs -------------------------------------------
@@ -419,9 +454,7 @@ def main(argv=None):
         # really did the work; an overflowed frame would have produced a background image and is an error here
         h.ctx.check_status()
         assert h.ctx.last_needed > 0
-    exchange_ms = None
-    if world > 1 and h.n_exchange:
-        exchange_ms = (h.t_allreduce / h.n_exchange, h.t_adamw / h.n_exchange)
+    exchange_rep = h.exchange_report() if (world > 1 and h.n_exchange) else None
     dom_in_region = None
     replicas_identical = None
     if not use_graph:
@@ -432,7 +465,7 @@ def main(argv=None):
         elapsed = float(tt.item())
         # frame-parallel replicas must hold bit-identical parameters after the same sequence of averaged gradients
         if hasattr(opt, "flat_params"):
-            chk = opt.flat_params.double().sum().reshape(1)
+            chk = opt.flat_params[:bucket.n_params].double().sum().reshape(1)
             lo, hi = chk.clone(), chk.clone()
             torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
             torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
@@ -447,6 +480,35 @@ def main(argv=None):
             t_long = float(tt.item())
         long_run = {"steps": LONG_STEPS, "value": round(world * LONG_STEPS / t_long, 3), "ms_per_step": round(1e3 * t_long / LONG_STEPS, 4),
                     "why": f"the {args.steps}-step timed region lasted {1e3 * elapsed:.1f} ms (< {MIN_TIMED_MS:.0f} ms)"}
+
+    # ---- N > 1: the OTHER exchange variant, measured the same way (every rank takes part), reported beside the headline ----------
+    exchange_variants = None
+    if world > 1 and not args.torch_adamw:
+        exchange_variants = {h.exchange_kind: dict(exchange_rep or {}, value=round(world * args.steps / elapsed, 3),
+                                                   ms_per_step=round(1e3 * elapsed / args.steps, 4), steps=args.steps,
+                                                   replicas_identical=replicas_identical, headline=True)}
+        other = "sharded" if h.exchange_kind == "allreduce" else "allreduce"
+        h2 = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
+                     torch_activations=args.torch_activations, torch_adamw=False, forward=args.forward, graph=args.graph,
+                     lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=other)
+        for _ in range(max(args.warmup, 3)):
+            h2.step()
+        torch.cuda.synchronize(dev)
+        if h2.use_graph:
+            h2.capture()
+        h2.t_phase = [0.0, 0.0, 0.0]; h2.n_exchange = 0
+        n2 = max(args.steps, 50)
+        t2, _ = h2.time_steps(n2, barrier)
+        tt = torch.tensor([t2], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        t2 = float(tt.item())
+        chk = h2.opt.flat_params[:h2.bucket.n_params].double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        exchange_variants[other] = dict(h2.exchange_report(), value=round(world * n2 / t2, 3), ms_per_step=round(1e3 * t2 / n2, 4), steps=n2,
+                                        replicas_identical=bool((lo == hi).item()), headline=False)
+        del h2
+        torch.cuda.empty_cache()
 
     # ---- per-kernel device times: eager replay of the same K iterations with a hipEvent pair around every kernel of the op -------
     # (graph mode: events inside a replayed graph cannot be read back, so this replay is also where the dominant kernel's launch
@@ -493,8 +555,8 @@ def main(argv=None):
     stages = {}
     for k, ms in stage_ms.items():
         gbs = all_b[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        stages[k] = {"ms": ms, "algorithmic_bytes": int(all_b[k]), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
-                     "traffic": pmc.get(k)}
+        stages[k] = {"ms": ms, "algorithmic_bytes": int(all_b[k]), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5)}
+        stages[k].update(_traffic_fields(pmc.get(k)))
 
     result = {
         "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)" if args.config == "cfg3" else f"train iters/sec ({args.config})",
@@ -515,7 +577,7 @@ def main(argv=None):
                      "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),
                      # PMC bytes were collected on the headline workload with exactly these kernel sources (profiles/pmc_latest.json is
                      # stamped with the sha256 of moss_amd/csrc/): null for any other workload or any other source state
-                     "traffic": pmc.get(dominant),
+                     **_traffic_fields(pmc.get(dominant)), "traffic_source": PMC_SOURCE,
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 5),
                      "timing": ("hipEvents attached to the kernel (hipExtLaunchKernelGGL start/stop) on its launch stream, over an eager "
                                 "replay of the SAME K iterations (parameters and optimizer state restored to the start of the "
@@ -535,9 +597,11 @@ def main(argv=None):
         result["rccl_ranks"] = rccl_ranks
         result["backend"] = torch.distributed.get_backend()
         result["replicas_identical"] = replicas_identical
-        if exchange_ms is not None:
-            result["allreduce_ms"], result["adamw_ms"] = round(exchange_ms[0], 4), round(exchange_ms[1], 4)
-            result["allreduce_bytes"] = int(bucket.flat.numel() * 4)
+        result["exchange"] = h.exchange_kind
+        if exchange_rep is not None:
+            result.update({k: v for k, v in exchange_rep.items() if k.endswith("_ms")})
+            result["allreduce_bytes"] = exchange_rep["bytes_reduced"]
+        result["exchange_variants"] = exchange_variants
     if world == 1:
         result["densify_side_ms"] = densify_side(pc, out)
     if world == 1 and not args.no_callers and headline:
@@ -548,6 +612,7 @@ def main(argv=None):
         if "spatial_order" in result["callers"]:
             result["value_spatial_order"] = result["callers"]["spatial_order"].get("value")
         result["value_lbs_in_op"] = result["callers"]["lbs_in_op"].get("value")
+        result["value_precomp"] = result["callers"]["precomp_graph"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
         result["cpu_baseline_autograd"] = cpu_baseline_autograd()
@@ -565,6 +630,8 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                          L1+SSIM loss, DensifyStats, flat AdamW, fused activation kernels (still cov3D_precomp from Python, still
                          synchronous and eager)
       lbs_in_op          the transforms applied inside the op (raw parameters, asynchronous forward, one hipGraph per step)
+      precomp_graph      cov3D_precomp built in Python from the fused-activated parameters (MOSS's shipped compute_cov3D_python=True,
+                         without LBS transforms), asynchronous forward, one hipGraph per step: `value_precomp`
       spatial_order      the HEADLINE configuration on the same Gaussians re-indexed along a Morton curve (densify.spatial_order, what
                          a caller would do whenever it rebuilds its tensors: densify / prune): the synthetic scene's own index order is
                          uncorrelated with position -- the least favourable case for the per-tile counters and the gathers by
@@ -578,6 +645,9 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         "dropin_fused_sides": dict(mode="lbs_python", activations="fused", torch_activations=False, torch_adamw=False, forward="sync", graph=0,
                                    fused_loss=True, caller_side="fused"),
         "lbs_in_op": dict(mode="lbs", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
+        # MOSS's shipped input mode (compute_cov3D_python=True, arguments/__init__.py:60: the covariance built by torch ops from the
+        # activated scales / rotations and handed over as cov3D_precomp) through the same graph path as the headline
+        "precomp_graph": dict(mode="precomp", activations="fused", torch_activations=False, torch_adamw=False, forward="async", graph=1),
     }
     if args.order == "as_generated" and args.mode in ("scale_rot", "lbs") and args.forward == "async" and args.graph:
         # (the pair is measured the same way -- same harness, same number of replays -- so that their RATIO is the effect of the order)
@@ -669,9 +739,26 @@ def _pmc_traffic():
             data = json.load(f)
         if data.get("csrc_sha256") != csrc_sha256():
             return {}
-        return {k: v.get("hbm_bytes_per_launch") for k, v in data.items() if isinstance(v, dict)}
+        return {k: v for k, v in data.items() if isinstance(v, dict)}
     except Exception:
         return {}
+
+
+PMC_SOURCE = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected by the builder (scripts/gpu_profile_round.sh, "
+              "separate counter-only passes over the eager form of this step), committed and stamped with the sha256 of moss_amd/csrc/; "
+              "NOT measured in this run -- null when the stamp does not match the checkout")
+
+
+def _traffic_fields(rec):
+    """traffic (+ how to read it) of one stage from its PMC record: a number for kernels whose reads are wide coalesced streams (the
+    guide's calibrated 2 x FETCH_SIZE + WRITE_SIZE), the UPPER end of [raw, 2 x raw] for gather kernels (interval beside it)."""
+    if not rec or rec.get("hbm_bytes_per_launch") is None:
+        return {"traffic": None}
+    out = {"traffic": rec["hbm_bytes_per_launch"]}
+    if rec.get("traffic_bound") == "upper" and rec.get("hbm_bytes_interval"):
+        out["traffic_interval"] = rec["hbm_bytes_interval"]
+        out["traffic_is"] = "upper bound (gather reads: FETCH_SIZE doubling uncalibrated)"
+    return out
 
 
 def cpu_baseline(scene, args, gt, gt_mask):
@@ -737,44 +824,85 @@ def dry_run_cpu(args):
     rank, world, _ = mdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     ranks = dist.get_world_size() if world > 1 else 1
-    params = [torch.nn.Parameter(torch.zeros(1000, 3)), torch.nn.Parameter(torch.zeros(1000, 16, 3))]
-    bucket = mdist.GradBucket(params)
-    flat_params = torch.zeros(bucket.flat.numel() - 4)
-    t_ar = [0.0]
+    variants = {}
 
-    def step():
-        bucket.flat.fill_(float(rank + 1))                   # "the backward": rank-dependent gradients
+    class _SgdShard:
+        """stand-in optimizer of the sharded path: p -= 0.1 g on this rank's shard (what FlatAdamW(shard=...) is to ShardedStep)"""
+        def __init__(self, bucket, rank):
+            per = bucket.shard_len
+            self.flat_params = torch.zeros(bucket.flat.numel())
+            self.grad_shard = torch.zeros(per)
+            self.first = min(rank * per, bucket.n_params)
+            self.count = min(self.first + per, bucket.n_params) - self.first
+
+        def step(self):
+            self.flat_params[self.first:self.first + self.count].add_(self.grad_shard[:self.count], alpha=-0.1)
+
+    def run(kind):
+        params = [torch.nn.Parameter(torch.zeros(1000, 3)), torch.nn.Parameter(torch.zeros(1000, 16, 3))]
+        bucket = mdist.GradBucket(params, world=world if kind == "sharded" else 1)
+        n = bucket.n_params
+        if kind == "sharded" and world > 1:
+            opt = _SgdShard(bucket, rank)
+            sharded = mdist.ShardedStep(bucket, opt, rank, world)
+            flat_params = opt.flat_params
+        else:
+            sharded, flat_params = None, torch.zeros(n)
+        t_ar = [0.0]
+
+        def step():
+            bucket.flat[:n].fill_(float(rank + 1))           # "the backward": rank-dependent gradients
+            bucket.loss_terms.fill_(float(rank + 1))
+            t0 = time.perf_counter()
+            if sharded is not None:
+                sharded.step()
+            else:
+                bucket.all_reduce_mean(None, world)
+            t_ar[0] += time.perf_counter() - t0
+            if sharded is None:
+                flat_params[:n].add_(bucket.flat[:n], alpha=-0.1)      # "the optimizer"
+        for _ in range(max(args.warmup, 1)):
+            step()
+        t_ar[0] = 0.0
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
-        bucket.all_reduce_mean(None, world)
-        t_ar[0] += time.perf_counter() - t0
-        flat_params.add_(bucket.flat[:-4], alpha=-0.1)       # "the optimizer"
-    for _ in range(max(args.warmup, 1)):
-        step()
-    t_ar[0] = 0.0
+        for _ in range(args.steps):
+            step()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        identical = True
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            chk = flat_params[:n].double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            identical = bool((lo == hi).item())
+            mean = (world + 1) / 2.0                                            # the mean of 1..world
+            loss_seen = float((sharded.loss_terms if sharded is not None else bucket.loss_terms)[0])
+            assert abs(loss_seen - mean) < 1e-6, (kind, loss_seen)
+            want = -0.1 * mean * (max(args.warmup, 1) + args.steps)
+            assert abs(float(flat_params[0]) - want) < 1e-4 * abs(want) and abs(float(flat_params[n - 1]) - want) < 1e-4 * abs(want), kind
+        return {"value": round(world * args.steps / elapsed, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                "exchange_ms": round(1e3 * t_ar[0] / args.steps, 4), "replicas_identical": identical,
+                "checksum": float(flat_params[:n].double().sum())}
+
+    variants[args.exchange] = run(args.exchange)
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    identical = True
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        chk = flat_params.double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        identical = bool((lo == hi).item())
-        assert abs(float(bucket.flat[0]) - (world + 1) / 2.0) < 1e-6          # the mean of 1..world
+        other = "sharded" if args.exchange == "allreduce" else "allreduce"
+        variants[other] = run(other)
+        assert variants[other]["checksum"] == variants[args.exchange]["checksum"], "the two exchange paths left different parameters"
+    head = variants[args.exchange]
     if rank == 0:
-        print(json.dumps({"metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)", "value": round(world * args.steps / elapsed, 3),
+        print(json.dumps({"metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)", "value": head["value"],
                           "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "DRY RUN: no GPU work (launcher / collective plumbing test)",
                           "config": {"workload": "dry run"}, "rccl_ranks": ranks, "backend": dist.get_backend() if world > 1 else None,
-                          "replicas_identical": identical, "allreduce_ms": round(1e3 * t_ar[0] / args.steps, 4), "adamw_ms": 0.0}))
+                          "replicas_identical": all(v["replicas_identical"] for v in variants.values()), "exchange": args.exchange,
+                          "allreduce_ms": head["exchange_ms"], "adamw_ms": 0.0, "exchange_variants": variants}))
 
 
 if __name__ == "__main__":

@@ -9,7 +9,9 @@
  *   - the implicit CUDA legacy default stream       ->  an explicit hipStream_t passed as void*.
  * All pointers are DEVICE pointers to contiguous fp32 (int32 for radii) unless stated otherwise; an absent
  * optional input is NULL (DGR/rasterize_points.cu passes the null data_ptr() of an empty tensor).
- * No torch types appear here; the Python side (moss_amd/diff_gaussian_rasterization) binds it with ctypes.
+ * No torch types appear here.  The rasterizer entry points are bound by the compiled PyTorch-ROCm extension
+ * moss_amd/csrc/torch_binding.cpp (the counterpart of DGR/rasterize_points.cu); the side kernels (k-NN, loss, AdamW,
+ * densification statistics) by ctypes in moss_amd/_lib.py.
  *
  * The three scratch buffers are opaque to the caller exactly as in the reference (their internal layout is
  * this library's own); the caller must keep them alive and unmodified between forward and
@@ -25,7 +27,12 @@
 extern "C" {
 #endif
 
-#define MOSS_ABI_VERSION 1
+/* Version 2 (round 3): the frame state is an ARGUMENT of the asynchronous forwards (version 1 armed it per host thread through
+ * moss_raster_frame_state(), removed); the `debug` argument is a bit set (MOSS_DEBUG_*); moss_adamw_state_bytes() replaces the
+ * caller's knowledge of the device-step block's size (288 bytes in early version-1 builds, 9216 later); diagnostics
+ * (environment knobs, stamp buffers) exist only in -DMOSS_DIAG builds.  A binding compiled against another version must refuse to
+ * load: compare ITS compile-time MOSS_ABI_VERSION with moss_abi_version(). */
+#define MOSS_ABI_VERSION 2
 
 /* error codes (negative returns) */
 #define MOSS_ERR_INVALID_ARG   (-1)   /* bad shape / null where required (AT_ERROR in DGR/rasterize_points.cu:57-59) */
@@ -53,8 +60,15 @@ const char* moss_last_error(void);
  *   Outputs need NOT be pre-zeroed (the reference requires zero-filled tensors; every element is written here).
  * Returns num_rendered >= 0 (the number of (Gaussian, tile) instances), or a negative error code.
  * Performs ONE stream synchronisation (to size the binning buffer), like the reference's blocking read
- * at rasterizer_impl.cu:283.  With debug != 0 the stream is synchronised and checked after every launch.
+ * at rasterizer_impl.cu:283.
+ * `debug` is a bit set.  MOSS_DEBUG_SYNC (1, the reference's `debug = true`): the stream is synchronised and checked after every
+ * launch (CHECK_CUDA, auxiliary.h:166-173).  MOSS_DEBUG_NO_BLOCK_CULL (2; forward AND the matching backward call): the blend kernels
+ * ignore the per-instance 4x4-block masks and test every list entry against every block.  The masks only SKIP (entry, block)
+ * pairs that cannot reach alpha >= 1/255: final_T and n_contrib are bit-identical either way, images and gradients equal up to
+ * float32 summation order (tests/test_gpu_ops.py::test_block_mask_culling_never_changes_a_result).  Per call, no global state.
  */
+#define MOSS_DEBUG_SYNC          1
+#define MOSS_DEBUG_NO_BLOCK_CULL 2
 int moss_raster_forward(
     moss_alloc_fn geometry_alloc, void* geometry_user,
     moss_alloc_fn binning_alloc, void* binning_user,
@@ -90,7 +104,21 @@ int moss_raster_forward(
  * If a frame needs more instances than `capacity`, nothing is rendered (outputs = background, gradients = 0) and the
  * overflow bit is set in the status words; poll them with moss_raster_read_status once the stream has advanced.
  * `debug` is not available in this mode (it synchronises by definition).
+ *
+ * `frame_state` (optional, may be NULL; no counterpart in the reference, which memsets its buffers in every forward): a caller-owned
+ * device block of moss_raster_frame_state_bytes(width, height) bytes, zero-initialised ONCE.  With it this call keeps the per-frame
+ * counters its kernels add to (tile histogram, tile cursors, error flags) in that block instead of in the image buffer and returns
+ * the block all-zero again (its sort kernel re-zeroes it; error paths clean it too), so no clear kernel runs in front of the
+ * preprocess kernel -- one launch less per frame (4 us inside a captured graph).  One block per concurrent user (stream); the same
+ * block serves every call of that user, also across image sizes up to the one it was sized for.  The library keeps NO state between
+ * calls: the block is an argument (ABI version 1 armed it per host thread).  Its address is a kernel argument, so a block handed
+ * to a call that was captured into a hipGraph must stay alive for as long as that graph is replayed.
+ * The 32-bit word MOSS_FRAME_STATE_DROPPED_WORD of the block is a STICKY counter: the library adds 1 for every frame that
+ * overflowed its capacity (and therefore rendered nothing) and never clears it; the caller reads it whenever it likes (e.g. once per
+ * few hundred replays of a captured step -- the status words only describe the LAST frame) and writes 0 back.
  */
+#define MOSS_FRAME_STATE_DROPPED_WORD 4
+size_t moss_raster_frame_state_bytes(int width, int height);
 int moss_raster_forward_async(
     moss_alloc_fn geometry_alloc, void* geometry_user,
     moss_alloc_fn binning_alloc, void* binning_user,
@@ -101,19 +129,7 @@ int moss_raster_forward_async(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream);
-
-/*
- * Frame state (optional; no counterpart in the reference, which memsets its buffers in every forward): a caller-owned device block of
- * moss_raster_frame_state_bytes(width, height) bytes, zero-initialised ONCE.  moss_raster_frame_state(ptr) makes the NEXT
- * moss_raster_forward* call of the calling host thread keep the per-frame counters its kernels add to (tile histogram, tile cursors,
- * error flags) in that block instead of in the image buffer; the forward returns the block all-zero again (its sort kernel re-zeroes
- * it; error paths clean it too), so no clear kernel runs in front of the preprocess kernel -- one launch less per frame (4 us inside a
- * captured graph).  One block per concurrent user (stream); the same block serves every call of that user, also across image sizes
- * up to the one it was sized for.
- */
-size_t moss_raster_frame_state_bytes(int width, int height);
-int moss_raster_frame_state(char* frame_state);
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream);
 
 /* Enqueue (on `stream`) a copy of the forward's 8 status words from the image buffer to pinned host memory:
  * [0] instances rendered  [1] longest tile list  [2] flags: bit0 prefiltered-point culled, bit1 capacity overflow
@@ -213,16 +229,27 @@ int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_a
                     int num_segments, const long long* segment_end, const float* segment_lr,
                     const int* segment_period, const int* segment_split, const float* segment_lr2,
                     float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
-/* Same update with the step counter kept on the device: `step_state` is MOSS_ADAMW_STATE_BYTES (9216) zero-initialised device bytes
+/* Same update with the step counter kept on the device: `step_state` is moss_adamw_state_bytes() (= MOSS_ADAMW_STATE_BYTES of the
+ * header the library was built from; ask the library, a binding's copy of the constant can be stale) zero-initialised device bytes
  * (32-bit words: [0] = int step, advanced by one per call by the update kernel itself; [8..11] = the bias corrections of the
  * current / next step, double-buffered by step parity; [64] and [128 + 64 g], g < 32 = its two-level block-completion counters,
  * each on a 256-byte line of its own).  n must be > 0.  Nothing in the call depends on a host-side
  * counter, so a captured hipGraph of a training step replays correctly. */
 #define MOSS_ADAMW_STATE_BYTES 9216
+size_t moss_adamw_state_bytes(void);
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
                             const int* segment_period, const int* segment_split, const float* segment_lr2,
                             float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
+
+/* The same update on a SHARD of the flat buffers: the arrays hold the elements [first, first + count) (first a multiple of 4) of the
+ * buffers the segment table -- global indices, as above -- describes.  step_state != NULL: device-side step counter (then `step` is
+ * ignored), else `step` counts from 1.  For N ranks that reduce-scatter the gradient bucket, update their 1/N of the parameters
+ * (moments memory and update time / N) and all-gather the result (moss_amd/dist.py ShardedStep). */
+int moss_adamw_flat_range(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                          int num_segments, const long long* segment_end, const float* segment_lr,
+                          const int* segment_period, const int* segment_split, const float* segment_lr2,
+                          float beta1, float beta2, float eps, float weight_decay, int step, void* step_state, void* stream);
 
 /*
  * k nearest reference points of every query point, 3-D, exact, k = 1..4: replaces the third-party
@@ -281,7 +308,7 @@ int moss_raster_forward_tf(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream);
 int moss_raster_backward_tf(
     int P, int D, int M, int R,
     const float* background, int width, int height,
@@ -317,7 +344,7 @@ int moss_raster_forward_raw(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, void* stream);
 int moss_raster_backward_raw(
     int P, int D, int M, int R,
     const float* background, int width, int height,
@@ -392,17 +419,19 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
 #define MOSS_STAGE_MERGE_GATHER   7   /* the second kernel of the tile sort: rank merge + per-instance emit */
 #define MOSS_NUM_STAGES           8
 void moss_raster_profile_enable(uint32_t stage_mask);
-/* Diagnostics: register a device buffer of 8 x (4 * padded tile count) uint64; while set, the forward blend kernel stores per
- * workgroup {total, barrier-1, staging, barrier-2, cull, trips} cycles of its first wave and {batches, trips} counts. NULL = off. */
+int moss_raster_profile_read(float* ms_sum /* [MOSS_NUM_STAGES] */, uint32_t* count /* [MOSS_NUM_STAGES] */);
+
+/* 1 if the library was built with -DMOSS_DIAG (python -m moss_amd.build --diag -> moss_amd/lib_diag/): it then reads MOSS_*
+ * environment knobs that select kernel variants for A/B timing -- some give WRONG results on purpose -- and exports the stamp
+ * entry points below.  The product build returns 0, reads no environment variable and does not export them. */
+int moss_build_has_diagnostics(void);
+#ifdef MOSS_DIAG
+/* register a device buffer of 8 x (4 * padded tile count) uint64; while set, the forward blend kernel stores per item
+ * {total, list length, starve, first trip, begin, trip cycles, rounds, trips} of its blender wave.  NULL = off. */
 void moss_raster_debug_set_stamps(unsigned long long* device_buffer);
 /* the same for the backward blend kernel: 16 words per wave (start, end of the segment phase, end, item counts and cycle sums) */
 void moss_raster_debug_set_bwd_stamps(unsigned long long* device_buffer);
-/* Diagnostics: override the blend kernels' use of the per-instance block masks (1 = use them, the default; 0 = treat every entry as a
- * hit for every 4x4 block; -1 = back to the MOSS_BLEND_CULL environment default).  The masks only SKIP pairs that cannot reach
- * alpha >= 1/255: final_T, n_contrib and all gradients are bit-identical either way, the images equal up to fp32 summation order
- * (tests/test_gpu_ops.py::test_block_mask_culling_never_changes_a_result). */
-void moss_raster_debug_set_cull(int mode);
-int moss_raster_profile_read(float* ms_sum /* [MOSS_NUM_STAGES] */, uint32_t* count /* [MOSS_NUM_STAGES] */);
+#endif
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,12 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmoss_raster.so")
-EXT_PATH = os.path.join(_HERE, "lib", "_moss_C.so")      # the compiled PyTorch extension (csrc/torch_binding.cpp) over the same C ABI
+# "lib" = the product build.  MOSS_AMD_LIB_DIR=lib_diag selects the DIAGNOSTIC build (python -m moss_amd.build --diag: -DMOSS_DIAG,
+# environment knobs that pick kernel variants, stamp buffers) -- for the A/B scripts under scripts/, never for results.
+_LIB_DIR = os.path.join(_HERE, os.environ.get("MOSS_AMD_LIB_DIR", "lib"))
+LIB_PATH = os.path.join(_LIB_DIR, "libmoss_raster.so")
+EXT_PATH = os.path.join(_LIB_DIR, "_moss_C.so")          # the compiled PyTorch extension (csrc/torch_binding.cpp) over the same C ABI
+ABI_VERSION = 2                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -36,8 +40,8 @@ def _declare(lib):
     lib.moss_raster_binning_bytes.argtypes = [_i]
     lib.moss_raster_frame_state_bytes.restype = C.c_size_t
     lib.moss_raster_frame_state_bytes.argtypes = [_i, _i]
-    lib.moss_raster_frame_state.restype = _i
-    lib.moss_raster_frame_state.argtypes = [_p]
+    lib.moss_build_has_diagnostics.restype = _i
+    lib.moss_adamw_state_bytes.restype = C.c_size_t
     lib.moss_raster_forward.restype = _i
     lib.moss_raster_forward.argtypes = [
         ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p,          # geometry / binning / image allocators
@@ -48,10 +52,11 @@ def _declare(lib):
         _p, _p, _p,                                        # viewmatrix, projmatrix, cam_pos
         _f, _f, _i,                                        # tan_fovx, tan_fovy, prefiltered
         _p, _p, _p, _p, _i, _p]                            # out_color, out_depth, out_alpha, radii, debug, stream
+    _fwd = list(lib.moss_raster_forward.argtypes)
     lib.moss_raster_forward_async.restype = _i
-    lib.moss_raster_forward_async.argtypes = list(lib.moss_raster_forward.argtypes)      # debug -> capacity (both int)
+    lib.moss_raster_forward_async.argtypes = _fwd[:-1] + [_p, _p]                         # debug -> capacity (both int), frame_state, stream
     lib.moss_raster_forward_tf.restype = _i
-    lib.moss_raster_forward_tf.argtypes = list(lib.moss_raster_forward.argtypes)          # cov3D_precomp -> transforms, debug -> capacity
+    lib.moss_raster_forward_tf.argtypes = _fwd[:-1] + [_p, _p]                            # cov3D_precomp -> transforms, debug -> capacity, frame_state
     lib.moss_raster_backward_tf.restype = _i
     lib.moss_raster_backward_tf.argtypes = [
         _i, _i, _i, _i,                                    # P, D, M, R
@@ -80,7 +85,7 @@ def _declare(lib):
     lib.moss_raster_forward_raw.argtypes = [
         ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _p, _i, _i,
         _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _i,
-        _p, _p, _p, _p, _i, _i, _p]                         # ..., radii, raw_flags, capacity, stream
+        _p, _p, _p, _p, _i, _i, _p, _p]                     # ..., radii, raw_flags, capacity, frame_state, stream
     lib.moss_raster_backward_raw.restype = _i
     lib.moss_raster_backward_raw.argtypes = [
         _i, _i, _i, _i, _p, _i, _i,
@@ -114,12 +119,12 @@ def _declare(lib):
     lib.moss_adamw_flat.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]
     lib.moss_adamw_flat_devstep.restype = _i
     lib.moss_adamw_flat_devstep.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]
+    lib.moss_adamw_flat_range.restype = _i
+    lib.moss_adamw_flat_range.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p, _p]
     lib.moss_gaussian_activate_forward.restype = _i
     lib.moss_gaussian_activate_forward.argtypes = [_i, _i] + [_p] * 12
     lib.moss_gaussian_activate_backward.restype = _i
     lib.moss_gaussian_activate_backward.argtypes = [_i, _i] + [_p] * 15
-    lib.moss_raster_debug_set_cull.restype = None
-    lib.moss_raster_debug_set_cull.argtypes = [_i]
     lib.moss_raster_profile_enable.restype = None
     lib.moss_raster_profile_enable.argtypes = [C.c_uint32]
     lib.moss_raster_profile_read.restype = _i
@@ -141,6 +146,10 @@ def lib() -> C.CDLL:
                         f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
                         "(run `python -m moss_amd.build`); there is no CPU/PyTorch fallback for this op")
                 handle = C.CDLL(LIB_PATH)
+                handle.moss_abi_version.restype = _i
+                if handle.moss_abi_version() != ABI_VERSION:
+                    raise ImportError(f"{LIB_PATH} implements ABI version {handle.moss_abi_version()}, this binding needs {ABI_VERSION}: "
+                                      "rebuild it (python -m moss_amd.build --force)")
                 _declare(handle)
                 _lib = handle
     return _lib
@@ -168,8 +177,10 @@ def ext():
                 spec = importlib.util.spec_from_loader("_moss_C", loader)
                 mod = importlib.util.module_from_spec(spec)
                 loader.exec_module(mod)
+                # abi_version() is the extension's COMPILE-TIME MOSS_ABI_VERSION: a stale _moss_C.so next to a rebuilt library is caught
                 if mod.abi_version() != lib().moss_abi_version():
-                    raise ImportError("moss_amd/lib/_moss_C.so and libmoss_raster.so disagree on the ABI version: rebuild both")
+                    raise ImportError(f"{EXT_PATH} was compiled against ABI version {mod.abi_version()}, libmoss_raster.so implements "
+                                      f"{lib().moss_abi_version()}: rebuild both (python -m moss_amd.build --force)")
                 _ext = mod
     return _ext
 

@@ -1,7 +1,12 @@
 """Builds moss_amd/lib/libmoss_raster.so (the C-ABI library of include/moss_raster.h) with hipcc for gfx950.
 
 In-tree build: the .so is git-ignored but travels to the GPU box with the repo snapshot.
-``python -m moss_amd.build [--force]``
+``python -m moss_amd.build [--force] [--diag]``
+
+``--diag`` builds the DIAGNOSTIC variant into ``moss_amd/lib_diag/`` as well: the same sources with ``-DMOSS_DIAG`` plus
+``scripts/diag/knobs.cpp`` -- MOSS_* environment knobs that select kernel variants for A/B timing (some give wrong results on
+purpose) and the stamp buffers of the timeline scripts.  The product build in ``moss_amd/lib/`` has neither and reads no environment
+variable; ``MOSS_AMD_LIB_DIR=lib_diag`` makes ``moss_amd._lib`` load the diagnostic pair instead (scripts/ only).
 """
 from __future__ import annotations
 
@@ -43,17 +48,33 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OUT_DIR, exist_ok=True)
+DIAG_DIR = os.path.join(HERE, "lib_diag")
+DIAG_EXTRA_SOURCE = os.path.join(ROOT, "scripts", "diag", "knobs.cpp")
+
+
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """Build the product pair (lib/libmoss_raster.so, lib/_moss_C.so); with ``diag`` ALSO the diagnostic pair in lib_diag/."""
+    lib = _build_into(OUT_DIR, [], force, verbose)
+    if diag:
+        _build_into(DIAG_DIR, ["-DMOSS_DIAG"], force, verbose)
+    return lib
+
+
+def _build_into(out_dir: str, defines, force: bool, verbose: bool) -> str:
+    os.makedirs(out_dir, exist_ok=True)
+    lib_path = os.path.join(out_dir, "libmoss_raster.so")
     headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "moss_raster.h"), os.path.abspath(__file__)]
     objs = []
     procs = []
-    for src, extra in SOURCES.items():
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+    sources = [(os.path.join(CSRC, src), extra) for src, extra in SOURCES.items()]
+    if defines:
+        sources.append((DIAG_EXTRA_SOURCE, ["-x", "hip"]))
+    for s, extra in sources:
+        src = os.path.basename(s)
+        o = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            cmd = [HIPCC] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [HIPCC] + COMMON + list(defines) + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -65,18 +86,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
         failed |= p.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or procs or _newer(LIB, objs):
-        # link under a temporary name and rename: a process that finds LIB never sees a half-written file
-        tmp = LIB + f".tmp{os.getpid()}"
+    if force or procs or _newer(lib_path, objs):
+        # link under a temporary name and rename: a process that finds the library never sees a half-written file
+        tmp = lib_path + f".tmp{os.getpid()}"
         subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs)
-        os.replace(tmp, LIB)
-    build_torch_extension(force=force, verbose=verbose)
-    return LIB
+        os.replace(tmp, lib_path)
+    build_torch_extension(force=force, verbose=verbose, out_dir=out_dir)
+    return lib_path
 
 
-def build_torch_extension(force: bool = False, verbose: bool = False) -> str:
-    """moss_amd/lib/_moss_C.so: host-only C++ (g++), the torch glue of the reference's rasterize_points.cu over the C ABI."""
+def build_torch_extension(force: bool = False, verbose: bool = False, out_dir: str = OUT_DIR) -> str:
+    """<out_dir>/_moss_C.so: host-only C++ (g++), the torch glue of the reference's rasterize_points.cu over the C ABI."""
     src = os.path.join(CSRC, "torch_binding.cpp")
+    EXT = os.path.join(out_dir, "_moss_C.so")
     if not (force or _newer(EXT, [src, os.path.join(ROOT, "include", "moss_raster.h"), os.path.abspath(__file__)])):
         return EXT
     import sysconfig
@@ -92,7 +114,7 @@ def build_torch_extension(force: bool = False, verbose: bool = False) -> str:
     for i in inc:
         cmd += ["-I", i]
     cmd += [src, "-o", tmp, "-L", tlib, "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
-            "-L", OUT_DIR, "-lmoss_raster", f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN"]
+            "-L", out_dir, "-lmoss_raster", f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -101,4 +123,4 @@ def build_torch_extension(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

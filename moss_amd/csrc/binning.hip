@@ -95,7 +95,10 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
         header[3] = 0u;
         header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u);       // (the preprocess kernel's flags: it finished before this one)
-        if (flags_acc != header + 2) *flags_acc = 0u;                       // frame state: zero again for the next forward
+        if (flags_acc != header + 2) {                                      // frame state: zero again for the next forward ...
+            *flags_acc = 0u;
+            if (overflow) flags_acc[FS_DROPPED_WORD] += 1u;                 // ... except its STICKY count of frames that rendered nothing
+        }
     }
     __syncthreads();
     for (int i = b; i < e; i++) {
@@ -612,12 +615,6 @@ export_binning_kernel(int T, GeomView g, const uint2* __restrict__ ranges, const
     }
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 }  // anonymous namespace
 
 __global__ void __launch_bounds__(256) clear_words_kernel(uint4* __restrict__ p, size_t n16)
@@ -641,6 +638,13 @@ __global__ void __launch_bounds__(256) zero_floats_kernel(float* __restrict__ p,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0f;
 }
 
+// The per-frame words of a caller's frame state: the flag word (its 16 bytes) and the tile counters; the sticky dropped-frame count stays.
+void clear_frame_state(char* frame_state, size_t bytes, hipStream_t s)
+{
+    launch_clear(frame_state, 16, s);
+    launch_clear(frame_state + FS_COUNTERS_OFFSET, bytes - FS_COUNTERS_OFFSET, s);
+}
+
 // Zero n floats of any alignment with a kernel (capture-safe, see launch_clear).
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s)
 {
@@ -651,7 +655,7 @@ void launch_zero_floats(float* ptr, size_t n, hipStream_t s)
 
 static int light_log2_knob()
 {
-    static const int v = std::max(0, std::min(31, env_int("MOSS_LIGHT_LOG2", LIGHT_TILE_LOG2)));
+    static const int v = std::max(0, std::min(31, knob("MOSS_LIGHT_LOG2", LIGHT_TILE_LOG2)));
     return v;
 }
 
@@ -666,15 +670,16 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 // read R back before the binning buffer exists (asynchronous forward).
 bool scatter_folds_scan(const FrameParams& fp)
 {
-    static const int on = env_int("MOSS_FOLD_SCAN", 1);
+    static const int on = knob("MOSS_FOLD_SCAN", 1);
     return on && fp.gx * fp.gy <= MAX_LDS_TILES;
 }
 
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
-    const int lds_hist = (T <= MAX_LDS_TILES) ? (((env_int("MOSS_EXPERIMENT", 0) & 2) != 0) ? 2 : 1) : 0;   // (2: timing experiment, no reservation atomics)
-    static const int per_thread = env_int("MOSS_SCATTER_ITEMS", 2);
+    // (2: timing experiment of MOSS_DIAG builds, no reservation atomics -- the keys are garbage and the forward stops behind this kernel)
+    const int lds_hist = (T <= MAX_LDS_TILES) ? (((knob("MOSS_EXPERIMENT", 0) & 2) != 0) ? 2 : 1) : 0;
+    static const int per_thread = knob("MOSS_SCATTER_ITEMS", 2);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
@@ -691,18 +696,19 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
     // themselves with the device-side values in the header
     if (R <= 0 || total_chunks <= 0) {
-        if (frame_state && part == 0) launch_clear(frame_state, frame_state_bytes, s);
+        if (frame_state && part == 0) clear_frame_state(frame_state, frame_state_bytes, s);
         return;
     }
     // at most two 1024-thread workgroups per CU in flight; the workgroups loop over the chunks
-    static const int max_grid = std::max(8, env_int("MOSS_SORT_GRID", 512));
+    static const int max_grid = std::max(8, knob("MOSS_SORT_GRID", 512));
     const int grid = std::min(total_chunks, max_grid);
     // diagnostics (scripts/sort_stamps.py): the stamp buffer's words [131072, 131072 + 16384) -- behind the forward blend's item stamps
-    static const int stamps_on = env_int("MOSS_SORT_STAMPS", 0);
+    static const int stamps_on = knob("MOSS_SORT_STAMPS", 0);
     unsigned long long* const sort_stamps = (stamps_on && g_stamps) ? g_stamps + 131072 : nullptr;
     if (part == 0)
     MOSS_LAUNCH_TIMED(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
-                       sort_stamps, reinterpret_cast<uint4*>(frame_state), (uint32_t)(frame_state ? frame_state_bytes / 16 : 0));
+                       sort_stamps, reinterpret_cast<uint4*>(frame_state ? frame_state + FS_COUNTERS_OFFSET : nullptr),
+                       (uint32_t)(frame_state ? (frame_state_bytes - FS_COUNTERS_OFFSET) / 16 : 0));   // (the first line belongs to the scan block)
     else
     MOSS_LAUNCH_TIMED(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);

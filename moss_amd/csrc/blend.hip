@@ -1135,12 +1135,6 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
     // every wave increments on its way out was 1024 serialised atomics at the very end of the kernel)
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 int device_cus()
 {
     static const int n = [] {
@@ -1161,7 +1155,7 @@ int resident_wgs_per_cu(K kernel, const char* env, int dflt, int cap)
 {
     int occ = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
-    return std::max(1, std::min(std::min(occ, cap), env_int(env, dflt)));
+    return std::max(1, std::min(std::min(occ, cap), knob(env, dflt)));
 }
 int forward_grid(int T)
 {
@@ -1171,9 +1165,10 @@ int forward_grid(int T)
 
 }  // anonymous namespace
 
+#ifdef MOSS_DIAG
 unsigned long long* g_stamps = nullptr;      // diagnostics buffer registered by moss_raster_debug_set_stamps (NULL = off)
 unsigned long long* g_bwd_stamps = nullptr;  // ... by moss_raster_debug_set_bwd_stamps: 16 words per wave of the backward blend kernel
-int g_cull_override = -1;                    // moss_raster_debug_set_cull
+#endif
 
 // gradient-record slabs per instance: one per 4x4 block (sparse: only blended pairs are written and flagged in inst_mask)
 int blend_subgroups() { return WAVE_BLOCKS; }
@@ -1182,14 +1177,14 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
                           float* out_color, float* out_depth, float* out_alpha, hipStream_t s)
 {
     (void)g;
-    static const int env_flags = env_int("MOSS_BLEND_CULL", 1);
-    const int flags = g_cull_override >= 0 ? g_cull_override : env_flags;
+    static const int cull_knob = knob("MOSS_BLEND_CULL", 1);
+    const int flags = fp.no_block_cull ? 0 : cull_knob;             // bit 0: use the per-instance block masks
     const int T = fp.gx * fp.gy;
     const int wgs = forward_grid(T);                                   // 4 independent waves per workgroup, 16 items per tile
     // hits per depth segment of the backward (0 = never cut: every block is ONE backward item, the round-1 behaviour)
-    static const int seg_hits_env = [] { const int v = env_int("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
+    static const int seg_hits_env = [] { const int v = knob("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
-    static const int role_swap = env_int("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = env_int("MOSS_FWD_PRIO", 0);
+    static const int role_swap = knob("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = knob("MOSS_FWD_PRIO", 0);
     MOSS_LAUNCH_TIMED(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                        im.queues + (size_t)Q_FWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                        im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
@@ -1200,11 +1195,11 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
                            const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, hipStream_t s)
 {
     (void)g;
-    static const int env_flags = env_int("MOSS_BLEND_CULL", 1);
-    // diagnostics (results are wrong with any of them): 16 = skip the segment items, 32 = block items ignore the cuts, 64 = segment
-    // items start from (T_final, 0)
-    static const int dbg = env_int("MOSS_BWD_DEBUG", 0) & (16 | 32 | 64);
-    const int flags = (g_cull_override >= 0 ? g_cull_override : env_flags) | dbg;
+    static const int cull_knob = knob("MOSS_BLEND_CULL", 1);
+    // diagnostics, MOSS_DIAG builds only (results are wrong with any of them): 16 = skip the segment items, 32 = block items ignore
+    // the cuts, 64 = segment items start from (T_final, 0)
+    static const int dbg = knob("MOSS_BWD_DEBUG", 0) & (16 | 32 | 64);
+    const int flags = (fp.no_block_cull ? 0 : cull_knob) | dbg;
     const int T = fp.gx * fp.gy;
     static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel, "MOSS_BWD_WGS_PER_CU", 4, 5);   // 27 KB of LDS each
     const int wgs = min(4 * T, device_cus() * bwd_wgs_per_cu);

@@ -36,6 +36,8 @@ constexpr size_t BUF_ALIGN = 256;
 constexpr int MAX_LDS_TILES = 8192;      // tile histograms are privatised in LDS up to this many tiles
 constexpr uint32_t ERRFLAG_PREFILTERED = 1u;
 constexpr uint32_t ERRFLAG_OVERFLOW = 2u;      // asynchronous forward: the frame needs more instances than the caller's capacity
+constexpr int FS_DROPPED_WORD = 4;             // frame state: sticky count of overflowed frames (include/moss_raster.h MOSS_FRAME_STATE_DROPPED_WORD)
+constexpr size_t FS_COUNTERS_OFFSET = 256;     // frame state: where the per-frame tile counters start
 
 inline size_t align_up(size_t v, size_t a = BUF_ALIGN) { return (v + a - 1) / a * a; }
 
@@ -126,6 +128,10 @@ struct ImageView {
     // counters that kernels ADD to -- the tile histogram, the tile cursors, the error-flag word -- live there instead of in this
     // buffer, and nothing has to be zeroed before the preprocess kernel: the scan block writes every header word and zeroes the
     // queue words, the sort kernel re-zeroes the frame state for the next forward.  (The clear was a 4 us launch of 20 waves.)
+    // Layout: word 0 = error flags of the frame in flight (zeroed by the scan block), word FS_DROPPED_WORD = STICKY count of frames
+    // that overflowed their capacity and rendered nothing (only ever incremented by the library: the caller reads and resets it --
+    // one look every few hundred replays of a captured step sees every dropped frame, not just the last one), byte 256 on = the
+    // tile histogram and cursors (re-zeroed by the sort kernel).
     static size_t frame_state_bytes(int W, int H)
     {
         const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -186,9 +192,19 @@ extern thread_local StageEvents g_stage_events;          // raster_api.hip
         }                                                                                                                 \
     } while (0)
 
-extern unsigned long long* g_stamps;   // optional forward-blend phase stamps (diagnostics), blend.hip
-extern unsigned long long* g_bwd_stamps;   // optional per-wave stamps of the backward blend kernel (diagnostics), blend.hip
-extern int g_cull_override;            // -1 = MOSS_BLEND_CULL decides; 0 / 1 = block-mask culling forced off / on (diagnostics), blend.hip
+// ---- tuning knobs and diagnostics.  The PRODUCT build has neither: knob(name, dflt) is the constant dflt, the stamp buffers are
+// null constants, and no translation unit under csrc/ reads the environment.  A build with -DMOSS_DIAG (python -m moss_amd.build --diag ->
+// moss_amd/lib_diag/, used by scripts/ only) reads MOSS_* environment variables through knob() and exports the
+// moss_raster_debug_set_*stamps entry points; some of its knobs produce WRONG results on purpose (timing experiments).
+#ifdef MOSS_DIAG
+int knob(const char* name, int dflt);                  // scripts/diag/knobs.cpp: the integer value of an environment variable, else dflt
+extern unsigned long long* g_stamps;                   // optional forward-blend phase stamps, blend.hip
+extern unsigned long long* g_bwd_stamps;               // optional per-wave stamps of the backward blend kernel, blend.hip
+#else
+constexpr int knob(const char*, int dflt) { return dflt; }
+constexpr unsigned long long* g_stamps = nullptr;
+constexpr unsigned long long* g_bwd_stamps = nullptr;
+#endif
 int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
 struct BinView {
@@ -237,6 +253,7 @@ struct FrameParams {
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int prefiltered;
     int raw;                 // RAW_* bits: which of opacity / scales / rotations arrive as MOSS's raw parameters (activated inside the op)
+    int no_block_cull;       // MOSS_DEBUG_NO_BLOCK_CULL of the call's `debug` argument: the blend kernels ignore the per-instance block masks
     const float* view_dev; const float* proj_dev; const float* campos_dev; const float* bg_dev;
 };
 
@@ -254,6 +271,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
 
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);
+void clear_frame_state(char* frame_state, size_t bytes, hipStream_t s);   // its per-frame words (not the sticky dropped-frame count)
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header, group bases
 bool scatter_folds_scan(const FrameParams& fp);                                                // asynchronous forward: no scan launch, see binning.hip

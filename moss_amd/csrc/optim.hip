@@ -14,8 +14,10 @@ struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; flo
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))   // (eight waves per SIMD: the scalar file admits six at 106 SGPRs)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
              Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
-             const float* __restrict__ step_state)
+             const float* __restrict__ step_state, long long first)
 {
+    // `first`: the arrays are the elements [first, first + n) of the flat buffers the segment table indexes (a rank's shard of the
+    // bucket, moss_adamw_flat_range); a multiple of 4, so that a thread's four elements never straddle it.
     int t_dev = 0;
     if (step_state) {
         // Device-resident step counter (graph replay): the LAST block of a step to finish stores t back and caches the bias
@@ -41,7 +43,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     // kernel's 165 MB are HBM time)
     const float inv_bc1 = 1.0f / bc1, inv_bc2_sqrt = 1.0f / bc2_sqrt;
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
-        const long long i = i4 * 4;
+        const long long i = i4 * 4, gi = first + i;          // index in the arrays / in the flat buffer (segment table)
         float pv[4], gv[4], mv[4], vv[4];
         const bool full = i + 4 <= n;
         if (full) {
@@ -57,14 +59,14 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
         // thread, stepped for the other elements.  A thread whose 4 elements straddle a segment end takes the general lookup.
         float lr4[4];
         {
-            long long seg_start = 0, seg_end = n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0;
+            long long seg_start = 0, seg_end = first + n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0;
 #pragma unroll
-            for (int s = 7; s >= 0; s--) if (s < segs.n && i < segs.end[s]) {
+            for (int s = 7; s >= 0; s--) if (s < segs.n && gi < segs.end[s]) {
                 seg_end = segs.end[s]; seg_start = s > 0 ? segs.end[s - 1] : 0;
                 lr_a = segs.lr[s]; lr_b = segs.lr2[s]; period = segs.period[s]; split = segs.split[s];
             }
-            if (i + 3 < seg_end) {
-                unsigned ph = period > 0 ? (unsigned)(i - seg_start) % (unsigned)period : 0u;
+            if (gi + 3 < seg_end) {
+                unsigned ph = period > 0 ? (unsigned)(gi - seg_start) % (unsigned)period : 0u;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     lr4[k] = (period > 0 && (int)ph >= split) ? lr_b : lr_a;
@@ -73,7 +75,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const long long idx = i + k;
+                    const long long idx = gi + k;
                     float lr = 0.f;
 #pragma unroll
                     for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) {
@@ -126,20 +128,20 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
 int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
                  const long long* segment_end, const float* segment_lr, const int* segment_period, const int* segment_split,
                  const float* segment_lr2, float beta1, float beta2, float eps, float weight_decay,
-                 float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream)
+                 float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream, long long first = 0)
 {
     Segs segs; segs.n = num_segments;
     for (int i = 0; i < 8; i++) {
-        segs.end[i] = i < num_segments ? segment_end[i] : n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f;
+        segs.end[i] = i < num_segments ? segment_end[i] : first + n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f;
         const bool pat = i < num_segments && segment_period && segment_split && segment_lr2 && segment_period[i] > 0;
         segs.period[i] = pat ? segment_period[i] : 0; segs.split[i] = pat ? segment_split[i] : 0; segs.lr2[i] = pat ? segment_lr2[i] : 0.f;
     }
     long long blocks = (n / 4 + 255) / 256;
-    static const long long max_blocks = [] { const char* v = getenv("MOSS_ADAMW_BLOCKS"); return (long long)((v && *v) ? atoi(v) : 2048); }();
+    static const long long max_blocks = knob("MOSS_ADAMW_BLOCKS", 2048);
     if (blocks > max_blocks) blocks = max_blocks;            // (2048: eight 256-thread blocks per CU, all resident at once)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
-                       segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state);
+                       segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state, first);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
 
@@ -171,4 +173,23 @@ extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* 
     return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
                               segment_split, segment_lr2, beta1, beta2, eps, weight_decay, 1.f, 1.f, (const float*)step_state,
                               (hipStream_t)stream);
+}
+
+extern "C" size_t moss_adamw_state_bytes(void) { return MOSS_ADAMW_STATE_BYTES; }
+
+// A rank's SHARD of the flat bucket (reduce-scatter -> AdamW on 1/N of the elements -> all-gather of the parameters, moss_amd/dist.py):
+// the arrays hold the elements [first, first + count) of the flat buffers the segment table (global indices) describes.
+extern "C" int moss_adamw_flat_range(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                     int num_segments, const long long* segment_end, const float* segment_lr,
+                                     const int* segment_period, const int* segment_split, const float* segment_lr2,
+                                     float beta1, float beta2, float eps, float weight_decay, int step, void* step_state, void* stream)
+{
+    if (first < 0 || (first & 3) || count < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq ||
+        !segment_end || !segment_lr || (!step_state && step < 1))
+        return MOSS_ERR_INVALID_ARG;
+    if (count == 0) return step_state ? MOSS_ERR_INVALID_ARG : 0;
+    const double bc1 = step_state ? 1.0 : 1.0 - pow((double)beta1, step), bc2 = step_state ? 1.0 : 1.0 - pow((double)beta2, step);
+    return moss::launch_adamw(count, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
+                              segment_split, segment_lr2, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
+                              (const float*)step_state, (hipStream_t)stream, first);
 }

@@ -1151,11 +1151,6 @@ static int device_cus()
     return n;
 }
 
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -1164,19 +1159,19 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
     // Gaussians per thread: more -> better aggregation of the tile-histogram atomics, fewer -> more waves in flight.
-    static const int per_thread = env_int("MOSS_PREPROCESS_ITEMS", 1);
+    static const int per_thread = knob("MOSS_PREPROCESS_ITEMS", 1);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
     const int stage_sh = (fp.M == 16 && shs != nullptr && colors_precomp == nullptr && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 &&
-                          lds_h + lds_s <= 65536 /* default dynamic-LDS limit of a launch */ && env_int("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
+                          lds_h + lds_s <= 65536 /* default dynamic-LDS limit of a launch */ && knob("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
     const size_t lds = lds_h + (stage_sh ? lds_s : 0);
     MOSS_LAUNCH_TIMED(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.flags_acc, radii_out, lds_hist, stage_sh,
-                       transforms, fp.raw | ((env_int("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0),
-                       (g_stamps && env_int("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr);
+                       transforms, fp.raw | ((knob("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0),
+                       (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr);
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
@@ -1187,17 +1182,17 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 const float* transforms, float* dL_dtransforms, hipStream_t s)
 {
     (void)colors_precomp;
-    static const int threads = std::max(64, env_int("MOSS_PREBWD_THREADS", 64) & ~63);
+    static const int threads = std::max(64, knob("MOSS_PREBWD_THREADS", 64) & ~63);
     // Rows of a block = groups of 2^gl2 consecutive Gaussians (gaussian_of_row); 6 = the block's 64 rows are consecutive: the default.
     // When the caller says that index neighbours are spatial neighbours (MOSS_HINT_SPATIAL_ORDER) 64 consecutive Gaussians are all-heavy
     // or all-light, and while every block of the grid is resident at once the kernel lasts as long as its heaviest block: then groups of
     // 16 from four places (bench frame in Morton order 29.3 -> 25.0 us).  Not otherwise: in an order without locality the groups cost
     // coalescing (stress case with image-covering Gaussians 91.5 -> 99.3 us), and once the grid runs in several rounds the dispatcher
     // does the balancing while the shared cache lines of 64 neighbours count for more (configs[4]: 81 us consecutive, 87-95 in groups).
-    static const int gl2_env = env_int("MOSS_PREBWD_GROUP_LOG2", 0);
-    static const int gather_knob = env_int("MOSS_GATHER", 0) == 1 ? 0x200 : env_int("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
+    static const int gl2_env = knob("MOSS_PREBWD_GROUP_LOG2", 0);
+    static const int gather_knob = knob("MOSS_GATHER", 0) == 1 ? 0x200 : knob("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     const int blocks = (fp.P + threads - 1) / threads;
-    const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && env_int("MOSS_PREBWD_STAGE", 1) &&
+    const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && knob("MOSS_PREBWD_STAGE", 1) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
     const size_t lds_bytes_staged = (size_t)threads * SH_ROW * sizeof(float) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4;
     static const int resident_per_cu = [&] {

@@ -87,9 +87,6 @@ struct Pinned {
 };
 thread_local Pinned g_pinned;
 
-// moss_raster_frame_state: the block the NEXT forward call of this host thread takes its per-frame counters from (consumed by it)
-thread_local char* g_next_frame_state = nullptr;
-
 FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float tan_fovy, float scale_modifier, int prefiltered,
                         const float* view, const float* proj, const float* campos, const float* bg)
 {
@@ -99,7 +96,7 @@ FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
     fp.focal_y = H / (2.0f * tan_fovy);         // rasterizer_impl.cu:224-225
     fp.focal_x = W / (2.0f * tan_fovx);
-    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0;
+    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0; fp.no_block_cull = 0;
     fp.view_dev = view; fp.proj_dev = proj; fp.campos_dev = campos; fp.bg_dev = bg;
     return fp;
 }
@@ -116,15 +113,12 @@ static int forward_impl(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug, void* stream, long long capacity,
-    const float* transforms, int raw_flags = 0)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int debug_flags, void* stream, long long capacity,
+    const float* transforms, int raw_flags = 0, char* frame_state = nullptr)
 {
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
-    // (the frame state announced for THIS call is taken here, whatever happens below: a call that fails its argument checks must not
-    // leave it to the next one; untouched, the block is still all-zero)
-    char* const frame_state = g_next_frame_state;
-    g_next_frame_state = nullptr;
+    const int debug = debug_flags & MOSS_DEBUG_SYNC;
     if (P < 0 || width <= 0 || height <= 0) return fail(MOSS_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (!out_color || !out_depth || !out_alpha || !background) return fail(MOSS_ERR_INVALID_ARG, "null output/background pointer");
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(MOSS_ERR_INVALID_ARG, "null allocator callback");
@@ -155,15 +149,16 @@ static int forward_impl(
     FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, prefiltered,
                                  viewmatrix, projmatrix, cam_pos, background);
     fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;     // scales / rotations are not read with a precomputed covariance
+    fp.no_block_cull = (debug_flags & MOSS_DEBUG_NO_BLOCK_CULL) ? 1 : 0;
     const int T = fp.gx * fp.gy;
 
     // The counters kernels ADD to (tile histogram, tile cursors, error flags) must be zero here.  With the caller's frame state
-    // (moss_raster_frame_state: all-zero between calls, re-zeroed by the sort kernel) nothing is launched for that; without it, a clear.
+    // (the `frame_state` argument: all-zero between calls, re-zeroed by the sort kernel) nothing is launched for that; without it, a clear.
     const size_t fs_bytes = ImageView::frame_state_bytes(width, height);
     if (frame_state) im.use_frame_state(frame_state, width, height);
     else launch_clear(im.header, im.clear_bytes(), s);                   // header + tile histogram + tile cursors
     // (a forward that ends before its sort kernel has run leaves the frame state dirty: clean it on those paths)
-    auto abandon_frame_state = [&]() { if (frame_state) launch_clear(frame_state, fs_bytes, s); };
+    auto abandon_frame_state = [&]() { if (frame_state) clear_frame_state(frame_state, fs_bytes, s); };
     { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
       launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, g, im, radii, s); }
     STAGE_CHECK("preprocess");
@@ -200,10 +195,12 @@ static int forward_impl(
     if (R > 0) {
         { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, fold_scan, capacity, s); }
         STAGE_CHECK("scatter");
+#ifdef MOSS_DIAG
         {   // timing experiment (scripts/exp_atomics.py): with the scatter's reservation atomics off the keys are garbage -- stop here
-            static const bool stop = getenv("MOSS_EXPERIMENT") && (atoi(getenv("MOSS_EXPERIMENT")) & 2);
+            static const bool stop = (knob("MOSS_EXPERIMENT", 0) & 2) != 0;
             if (stop) { abandon_frame_state(); return R; }
         }
+#endif
         { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 0); }
         { StageTimer tm(MOSS_STAGE_MERGE_GATHER, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 1); }
         STAGE_CHECK("tile_sort");
@@ -235,13 +232,13 @@ int moss_raster_forward_async(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream)
 {
     if (capacity < 0) return fail(MOSS_ERR_INVALID_ARG, "capacity must be >= 0");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity, nullptr);
+                        0, stream, capacity, nullptr, 0, frame_state);
 }
 
 // n2 extension: like moss_raster_forward / _async (capacity < 0: synchronous, debug off) with a per-Gaussian 3x3
@@ -252,13 +249,13 @@ int moss_raster_forward_tf(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream)
 {
     if (P > 0 && (!scales || !rotations || !transforms)) return fail(MOSS_ERR_INVALID_ARG, "scales, rotations and transforms are required");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity < 0 ? -1 : capacity, transforms);
+                        0, stream, capacity < 0 ? -1 : capacity, transforms, 0, frame_state);
 }
 
 int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out /* 8 words */, void* stream)
@@ -270,7 +267,6 @@ int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out 
 }
 
 size_t moss_raster_frame_state_bytes(int width, int height) { return ImageView::frame_state_bytes(width, height); }
-int moss_raster_frame_state(char* frame_state) { g_next_frame_state = frame_state; return 0; }
 
 int moss_abi_version(void) { return MOSS_ABI_VERSION; }
 const char* moss_last_error(void) { return g_err; }
@@ -289,10 +285,11 @@ static int backward_impl(
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug_flags, void* stream,
     const float* transforms, float* dL_dtransforms, const float* opacities = nullptr, int raw_flags = 0)
 {
     (void)alphas; (void)radii;
+    const int debug = debug_flags & MOSS_DEBUG_SYNC;
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(MOSS_ERR_INVALID_ARG, "bad sizes");
@@ -310,6 +307,7 @@ static int backward_impl(
     FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, 0,
                                  viewmatrix, projmatrix, campos, background);
     fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;
+    fp.no_block_cull = (debug_flags & MOSS_DEBUG_NO_BLOCK_CULL) ? 1 : 0;
     if ((fp.raw & RAW_OPACITY) && !opacities) return fail(MOSS_ERR_INVALID_ARG, "raw opacities are required to chain through the sigmoid");
     if (R > 0) {
         { StageTimer tm(MOSS_STAGE_BLEND_BWD, s); launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s); }
@@ -370,14 +368,14 @@ int moss_raster_forward_raw(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, void* stream)
 {
     if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (!scales || !rotations)) return fail(MOSS_ERR_INVALID_ARG, "scales and rotations are required");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags);
+                        0, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags, frame_state);
 }
 
 int moss_raster_backward_raw(
@@ -446,9 +444,18 @@ int moss_raster_export_binning(const char* geom_buffer, const char* binning_buff
     return 0;
 }
 
+#ifdef MOSS_DIAG
 void moss_raster_debug_set_stamps(unsigned long long* device_buffer) { moss::g_stamps = device_buffer; }
 void moss_raster_debug_set_bwd_stamps(unsigned long long* device_buffer) { moss::g_bwd_stamps = device_buffer; }
-void moss_raster_debug_set_cull(int mode) { moss::g_cull_override = mode; }
+#endif
+int moss_build_has_diagnostics(void)
+{
+#ifdef MOSS_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 void moss_raster_profile_enable(uint32_t stage_mask)
 {

@@ -86,7 +86,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
                     const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations, double scale_modifier,
                     const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
                     double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const torch::Tensor& sh,
-                    int64_t degree, const torch::Tensor& campos, bool prefiltered, bool debug,
+                    int64_t degree, const torch::Tensor& campos, bool prefiltered, int64_t debug /* bool in the reference; MOSS_DEBUG_* bits */,
                     const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, int64_t capacity,
                     const c10::optional<torch::Tensor>& frame_state)
 {
@@ -133,28 +133,30 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     float *oc = reinterpret_cast<float*>(out_color.data_ptr()), *od = reinterpret_cast<float*>(out_depth.data_ptr()),
           *oa = reinterpret_cast<float*>(out_alpha.data_ptr());
     const int cap = use_async ? static_cast<int>(capacity) : -1;
-    if (frame_state.has_value() && frame_state->defined() && P > 0) {
+    char* p_fs = nullptr;                                   // the caller's frame state: an argument of the asynchronous forwards (ABI 2)
+    if (use_async && frame_state.has_value() && frame_state->defined()) {
         TORCH_CHECK(frame_state->is_cuda() && frame_state->is_contiguous() && frame_state->scalar_type() == torch::kByte &&
+                    frame_state->device() == means3D.device() &&
                     (size_t)frame_state->numel() >= moss_raster_frame_state_bytes(W, H), "frame_state: a zero-initialised byte tensor of moss_raster_frame_state_bytes on the GPU");
-        moss_raster_frame_state(reinterpret_cast<char*>(frame_state->data_ptr()));     // consumed by the forward call below
+        p_fs = reinterpret_cast<char*>(frame_state->data_ptr());
     }
     int rc;
     if (raw_flags)
         rc = moss_raster_forward_raw(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
                                      p_scl, (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
-                                     prefiltered ? 1 : 0, oc, od, oa, p_radii, (int)raw_flags, cap, stream);
+                                     prefiltered ? 1 : 0, oc, od, oa, p_radii, (int)raw_flags, cap, p_fs, stream);
     else if (has_tf)
         rc = moss_raster_forward_tf(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
                                     p_scl, (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
-                                    prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, stream);
+                                    prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, p_fs, stream);
     else if (use_async)
         rc = moss_raster_forward_async(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col,
                                        p_opa, p_scl, (float)scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, (float)tan_fovx,
-                                       (float)tan_fovy, prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, stream);
+                                       (float)tan_fovy, prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, p_fs, stream);
     else
         rc = moss_raster_forward(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
                                  p_scl, (float)scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
-                                 prefiltered ? 1 : 0, oc, od, oa, p_radii, debug ? 1 : 0, stream);
+                                 prefiltered ? 1 : 0, oc, od, oa, p_radii, (int)debug, stream);
     if (rc < 0) raise(rc, "rasterize_gaussians");
     return std::make_tuple((int64_t)rc, out_color, out_depth, out_alpha, radii, geom, binning, img);
 }
@@ -169,7 +171,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                              const c10::optional<torch::Tensor>& dL_dout_color, const c10::optional<torch::Tensor>& dL_dout_depth,
                              const c10::optional<torch::Tensor>& dL_dout_alpha, const torch::Tensor& sh, int64_t degree,
                              const torch::Tensor& campos, const torch::Tensor& geomBuffer, int64_t R, const torch::Tensor& binningBuffer,
-                             const torch::Tensor& imageBuffer, const torch::Tensor& alphas, bool debug,
+                             const torch::Tensor& imageBuffer, const torch::Tensor& alphas, int64_t debug,
                              const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, const c10::optional<torch::Tensor>& opacities,
                              const c10::optional<torch::Tensor>& sink_means3D, const c10::optional<torch::Tensor>& sink_opacity,
                              const c10::optional<torch::Tensor>& sink_sh, const c10::optional<torch::Tensor>& sink_scales,
@@ -236,7 +238,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                                       (float)scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
                                       ptr<int>(radii, "radii", keep, torch::kInt32), p_geom, p_bin, p_img, g_c, g_d, g_a, f(dL_dmeans2D),
                                       f(dL_dconic), f(dL_dopacity), f(dL_dcolors), f(dL_dmeans3D), f(dL_dcov3D), p_dsh, f(dL_dscales),
-                                      f(dL_drotations), debug ? 1 : 0, stream);
+                                      f(dL_drotations), (int)debug, stream);
         }
         if (rc < 0) raise(rc, "rasterize_gaussians_backward");
     }
@@ -279,5 +281,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("sink_means3D") = py::none(), py::arg("sink_opacity") = py::none(), py::arg("sink_sh") = py::none(),
           py::arg("sink_scales") = py::none(), py::arg("sink_rotations") = py::none());
     m.def("mark_visible", &mark_visible);
-    m.def("abi_version", []() { return moss_abi_version(); });
+    // the version of the header THIS module was compiled against (not the library's answer: moss_amd/_lib.py compares the two, so a
+    // stale _moss_C.so next to a rebuilt libmoss_raster.so refuses to load instead of passing arguments in the old layout)
+    m.def("abi_version", []() { return (int)MOSS_ABI_VERSION; });
 }

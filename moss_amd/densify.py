@@ -106,7 +106,7 @@ def spatial_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
     starts from the SMPL vertices in mesh order and appends clones and splits next to nothing in particular
     (scene/gaussian_model.py: densification_postfix); re-indexing the set along a space-filling curve whenever it is rebuilt anyway
     (densify / prune, every few hundred iterations) keeps index neighbours spatial neighbours.  Apply the returned permutation to
-    every per-Gaussian tensor AND to the optimizer state (`FlatAdamW.permute`)."""
+    every per-Gaussian tensor AND to the optimizer state (`FlatAdamW.permute_rows`; `GaussianSet.reorder_spatially` does both)."""
     with torch.no_grad():
         p = xyz.detach().float()
         lo = p.min(dim=0).values

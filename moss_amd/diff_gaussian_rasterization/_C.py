@@ -23,6 +23,17 @@ HINT_SPATIAL_ORDER = 8                               # MOSS_HINT_SPATIAL_ORDER: 
 last_num_rendered = 0   # num_rendered of the most recent forward call of ANY context (kept for callers that predate contexts)
 
 _SINK_NAMES = ("sh", "means3D", "opacity", "scales", "rotations")
+FRAME_STATE_DROPPED_WORD = 4                         # include/moss_raster.h MOSS_FRAME_STATE_DROPPED_WORD
+
+
+class CapacityOverflow(RuntimeError):
+    """An asynchronous forward needed more (Gaussian, tile) instances than its binning capacity: that frame rendered nothing
+    (outputs = background, gradients = 0).  ``needed`` / ``capacity``: the frame's demand and the capacity the context has now."""
+
+    def __init__(self, needed, capacity):
+        super().__init__(f"rasterize_gaussians (async): a frame needed {needed} (Gaussian, tile) instances but the binning "
+                         f"buffer was sized for fewer; that frame rendered nothing. Capacity is now {capacity}.")
+        self.needed, self.capacity = needed, capacity
 
 
 class RasterContext:
@@ -49,6 +60,7 @@ class RasterContext:
         self.last_num_rendered = 0
         self.sinks = dict.fromkeys(_SINK_NAMES)
         self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
+        self._retired_frame_states = []   # outgrown blocks: a captured hipGraph may still hold their address (see _frame_state)
 
     # ---- asynchronous forward -------------------------------------------------------------------------------------------------
     def set_async(self, enabled: bool, capacity: int = 0, margin: float = 2.0):
@@ -74,8 +86,7 @@ class RasterContext:
         if needed * 1.25 > self.capacity:                       # drifting towards the limit: grow ahead of time
             self.capacity = int(needed * self.margin) + 1024
         if flags & 2:
-            raise RuntimeError(f"rasterize_gaussians (async): a frame needed {needed} (Gaussian, tile) instances but the binning "
-                               f"buffer was sized for fewer; that frame rendered nothing. Capacity is now {self.capacity}.")
+            raise CapacityOverflow(needed, self.capacity)
         if flags & 1:
             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
 
@@ -96,13 +107,38 @@ class RasterContext:
         self._consume_status(block=True)
 
     def _frame_state(self, dev, width, height):
-        """The zero-initialised block of C ABI ``moss_raster_frame_state`` for this context (one per context: its forwards are ordered
-        on one stream); re-made when the device changes or a larger image comes along.  With it no clear kernel runs per forward."""
+        """The zero-initialised ``frame_state`` block of the asynchronous forwards (C ABI ``moss_raster_forward_async``) for this
+        context (one per context: its forwards are ordered on one stream); a new one when the device changes or a larger image comes
+        along.  With it no clear kernel runs per forward.
+
+        A block that has been handed out is NEVER freed while the context lives: its address is a kernel argument of any hipGraph
+        captured with this context (``GraphedStep``), and a graph replayed after, say, an eager full-resolution evaluation render on
+        the same context would otherwise add its tile histograms into freed -- possibly reused -- memory.  Outgrown
+        blocks (a few KB each) are parked in ``_retired_frame_states``; each stays all-zero between the forwards that use it."""
         n = int(lib().moss_raster_frame_state_bytes(int(width), int(height)))
         fs = self.frame_state
         if fs is None or fs.device != dev or fs.numel() < n:
+            if fs is not None:
+                self._retired_frame_states.append(fs)
+                for old in self._retired_frame_states:       # an older block of this device that is large enough serves again
+                    if old.device == dev and old.numel() >= n:
+                        self.frame_state = old
+                        return old
             fs = self.frame_state = torch.zeros(n, dtype=torch.uint8, device=dev)
         return fs
+
+    def read_dropped_frames(self, reset: bool = True) -> int:
+        """How many asynchronous forwards of this context overflowed their capacity (each rendered NOTHING: zero gradients, while an
+        optimizer in the same captured step kept stepping) since the last reset: the sticky counter the library keeps in the frame
+        state.  Synchronises the device; call it outside graph capture (``GraphedStep.check`` does)."""
+        n = 0
+        for fs in [self.frame_state] + self._retired_frame_states:
+            if fs is not None and fs.is_cuda:
+                w = fs.view(torch.int32)[FRAME_STATE_DROPPED_WORD:FRAME_STATE_DROPPED_WORD + 1]
+                n += int(w.item())
+                if reset:
+                    w.zero_()
+        return n
 
     # ---- gradient sinks ---------------------------------------------------------------------------------------------------------
     def set_grad_sink(self, sh=None, means3D=None, opacity=None, scales=None, rotations=None):
@@ -153,7 +189,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         cx._consume_status(block=False)
     res = ext().rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
                                     viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), sh,
-                                    int(degree), campos, bool(prefiltered), bool(debug), transforms, int(raw_flags),
+                                    int(degree), campos, bool(prefiltered), int(debug), transforms, int(raw_flags),
                                     int(cx.capacity) if use_async else -1,
                                     cx._frame_state(means3D.device, image_width, image_height) if use_async else None)
     rendered, img = res[0], res[7]
@@ -183,7 +219,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return tuple(ext().rasterize_gaussians_backward(
         background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
         float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, int(degree), campos, geomBuffer, int(R),
-        binningBuffer, imageBuffer, alphas, bool(debug), transforms, int(raw_flags), opacities,
+        binningBuffer, imageBuffer, alphas, int(debug), transforms, int(raw_flags), opacities,
         cx._sink("means3D"), cx._sink("opacity"), cx._sink("sh"), cx._sink("scales"), cx._sink("rotations")))
 
 

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from ._C import RasterContext, set_async, check_async_status, set_grad_sink  # noqa: F401  (opt-in: asynchronous forward / graph capture, gradient sinks; per-rasterizer state)
+from ._C import CapacityOverflow, RasterContext, set_async, check_async_status, set_grad_sink  # noqa: F401  (opt-in: asynchronous forward / graph capture, gradient sinks; per-rasterizer state)
 
 
 class GaussianRasterizationSettings(NamedTuple):

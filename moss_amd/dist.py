@@ -32,6 +32,16 @@ def init_from_env(backend: str | None = None):
     return rank, world, local_rank
 
 
+def shard_layout(n: int, world: int):
+    """(elements per shard, padded length) of a flat vector of `n` elements cut into `world` EQUAL shards: ceil(n / world) rounded up
+    to a multiple of 4 elements (the update kernel works on float4 and every shard then starts 16-byte aligned; reduce-scatter /
+    all-gather want equal counts).  The padding (< 4 * world elements) is exchanged with the rest and never read."""
+    world = max(int(world), 1)
+    per = -(-int(n) // world)
+    per = (per + 3) // 4 * 4
+    return per, per * world
+
+
 def shard_views(num_views: int, rank: int, world: int):
     """View indices of this rank: r, r+n, r+2n, ... (independent units, no data-path exchange)."""
     return list(range(rank, num_views, world))
@@ -39,19 +49,26 @@ def shard_views(num_views: int, rank: int, world: int):
 
 class GradBucket:
     """One flat fp32 buffer for all parameter gradients (+4 slots for the loss and its three terms); a single all-reduce
-    averages it."""
+    averages it.  Layout: [gradients, in parameter order | pad to a multiple of 4 | loss, L1, SSIM, mask L2 | pad]; ``world`` > 1
+    pads the buffer to `world` equal shards (``shard_layout``) so that the same buffer serves the reduce-scatter of the sharded
+    optimizer path (``ShardedStep``); the 4-float loss block is 4-aligned, so it never straddles two shards."""
 
-    def __init__(self, params):
+    def __init__(self, params, world: int = 1):
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
-        total = sum(self.sizes) + 4
+        self.n_params = sum(self.sizes)
+        self.tail = (self.n_params + 3) // 4 * 4           # offset of the loss block
+        self.n_exchange = self.tail + 4                    # what has to travel: gradients + loss block
+        self.world = max(int(world), 1)
+        self.shard_len, padded = shard_layout(self.n_exchange, self.world)
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(padded if self.world > 1 else self.n_exchange, dtype=torch.float32, device=dev)
         self.views = []
         off = 0
         for p, n in zip(self.params, self.sizes):
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
+        off = self.tail
         self.loss_slot = self.flat[off:off + 1]
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {}
@@ -118,3 +135,53 @@ class GradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(world)
         return self.loss_slot
+
+
+def _reduce_scatter_mean(out: torch.Tensor, inp: torch.Tensor, world: int):
+    """out (per) = this rank's shard of the MEAN over ranks of inp (world * per).  RCCL: one reduce-scatter with ncclAvg.  gloo (the
+    CPU tests) implements no reduce-scatter: all-reduce and keep the shard -- the same values, which is all those tests need."""
+    if dist.get_backend() == "nccl":
+        try:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG)
+            return
+        except (RuntimeError, ValueError):                   # a build without ncclAvg refuses before launching anything
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+            out.div_(world)
+            return
+    dist.all_reduce(inp, op=dist.ReduceOp.SUM)
+    r = dist.get_rank()
+    out.copy_(inp[r * out.numel():(r + 1) * out.numel()])
+    out.div_(world)
+
+
+class ShardedStep:
+    """The exchange of an N > 1 step with the optimizer SHARDED over the ranks (the alternative to
+    ``GradBucket.all_reduce_mean`` + a full optimizer step on every rank):
+
+        reduce-scatter (mean) of the gradient bucket  ->  AdamW on this rank's 1/N of the flat parameters  ->  all-gather of the
+        updated parameters (in place: every rank's shard is a slice of the same flat buffer).
+
+    The bytes on the xGMI links equal those of the ring all-reduce it replaces (which IS a reduce-scatter followed by an all-gather);
+    the update's time and the moments' memory divide by N.  The averaged loss block rides along: its owner copies it from its
+    gradient shard into the parameter buffer's tail before the all-gather, after which ``loss_terms`` holds it on every rank.
+    ``optimizer``: anything with ``flat_params`` (padded to world * shard_len), ``grad_shard`` (shard_len), ``first`` / ``count`` and
+    ``step()`` -- ``FlatAdamW(shard=(rank, world))``; the CPU tests pass a torch restatement of the same update."""
+
+    def __init__(self, bucket: GradBucket, optimizer, rank: int, world: int):
+        if bucket.world != world:
+            raise ValueError(f"the bucket was laid out for {bucket.world} shards, the group has {world} ranks: GradBucket(params, world={world})")
+        self.bucket, self.opt, self.rank, self.world = bucket, optimizer, int(rank), int(world)
+        per = bucket.shard_len
+        if optimizer.flat_params.numel() != per * world or optimizer.grad_shard.numel() != per:
+            raise ValueError("the optimizer's flat_params / grad_shard do not match the bucket's shard layout")
+        self.tail_rank, self.tail_off = divmod(bucket.tail, per)              # who owns the loss block, and where in its shard
+        self.loss_terms = optimizer.flat_params[bucket.tail:bucket.tail + 4]
+
+    def step(self):
+        b, o, per = self.bucket, self.opt, self.bucket.shard_len
+        _reduce_scatter_mean(o.grad_shard, b.flat, self.world)
+        o.step()
+        if self.rank == self.tail_rank:
+            self.loss_terms.copy_(o.grad_shard[self.tail_off:self.tail_off + 4])
+        dist.all_gather_into_tensor(o.flat_params, o.flat_params[self.rank * per:(self.rank + 1) * per])
+        return self.loss_terms[:1]

@@ -48,16 +48,28 @@ class GaussianSet(nn.Module):
         per-Gaussian kernels does (profiles/r02_notes.md, finding 30).  Meant for the moments the set is rebuilt anyway (MOSS:
         densify / prune, scene/gaussian_model.py:densification_postfix); not capturable.  Returns the permutation: per-Gaussian state
         kept OUTSIDE this module and the optimizer (``DensifyStats`` accumulators, an LBS transform table) must be indexed with it too --
-        MOSS resets its own accumulators at exactly these moments (densification_postfix)."""
+        MOSS resets its own accumulators at exactly these moments (densification_postfix).
+
+        ``optimizer``: a ``FlatAdamW`` (its ``permute_rows`` moves parameters and moments together), or a ``torch.optim`` optimizer
+        (the ``exp_avg`` / ``exp_avg_sq`` / ``max_exp_avg_sq`` rows of every permuted parameter are permuted with it); anything else
+        raises.  ``optimizer=None`` is valid ONLY while no optimizer state exists for these parameters (before the first step, or
+        when the caller rebuilds its optimizer afterwards): a Gaussian would otherwise continue with another Gaussian's moments."""
         from .densify import spatial_order
         perm = spatial_order(self._xyz.detach())
+        rows = [p for p in self.parameters() if p.dim() >= 1 and p.shape[0] == perm.numel()]
         if optimizer is not None and hasattr(optimizer, "permute_rows"):
             optimizer.permute_rows(perm)                     # (the parameters live in its flat buffer: moved there)
-        else:
+        elif optimizer is None or isinstance(optimizer, torch.optim.Optimizer):
             with torch.no_grad():
-                for p in self.parameters():
-                    if p.dim() >= 1 and p.shape[0] == perm.numel():
-                        p.copy_(p[perm].clone())
+                for p in rows:
+                    p.copy_(p[perm].clone())
+                    st = optimizer.state.get(p, {}) if optimizer is not None else {}
+                    for k, v in st.items():                  # torch.optim.Adam(W): exp_avg, exp_avg_sq (, max_exp_avg_sq); `step` is a scalar
+                        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == perm.numel():
+                            v.copy_(v[perm.to(v.device)].clone())
+        else:
+            raise TypeError(f"reorder_spatially: cannot permute the state of a {type(optimizer).__name__}; pass a FlatAdamW, a "
+                            "torch.optim.Optimizer, or None before any optimizer state exists")
         self.spatially_ordered = True
         return perm
 

@@ -9,9 +9,12 @@ Rules the captured function must follow (``bench.py`` and tests/test_gpu_ops.py:
 * run the step eagerly a few times first (the first synchronous forward sizes the binning capacity; allocator warm-up);
 * return only DETACHED tensors: an output that still has a ``grad_fn`` keeps the step's autograd graph alive into the next replay;
 * no ``hipMemsetAsync`` inside (memset nodes did not re-execute on replay with ROCm 7.2: clear with a kernel), no host reads;
-* call ``step.check()`` every few hundred steps (or ``diff_gaussian_rasterization.check_async_status()`` after the last replay; a
-  frame that overflowed is counted in ``step.dropped_frames`` and the step is re-captured with the grown capacity, not raised):
+* call ``step.check()`` every few hundred steps (or ``diff_gaussian_rasterization.check_async_status()`` after the last replay):
   the binning capacity is baked into the graph, and a scene whose instance count grows needs a re-capture before it overflows.
+  EVERY frame that overflowed between two checks is counted in ``step.dropped_frames`` (the library keeps a sticky counter in the
+  context's frame state; the status words alone describe only the last frame) and the step is re-captured with the grown capacity,
+  not raised.  Such a frame rendered nothing: its gradients were zero while the captured AdamW still advanced its step count and
+  decayed the moments and weights -- a dropped frame is a (weight-decay-only) optimizer step, not a skipped one.
 """
 from __future__ import annotations
 
@@ -59,12 +62,13 @@ class GraphedStep:
         capacity, captures the step again with the grown one.  Returns True if it re-captured."""
         from .diff_gaussian_rasterization import _C
         cx = self.context or _C.DEFAULT
+        last_overflowed = False
         try:
             cx.check_status()
-        except RuntimeError as e:
-            if "binning" not in str(e):
-                raise
-            self.dropped_frames += 1                         # the frame rendered nothing; check_status already grew the capacity
+        except _C.CapacityOverflow:
+            last_overflowed = True                           # the frame rendered nothing; check_status already grew the capacity
+        # every overflowed frame since the last check, not only the last one (the sticky counter of the frame state)
+        self.dropped_frames += max(cx.read_dropped_frames(), 1 if last_overflowed else 0)
         if cx.capacity != self.captured_capacity:
             # no eager warm-up run: the step was running a moment ago, and an eager fn() would be one more (uncounted) training step.
             # NOTE self.outputs is re-bound: callers must read step.outputs / the return value of step() afresh after a check().

@@ -13,9 +13,14 @@ from ._lib import check, lib
 
 
 class FlatAdamW:
-    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.01, capturable=False):
+    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.01, capturable=False, shard=None):
         """capturable=True keeps the step counter on the device (``moss_adamw_flat_devstep``) so that a hipGraph capture of
-        the training step replays with the right bias correction (the analogue of torch.optim.AdamW(capturable=True))."""
+        the training step replays with the right bias correction (the analogue of torch.optim.AdamW(capturable=True)).
+
+        ``shard=(rank, world)``: this rank updates only its 1/world of the flat parameter buffer (the bucket's ``shard_layout``: the
+        bucket must have been made with the same ``world``) and keeps moments for that shard alone (moments memory and update time
+        / world); the caller reduce-scatters the gradient bucket into ``grad_shard`` before ``step()`` and all-gathers ``flat_params``
+        after it -- ``moss_amd.dist.ShardedStep`` does both."""
         self.bucket = bucket
         params = bucket.params
         lr_of, pat_of = {}, {}
@@ -26,7 +31,12 @@ class FlatAdamW:
                 pat_of[id(p)] = grp.get("lr_pattern")
         total = sum(bucket.sizes)
         dev = params[0].device
-        self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        if self.shard is not None and self.shard[1] != bucket.world:
+            raise ValueError(f"shard=(rank, {self.shard[1]}) but the bucket was laid out for {bucket.world} shards")
+        # (sharded: the parameter buffer mirrors the bucket's padded layout -- parameters, loss block, padding -- so that the
+        # all-gather of the updated shards is in place)
+        self.flat_params = torch.zeros(bucket.flat.numel() if self.shard is not None else total, dtype=torch.float32, device=dev)
         off = 0
         ends, lrs, periods, splits, lr2s = [], [], [], [], []
         for p, n in zip(params, bucket.sizes):
@@ -45,11 +55,20 @@ class FlatAdamW:
         self.seg_split = (C.c_int * len(ends))(*splits)
         self.seg_lr2 = (C.c_float * len(ends))(*lr2s)
         self.nseg = len(ends)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        if self.shard is None:
+            self.first, self.count = 0, total
+        else:
+            per = bucket.shard_len
+            first = min(self.shard[0] * per, total)
+            self.first, self.count = first, min(first + per, total) - first          # (the loss block and the padding are no parameters)
+            # the reduce-scattered gradients of this rank's shard land here (equal-sized on every rank: the collective needs that)
+            self.grad_shard = torch.zeros(per, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.t = 0
-        self.step_state = torch.zeros(2304, dtype=torch.int32, device=dev) if capturable else None     # csrc/optim.hip: counters on lines of their own
+        # device-side step counter + completion counters, each on a cache line of its own: the LIBRARY says how large (csrc/optim.hip)
+        self.step_state = torch.zeros(int(lib().moss_adamw_state_bytes()) // 4, dtype=torch.int32, device=dev) if capturable else None
 
     def snapshot(self):
         """Copies of everything a step changes (parameters, both moments, step counters)."""
@@ -65,6 +84,9 @@ class FlatAdamW:
         """Re-index the Gaussians: row i of every parameter whose leading dimension is len(perm) -- and of its two moments -- becomes
         the old row perm[i] (e.g. ``moss_amd.densify.spatial_order(xyz)``).  The step count is shared and stays.  Not capturable:
         call it between graph captures, where MOSS rebuilds its tensors anyway (densify / prune)."""
+        if self.shard is not None:
+            raise RuntimeError("permute_rows on a sharded FlatAdamW: the moments of a parameter row live on several ranks; gather, "
+                               "permute and rebuild the optimizer instead")
         n_rows = int(perm.numel())
         perm = perm.to(self.flat_params.device)
         off = 0
@@ -79,6 +101,18 @@ class FlatAdamW:
     def step(self):
         self.t += 1
         dev = self.flat_params.device
+        if self.shard is not None:
+            if self.count == 0:
+                return
+            with torch.cuda.device(dev):
+                rc = lib().moss_adamw_flat_range(self.first, self.count, self.flat_params[self.first:].data_ptr(), self.grad_shard.data_ptr(),
+                                                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
+                                                 self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]),
+                                                 float(self.eps), float(self.weight_decay), self.t,
+                                                 None if self.step_state is None else self.step_state.data_ptr(),
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+            check(rc, "adamw_flat_range")
+            return
         if self.step_state is not None:
             with torch.cuda.device(dev):
                 rc = lib().moss_adamw_flat_devstep(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(),

@@ -37,14 +37,12 @@ for seed in range(first, first + n_cases):
         if t.R > 0:
             g = tp._check_backward(d, dev, fw, t, e, zero_depth=bool(seed & 1), tol=2e-2, cos_gap=1e-3)
             # the block masks must be conservative: with culling off the decisions and every gradient equals up to rounding
-            L.moss_raster_debug_set_cull(0)
-            try:
-                t0 = hp.hip_forward(d, dev)
-                dc, dd, da = hp.image_grads(d.H, d.W, zero_depth=bool(seed & 1))
-                m = hp.stable_mask(d, fw, thr=1e-4)              # (the incoming gradients of tp._check_backward: stable pixels only)
-                g0 = hp.hip_backward(d, t0, dc * m, dd * m, da * m, dev)
-            finally:
-                L.moss_raster_debug_set_cull(-1)
+            # (MOSS_DEBUG_NO_BLOCK_CULL = 2 on both calls; the in-op transform / raw-parameter entry points take no debug argument)
+            nocull = 0 if d.transforms is not None else 2
+            t0 = hp.hip_forward(d, dev, debug=nocull)
+            dc, dd, da = hp.image_grads(d.H, d.W, zero_depth=bool(seed & 1))
+            m = hp.stable_mask(d, fw, thr=1e-4)              # (the incoming gradients of tp._check_backward: stable pixels only)
+            g0 = hp.hip_backward(d, t0, dc * m, dd * m, da * m, dev, debug=nocull)
             for a, b in ((t.color, t0.color), (t.alpha, t0.alpha), (t.depth, t0.depth)):     # equal up to the order of the per-slot sums
                 assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), "culling changed the image"
             # The sums the kernels form themselves (means2D, colours, opacity, SH) equal to 1e-5 of the largest value: with culling

@@ -30,6 +30,32 @@ def test_fused_loss_matches_torch_reference(gpu, hip_lib, shape):
     assert hp.rel_err(al.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_fused_loss_matches_reference_golden(gpu, hip_lib, i):
+    """The HIP loss kernels against the REFERENCE'S OWN numbers, no restatement in between: tests/golden/loss.npz
+    holds l1_loss / ssim values, total = l1 + 0.2 (1 - ssim) and its autograd gradient as computed by the reference's
+    utils/loss_utils.py:41-87 (imported in the build container by tests/golden/make_golden.py, float64 inputs) on two random image
+    pairs (48x40: ragged against the kernels' 32x32 tiles; 64x64).  lambda_mask = 0 switches the mask term off, as the fixture has
+    none.  Tolerances: values 2e-6 absolute (float32 kernels, sums of <= 12k terms; the reference's own float32 evaluation of ssim
+    differs from its float64 one by up to 1e-7), gradient 2e-5 of its largest element."""
+    import os
+    from moss_amd.loss import training_loss_fused
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss.npz"))
+    a = torch.from_numpy(g[f"l{i}_a"]).float().to(gpu).requires_grad_(True)
+    b = torch.from_numpy(g[f"l{i}_b"]).float().to(gpu)
+    _, H, W = a.shape
+    alpha = torch.zeros(1, H, W, device=gpu, requires_grad=True); mask = torch.zeros(1, H, W, device=gpu)
+    terms = torch.zeros(4, device=gpu)
+    out = training_loss_fused(a, alpha, b, mask, lambda_dssim=0.2, lambda_mask=0.0, terms_out=terms)
+    (out * 1.0).backward()
+    total, l1, ssim_v, _ = [float(x) for x in terms.cpu()]
+    assert abs(l1 - float(g[f"l{i}_l1"])) < 2e-6
+    assert abs(ssim_v - float(g[f"l{i}_ssim"])) < 2e-6
+    assert abs(total - float(g[f"l{i}_total"])) < 2e-6 and float(out) == total
+    assert hp.rel_err(a.grad.cpu().numpy(), g[f"l{i}_grad"]) < 2e-5
+    assert float(alpha.grad.abs().max()) == 0.0               # lambda_mask = 0: no gradient reaches alpha
+
+
 # ---------------------------------------------------------------- distCUDA2
 @pytest.mark.parametrize("P", [1, 3, 4, 5, 1000, 6890, 20000])
 def test_dist2_bit_exact_vs_bruteforce_oracle(gpu, hip_lib, P):
@@ -322,8 +348,8 @@ def test_async_forward_equals_sync_forward(gpu, hip_lib, async_mode, raw):
     for _ in range(2):
         got = _train_like_step(pc, cam, pipe, bg, w)          # asynchronous
     async_mode.check_async_status()
-    # the context's frame state (per-frame counters of the asynchronous forward, C ABI moss_raster_frame_state) was used -- no clear
-    # kernel ran -- and is all-zero again
+    # the context's frame state (per-frame counters of the asynchronous forward, the `frame_state` ARGUMENT of the C ABI since version
+    # 2) was used -- no clear kernel ran -- and is all-zero again
     fs = async_mode._C.ASYNC.frame_state
     assert fs is not None and int(fs.count_nonzero()) == 0
     for a, b, c in zip(ref[:3], first[:3], got[:3]):
@@ -352,9 +378,14 @@ def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode
     assert torch.equal(radii, ref[2])                          # preprocess still ran
     for g in grads:
         assert float(g.abs().max()) == 0.0
-    with pytest.raises(RuntimeError, match="needed"):
+    with pytest.raises(async_mode.CapacityOverflow, match="needed") as exc:
         async_mode.check_async_status()
-    assert int(async_mode._C.ASYNC.frame_state.count_nonzero()) == 0      # the overflowed frame left its counters clean too
+    assert isinstance(exc.value, RuntimeError) and exc.value.needed > 2048
+    # the library's STICKY dropped-frame counter (frame state word MOSS_FRAME_STATE_DROPPED_WORD) saw exactly that frame; reading
+    # resets it, and then the overflowed frame has left every other counter clean too
+    assert async_mode._C.ASYNC.read_dropped_frames(reset=False) == 1 and async_mode._C.ASYNC.read_dropped_frames() == 1
+    assert async_mode._C.ASYNC.read_dropped_frames() == 0
+    assert int(async_mode._C.ASYNC.frame_state.count_nonzero()) == 0
     assert async_mode._C.ASYNC.capacity > 2048
     got = _train_like_step(pc, cam, pipe, bg, w)               # the grown capacity fits
     async_mode.check_async_status()
@@ -432,6 +463,47 @@ def test_flat_adamw_device_step_counter(gpu, hip_lib):
     assert int(opt.step_state[0]) == 5
     for p, q in zip(pa, pb):
         assert hp.rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-6
+
+
+def test_sharded_flat_adamw_equals_the_full_update(gpu, hip_lib):
+    """moss_adamw_flat_range (FlatAdamW(shard=(r, w))): the w shards of the update, each with the moments of its own elements only,
+    give bit for bit the parameters of the full update -- learning-rate segments, the periodic SH pattern and shard boundaries that
+    fall inside a segment included; device-side and host-side step counters."""
+    from moss_amd.dist import GradBucket
+    from moss_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    shapes = [(301, 3), (301, 16, 3), (301, 1), (301, 4)]
+    world = 4
+
+    def groups(ps):
+        return [{"params": [ps[0]], "lr": 0.01}, {"params": [ps[1]], "lr": 0.0025, "lr_pattern": (48, 3, 0.0025 / 20)},
+                {"params": [ps[2]], "lr": 0.05}, {"params": [ps[3]], "lr": 0.001}]
+    init = [torch.randn(*s) for s in shapes]
+    for capturable in (False, True):
+        pf = [torch.nn.Parameter(t.clone().to(gpu)) for t in init]
+        bf = GradBucket(pf)
+        full = FlatAdamW(groups(pf), bf, eps=1e-15, capturable=capturable)
+        shards = []
+        for r in range(world):
+            ps = [torch.nn.Parameter(t.clone().to(gpu)) for t in init]
+            b = GradBucket(ps, world=world)
+            shards.append((b, FlatAdamW(groups(ps), b, eps=1e-15, capturable=capturable, shard=(r, world))))
+        n = bf.n_params
+        assert sum(o.count for _, o in shards) == n and all(o.exp_avg.numel() == max(o.count, 1) for _, o in shards)
+        for it in range(4):
+            g = torch.randn(n, device=gpu)
+            bf.flat[:n] = g
+            full.step()
+            for r, (b, o) in enumerate(shards):
+                per = b.shard_len
+                o.grad_shard.zero_()
+                o.grad_shard[:o.count] = g[o.first:o.first + o.count]          # what the reduce-scatter would have left here
+                o.step()
+            # "all-gather": every rank's shard of the parameters
+            got = torch.cat([o.flat_params[o.first:o.first + o.count] for _, o in shards])
+            assert torch.equal(got, full.flat_params[:n]), (capturable, it)
+            for b, o in shards:                                               # ... copied into every replica for the next step
+                o.flat_params[:n] = got
 
 
 def test_spatial_order_hint_changes_no_result(gpu, hip_lib):
@@ -925,39 +997,36 @@ def test_raw_parameters_inside_the_op_equal_the_torch_getters(gpu, hip_lib, with
 
 def test_block_mask_culling_never_changes_a_result(gpu, hip_lib):
     """The per-instance block masks only SKIP (entry, block) pairs that cannot reach alpha >= 1/255 in that block.  With the masks
-    switched off (moss_raster_debug_set_cull(0): every entry is blended against every block) the DECISIONS must be the same:
+    switched off (``debug = MOSS_DEBUG_NO_BLOCK_CULL`` on the forward and the backward call -- an argument since ABI 2, a process-wide
+    switch before: every entry is blended against every block) the DECISIONS must be the same:
     final_T and n_contrib bit-identical; colour / depth / alpha equal up to fp32 summation order (a pixel's sums are kept as four
     per-slot partial sums, and which slot an entry lands in depends on how many entries were skipped before it); every gradient equal
     up to rounding -- since round 2 the forward cuts a block's list every 64 HITS into depth segments, the unculled run cuts elsewhere,
-    and a segment starts its suffix state from the stored sums instead of from the recurrence (1e-5 of the largest value; bit-identical
-    in round 1, and still with MOSS_SEG_HITS=0).  Checked on
-    the body scene, on anisotropic random Gaussians with per-Gaussian transforms, and with Gaussians that cover the whole image
-    and opacities around the 1/255 threshold."""
-    cases = [hp.inputs_of(scenes.config2(), "scale_rot"), hp.inputs_of(scenes.config1(), "lbs")]
+    and a segment starts its suffix state from the stored sums instead of from the recurrence (1e-5 of the largest value).  Checked on
+    the body scene, on anisotropic random Gaussians with a precomputed (transformed) covariance, and with Gaussians that cover the
+    whole image and opacities around the 1/255 threshold."""
+    NO_BLOCK_CULL = 2                                                        # include/moss_raster.h MOSS_DEBUG_NO_BLOCK_CULL
+    cases = [hp.inputs_of(scenes.config2(), "scale_rot"), hp.inputs_of(scenes.config1(), "precomp")]
     big = scenes.config1(P=600, W=200, H=136, seed=77)
     big.scales[:12] *= 40.0
     big.opacities[:200] = torch.linspace(0.0, 0.02, 200)[:, None]            # around the 1/255 threshold
     cases.append(hp.inputs_of(big, "scale_rot"))
-    try:
-        for d in cases:
-            outs = []
-            for mode in (1, 0):
-                hip_lib.moss_raster_debug_set_cull(mode)
-                t = hp.hip_forward(d, gpu)
-                e = hp.hip_export(d, t, gpu)
-                dc, dd, da = hp.image_grads(d.H, d.W, seed=3)
-                g = hp.hip_backward(d, t, dc, dd, da, gpu)
-                outs.append(([t.color.cpu(), t.depth.cpu(), t.alpha.cpu()],
-                             [torch.from_numpy(e.final_T), torch.from_numpy(e.n_contrib.astype(np.int64))],
-                             [v.cpu() for v in vars(g).values() if v is not None]))
-            for a, b in zip(outs[0][0], outs[1][0]):
-                assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
-            for a, b in zip(outs[0][1], outs[1][1]):
-                assert torch.equal(a, b)
-            for a, b in zip(outs[0][2], outs[1][2]):
-                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-30
-    finally:
-        hip_lib.moss_raster_debug_set_cull(-1)
+    for d in cases:
+        outs = []
+        for dbg in (0, NO_BLOCK_CULL):
+            t = hp.hip_forward(d, gpu, debug=dbg)
+            e = hp.hip_export(d, t, gpu)
+            dc, dd, da = hp.image_grads(d.H, d.W, seed=3)
+            g = hp.hip_backward(d, t, dc, dd, da, gpu, debug=dbg)
+            outs.append(([t.color.cpu(), t.depth.cpu(), t.alpha.cpu()],
+                         [torch.from_numpy(e.final_T), torch.from_numpy(e.n_contrib.astype(np.int64))],
+                         [v.cpu() for v in vars(g).values() if v is not None]))
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert torch.equal(a, b)
+        for a, b in zip(outs[0][2], outs[1][2]):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-30
 
 
 def test_two_renders_into_one_backward_with_gradient_sinks(gpu, hip_lib):

@@ -69,6 +69,9 @@ def _end_to_end(d, gpu, key, adjudicate=True, per_gaussian=tp.PER_GAUSSIAN_TOL):
     okc = ok.reshape(d.H, d.W)
     for name, a, b in (("color", e.color, fw.color), ("depth", e.depth, fw.depth), ("alpha", e.alpha, fw.alpha)):
         assert hp.rel_err(a[:, okc], b[:, okc]) < tp.IMG_TOL, name
+    # ... and EVERY pixel, the fragile ones included: within what one or two flipped decisions can move it; n_contrib differs only
+    # there, on a measured and bounded fraction of the image
+    flips = tp.check_every_pixel(d, fw, e)
     img_adj = {}
     for name, a, b32, b64 in (("color", e.color, fw.color, fw64.color), ("alpha", e.alpha, fw.alpha, fw64.alpha),
                               ("final_T", e.final_T.reshape(1, d.H, d.W), fw.final_T.reshape(1, d.H, d.W), fw64.final_T.reshape(1, d.H, d.W))):
@@ -92,7 +95,9 @@ def _end_to_end(d, gpu, key, adjudicate=True, per_gaussian=tp.PER_GAUSSIAN_TOL):
         adj[n] = (e_hip, e_orc, excess)
         if adjudicate:
             assert excess <= ADJ_FLOOR, f"{n}: HIP is up to {e_hip:.3g} of the contribution mass from float64 (the float32 oracle {e_orc:.3g}); {excess:.3g} beyond the allowance"
-    _note(key, {"fragile_pixels": float(1.0 - m.mean()), "images_vs_f64 (hip, oracle32)": img_adj,
+    unmasked = tp.check_backward_unmasked(d, gpu, fw, t, e)   # incoming gradients on every pixel, whole-tensor bars
+    _note(key, {"fragile_pixels": float(1.0 - m.mean()), "every_pixel": flips, "backward_unmasked (relmax, 1-cos)": unmasked,
+                "images_vs_f64 (hip, oracle32)": img_adj,
                 "grads_vs_oracle32 (relmax, 1-cos, per-Gaussian scaled)": errs, "grads_vs_f64 scaled (hip, float32 restatements, excess)": adj})
     return errs, adj
 
@@ -106,10 +111,15 @@ def test_cfg2_end_to_end_and_adjudicated(gpu, hip_lib):
     _end_to_end(hp.inputs_of(scenes.config2(), "precomp"), gpu, "cfg2_precomp")
 
 
-@pytest.mark.parametrize("mode", ["scale_rot", "precomp"])
+@pytest.mark.parametrize("mode", ["scale_rot", "precomp", "lbs"])
 def test_cfg3_end_to_end_and_adjudicated(gpu, hip_lib, mode):
-    """BASELINE configs[2] at full size, both covariance modes, HIP fwd+bwd against oracle fwd+bwd and against float64."""
-    _end_to_end(hp.inputs_of(scenes.config3(), mode), gpu, f"cfg3_{mode}")
+    """BASELINE configs[2] at full size, both covariance modes and MOSS's real data flow -- per-Gaussian LBS-like transforms applied
+    inside the op (row n2, what `value_lbs_in_op` of the bench measures) -- HIP fwd+bwd against oracle fwd+bwd and against float64."""
+    sc = scenes.config3()
+    if mode == "lbs":
+        gT = torch.Generator().manual_seed(1234)                # the transforms bench.py uses (lbs_transforms)
+        sc.transforms = torch.eye(3) + 0.05 * torch.randn(sc.means3D.shape[0], 3, 3, generator=gT)
+    _end_to_end(hp.inputs_of(sc, mode), gpu, f"cfg3_{mode}")
 
 
 def test_cfg5_precomp_full_size(gpu, hip_lib):

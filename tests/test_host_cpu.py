@@ -14,15 +14,84 @@ from moss_amd import scenes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol(hip_lib):
-    text = open(os.path.join(ROOT, "include", "moss_raster.h")).read()
+def _declared(text):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = set(re.findall(r"\b(moss_[a-z0-9_]+)\s*\(", text)) - {"moss_alloc_fn"}
-    assert len(names) >= 15
+    return set(re.findall(r"\b(moss_[a-z0-9_]+)\s*\(", text)) - {"moss_alloc_fn"}
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    """The PRODUCT library exports everything the header declares outside its ``#ifdef MOSS_DIAG`` block -- and nothing of that block
+    (diagnostics do not ship)."""
+    text = open(os.path.join(ROOT, "include", "moss_raster.h")).read()
+    diag_block = re.search(r"#ifdef MOSS_DIAG\n(.*?)#endif", text, flags=re.S)
+    assert diag_block
+    diag_names = _declared(diag_block.group(1))
+    names = _declared(text.replace(diag_block.group(0), ""))
+    assert len(names) >= 15 and diag_names == {"moss_raster_debug_set_stamps", "moss_raster_debug_set_bwd_stamps"}
     for n in sorted(names):
         assert hasattr(hip_lib, n), f"{n} is declared in include/moss_raster.h but not exported"
-    assert hip_lib.moss_abi_version() == 1
+    for n in sorted(diag_names):
+        assert not hasattr(hip_lib, n), f"{n} is a diagnostic entry point and must not be in the product build"
+    assert hip_lib.moss_build_has_diagnostics() == 0
+    assert re.search(r"#define\s+MOSS_ABI_VERSION\s+2\b", text) and hip_lib.moss_abi_version() == 2
     assert hip_lib.moss_last_error() == b""
+    assert hip_lib.moss_adamw_state_bytes() == int(re.search(r"#define\s+MOSS_ADAMW_STATE_BYTES\s+(\d+)", text).group(1))
+
+
+def test_product_build_reads_no_environment_variable():
+    """No translation unit under moss_amd/csrc/ mentions getenv, and the built product library does not import it (the knobs of the
+    A/B scripts exist only in the -DMOSS_DIAG build, whose getenv lives in scripts/diag/knobs.cpp)."""
+    import subprocess
+    for f in os.listdir(os.path.join(ROOT, "moss_amd", "csrc")):
+        assert "getenv" not in open(os.path.join(ROOT, "moss_amd", "csrc", f)).read(), f
+    from moss_amd import _lib
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert syms and "getenv" not in syms
+
+
+def test_extension_reports_its_compile_time_abi_version(monkeypatch):
+    """`_moss_C.abi_version()` used to call the library, so `_lib.ext()` compared the library with itself.  It now returns
+    the MOSS_ABI_VERSION of the header the extension was COMPILED against, and a library of another version refuses to load."""
+    from moss_amd import _lib
+    src = open(os.path.join(ROOT, "moss_amd", "csrc", "torch_binding.cpp")).read()
+    assert re.search(r'm\.def\("abi_version",\s*\[\]\(\)\s*\{\s*return\s*\(int\)MOSS_ABI_VERSION;', src)
+    assert _lib.ext().abi_version() == _lib.ABI_VERSION == _lib.lib().moss_abi_version()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 1)
+    with pytest.raises(ImportError, match="ABI version"):
+        _lib.lib()
+
+
+def test_frame_state_blocks_are_never_freed_by_a_context():
+    """a RasterContext must keep every frame-state block it has handed out (a captured hipGraph holds its address)."""
+    from moss_amd.diff_gaussian_rasterization import RasterContext
+    cx = RasterContext()
+    dev = torch.device("cpu")                              # (allocation policy only: no kernel runs)
+    a = cx._frame_state(dev, 512, 512)
+    assert cx._frame_state(dev, 256, 256) is a             # a smaller image is served by the same block
+    b = cx._frame_state(dev, 2048, 2048)                   # a larger one by a new block ...
+    assert b is not a and any(t is a for t in cx._retired_frame_states)      # ... while the old one stays alive
+    assert cx._frame_state(dev, 512, 512) is b
+    assert int(a.count_nonzero()) == 0 and int(b.count_nonzero()) == 0
+
+
+def test_reorder_spatially_moves_torch_optimizer_state_too():
+    """with a torch.optim optimizer the moments must be permuted with the parameters; an unknown optimizer type raises."""
+    from moss_amd.gaussian_model import GaussianSet
+    s = scenes.config1()
+    pc = GaussianSet(s, device="cpu")
+    opt = torch.optim.AdamW(pc.param_groups(), lr=0.0, eps=1e-15)
+    for p in pc.parameters():
+        p.grad = torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) / p.numel()
+    opt.step()
+    before = {id(p): (p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in pc.parameters()}
+    perm = pc.reorder_spatially(opt)
+    assert sorted(perm.tolist()) == list(range(s.P)) and not torch.equal(perm, torch.arange(s.P))
+    for p in pc.parameters():
+        p0, m0, v0 = before[id(p)]
+        assert torch.equal(p.detach(), p0[perm]) and torch.equal(opt.state[p]["exp_avg"], m0[perm]) and torch.equal(opt.state[p]["exp_avg_sq"], v0[perm])
+    with pytest.raises(TypeError, match="cannot permute the state"):
+        pc.reorder_spatially(object())
 
 
 def test_scratch_size_functions_are_host_only_and_monotonic(hip_lib):
@@ -133,6 +202,20 @@ def test_shard_views():
     assert sorted(sum(parts, [])) == list(range(10)) and parts[1] == [1, 5, 9]
 
 
+def test_bucket_shard_layout():
+    """GradBucket(params, world): equal 4-aligned shards that cover gradients + loss block; the loss block never straddles two."""
+    from moss_amd.dist import GradBucket, shard_layout
+    for sizes, world in (((5, 3), 2), ((1001, 7, 16), 8), ((100000 * 59,), 8), ((3,), 4)):
+        params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+        b = GradBucket(params, world=world)
+        per, padded = shard_layout(b.n_exchange, world)
+        assert b.shard_len == per and b.flat.numel() == padded == per * world and per % 4 == 0
+        assert b.tail % 4 == 0 and b.tail >= sum(sizes) and b.tail // per == (b.tail + 3) // per
+        assert b.loss_terms.data_ptr() == b.flat[b.tail:].data_ptr()
+    b1 = GradBucket([torch.nn.Parameter(torch.zeros(10))])
+    assert b1.flat.numel() == 12 + 4 and b1.world == 1
+
+
 def _rank_main(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -173,6 +256,90 @@ def test_frame_parallel_gradient_bucket_gloo_world2():
         assert torch.allclose(g0, torch.full((5, 3), 1.5))                  # mean of 1 and 2
         assert torch.allclose(g1, torch.full((7,), 15.0))                   # mean of 10 and 20
         assert torch.allclose(loss, torch.tensor([(15.0 + 30.0) / 2]))      # mean of the two ranks' losses
+
+
+class _TorchAdamWShard:
+    """torch restatement of FlatAdamW(shard=...) for the CPU test of the exchange (the HIP kernel needs a GPU): AdamW on
+    flat_params[first : first + count] with the gradients in grad_shard."""
+    def __init__(self, bucket, params0, rank, lr=0.01, betas=(0.9, 0.999), eps=1e-15, wd=0.01):
+        per = bucket.shard_len
+        self.flat_params = torch.zeros(bucket.flat.numel())
+        self.flat_params[:bucket.n_params] = params0
+        self.grad_shard = torch.zeros(per)
+        self.first = min(rank * per, bucket.n_params)
+        self.count = min(self.first + per, bucket.n_params) - self.first
+        self.m, self.v, self.t = torch.zeros(self.count), torch.zeros(self.count), 0
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, wd
+
+    def step(self):
+        self.t += 1
+        _adamw_update(self.flat_params[self.first:self.first + self.count], self.grad_shard[:self.count], self.m, self.v, self.t,
+                      self.lr, self.betas, self.eps, self.wd)
+
+
+def _adamw_update(p, g, m, v, t, lr, betas, eps, wd):
+    p.mul_(1 - lr * wd)
+    m.mul_(betas[0]).add_(g, alpha=1 - betas[0]); v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    p.addcdiv_(m / (1 - betas[0] ** t), (v.sqrt() / (1 - betas[1] ** t) ** 0.5).add_(eps), value=-lr)
+
+
+def _exchange_rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from moss_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37, 3), (37, 16, 3), (37, 1)]                                  # 37 * 52 = 1924 parameters (+ the 4-float loss block): two shards of 964
+    init = [torch.randn(s, generator=g) for s in shapes]
+    out = {}
+    for kind in ("allreduce", "sharded"):
+        params = [torch.nn.Parameter(x.clone()) for x in init]
+        bucket = mdist.GradBucket(params, world=world if kind == "sharded" else 1)
+        n = bucket.n_params
+        p0 = torch.cat([x.reshape(-1) for x in init])
+        if kind == "sharded":
+            opt = _TorchAdamWShard(bucket, p0, rank)
+            ex = mdist.ShardedStep(bucket, opt, rank, world)
+        else:
+            flat, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+        gr = torch.Generator().manual_seed(100 + rank)                        # every rank its own "view"
+        for t in range(1, 4):
+            bucket.flat[:n] = torch.randn(n, generator=gr)
+            bucket.loss_terms[:] = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1) * t
+            if kind == "sharded":
+                loss = ex.step()
+                terms = ex.loss_terms.clone()
+            else:
+                loss = bucket.all_reduce_mean(None, world)
+                terms = bucket.loss_terms.clone()
+                _adamw_update(flat, bucket.flat[:n], m, v, t, 0.01, (0.9, 0.999), 1e-15, 0.01)
+            assert torch.allclose(terms, torch.tensor([1.0, 2.0, 3.0, 4.0]) * t * (world + 1) / 2) and float(loss) == float(terms[0])
+        out[kind] = (opt.flat_params[:n] if kind == "sharded" else flat).numpy().copy()
+        if kind == "sharded":
+            assert opt.count == (964 if rank == 0 else 960) and opt.m.numel() == opt.count     # (1924 + 4) / 2 = 964 per shard; moments for the shard only
+    q.put((rank, out["allreduce"], out["sharded"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_exchange_equals_allreduce_gloo_world2():
+    """reduce-scatter -> AdamW on the rank's shard -> all-gather (moss_amd.dist.ShardedStep) leaves the SAME
+    parameters on every rank as all-reduce -> full AdamW, and both replicas agree; the averaged loss block reaches every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_exchange_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, a0, s0), (_, a1, s1) = res
+    assert np.array_equal(a0, a1) and np.array_equal(s0, s1)                  # replicas identical, either path
+    np.testing.assert_allclose(s0, a0, rtol=0, atol=1e-7)                     # and the two paths agree
+    assert np.abs(a0).max() > 0.1
 
 
 def _stats_rank_main(rank, world, port, q):
@@ -247,6 +414,10 @@ def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
     assert res["replicas_identical"] is True and res["backend"] == "gloo"
     assert res["allreduce_ms"] >= 0.0 and "adamw_ms" in res and res["value"] > 0
+    # both exchange paths were run, each reports its numbers, and they left identical parameters (asserted inside the ranks too)
+    ev = res["exchange_variants"]
+    assert set(ev) == {"allreduce", "sharded"} and res["exchange"] == "allreduce"
+    assert ev["allreduce"]["checksum"] == ev["sharded"]["checksum"] and all(v["replicas_identical"] for v in ev.values())
     # a rank that fails takes the launcher down with a non-zero exit code and no JSON line
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=300)         # no GPU here: every rank asserts
