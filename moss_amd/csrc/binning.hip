@@ -55,7 +55,7 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
                                              uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
                                              uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */,
                                              int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
-                                             uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues)
+                                             uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table)
 {
     const int tid = threadIdx.x;
     // every header word is WRITTEN here and the queue words are zeroed (the blend kernels pop from them): nothing in the image
@@ -75,6 +75,7 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
     // If this frame needs more, render NOTHING (all ranges empty, no queued work) and raise the overflow flag: the
     // following kernels stay inside the buffer and the host reports the error at its next check.
     const bool overflow = total > capacity;
+    const uint32_t off_first = off;                      // where this thread's first tile starts (the loop below walks on from here)
     for (int i = b; i < e; i++) {
         const uint32_t v = overflow ? 0u : tile_count[i];
         ranges[i] = make_uint2(off, off + v); off += v;
@@ -101,9 +102,15 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         }
     }
     __syncthreads();
-    for (int i = b; i < e; i++) {
-        const uint32_t v = overflow ? 0u : tile_count[i];
-        tile_order[atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u)] = (uint32_t)i;
+    {
+        uint32_t o = overflow ? 0u : off_first;
+        for (int i = b; i < e; i++) {
+            const uint32_t v = overflow ? 0u : tile_count[i];
+            const uint32_t rank = atomicAdd(&s_bucket[v ? (uint32_t)__clz((int)v) : 32u], 1u);
+            tile_order[rank] = (uint32_t)i;
+            work_table[rank] = make_uint4((uint32_t)i, o, o + v, 0u);       // {tile, list start, list end}: an item's start-up in one load
+            o += v;
+        }
     }
     // where the inst_pos slot runs of every group of 256 Gaussians start (the preprocess kernel left group-relative run starts
     // and the groups' totals): the reference's device-wide scan of tiles_touched, rasterizer_impl.cu:279, at 1/256 of its length
@@ -125,13 +132,13 @@ __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
             uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
             int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
-            uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues)
+            uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_bucket[34];
     scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                       n_groups, group_tot, group_base, flags_acc, queues);
+                       n_groups, group_tot, group_base, flags_acc, queues, work_table);
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111).  A block reserves, per tile, a contiguous run of slots
@@ -144,7 +151,8 @@ __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ keys, int lds_hist, uint32_t* __restrict__ header, int fold_scan,
                const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
-               uint32_t capacity, int light_log2, uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues)
+               uint32_t capacity, int light_log2, uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues,
+               uint4* __restrict__ work_table)
 {
     extern __shared__ uint32_t s_mem[];
     __shared__ uint32_t s_wave[4];
@@ -155,7 +163,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         n_blocks--;
         if ((int)blockIdx.x == n_blocks) {
             scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                              (P + 255) / 256, g.group_tot, g.group_base, flags_acc, queues);
+                              (P + 255) / 256, g.group_tot, g.group_base, flags_acc, queues, work_table);
             return;
         }
     } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
@@ -663,7 +671,7 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 {
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header, cap, light_log2_knob(), (P + 255) / 256, g.group_tot, g.group_base, im.flags_acc, im.queues);
+                       im.header, cap, light_log2_knob(), (P + 255) / 256, g.group_tot, g.group_base, im.flags_acc, im.queues, im.work_table);
 }
 
 // The scan can ride along with the scatter (no launch of its own) when the tile histogram fits the scatter's LDS and nobody has to
@@ -686,7 +694,8 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
     const int fold = (fold_scan && lds_hist) ? 1 : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks + fold), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
-                       lds_hist, im.header, fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob(), im.flags_acc, im.queues);
+                       lds_hist, im.header, fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob(), im.flags_acc, im.queues,
+                       im.work_table);
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,

@@ -517,6 +517,9 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     bool finished = __ballot(live > 0.0f) == 0ull;
 
     // one trip: 4 consecutive hits x 16 pixels; returns true when every pixel of the block is finished
+    // (Round 3 software-pipelined this -- the next trip's alpha evaluated inside the current trip, compiled with the max-ilp scheduling
+    // strategy so that the two chains interleave: 40.4 -> 42.8 us.  The SIMDs that set the kernel's length host two blenders and are
+    // bound by instruction ISSUE, not by one wave's dependent latencies; the extra copies cost more than the overlap gave.)
     auto trip = [&](const Fetched& f) -> bool {
         const PairEval pe = eval_pair(f.a.x - pixx, f.a.y - pixy, f.b.x, f.b.y, f.b.z, f.b.w);
         const float al = pe.alpha * live * f.valid;                    // 0 for finished / outside pixels and padding slots
@@ -866,12 +869,12 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
 // names the XCD): the 16 blocks of a tile are pulled by waves that share an L2 (PMC: the forward kernel's HBM traffic equals its
 // algorithmic bytes).  Tiles are dealt to the queues in LPT order, rank r -> queue r % nq; of a queue's tiles the first hx are
 // heavy (16 block items each), the rest light (4 quadrant items each).
-struct WaveItem { int tile, sub, rank; bool heavy, valid; };
+struct WaveItem { int tile, sub, rank; bool heavy, valid; uint2 rg; };
 // The FIRST item of a wave is its own rank among the waves of its queue -- no atomic: with one returning atomic per wave at kernel
 // start the last of 1024 waves waited 2-12 us for its first item (same-line atomics serialise, see common.h).  Later items:
 // (waves of the queue) + the value of the queue head.
 __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int nq, int qx, int hx, int n_work,
-                                              const uint32_t* __restrict__ tile_order, int first_rank, int q_waves)
+                                              const uint4* __restrict__ work_table, int first_rank, int q_waves)
 {
     int qi = first_rank;
     if (first_rank < 0) {
@@ -884,13 +887,15 @@ __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int n
     it.sub = it.heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
     it.rank = k * nq + qx;
     it.valid = it.rank < n_work;
-    it.tile = it.valid ? (int)tile_order[it.rank] : 0;
+    // {tile, list start, list end} of the rank in ONE load (the scan block's work table; rank -> tile -> range were two round trips)
+    const uint4 wt = it.valid ? work_table[it.rank] : make_uint4(0u, 0u, 0u, 0u);
+    it.tile = (int)wt.x; it.rg = make_uint2(wt.y, wt.z);
     return it;
 }
 
 __global__ void __launch_bounds__(256)
 blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
-                          uint32_t* __restrict__ queue_head, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
+                          uint32_t* __restrict__ queue_head, const uint4* __restrict__ work_table, const float4* __restrict__ inst_rec,
                           const uint16_t* __restrict__ inst_bmask,
                           const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                           float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
@@ -906,6 +911,13 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     __shared__ PairCtl s_ctl[FWD_PAIRS_PER_WG];
     static_assert(sizeof(PairRing) >= 2 * 64 * 3 * sizeof(float4), "the light path's rings live inside the pair's ring");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pair = wv >> 1;
+    // A pair's FIRST item is its rank in its queue, and whether that is a heavy or a light item only the header says: the work-table
+    // entry it would be as a heavy item (the common case) is requested here, together with the header words, so that the start-up
+    // chain of the kernel is (header | table entry) -> block masks -> records -> first trip: three round trips where round 2 had
+    // five (header -> tile order -> range -> masks -> records).
+    const int nq_ = min(NUM_XCD_QUEUES, (int)gridDim.x), qx_ = (int)blockIdx.x % nq_;
+    const int first_qi = ((int)blockIdx.x / nq_) * FWD_PAIRS_PER_WG + pair;
+    const uint4 first_wt = work_table[min((first_qi >> 4) * nq_ + qx_, T_tiles - 1)];
     // Which wave of the pair blends: the waves of a workgroup sit on SIMD 0..3 in order, and a CU hosts several workgroups -- the roles
     // are swapped between them so that a SIMD gets blenders (busy) and scanners (mostly waiting) in equal numbers.
     const bool is_scanner = (((wv ^ role_swap ^ (int)((blockIdx.x >> 3) / 32u)) & 1) == 0);
@@ -929,7 +941,8 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
         it.sub = it.heavy ? (qi & 15) : ((qi - WAVE_BLOCKS * hx) & 3);
         it.rank = k * nq + qx;
         it.valid = it.rank < n_work;
-        it.tile = it.valid ? (int)tile_order[it.rank] : 0;
+        const uint4 wt = !it.valid ? make_uint4(0u, 0u, 0u, 0u) : (qi == first_qi && it.heavy) ? first_wt : work_table[it.rank];
+        it.tile = (int)wt.x; it.rg = make_uint2(wt.y, wt.z);
         return it;
     };
     auto pop = [&]() -> int {
@@ -945,7 +958,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
         int qi = my_rank;
         for (;;) {
             const WaveItem it = decode(qi);
-            const uint2 rg = it.valid ? ranges[it.tile] : make_uint2(0u, 0u);
+            const uint2 rg = it.rg;
             const bool heavy = it.valid && it.heavy;
             uint32_t nx[CHAPTER];
             if (heavy) {                                     // the first chapter of block masks: requested before the wait below
@@ -1005,7 +1018,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
         light_qi = -1;
         const WaveItem it = decode(qi);
         if (!it.valid) break;
-        light_forward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
+        light_forward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
                            out_alpha, final_T, n_contrib, flags);
     }
 
@@ -1026,8 +1039,8 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
 }
 
 __global__ void __launch_bounds__(256, 4)      // (four waves per SIMD: at most 128 VGPRs)
-blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
-                           uint32_t* __restrict__ queue_head, const uint2* __restrict__ ranges, const float4* __restrict__ inst_rec,
+blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_table, const uint32_t* __restrict__ header,
+                           uint32_t* __restrict__ queue_head, const float4* __restrict__ inst_rec,
                            const uint16_t* __restrict__ inst_bmask,
                            const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                            const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
@@ -1110,17 +1123,17 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint32_t* __restrict__ ti
     (void)first_rank;
     for (;;) {
         const unsigned long long tq0 = WSTAMP();
-        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, tile_order, -1, 0);
+        const WaveItem it = pull_item(queue_head + (size_t)qx * QLINE_WORDS, lane, nq, qx, hx, n_work, work_table, -1, 0);
         const unsigned long long tq1 = WSTAMP();
         c_tailpop += tq1 - tq0;
         if (!it.valid) break;
         n_tail++;
         if (it.heavy)
-            heavy_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
+            heavy_backward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
                                 n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags,
                                 (flags & 32) ? 0 : (int)tail_start[(size_t)it.tile * WAVE_BLOCKS + it.sub], 0x7fffffff, nullptr);
         else
-            light_backward_item(W, H, gx, it.tile, it.sub, lane, ranges[it.tile], inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
+            light_backward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
                                 dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
         c_tail += WSTAMP() - tq1;
     }
@@ -1186,7 +1199,7 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
     static const int role_swap = knob("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = knob("MOSS_FWD_PRIO", 0);
     MOSS_LAUNCH_TIMED(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
-                       im.queues + (size_t)Q_FWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                       im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                        im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
                        role_swap, prio_mode);
 }
@@ -1204,8 +1217,8 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel, "MOSS_BWD_WGS_PER_CU", 4, 5);   // 27 KB of LDS each
     const int wgs = min(4 * T, device_cus() * bwd_wgs_per_cu);
     // the queue heads are zero here: cleared by the forward, rewound after each backward (preprocess_backward_kernel)
-    MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.tile_order, im.header,
-                       im.queues + (size_t)Q_BWD * QLINE_WORDS, im.ranges, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
+    MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.work_table, im.header,
+                       im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
                        dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
                        flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
                        forward_grid(T) /* the forward kernel's grid */);

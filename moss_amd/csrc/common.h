@@ -103,6 +103,8 @@ struct ImageView {
     uint32_t* flags_acc;     // where the preprocess kernel ORs its error flags: &header[2], or the caller's frame state (below)
     uint32_t* tail_start;    // per (tile, 4x4 block): list position where the part of the block's list NOT covered by depth segments begins
     uint32_t* seg_counts;    // [NUM_XCD_QUEUES][MAX_FWD_QUEUE_WAVES]: segments each forward wave left in its slot range
+    uint4* work_table;       // per RANK of tile_order (tiles with work first, longest class first): {tile, list start, list end, -} -- what a
+                             // blend wave needs to start an item, in ONE load (rank -> tile -> range were two dependent round trips)
     static ImageView at(char* base, int W, int H)
     {
         ImageView v; char* p = base;
@@ -115,12 +117,14 @@ struct ImageView {
         v.final_T = carve<float>(p, N); v.n_contrib = carve<uint32_t>(p, N);
         v.tail_start = carve<uint32_t>(p, 16 * T);
         v.seg_counts = carve<uint32_t>(p, (size_t)NUM_XCD_QUEUES * MAX_FWD_QUEUE_WAVES);
+        v.work_table = carve<uint4>(p, T);
         return v;
     }
     static size_t bytes(int W, int H)
     {
         char* z = nullptr; ImageView v = at(z, W, H);
-        return (size_t)((char*)v.seg_counts - z) + align_up((size_t)NUM_XCD_QUEUES * MAX_FWD_QUEUE_WAVES * 4);
+        const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        return (size_t)((char*)v.work_table - z) + align_up(T * sizeof(uint4));
     }
     // header + queues + tile_count + tile_cursor are contiguous (each carved at 16-byte granularity or coarser): one clear covers them
     size_t clear_bytes() const { return (size_t)((char*)ranges - (char*)header); }
