@@ -3,6 +3,8 @@
 //
 // Same algorithmic skeleton as the reference (Morton order -> boxes of 1024 consecutive points -> per point, scan
 // only boxes that can still hold a closer neighbour), re-shaped for CDNA4:
+//   * the Morton keys are sorted by a device-wide bitonic network (LDS tiles + streaming steps, see launch_sort_keys), not by one
+//     workgroup;
 //   * the scene bounding box is reduced ON THE DEVICE with ordered-integer atomics and consumed from device memory,
 //     so there is no host round trip at all (the reference blocks twice, simple_knn.cu:197,200);
 //   * points are gathered once into Morton order as float4 {x,y,z,original index}; a 256-thread workgroup then owns
@@ -72,29 +74,81 @@ morton_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__
     keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
 }
 
-// single workgroup, in-place bitonic network over n 64-bit keys in global memory (cold path: called once at model init)
+// ---- sort of the n 64-bit keys (Morton code << 32 | index), in place, ascending.  A bitonic network whose phases start with a
+// MIRRORED step (element i of a 2^lk block against element 2^lk - 1 - i), so that every later step of the phase is a plain ascending
+// compare-exchange at distance j and elements past n behave as +infinity without being stored (`hi < n`).
+//   * everything at distance < SORT_TILE stays inside a tile of SORT_TILE keys: done in LDS, many steps per launch
+//     (sort_tiles_kernel: all phases up to the tile size; sort_tail_kernel: the last log2(SORT_TILE) steps of a larger phase);
+//   * the steps at distance >= SORT_TILE are one streaming launch each (sort_step_kernel).
+// Round 2 ran the whole network in ONE 1024-thread workgroup (fine for the 6 890 SMPL vertices of MOSS's initialisation,
+// scene/gaussian_model.py:185; a cliff at the 100k - 1M points the rest of this library is sized for: 210 steps x 1M keys on one CU).
+// Now 1 launch up to 2048 points and 1 + sum_{lk = 12}^{ceil(log2 n)} (lk - 10) launches beyond (55 for a million points), every
+// one of them on the whole device.  Cold path either way: distCUDA2 runs when a model is created.
+constexpr uint32_t SORT_TILE_LOG2 = 11, SORT_TILE = 1u << SORT_TILE_LOG2;         // keys per workgroup of the LDS kernels (16 KB)
+
+__device__ __forceinline__ void cmpx(uint64_t& x, uint64_t& y) { if (x > y) { const uint64_t t = x; x = y; y = t; } }
+
+// phases lk = 1 .. min(SORT_TILE_LOG2, lpad) entirely inside each tile: afterwards every tile of SORT_TILE keys is sorted
 __global__ void __launch_bounds__(1024)
-sort_keys_kernel(uint64_t* __restrict__ a, uint32_t n)
+sort_tiles_kernel(uint64_t* __restrict__ a, uint32_t n, uint32_t lpad)
+{
+    __shared__ uint64_t s[SORT_TILE];
+    const uint32_t base = blockIdx.x * SORT_TILE, t = threadIdx.x;
+    for (uint32_t i = t; i < SORT_TILE; i += 1024u) s[i] = base + i < n ? a[base + i] : ~0ull;
+    __syncthreads();
+    const uint32_t last = min(lpad, SORT_TILE_LOG2);
+    for (uint32_t lk = 1; lk <= last; lk++) {
+        const uint32_t lhk = lk - 1, off = t & ((1u << lhk) - 1u), blk = t >> lhk;
+        { const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + ((1u << lk) - 1u) - off; cmpx(s[lo], s[hi]); }
+        __syncthreads();
+        for (int lj = (int)lhk - 1; lj >= 0; lj--) {
+            const uint32_t j = 1u << lj, lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u));
+            cmpx(s[lo], s[lo + j]);
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = t; i < SORT_TILE; i += 1024u) if (base + i < n) a[base + i] = s[i];
+}
+
+// one step of a phase lk > SORT_TILE_LOG2 at a distance that crosses tiles: the mirrored first step (lj < 0) or a plain step lj
+__global__ void __launch_bounds__(256)
+sort_step_kernel(uint64_t* __restrict__ a, uint32_t n, uint32_t half, uint32_t lk, int lj)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= half) return;
+    uint32_t lo, hi;
+    if (lj < 0) { const uint32_t lhk = lk - 1, off = t & ((1u << lhk) - 1u), blk = t >> lhk; lo = (blk << lk) + off; hi = (blk << lk) + ((1u << lk) - 1u) - off; }
+    else { const uint32_t j = 1u << lj; lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u)); hi = lo + j; }
+    if (hi < n) { uint64_t x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+}
+
+// the last SORT_TILE_LOG2 steps (distances SORT_TILE / 2 ... 1) of a larger phase, inside each tile
+__global__ void __launch_bounds__(1024)
+sort_tail_kernel(uint64_t* __restrict__ a, uint32_t n)
+{
+    __shared__ uint64_t s[SORT_TILE];
+    const uint32_t base = blockIdx.x * SORT_TILE, t = threadIdx.x;
+    for (uint32_t i = t; i < SORT_TILE; i += 1024u) s[i] = base + i < n ? a[base + i] : ~0ull;
+    __syncthreads();
+    for (int lj = (int)SORT_TILE_LOG2 - 1; lj >= 0; lj--) {
+        const uint32_t j = 1u << lj, lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u));
+        cmpx(s[lo], s[lo + j]);
+        __syncthreads();
+    }
+    for (uint32_t i = t; i < SORT_TILE; i += 1024u) if (base + i < n) a[base + i] = s[i];
+}
+
+void launch_sort_keys(uint64_t* keys, uint32_t n, hipStream_t s)
 {
     uint32_t lpad = 0;
     while ((1u << lpad) < n) lpad++;
-    const uint32_t half = (1u << lpad) >> 1;
-    for (uint32_t lk = 1; lk <= lpad; lk++) {
-        const uint32_t lhk = lk - 1, hkm = (1u << lhk) - 1u;
-        for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-            const uint32_t blk = t >> lhk, off = t & hkm;
-            const uint32_t lo = (blk << lk) + off, hi = (blk << lk) + ((1u << lk) - 1u) - off;
-            if (hi < n) { const uint64_t x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
-        }
-        __syncthreads();
-        for (int lj = (int)lhk - 1; lj >= 0; lj--) {
-            const uint32_t j = 1u << lj;
-            for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
-                const uint32_t lo = ((t >> lj) << (lj + 1)) + (t & (j - 1u)), hi = lo + j;
-                if (hi < n) { const uint64_t x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
-            }
-            __syncthreads();
-        }
+    const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE, half = (1u << lpad) >> 1;
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tiles), dim3(1024), 0, s, keys, n, lpad);
+    for (uint32_t lk = SORT_TILE_LOG2 + 1; lk <= lpad; lk++) {
+        hipLaunchKernelGGL(sort_step_kernel, dim3((half + 255) / 256), dim3(256), 0, s, keys, n, half, lk, -1);
+        for (int lj = (int)lk - 2; lj >= (int)SORT_TILE_LOG2; lj--)
+            hipLaunchKernelGGL(sort_step_kernel, dim3((half + 255) / 256), dim3(256), 0, s, keys, n, half, lk, lj);
+        hipLaunchKernelGGL(sort_tail_kernel, dim3(tiles), dim3(1024), 0, s, keys, n);
     }
 }
 
@@ -227,7 +281,7 @@ extern "C" int moss_knn_dist2(int P, const float* points, float* mean_dists, cha
     if (hipMemsetAsync(v.mm + 3, 0x00, 3 * sizeof(uint32_t), s) != hipSuccess) return MOSS_ERR_HIP;
     hipLaunchKernelGGL(bounds_kernel, dim3(blocks < 128 ? blocks : 128), dim3(256), 0, s, P, points, v.mm);
     hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, s, P, points, v.mm, v.keys);
-    hipLaunchKernelGGL(sort_keys_kernel, dim3(1), dim3(1024), 0, s, v.keys, (uint32_t)P);
+    launch_sort_keys(v.keys, (uint32_t)P, s);
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, P, points, v.keys, v.sorted);
     hipLaunchKernelGGL(box_kernel, dim3(num_boxes), dim3(256), 0, s, P, v.sorted, v.boxes);
     hipLaunchKernelGGL(mean_dist_kernel, dim3(blocks), dim3(256), 0, s, P, v.sorted, v.boxes, num_boxes, mean_dists);

@@ -69,6 +69,47 @@ def test_dist2_bit_exact_vs_bruteforce_oracle(gpu, hip_lib, P):
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("P", [2049, 150_000, 1_000_003])
+def test_dist2_at_the_sizes_the_rasterizer_is_tested_at(gpu, hip_lib, P):
+    """distCUDA2 sorted its Morton keys in ONE workgroup -- fine at 6 890 points, a cliff at 100k - 1M.  The sort is
+    now device-wide (knn.hip: launch_sort_keys; 2049 points = the first size with a cross-tile step, the others not powers of two).
+    The C oracle is O(P^2) on one host thread, so up to 150k points the reference here is the same exhaustive search in float32 torch
+    on the GPU, in the kernel's operation order ((dx dx + dy dy) + dz dz, each operation rounded; three smallest summed ascending, / 3):
+    BIT-EXACT.  At a million points the exhaustive search is out of reach (10^12 pairs): the three nearest other points then come from
+    the exact grid k-NN of this library, which ranks by the ROUNDED Euclidean distance -- where two candidates tie after the square
+    root it may name the other one as third neighbour, so there: equal within 1e-6 relative, bit-equal for > 99.9 % of the points."""
+    from moss_amd.simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(P)
+    pts = scenes.body_points(P, g).to(gpu)
+    got = distCUDA2(pts)
+    assert float(got.min()) > 0.0
+    if P <= 150_000:
+        best = torch.empty(P, 3, device=gpu)
+        x, y, z = pts[:, 0].contiguous(), pts[:, 1].contiguous(), pts[:, 2].contiguous()
+        for r0 in range(0, P, 4096):
+            r1 = min(P, r0 + 4096)
+            dx = x[None, :] - x[r0:r1, None]; d2 = dx * dx
+            dy = y[None, :] - y[r0:r1, None]; d2 = d2 + dy * dy
+            dz = z[None, :] - z[r0:r1, None]; d2 = d2 + dz * dz
+            d2[torch.arange(r1 - r0, device=gpu), torch.arange(r0, r1, device=gpu)] = float("inf")
+            best[r0:r1] = torch.topk(d2, 3, dim=1, largest=False, sorted=True).values
+            del dx, dy, dz, d2
+        # (the sum and the division by 3 in numpy float32: torch divides by a scalar through a reciprocal multiplication on the GPU)
+        b = best.cpu().numpy()
+        want = ((b[:, 0] + b[:, 1]) + b[:, 2]) / np.float32(3.0)
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        return
+    from moss_amd.knn_cuda import KnnGrid
+    _, idx = KnnGrid(pts).query(pts, 4)                      # the query point itself comes first (distance 0, lowest index on ties)
+    d = pts[idx[:, 1:]] - pts[:, None, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    b = torch.sort(d2, dim=1).values.cpu().numpy()
+    want = ((b[:, 0] + b[:, 1]) + b[:, 2]) / np.float32(3.0)
+    got = got.cpu().numpy()
+    assert float((np.abs(got - want) / want).max()) < 1e-6
+    assert float((got.view(np.uint32) == want.view(np.uint32)).mean()) > 0.999
+
+
 def test_dist2_empty(gpu, hip_lib):
     from moss_amd.simple_knn._C import distCUDA2
     assert distCUDA2(torch.zeros(0, 3, device=gpu)).shape == (0,)
