@@ -893,7 +893,10 @@ __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int n
     return it;
 }
 
-__global__ void __launch_bounds__(256)
+// PAIRS = wave pairs per workgroup: 2 (256 threads, four workgroups per CU: the product configuration) or 8 (ONE 1024-thread workgroup
+// per CU, all its pairs sharing LDS: the experimental form, diagnostic builds only, MOSS_FWD_PAIRS=8).
+template <int PAIRS>
+__global__ void __launch_bounds__(128 * PAIRS)
 blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
                           uint32_t* __restrict__ queue_head, const uint4* __restrict__ work_table, const float4* __restrict__ inst_rec,
                           const uint16_t* __restrict__ inst_bmask,
@@ -905,23 +908,28 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
 {
     // Two wave PAIRS per workgroup (see PairCtl): per pair a record ring + hit list, the cuts of the block being blended, and the
     // control words.  A light item uses 3 KB of the pair's ring per wave as its record ring.
-    __shared__ PairRing s_ring[FWD_PAIRS_PER_WG];
-    __shared__ float s_cut_sums[FWD_PAIRS_PER_WG][MAX_CUTS * 16 * 6];
-    __shared__ uint2 s_cut_pos[FWD_PAIRS_PER_WG][MAX_CUTS];
-    __shared__ PairCtl s_ctl[FWD_PAIRS_PER_WG];
+    // (dynamic LDS, FwdLds<PAIRS>::bytes: eight pairs are 157 KB, beyond what a static allocation may hold)
+    extern __shared__ __attribute__((aligned(16))) char s_fwd_lds[];
+    PairRing* const s_ring = reinterpret_cast<PairRing*>(s_fwd_lds);
+    float (*const s_cut_sums)[MAX_CUTS * 16 * 6] = reinterpret_cast<float (*)[MAX_CUTS * 16 * 6]>(s_ring + PAIRS);
+    uint2 (*const s_cut_pos)[MAX_CUTS] = reinterpret_cast<uint2 (*)[MAX_CUTS]>(s_cut_sums + PAIRS);
+    PairCtl* const s_ctl = reinterpret_cast<PairCtl*>(s_cut_pos + PAIRS);
     static_assert(sizeof(PairRing) >= 2 * 64 * 3 * sizeof(float4), "the light path's rings live inside the pair's ring");
+    static_assert(sizeof(PairRing) % 16 == 0, "the arrays behind the rings stay 16-byte aligned");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pair = wv >> 1;
     // A pair's FIRST item is its rank in its queue, and whether that is a heavy or a light item only the header says: the work-table
     // entry it would be as a heavy item (the common case) is requested here, together with the header words, so that the start-up
     // chain of the kernel is (header | table entry) -> block masks -> records -> first trip: three round trips where round 2 had
     // five (header -> tile order -> range -> masks -> records).
     const int nq_ = min(NUM_XCD_QUEUES, (int)gridDim.x), qx_ = (int)blockIdx.x % nq_;
-    const int first_qi = ((int)blockIdx.x / nq_) * FWD_PAIRS_PER_WG + pair;
+    const int first_qi = ((int)blockIdx.x / nq_) * PAIRS + pair;
     const uint4 first_wt = work_table[min((first_qi >> 4) * nq_ + qx_, T_tiles - 1)];
     // Which wave of the pair blends: the waves of a workgroup sit on SIMD 0..3 in order, and a CU hosts several workgroups -- the roles
     // are swapped between them so that a SIMD gets blenders (busy) and scanners (mostly waiting) in equal numbers.
-    const bool is_scanner = (((wv ^ role_swap ^ (int)((blockIdx.x >> 3) / 32u)) & 1) == 0);
-    if (threadIdx.x < FWD_PAIRS_PER_WG * (int)(sizeof(PairCtl) / 4)) reinterpret_cast<uint32_t*>(s_ctl)[threadIdx.x] = 0u;
+    // (eight pairs in one workgroup: pairs p and p + 2 sit on the same two SIMDs -- the roles swap between them)
+    const bool is_scanner = PAIRS == 2 ? (((wv ^ role_swap ^ (int)((blockIdx.x >> 3) / 32u)) & 1) == 0)
+                                       : (((wv ^ role_swap ^ (pair >> 1)) & 1) == 0);
+    if (threadIdx.x < PAIRS * (int)(sizeof(PairCtl) / 4)) reinterpret_cast<uint32_t*>(s_ctl)[threadIdx.x] = 0u;
     __syncthreads();                                         // (the only workgroup barrier of the kernel)
     PairRing* const L = &s_ring[pair];
     PairCtl* const ctl = &s_ctl[pair];
@@ -930,8 +938,8 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
     const int hx = n_heavy > qx ? (n_heavy - qx + nq - 1) / nq : 0;
-    const int q_pairs = FWD_PAIRS_PER_WG * (((int)gridDim.x - qx + nq - 1) / nq);     // pairs that pull from this queue
-    const int my_rank = ((int)blockIdx.x / nq) * FWD_PAIRS_PER_WG + pair;             // this pair's rank among them
+    const int q_pairs = PAIRS * (((int)gridDim.x - qx + nq - 1) / nq);                // pairs that pull from this queue
+    const int my_rank = ((int)blockIdx.x / nq) * PAIRS + pair;                        // this pair's rank among them
     uint32_t* const my_head = queue_head + (size_t)qx * QLINE_WORDS;
     // queue index -> item.  Of a queue's tiles the first hx are heavy (16 block items each), the rest light (4 quadrant items each).
     auto decode = [&](int qi) -> WaveItem {
@@ -1025,7 +1033,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     // Tiles without instances get the background only (forward.cu:374-382 with an empty range); done after the queue so that
     // the heavy items start immediately.
     const int pl = lane >> 2;
-    const int wave_id = (int)blockIdx.x * 4 + wv, n_waves = (int)gridDim.x * 4;
+    const int wave_id = (int)blockIdx.x * (2 * PAIRS) + wv, n_waves = (int)gridDim.x * (2 * PAIRS);
     for (int i = WAVE_BLOCKS * n_work + wave_id; i < WAVE_BLOCKS * T_tiles; i += n_waves) {
         const int tile = (int)tile_order[i >> 4], blk = i & 15;
         const int px = (tile % gx) * TILE + (blk & 3) * 4 + (pl & 3), py = (tile / gx) * TILE + (blk >> 2) * 4 + (pl >> 2);
@@ -1047,7 +1055,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
                            float* __restrict__ inst_grad /* [16][R][12] */, size_t slab_stride, uint32_t* __restrict__ inst_mask,
                            int flags, unsigned long long* __restrict__ wstamps /* diagnostics: 16 words per wave, else NULL */,
                            const uint4* __restrict__ seg_desc, const float* __restrict__ seg_state, uint32_t seg_cap,
-                           const uint32_t* __restrict__ tail_start, const uint32_t* __restrict__ seg_counts, int fwd_grid)
+                           const uint32_t* __restrict__ tail_start, const uint32_t* __restrict__ seg_counts, int fwd_grid, int fwd_pairs)
 {
     __shared__ HeavyLdsBwd s_heavy[4];                       // per wave: 6.6 KB; a light item uses its first 3 KB as the record ring
     __shared__ uint16_t s_prefix[MAX_FWD_QUEUE_WAVES];       // inclusive prefix sums of the forward waves' segment counts (this XCD's region;
@@ -1075,7 +1083,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
         // The forward waves of this XCD filled private slot ranges; their counts give every segment of the region a flat index.  Each
         // wave builds the prefix table itself (all four waves of the workgroup write the same values: no barrier needed).
         const int fq = min(NUM_XCD_QUEUES, fwd_grid);
-        const int f_waves = qx < fq ? FWD_PAIRS_PER_WG * ((fwd_grid - qx + fq - 1) / fq) : 0;   // forward pairs (blender waves) that fed this region
+        const int f_waves = qx < fq ? fwd_pairs * ((fwd_grid - qx + fq - 1) / fq) : 0;          // forward pairs (blender waves) that fed this region
         uint32_t total = 0u;
         if (f_waves > 0 && f_waves <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) {
             const uint32_t* cnt = seg_counts + (size_t)qx * MAX_FWD_QUEUE_WAVES;
@@ -1164,16 +1172,29 @@ int device_cus()
 // together -- a wave's FIRST work item is its rank in its queue (no atomic), so a workgroup that only started once another one had
 // left would sit on its items until then (measured: +10 us when 4 were launched where 3 fit).
 template <typename K>
-int resident_wgs_per_cu(K kernel, const char* env, int dflt, int cap)
+int resident_wgs_per_cu(K kernel, const char* env, int dflt, int cap, int threads = 256, size_t lds = 0)
 {
     int occ = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = 1;
     return std::max(1, std::min(std::min(occ, cap), knob(env, dflt)));
+}
+template <int PAIRS> struct FwdLds { static constexpr size_t bytes = (size_t)PAIRS * (sizeof(PairRing) + sizeof(float) * MAX_CUTS * 16 * 6 + sizeof(uint2) * MAX_CUTS + sizeof(PairCtl)); };
+// wave pairs per workgroup of the forward kernel: 2 (product), or 8 = one workgroup per CU (diagnostic builds, MOSS_FWD_PAIRS=8)
+int forward_pairs()
+{
+    static const int p = knob("MOSS_FWD_PAIRS", FWD_PAIRS_PER_WG) == 8 ? 8 : FWD_PAIRS_PER_WG;
+    return p;
 }
 int forward_grid(int T)
 {
-    static const int per_cu = resident_wgs_per_cu(blend_forward_wave_kernel, "MOSS_BLEND_WGS_PER_CU", 4, 4);
-    return min(4 * T, device_cus() * per_cu);
+    static const int per_cu = [] {
+        if (forward_pairs() == 8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blend_forward_wave_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdLds<8>::bytes);
+            return resident_wgs_per_cu(blend_forward_wave_kernel<8>, "MOSS_BLEND_WGS_PER_CU", 1, 1, 1024, FwdLds<8>::bytes);
+        }
+        return resident_wgs_per_cu(blend_forward_wave_kernel<2>, "MOSS_BLEND_WGS_PER_CU", 4, 4, 256, FwdLds<2>::bytes);
+    }();
+    return min((8 / forward_pairs()) * T, device_cus() * per_cu);
 }
 
 }  // anonymous namespace
@@ -1198,10 +1219,16 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     static const int seg_hits_env = [] { const int v = knob("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
     static const int role_swap = knob("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = knob("MOSS_FWD_PRIO", 0);
-    MOSS_LAUNCH_TIMED(blend_forward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
-                       im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
-                       im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
-                       role_swap, prio_mode);
+    if (forward_pairs() == 8)
+        MOSS_LAUNCH_TIMED(blend_forward_wave_kernel<8>, dim3(wgs), dim3(1024), FwdLds<8>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+                          im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                          im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
+                          role_swap, prio_mode);
+    else
+        MOSS_LAUNCH_TIMED(blend_forward_wave_kernel<2>, dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+                          im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                          im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
+                          role_swap, prio_mode);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
@@ -1221,7 +1248,7 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
                        im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
                        dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
                        flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
-                       forward_grid(T) /* the forward kernel's grid */);
+                       forward_grid(T) /* the forward kernel's grid */, forward_pairs());
 }
 
 }  // namespace moss

@@ -29,6 +29,8 @@ from fuzz_scenes import random_scene  # noqa: E402
 bad = 0
 failures = []
 for seed in range(first, first + n_cases):
+    if (seed - first) % 100 == 0:
+        print(f"[progress] seed {seed} ({seed - first} of {n_cases} done, {bad} flagged)", flush=True)
     s, mode, degree, colors = random_scene(seed)
     try:
         d = hp.inputs_of(s, mode, degree=degree, colors=colors, bg=s.bg.tolist())
