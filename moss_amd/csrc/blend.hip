@@ -1180,18 +1180,27 @@ int resident_wgs_per_cu(K kernel, const char* env, int dflt, int cap, int thread
 }
 template <int PAIRS> struct FwdLds { static constexpr size_t bytes = (size_t)PAIRS * (sizeof(PairRing) + sizeof(float) * MAX_CUTS * 16 * 6 + sizeof(uint2) * MAX_CUTS + sizeof(PairCtl)); };
 // wave pairs per workgroup of the forward kernel: 2 (product), or 8 = one workgroup per CU (diagnostic builds, MOSS_FWD_PAIRS=8)
+// (Measured, round 3: eight pairs in ONE workgroup per CU -- the form in which pairs could hand work to each other through LDS -- is
+// 47.1 us against 40.4: its sixteen waves are of one age, the SIMD arbiter then shares issue slots evenly, and the longest item runs
+// at ~760 cycles per trip for as long as its SIMD-mate lives instead of at 520-610 as the older wave of two workgroups.)
 int forward_pairs()
 {
+#ifdef MOSS_DIAG
     static const int p = knob("MOSS_FWD_PAIRS", FWD_PAIRS_PER_WG) == 8 ? 8 : FWD_PAIRS_PER_WG;
     return p;
+#else
+    return FWD_PAIRS_PER_WG;
+#endif
 }
 int forward_grid(int T)
 {
     static const int per_cu = [] {
+#ifdef MOSS_DIAG
         if (forward_pairs() == 8) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blend_forward_wave_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdLds<8>::bytes);
             return resident_wgs_per_cu(blend_forward_wave_kernel<8>, "MOSS_BLEND_WGS_PER_CU", 1, 1, 1024, FwdLds<8>::bytes);
         }
+#endif
         return resident_wgs_per_cu(blend_forward_wave_kernel<2>, "MOSS_BLEND_WGS_PER_CU", 4, 4, 256, FwdLds<2>::bytes);
     }();
     return min((8 / forward_pairs()) * T, device_cus() * per_cu);
@@ -1219,12 +1228,14 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     static const int seg_hits_env = [] { const int v = knob("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
     static const int role_swap = knob("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = knob("MOSS_FWD_PRIO", 0);
+#ifdef MOSS_DIAG
     if (forward_pairs() == 8)
         MOSS_LAUNCH_TIMED(blend_forward_wave_kernel<8>, dim3(wgs), dim3(1024), FwdLds<8>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
                           role_swap, prio_mode);
     else
+#endif
         MOSS_LAUNCH_TIMED(blend_forward_wave_kernel<2>, dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
