@@ -3,16 +3,22 @@
 # Outputs under gpurun_out/<tag>/ ; copy the summaries into profiles/ (pmc_stage_summary.json -> profiles/pmc_latest.json: it is
 # stamped with the sha256 of moss_amd/csrc/, and bench.py reports `traffic` only while that stamp matches the checkout).
 export TMPDIR=/tmp
-TAG=${1:-r02_final}
-OUT=$PWD/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT/pmc; cd /tmp
+TAG=${1:-r03_final}
+OUT=$PWD/gpurun_out/$TAG
+if [ -z "$PMC_ONLY" ]; then rm -rf $OUT; fi
+mkdir -p $OUT/pmc; cd /tmp
+if [ -z "$PMC_ONLY" ]; then
 # the bench line as the driver sees it (no profiler attached), then the same command under rocprofv3 (whose tool perturbs the
 # bench's own kernel-attached events by ~10 %: its line is kept beside the kernel statistics for reference only)
 python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_plain_stdout.log 2>&1
 grep "^{\"metric\"" $OUT/bench_plain_stdout.log > $OUT/bench_line.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_stdout.log 2>&1
 grep "^{\"metric\"" $OUT/bench_stdout.log > $OUT/bench_line_under_rocprof.json
+fi
 pmc() { n=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc -o $n -- python3 $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 30 --warmup 10 --no-cpu-baseline > $OUT/pmc/$n.log 2>&1
+  # (--no-callers: the drop-in caller variants are thousands of torch launches, every one serialised under --pmc -- minutes of silence)
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc -o $n -- python3 $GRAFT_REPO_ROOT/bench.py --graph 0 --steps 30 --warmup 10 --no-cpu-baseline --no-callers > $OUT/pmc/$n.log 2>&1
+  echo "pmc pass $n done"
 }
 pmc p1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
 pmc p2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
