@@ -360,7 +360,7 @@ __device__ __forceinline__ void dma_records(LDS* L, const float4* __restrict__ r
     }
 }
 
-struct Fetched { float4 a, b, c; float pos1, valid; };   // pos1 = 1-based list position; valid = 0 for a padding slot
+struct Fetched { float4 a, b, c; float pos1; };   // pos1 = 1-based list position (as a float; 0 / 3e38 for a padding slot of the forward / backward)
 
 // ---- depth segments (see common.h): per-wave emission state of the forward kernel.  Every forward wave owns a private range of
 // slots in its XCD's region and fills it front to back: NO atomics and NO global-memory traffic while a block is being blended (a
@@ -471,7 +471,7 @@ __device__ __forceinline__ void heavy_forward_scan(int blk, int lane, const uint
             grp++;
             if (m != 0ull) {
                 const int r = nlist + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if ((m >> lane) & 1ull) L->lst[r & LMASK] = (uint32_t)(scan_pos + lane);
+                if ((m >> lane) & 1ull) L->lst[r & LMASK] = __float_as_uint((float)(scan_pos + lane + 1));     // position + 1, as a float (exact below 2^24)
                 const int c = __popcll(m);
                 nlist += c; new_hits += c;
             }
@@ -481,8 +481,22 @@ __device__ __forceinline__ void heavy_forward_scan(int blk, int lane, const uint
         if (!stop) stop = lds_peek(&ctl->stop_seq) == seq;
         if (stop) break;
         __builtin_amdgcn_wave_barrier();
-        if (nlist > F) { dma_records(L, recs, F, nlist, nlist, lane); F = nlist; }
+        if (nlist > F) { dma_records<true>(L, recs, F, nlist, nlist, lane); F = nlist; }
         __builtin_amdgcn_s_waitcnt(0);                       // the records (and the list) are in LDS
+        if (scan_done && (F & 3) != 0) {
+            // The list is complete: pad it to whole trips with entries NOBODY blends -- an all-zero record has opacity 0, hence alpha 0
+            // for every pixel -- so that the blender's trips need neither a validity flag per slot nor a test for it (three of its ~57
+            // vector instructions; the kernel's critical SIMDs are bound by instruction issue).  The slots are free: the ring holds
+            // at most RCAP - 64 live entries in front of them, and the DMA batches that could overwrite them have landed (wait above).
+            const int pad = 4 - (F & 3);
+            if (lane < pad) {
+                const int li = F + lane;
+                L->a[li & PairRing::RMASK] = make_float4(0.f, 0.f, 0.f, 0.f); L->b[li & PairRing::RMASK] = make_float4(0.f, 0.f, 0.f, 0.f);
+                L->c[li & PairRing::RMASK] = make_float4(0.f, 0.f, 0.f, 0.f);
+                L->lst[li & LMASK] = __float_as_uint(0.0f);
+            }
+            F += pad;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         lds_poke(&ctl->ready, (uint32_t)F | (scan_done ? 0x80000000u : 0u));
         if (scan_done) break;
@@ -522,7 +536,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     // bound by instruction ISSUE, not by one wave's dependent latencies; the extra copies cost more than the overlap gave.)
     auto trip = [&](const Fetched& f) -> bool {
         const PairEval pe = eval_pair(f.a.x - pixx, f.a.y - pixy, f.b.x, f.b.y, f.b.z, f.b.w);
-        const float al = pe.alpha * live * f.valid;                    // 0 for finished / outside pixels and padding slots
+        const float al = pe.alpha * live;                              // 0 for finished / outside pixels (padding slots hold zero records: alpha 0)
         // none of the four entries reaches any live pixel (the block masks are conservative): nothing changes -- T, the sums, the
         // stop flags -- so the rest of the trip is skipped (-1.6 us on the kernel, same-box A/B)
         if (__ballot(al > 0.0f) == 0ull) return false;
@@ -577,9 +591,9 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     // after a trip that consumed four real hits and left `hits_done` behind it: cut if that count is a multiple of the segment length
     auto maybe_cut = [&](const Fetched& f, int hits_done, bool last_of_all) {
         if ((hits_done & (se.seg_hits - 1)) != 0 || last_of_all) return;
+        // (only the item's LAST trip can hold padding slots, and it never cuts: last_of_all)
         const int last_pos1 = (int)__builtin_amdgcn_readlane(__float_as_int(f.pos1), 3);      // slot 3 of pixel 0: the trip's last hit
-        const int last_valid = (int)__builtin_amdgcn_readlane(__float_as_int(f.valid), 3);
-        if (last_valid != 0) emit_cut((int)__int_as_float(last_pos1));
+        emit_cut((int)__int_as_float(last_pos1));
     };
 
     int C = 0;                                               // list entries [0, C) are blended
@@ -607,7 +621,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
                 const int li = C + 4 * t + slot;
                 Fetched f;
                 f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];      // (stale past `ready`: masked)
-                f.pos1 = (float)(L->lst[li & LMASK] + 1u); f.valid = li < ready ? 1.0f : 0.0f;
+                f.pos1 = __uint_as_float(L->lst[li & LMASK]);
                 return f;
             };
             Fetched f0 = get(0);
@@ -848,7 +862,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
                 const int li = C + 4 * t + slot;
                 Fetched f;
                 f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];
-                f.pos1 = __uint_as_float(L->lst[li & LMASK]); f.valid = 1.0f;
+                f.pos1 = __uint_as_float(L->lst[li & LMASK]);
                 return f;
             };
             Fetched f0 = get(0);
