@@ -548,15 +548,12 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y * fm : X;
         Y = DPP_MOV(X, 0x90);
         const float Tb = slot == 0 ? T : Y;                            // T in front of this slot's entry
-        const float st = (X < 0.0001f) ? al : 0.0f;                    // > 0: this entry ends the pixel (forward.cu:351-356)
-        const unsigned long long sb = __ballot(st > 0.0f);
+        const bool stp = al > 0.0f && X < 0.0001f;                     // this entry ends the pixel (forward.cu:351-356)
+        const unsigned long long sb = __ballot(stp);
         const uint32_t q = (uint32_t)(sb >> gbase) & 15u;              // stop flags of this pixel's slots
-        const uint32_t below = q & below_mask;                         // an earlier slot already stopped the pixel
-        float wgt = al * Tb;
-        wgt = (st > 0.0f) ? 0.0f : wgt;
-        wgt = (below != 0u) ? 0.0f : wgt;
-        const float ts = (st > 0.0f) ? Tb : T_stop;
-        T_stop = (below != 0u) ? T_stop : ts;                          // the first stopping slot records the final T
+        const bool below = (q & below_mask) != 0u;                     // an earlier slot already stopped the pixel
+        const float wgt = (stp || below) ? 0.0f : al * Tb;
+        T_stop = (stp && !below) ? Tb : T_stop;                        // the first stopping slot records the final T
         Cr = __fmaf_rn(f.c.x, wgt, Cr); Cg = __fmaf_rn(f.c.y, wgt, Cg); Cb = __fmaf_rn(f.c.z, wgt, Cb);
         weight += wgt;
         Dacc = __fmaf_rn(f.c.w, wgt, Dacc);
@@ -618,10 +615,12 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
             if (t_first == 0) t_first = t4 - t_begin;
             n_trips += ntrip;
             auto get = [&](int t) -> Fetched {
-                const int li = C + 4 * t + slot;
+                // (C and 4t are multiples of four and wave-uniform: the ring index of the trip is a SCALAR, the slot is added without a
+                // wrap test -- one vector add for the address where `(C + 4t + slot) & RMASK` per lane was five instructions)
+                const int li = ((C + 4 * t) & RMASK) + slot;
                 Fetched f;
-                f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];      // (stale past `ready`: masked)
-                f.pos1 = __uint_as_float(L->lst[li & LMASK]);
+                f.a = L->a[li]; f.b = L->b[li]; f.c = L->c[li];
+                f.pos1 = f.a.w;                                                             // the entry's 1-based list position (merge_gather)
                 return f;
             };
             Fetched f0 = get(0);
@@ -852,17 +851,19 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         if (nlist > F) { dma_records<true>(L, recs, F, nlist, nlist, lane); F = nlist; }
         // the last trip's padding slots (list entries nlist .. next multiple of four: free, the list holds at most LCAP entries from C
         // on): a position no pixel reaches; their ring slots hold the tile's first record (see dma_records)
-        if (scan_done && lane < ((C - nlist) & 3)) L->lst[(nlist + lane) & LMASK] = __float_as_uint(3.0e38f);
         __builtin_amdgcn_s_waitcnt(0);
+        // (the position a trip compares is the fourth word of the entry's record: for the padding slots it is overwritten in the ring,
+        // AFTER the batch that holds them has landed)
+        if (scan_done && lane < ((C - nlist) & 3)) L->a[(nlist + lane) & RMASK].w = 3.0e38f;
         __builtin_amdgcn_wave_barrier();
         const int avail = nlist - C;
         const int ntrip = (avail >> 2) + ((scan_done && (avail & 3) != 0) ? 1 : 0);
         if (ntrip > 0 && !(flags & 2)) {
             auto get = [&](int t) -> Fetched {
-                const int li = C + 4 * t + slot;
+                const int li = ((C + 4 * t) & RMASK) + slot;                               // (scalar ring index + slot: see the forward kernel)
                 Fetched f;
-                f.a = L->a[li & RMASK]; f.b = L->b[li & RMASK]; f.c = L->c[li & RMASK];
-                f.pos1 = __uint_as_float(L->lst[li & LMASK]);
+                f.a = L->a[li]; f.b = L->b[li]; f.c = L->c[li];
+                f.pos1 = f.a.w;
                 return f;
             };
             Fetched f0 = get(0);
