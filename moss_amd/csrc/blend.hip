@@ -534,12 +534,24 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     // (Round 3 software-pipelined this -- the next trip's alpha evaluated inside the current trip, compiled with the max-ilp scheduling
     // strategy so that the two chains interleave: 40.4 -> 42.8 us.  The SIMDs that set the kernel's length host two blenders and are
     // bound by instruction ISSUE, not by one wave's dependent latencies; the extra copies cost more than the overlap gave.)
+    // Per-lane CONDITIONS of the trip are kept as 64-bit lane masks in scalar registers (v_cmp writes one; s_and / s_andn2 combine them;
+    // __builtin_amdgcn_inverse_ballot_w64 turns one back into the select condition of a v_cndmask): "this pair blends", "this entry
+    // stops its pixel", "an earlier slot stopped it", "the pixel is alive".  As float flags they cost a multiply, a compare and a select
+    // each (round 2); the SIMDs that set this kernel's length are bound by vector-instruction issue (profiles/r03_notes.md, finding 2)
+    // and the scalar unit has room: 51 -> 44 vector instructions per trip.  The arithmetic is eval_pair's, operation for operation.
+    constexpr int FCMP_OGE = 3, FCMP_OLT = 4, FCMP_OLE = 5, ICMP_NE = 33;
+    unsigned long long live_m = __ballot(live > 0.0f);
     auto trip = [&](const Fetched& f) -> bool {
-        const PairEval pe = eval_pair(f.a.x - pixx, f.a.y - pixy, f.b.x, f.b.y, f.b.z, f.b.w);
-        const float al = pe.alpha * live;                              // 0 for finished / outside pixels (padding slots hold zero records: alpha 0)
+        const float dx = f.a.x - pixx, dy = f.a.y - pixy;
+        const float qv = __fmaf_rn(f.b.x * dx, dx, (f.b.z * dy) * dy);         // power = -0.5*(A dx^2 + C dy^2) - B dx dy  (eval_pair)
+        const float power = __fmaf_rn(-0.5f, qv, -(f.b.y * dx) * dy);
+        const float ao = fminf(0.99f, f.b.w * __expf(power));
+        // pairs that blend: power <= 0, alpha >= 1/255 (forward.cu:340-350), pixel alive (padding slots hold zero records: alpha 0)
+        const unsigned long long m = __builtin_amdgcn_fcmpf(power, 0.0f, FCMP_OLE) & __builtin_amdgcn_fcmpf(ao, 1.0f / 255.0f, FCMP_OGE) & live_m;
         // none of the four entries reaches any live pixel (the block masks are conservative): nothing changes -- T, the sums, the
         // stop flags -- so the rest of the trip is skipped (-1.6 us on the kernel, same-box A/B)
-        if (__ballot(al > 0.0f) == 0ull) return false;
+        if (m == 0ull) return false;
+        const float al = __builtin_amdgcn_inverse_ballot_w64(m) ? ao : 0.0f;
         const float fm = 1.0f - al;
         // multiplied in list order: bit-identical to the serial loop
         float X = T * fm, Y;
@@ -548,19 +560,19 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y * fm : X;
         Y = DPP_MOV(X, 0x90);
         const float Tb = slot == 0 ? T : Y;                            // T in front of this slot's entry
-        const bool stp = al > 0.0f && X < 0.0001f;                     // this entry ends the pixel (forward.cu:351-356)
-        const unsigned long long sb = __ballot(stp);
+        const unsigned long long sb = __builtin_amdgcn_fcmpf(X, 0.0001f, FCMP_OLT) & m;     // this entry ends its pixel (forward.cu:351-356)
         const uint32_t q = (uint32_t)(sb >> gbase) & 15u;              // stop flags of this pixel's slots
-        const bool below = (q & below_mask) != 0u;                     // an earlier slot already stopped the pixel
-        const float wgt = (stp || below) ? 0.0f : al * Tb;
-        T_stop = (stp && !below) ? Tb : T_stop;                        // the first stopping slot records the final T
+        const unsigned long long mb = __builtin_amdgcn_uicmp(q & below_mask, 0u, ICMP_NE);  // an earlier slot already stopped the pixel
+        const unsigned long long dead = sb | mb;                       // pairs that are NOT blended after all
+        const float wgt = __builtin_amdgcn_inverse_ballot_w64(dead) ? 0.0f : al * Tb;
+        T_stop = __builtin_amdgcn_inverse_ballot_w64(sb & ~mb) ? Tb : T_stop;               // the first stopping slot records the final T
         Cr = __fmaf_rn(f.c.x, wgt, Cr); Cg = __fmaf_rn(f.c.y, wgt, Cg); Cb = __fmaf_rn(f.c.z, wgt, Cb);
         weight += wgt;
         Dacc = __fmaf_rn(f.c.w, wgt, Dacc);
-        last_contributor = (wgt > 0.0f) ? f.pos1 : last_contributor;
+        last_contributor = __builtin_amdgcn_inverse_ballot_w64(m & ~dead) ? f.pos1 : last_contributor;
         T = DPP_MOV(X, 0xFF);
-        live = (q != 0u) ? 0.0f : live;
-        return __ballot(live > 0.0f) == 0ull;
+        live_m &= ~__builtin_amdgcn_uicmp(q, 0u, ICMP_NE);
+        return live_m == 0ull;
     };
 
     // A cut after the hit at list position p_cur - 1: everything this block blended from p_prev up to here becomes a backward work
