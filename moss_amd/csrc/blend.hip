@@ -1037,7 +1037,13 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
             if (lds_peek(&ctl->post_kind) == 0u) break;
             const int tile = (int)lds_peek(&ctl->post_tile), blk = (int)lds_peek(&ctl->post_blk), rank = (int)lds_peek(&ctl->post_rank);
             const uint2 rg = make_uint2(lds_peek(&ctl->rg_x), lds_peek(&ctl->rg_y));
-            if (prio_mode != 0) set_wave_prio(prio_of_length(rg.y - rg.x));
+            // (4: every blender above every scanner; 5: additionally the blenders of the LATER dispatch rounds above those of the
+            // earlier ones -- priority outranks age, so this turns the age order of a SIMD's two blenders around; 6: all blenders 3)
+            if (prio_mode == 4) set_wave_prio(1);
+            else if (prio_mode == 5) set_wave_prio(((int)blockIdx.x * 4 / (int)gridDim.x) >= 2 ? 2 : 1);
+            else if (prio_mode == 6) set_wave_prio(3);
+            else if (prio_mode == 7) set_wave_prio(1 + ((int)blockIdx.x * 4 / (int)gridDim.x) / 2);
+            else if (prio_mode != 0) set_wave_prio(prio_of_length(rg.y - rg.x));
             heavy_forward_blend(W, H, gx, tile, blk, lane, rg, L, ctl, seq, bg_color, out_color, out_depth, out_alpha, final_T, n_contrib,
                                 flags, stamps ? stamps + (size_t)(rank * WAVE_BLOCKS + blk) * 8 : nullptr, se, tail_start);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
