@@ -65,6 +65,20 @@ __device__ __forceinline__ PairEval eval_pair(float dx, float dy, float A, float
         if (SLOTS > 4) v = OP(v, DPP_MOV(v, 0x141));      /* row_half_mirror     */ \
         if (SLOTS > 8) v = OP(v, DPP_MOV(v, 0x140));      /* row_mirror          */ \
     }
+// predicates of __builtin_amdgcn_fcmpf / uicmp (the compare's 64-bit lane mask lands in a scalar register pair)
+constexpr int FCMP_OGE = 3, FCMP_OLT = 4, FCMP_OLE = 5, ICMP_NE = 33;
+// lane (pixel, slot) takes `keep` where its bit in keep_mask is set, else the value `prev` holds in the lane of the previous slot of
+// the same pixel (quad_perm:[0,0,1,2]): ONE v_cndmask_b32 with the DPP read on its first source (the compiler's own select takes its
+// condition from an arbitrary scalar pair, an encoding without DPP, and spends a v_mov_b32_dpp in front of it).  The two wait
+// states a DPP read needs after the write of its source are inside the statement (the scalar move and the s_nop): the compiler does
+// not look into it.
+__device__ __forceinline__ float take_prev_slot_unless(float prev, float keep, unsigned long long keep_mask)
+{
+    float r;
+    asm("s_mov_b64 vcc, %3\n\ts_nop 0\n\tv_cndmask_b32_dpp %0, %1, %2, vcc quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf"
+        : "=v"(r) : "v"(prev), "v"(keep), "s"(keep_mask) : "vcc");
+    return r;
+}
 #define OP_MUL(a, b) ((a) * (b))
 #define OP_ADD(a, b) ((a) + (b))
 #define OP_MAX(a, b) fmaxf((a), (b))
@@ -224,7 +238,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
         if (dL_dalphas) gpa = dL_dalphas[pix_id];
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const float nTb = -T_final * bg_dot;
     // records and mask words are addressed by the instance's SLOT (its place in its Gaussian's run, carried in the record's third
     // word): the per-Gaussian gather then needs no position table
     float* const my_grad = inst_grad + (size_t)q * slab_stride;                             // light tiles use slabs / mask bits 0..3
@@ -268,21 +282,19 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 const float rinv = __builtin_amdgcn_rcpf(mm);
                 const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));
                 const float To = T * rinv;                                           // T after the division (backward.cu:516)
-                float dL_dopa = __fmaf_rn(u - Q, To, (-T_final * rinv) * bg_dot);    // (u - Q) = sum_k (x_k - accum_k) g_k
-                dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
+                const float dL_dopa = __fmaf_rn(u - Q, To, nTb * rinv);              // (u - Q) = sum_k (x_k - accum_k) g_k
                 Q = __fmaf_rn(mm, Q, al * u);
                 T = To;
+                // (the record's geometry sums go without their constant factors: see the heavy path's trip)
                 const float dchannel_dcolor = al * To;
-                const float dL_dG = b.w * dL_dopa;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * b.x - gdy * b.y;
-                const float dG_ddely = -gdy * b.z - gdx * b.y;
-                const float hdG = -0.5f * dL_dG;
+                const float v8 = G * dL_dopa;                                       // G = 0 for a skipped pair
+                const float w = b.w * v8;
+                const float wx = w * dx, wy = w * dy;
                 v[k][0] = dchannel_dcolor * gpr; v[k][1] = dchannel_dcolor * gpg; v[k][2] = dchannel_dcolor * gpb;
-                v[k][3] = dL_dG * dG_ddelx * ddelx_dx;
-                v[k][4] = dL_dG * dG_ddely * ddely_dy;
-                v[k][5] = hdG * gdx * dx; v[k][6] = hdG * gdx * dy; v[k][7] = hdG * gdy * dy;
-                v[k][8] = G * dL_dopa;
+                v[k][3] = __fmaf_rn(wx, b.x, wy * b.y);
+                v[k][4] = __fmaf_rn(wy, b.z, wx * b.y);
+                v[k][5] = wx * dx; v[k][6] = wx * dy; v[k][7] = wy * dy;
+                v[k][8] = v8;
                 pos4[k] = pos; slot4[k] = __float_as_uint(a.z);
                 any4[k] = __ballot(al > 0.0f) != 0ull;
             }
@@ -511,7 +523,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
                                                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
                                                     unsigned long long* stamp_out, SegEmit& se, uint32_t* __restrict__ tail_start)
 {
-    constexpr int LMASK = PairRing::LMASK, RMASK = PairRing::RMASK;
+    constexpr int RMASK = PairRing::RMASK;
     const int slot = lane & 3, pl = lane >> 2, gbase = lane & ~3;
     const uint32_t below_mask = (1u << slot) - 1u;
     const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
@@ -539,7 +551,6 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     // stops its pixel", "an earlier slot stopped it", "the pixel is alive".  As float flags they cost a multiply, a compare and a select
     // each (round 2); the SIMDs that set this kernel's length are bound by vector-instruction issue (profiles/r03_notes.md, finding 2)
     // and the scalar unit has room: 51 -> 44 vector instructions per trip.  The arithmetic is eval_pair's, operation for operation.
-    constexpr int FCMP_OGE = 3, FCMP_OLT = 4, FCMP_OLE = 5, ICMP_NE = 33;
     unsigned long long live_m = __ballot(live > 0.0f);
     auto trip = [&](const Fetched& f) -> bool {
         const float dx = f.a.x - pixx, dy = f.a.y - pixy;
@@ -717,9 +728,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     const int slot = lane & 3, pl = lane >> 2;
     // which of the reduce-scatter's outputs this lane ends up holding (see the reduction below)
     const int row = lane >> 4, rh = row >> 1, rp = row & 1;
-    const int m0 = 2 * rp + rh, m1 = 4 + m0;
-    const bool writer = (lane & 15) < 4;                     // one lane per (row, slot)
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const uint32_t m0_bytes = 4u * (uint32_t)(2 * rp + rh);  // value m0 of the record, m1 = m0 + 4
     const int ox = (tile % gx) * TILE + (blk & 3) * 4, oy = (tile / gx) * TILE + (blk >> 2) * 4;
     const int px = ox + (pl & 3), py = oy + (pl >> 2);
     const bool inside = px < W && py < H;
@@ -734,6 +743,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         n_eff = last_contributor;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) n_eff = max(n_eff, __shfl_xor(n_eff, d));
+        n_eff = __builtin_amdgcn_readfirstlane(n_eff);
     }
     if (n_eff <= lo) return;                                 // nothing was blended into this range: no record, no mask bit
 
@@ -769,56 +779,76 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     // (positions are compared as floats -- exact below 2^24 -- and a padding slot of the last trip carries a position behind every
     // contributor: no integer conversion and no validity flag in the trip; this kernel is bound by vector-instruction issue)
     const float last_contributor_f = (float)last_contributor;
+    const float nTb = -T_final * bg_dot;
+    // wave-uniform address of the block's slab as a buffer resource: a record store is one 32-bit offset + an immediate
+    const __amdgpu_buffer_rsrc_t rs_grad = __builtin_amdgcn_make_buffer_rsrc((void*)my_grad, 0, 0xffffff00u, 0x00020000u);
     auto trip = [&](const Fetched& f) {
         const float dx = f.a.x - pixx, dy = f.a.y - pixy;
-        const PairEval pe = eval_pair(dx, dy, f.b.x, f.b.y, f.b.z, f.b.w);
-        const float al = (f.pos1 <= last_contributor_f) ? pe.alpha : 0.0f;   // position < last contributor (backward.cu:499-514); 0 = pair skipped
-        const float G = (al > 0.0f) ? pe.G : 0.0f;
+        // the pair's alpha exactly as the forward kernel decides it (eval_pair); the three skip tests (power > 0, alpha < 1/255:
+        // backward.cu:507-514; position behind the pixel's last contributor: backward.cu:499) as lane masks in scalar registers
+        const float qf = __fmaf_rn(f.b.x * dx, dx, (f.b.z * dy) * dy);
+        const float power = __fmaf_rn(-0.5f, qf, -(f.b.y * dx) * dy);
+        const float G0 = __expf(power);
+        const float ao = fminf(0.99f, f.b.w * G0);
+        const unsigned long long contrib = __builtin_amdgcn_fcmpf(power, 0.0f, FCMP_OLE) & __builtin_amdgcn_fcmpf(ao, 1.0f / 255.0f, FCMP_OGE) &
+                                           __builtin_amdgcn_fcmpf(f.pos1, last_contributor_f, FCMP_OLE);
+        const bool on = __builtin_amdgcn_inverse_ballot_w64(contrib);
+        const float al = on ? ao : 0.0f;                     // 0 = pair skipped
+        const float G = on ? G0 : 0.0f;
         // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
         const float mm = 1.0f - al;
         const float rinv = __builtin_amdgcn_rcpf(mm);
         const float u = __fmaf_rn(f.c.x, gpr, __fmaf_rn(f.c.y, gpg, __fmaf_rn(f.c.z, gpb, __fmaf_rn(f.c.w, gpd, gpa))));
         const float kq = al * u;
-        // run the four slots' transforms in visiting order: slot s starts from the output of slot s-1
-        float Ti = T, Qi = Q;
-        float To = Ti * rinv, Qo = __fmaf_rn(mm, Qi, kq);
-#pragma unroll
-        for (int k = 1; k <= 3; k++) {
-            const float yT = DPP_MOV(To, 0x90), yQ = DPP_MOV(Qo, 0x90);
-            Ti = slot >= k ? yT : Ti; Qi = slot >= k ? yQ : Qi;
-            To = Ti * rinv; Qo = __fmaf_rn(mm, Qi, kq);
-        }
+        // The four slots' transforms in visiting order.  T: slot s ends with T times the product of the slots' 1/(1-alpha) up to its
+        // own -- a prefix product over the pixel's four lanes in two steps (the multiply takes its DPP operand directly).  Q: slot s
+        // starts from the output of slot s-1, three dependent steps of one fused select and one FMA.
+        float P = rinv;
+        { const float y = DPP_MOV(P, 0x90) * P; P = slot >= 1 ? y : P; }     // quad_perm:[0,0,1,2]: r0, r0 r1, r1 r2, r2 r3
+        { const float y = DPP_MOV(P, 0x44) * P; P = slot >= 2 ? y : P; }     // quad_perm:[0,1,0,1]: r0, r0 r1, r0 r1 r2, r0 r1 r2 r3
+        const float To = T * P;
+        float Qi = Q;
+        float Qo = __fmaf_rn(mm, Qi, kq);
+        Qi = take_prev_slot_unless(Qo, Qi, 0x1111111111111111ull); Qo = __fmaf_rn(mm, Qi, kq);
+        Qi = take_prev_slot_unless(Qo, Qi, 0x3333333333333333ull); Qo = __fmaf_rn(mm, Qi, kq);
+        Qi = take_prev_slot_unless(Qo, Qi, 0x7777777777777777ull); Qo = __fmaf_rn(mm, Qi, kq);
         T = DPP_MOV(To, 0xFF); Q = DPP_MOV(Qo, 0xFF);               // the pixel's state after these four entries
 
-        // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k
-        float dL_dopa = __fmaf_rn(u - Qi, To, (-T_final * rinv) * bg_dot);
-        dL_dopa = (al > 0.0f) ? dL_dopa : 0.0f;
-        const float dchannel_dcolor = al * To;
-        const float dL_dG = f.b.w * dL_dopa;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * f.b.x - gdy * f.b.y;
-        const float dG_ddely = -gdy * f.b.z - gdx * f.b.y;
-        const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
-        const float v3 = dL_dG * dG_ddelx * ddelx_dx;
-        const float v4 = dL_dG * dG_ddely * ddely_dy;
-        const float hdG = -0.5f * dL_dG;
-        const float v5 = hdG * gdx * dx, v6 = hdG * gdx * dy, v7 = hdG * gdy * dy;
-        const float v8 = G * dL_dopa;
-
-        const unsigned long long contrib = __ballot(al > 0.0f);
         if (contrib != 0ull) {
+            // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k.  G = 0 for a skipped pair zeroes
+            // everything below but the colour terms, which carry alpha = 0.
+            // The record holds the sums WITHOUT their constant factors (the per-Gaussian kernel applies them once per Gaussian):
+            //   [3] sum w (A dx + B dy)   x -0.5 W = dL/dmean2D.x      [5] sum w dx dx   x -0.5 = dL/dconic.x
+            //   [4] sum w (C dy + B dx)   x -0.5 H = dL/dmean2D.y      [6] sum w dx dy   x -0.5 = dL/dconic.y   [7] sum w dy dy: .w
+            // with w = dL/dG * G (backward.cu:566-580 factored)
+            const float dL_dopa = __fmaf_rn(u - Qi, To, nTb * rinv);
+            const float v8 = G * dL_dopa;
+            const float w = f.b.w * v8;
+            const float wx = w * dx, wy = w * dy;
+            const float v3 = __fmaf_rn(wx, f.b.x, wy * f.b.y);
+            const float v4 = __fmaf_rn(wy, f.b.z, wx * f.b.y);
+            const float v5 = wx * dx, v6 = wx * dy, v7 = wy * dy;
+            const float dchannel_dcolor = al * To;
+            const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
             // reduce-scatter over the wave's pixels, separately per slot: after fold32 the lower/upper half-waves hold
             // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
             const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);
             const float s0 = row_slot_sum<4>(fold16(r0, r1)), s1 = row_slot_sum<4>(fold16(r2, r3)),
                         s2 = row_slot_sum<4>(fold16(r4, 0.0f));
-            // an entry leaves a record (and its block bit) only if one of the block's pixels blended it
-            const bool slot_any = ((contrib >> slot) & 0x1111111111111111ull) != 0ull;
-            if (writer && slot_any) {
+            // an entry leaves a record (and its block bit) only if one of the block's pixels blended it: OR of the pixels' bits per
+            // slot (scalar unit), spread over the writer lanes (lane & 15 = slot: bits s, 16 + s, 32 + s, 48 + s)
+            unsigned long long any = contrib;
+            any |= any >> 32; any |= any >> 16; any |= any >> 8; any |= any >> 4;
+            const uint32_t any_rows = ((uint32_t)any & 15u) * 0x00010001u;
+            if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)any_rows << 32) | any_rows)) {
                 const uint32_t gslot = __float_as_uint(f.a.z);
-                float* dst = my_grad + (size_t)gslot * NPART;
-                dst[m0] = s0; dst[m1] = s1;
-                if (row == 0) { dst[8] = s2; atomicOr(&my_mask[gslot], blk_bit); }
+                const uint32_t o = __umul24(gslot, (uint32_t)(NPART * 4)) + m0_bytes;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s0), rs_grad, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s1), rs_grad, o + 16u, 0, 0);
+                if (row == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s2), rs_grad, o + 32u, 0, 0);
+                    atomicOr(&my_mask[gslot], blk_bit);
+                }
             }
         }
     };
@@ -868,22 +898,27 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         // AFTER the batch that holds them has landed)
         if (scan_done && lane < ((C - nlist) & 3)) L->a[(nlist + lane) & RMASK].w = 3.0e38f;
         __builtin_amdgcn_wave_barrier();
+        // (both counters are wave-uniform, but their uses in lane arithmetic above make the compiler keep them in vector registers
+        // and derive the trip loop's ring index from those: two vector instructions per trip)
+        C = __builtin_amdgcn_readfirstlane(C); nlist = __builtin_amdgcn_readfirstlane(nlist);
         const int avail = nlist - C;
         const int ntrip = (avail >> 2) + ((scan_done && (avail & 3) != 0) ? 1 : 0);
         if (ntrip > 0 && !(flags & 2)) {
-            auto get = [&](int t) -> Fetched {
-                const int li = ((C + 4 * t) & RMASK) + slot;                               // (scalar ring index + slot: see the forward kernel)
+            auto get = [&](int ring_slot) -> Fetched {                                      // (scalar ring index + slot: see the forward kernel)
+                const int li = ring_slot + slot;
                 Fetched f;
                 f.a = L->a[li]; f.b = L->b[li]; f.c = L->c[li];
                 f.pos1 = f.a.w;
                 return f;
             };
-            Fetched f0 = get(0);
+            int rs = C & RMASK;
+            Fetched f0 = get(rs);
             for (int t = 0; t < ntrip; t += 2) {
-                const Fetched f1 = get(t + 1);
+                const Fetched f1 = get((rs + 4) & RMASK);
                 trip(f0);
                 if (t + 1 >= ntrip) break;
-                f0 = get(t + 2);
+                rs = (rs + 8) & RMASK;
+                f0 = get(rs);
                 trip(f1);
             }
         }
@@ -916,7 +951,8 @@ __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int n
     it.valid = it.rank < n_work;
     // {tile, list start, list end} of the rank in ONE load (the scan block's work table; rank -> tile -> range were two round trips)
     const uint4 wt = it.valid ? work_table[it.rank] : make_uint4(0u, 0u, 0u, 0u);
-    it.tile = (int)wt.x; it.rg = make_uint2(wt.y, wt.z);
+    it.tile = __builtin_amdgcn_readfirstlane((int)wt.x);
+    it.rg = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)wt.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)wt.z));
     return it;
 }
 
@@ -943,7 +979,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     PairCtl* const s_ctl = reinterpret_cast<PairCtl*>(s_cut_pos + PAIRS);
     static_assert(sizeof(PairRing) >= 2 * 64 * 3 * sizeof(float4), "the light path's rings live inside the pair's ring");
     static_assert(sizeof(PairRing) % 16 == 0, "the arrays behind the rings stay 16-byte aligned");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pair = wv >> 1;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wv >> 1;   // (the wave's index is wave-uniform: say so)
     // A pair's FIRST item is its rank in its queue, and whether that is a heavy or a light item only the header says: the work-table
     // entry it would be as a heavy item (the common case) is requested here, together with the header words, so that the start-up
     // chain of the kernel is (header | table entry) -> block masks -> records -> first trip: three round trips where round 2 had
@@ -1094,7 +1130,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
     __shared__ uint16_t s_prefix[MAX_FWD_QUEUE_WAVES];       // inclusive prefix sums of the forward waves' segment counts (this XCD's region;
                                                              // 16 bits: the forward cuts nothing when a region has more than 65535 slots)
     static_assert(sizeof(HeavyLdsBwd) >= 64 * 3 * sizeof(float4), "the light path's ring lives inside the heavy path's LDS");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: say so)
     float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(&s_heavy[wv]);
     const int n_work = (int)header[5];
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
@@ -1129,7 +1165,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
                 if (b0 + lane < f_waves) s_prefix[b0 + lane] = (uint16_t)v;
                 carry = (uint32_t)__shfl((int)v, 63);
             }
-            total = carry;
+            total = (uint32_t)__builtin_amdgcn_readfirstlane((int)carry);
             __builtin_amdgcn_wave_barrier();
         }
         const uint32_t share = seg_cap / (uint32_t)max(f_waves, 1);
@@ -1142,7 +1178,10 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
             while (lo_w < hi_w) { const int mid = (lo_w + hi_w) >> 1; if ((uint32_t)s_prefix[mid] <= i) lo_w = mid + 1; else hi_w = mid; }
             const uint32_t before = lo_w > 0 ? (uint32_t)s_prefix[lo_w - 1] : 0u;
             const size_t slot_idx = (size_t)qx * seg_cap + (size_t)lo_w * share + (i - before);
-            const uint4 d = seg_desc[slot_idx];
+            uint4 d = seg_desc[slot_idx];
+            // (wave-uniform by construction; saying so keeps the item's loop control, ring indices and slab address in scalar registers)
+            d.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x); d.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
+            d.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z); d.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w);
             const unsigned long long tp1 = WSTAMP();
             c_pop += tp1 - tp0;
             n_seg++;
@@ -1172,7 +1211,8 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
         if (it.heavy)
             heavy_backward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
                                 n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags,
-                                (flags & 32) ? 0 : (int)tail_start[(size_t)it.tile * WAVE_BLOCKS + it.sub], 0x7fffffff, nullptr);
+                                (flags & 32) ? 0 : __builtin_amdgcn_readfirstlane((int)tail_start[(size_t)it.tile * WAVE_BLOCKS + it.sub]),
+                                0x7fffffff, nullptr);
         else
             light_backward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
                                 dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);

@@ -707,7 +707,8 @@ constexpr int GATHER_CAP = 320;                          // records of a wave ga
 constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
 template <bool STAGE_SH>
 __global__ void __launch_bounds__(256)
-preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float scale_modifier,
+preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float mean2d_sx, float mean2d_sy,
+                           float scale_modifier,
                            const float* __restrict__ means3D, const float* __restrict__ shs,
                            const float* __restrict__ scales, const float* __restrict__ rotations,
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
@@ -998,6 +999,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     PSTAMP(1);
     if (STAGE_SH) __syncthreads();                           // SH records are in LDS
     PSTAMP(2);
+    // the blend kernel's records carry the geometry sums without their constant factors (blend.hip, the backward trip):
+    // d pixel / d ndc = W/2, H/2 (backward.cu:472-473, 574-575) and the -1/2 of the exponent (backward.cu:578-580)
+    gmx *= mean2d_sx; gmy *= mean2d_sy; gca *= -0.5f; gcb *= -0.5f; gcc *= -0.5f;
     if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
@@ -1205,7 +1209,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
 #define LAUNCH_PB(STAGE)                                                                                                        \
     MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
                        ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \
-                       fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, fp.scale_modifier,                   \
+                       fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, -0.5f * (float)fp.W, -0.5f * (float)fp.H, fp.scale_modifier, \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues)
