@@ -538,7 +538,8 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     inst_mask[slot] = 0u;                                     // no gradient record yet (set by the backward blend)
     // (fourth word: the entry's 1-based position in its tile's list, as a float -- what the blend kernels record as the last contributor
     // and compare against it; exact below 2^24.  With it in the record a blender reads nothing but the record ring per entry.)
-    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(slot), (float)(rank + 1u)); rec[1] = gb; rec[2] = gc;
+    // (second word: {B, C, A, opacity} -- the order in which the blend trips multiply the conic by (dx, dy) as register pairs: blend.hip, pair_power)
+    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(slot), (float)(rank + 1u)); rec[1] = make_float4(gb.y, gb.z, gb.x, gb.w); rec[2] = gc;
     // (non-temporal or write-through stores here: +3 / +7 us -- the write-back at the kernel's end is cheaper)
     {
         // which 4x4 pixel blocks of this tile the entry's alpha >= 1/255 bounding box {x, y, hx, hy} touches (pixel centres are

@@ -40,6 +40,23 @@ namespace {
 constexpr int NPART = GRAD_REC_FLOATS;   // 9 partial gradients per (instance, block) record, padded (common.h)
 
 struct PairEval { float power, G, alpha; };
+typedef float v2f __attribute__((ext_vector_type(2)));        // an aligned register pair: v_pk_add / v_pk_mul / v_pk_fma_f32 do both halves at once
+
+// The exponent of one (pixel, entry) pair in the heavy paths' trips, where vector-instruction issue is what the kernels wait for: the
+// operations of eval_pair below, one for one (same roundings, same order), but the two products by dx / dy that do not feed an FMA
+// are done as PAIRS -- (B dx, C dy), then ((B dx) dy, (C dy) dy) -- which is why the record's second word is {B, C, A, opacity}
+// (merge_gather_kernel): (B, C) and (x, y) are aligned register pairs as they come out of the LDS read.  Six instructions for nine.
+struct PairGeom { v2f d; float power; };                      // d = (dx, dy)
+__device__ __forceinline__ PairGeom pair_power(const float4& a, const float4& b, v2f pix)
+{
+    PairGeom r;
+    r.d = v2f{a.x, a.y} - pix;
+    const v2f bc = v2f{b.x, b.y} * r.d;                       // (B dx, C dy)
+    const v2f t = bc * v2f{r.d.y, r.d.y};                     // ((B dx) dy, (C dy) dy)
+    const float q = __fmaf_rn(b.z * r.d.x, r.d.x, t.y);       // power = -0.5*(A dx^2 + C dy^2) - B dx dy
+    r.power = __fmaf_rn(-0.5f, q, -t.x);
+    return r;
+}
 
 // alpha of one (pixel, entry) pair, 0 if the pair fails either skip test of forward.cu:340-350 / backward.cu:507-514
 __device__ __forceinline__ PairEval eval_pair(float dx, float dy, float A, float B, float C, float opacity)
@@ -174,7 +191,7 @@ __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int til
             const int e = __ffsll((long long)m) - 1;         // wave-uniform: the records are LDS broadcasts
             m &= m - 1ull;
             const float4 a = ring[e][0], b = ring[e][1], c = ring[e][2];
-            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.x, b.y, b.z, b.w);
+            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.z, b.x, b.y, b.w);   // (record word b = {B, C, A, opacity})
             const float al = live ? pe.alpha : 0.0f;
             const float test_T = T * (1.0f - al);
             const bool stop = al > 0.0f && test_T < 0.0001f;                  // forward.cu:351-356: this entry is NOT blended
@@ -275,7 +292,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 const int pos = n_eff - 1 - (base + e);
                 const float4 a = ring[e][0], b = ring[e][1], c = ring[e][2];
                 const float dx = a.x - pixx, dy = a.y - pixy;
-                const PairEval pe = eval_pair(dx, dy, b.x, b.y, b.z, b.w);
+                const PairEval pe = eval_pair(dx, dy, b.z, b.x, b.y, b.w);                   // (record word b = {B, C, A, opacity})
                 const float al = (valid && pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514
                 const float G = (al > 0.0f) ? pe.G : 0.0f;
                 const float mm = 1.0f - al;
@@ -285,14 +302,13 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 const float dL_dopa = __fmaf_rn(u - Q, To, nTb * rinv);              // (u - Q) = sum_k (x_k - accum_k) g_k
                 Q = __fmaf_rn(mm, Q, al * u);
                 T = To;
-                // (the record's geometry sums go without their constant factors: see the heavy path's trip)
+                // (the record holds moments of w: see the heavy path's trip)
                 const float dchannel_dcolor = al * To;
                 const float v8 = G * dL_dopa;                                       // G = 0 for a skipped pair
                 const float w = b.w * v8;
                 const float wx = w * dx, wy = w * dy;
                 v[k][0] = dchannel_dcolor * gpr; v[k][1] = dchannel_dcolor * gpg; v[k][2] = dchannel_dcolor * gpb;
-                v[k][3] = __fmaf_rn(wx, b.x, wy * b.y);
-                v[k][4] = __fmaf_rn(wy, b.z, wx * b.y);
+                v[k][3] = wx; v[k][4] = wy;
                 v[k][5] = wx * dx; v[k][6] = wx * dy; v[k][7] = wy * dy;
                 v[k][8] = v8;
                 pos4[k] = pos; slot4[k] = __float_as_uint(a.z);
@@ -537,7 +553,13 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     unsigned long long d_trip = 0, d_starve = 0, n_rounds = 0, n_trips = 0, t_first = 0;
 
     float T = 1.0f, T_stop = -1.0f;
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f, weight = 0.f, Dacc = 0.f;      // this slot's share of the pixel's sums
+    v2f Crg = v2f{0.f, 0.f}, CbD = v2f{0.f, 0.f};                       // this slot's share of the pixel's sums: (r, g), (b, depth), weight
+    float weight = 0.f;
+#define Cr Crg.x
+#define Cg Crg.y
+#define Cb CbD.x
+#define Dacc CbD.y
+    const v2f pix2 = v2f{pixx, pixy};
     float last_contributor = 0.0f;                                       // list positions < 2^24: exact in fp32
     float live = inside ? 1.0f : 0.0f;
     bool finished = __ballot(live > 0.0f) == 0ull;
@@ -553,9 +575,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     // and the scalar unit has room: 51 -> 44 vector instructions per trip.  The arithmetic is eval_pair's, operation for operation.
     unsigned long long live_m = __ballot(live > 0.0f);
     auto trip = [&](const Fetched& f) -> bool {
-        const float dx = f.a.x - pixx, dy = f.a.y - pixy;
-        const float qv = __fmaf_rn(f.b.x * dx, dx, (f.b.z * dy) * dy);         // power = -0.5*(A dx^2 + C dy^2) - B dx dy  (eval_pair)
-        const float power = __fmaf_rn(-0.5f, qv, -(f.b.y * dx) * dy);
+        const float power = pair_power(f.a, f.b, pix2).power;
         const float ao = fminf(0.99f, f.b.w * __expf(power));
         // pairs that blend: power <= 0, alpha >= 1/255 (forward.cu:340-350), pixel alive (padding slots hold zero records: alpha 0)
         const unsigned long long m = __builtin_amdgcn_fcmpf(power, 0.0f, FCMP_OLE) & __builtin_amdgcn_fcmpf(ao, 1.0f / 255.0f, FCMP_OGE) & live_m;
@@ -577,9 +597,9 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         const unsigned long long dead = sb | mb;                       // pairs that are NOT blended after all
         const float wgt = __builtin_amdgcn_inverse_ballot_w64(dead) ? 0.0f : al * Tb;
         T_stop = __builtin_amdgcn_inverse_ballot_w64(sb & ~mb) ? Tb : T_stop;               // the first stopping slot records the final T
-        Cr = __fmaf_rn(f.c.x, wgt, Cr); Cg = __fmaf_rn(f.c.y, wgt, Cg); Cb = __fmaf_rn(f.c.z, wgt, Cb);
+        Crg = __builtin_elementwise_fma(v2f{f.c.x, f.c.y}, v2f{wgt, wgt}, Crg);          // (two packed FMAs for the four sums)
+        CbD = __builtin_elementwise_fma(v2f{f.c.z, f.c.w}, v2f{wgt, wgt}, CbD);
         weight += wgt;
-        Dacc = __fmaf_rn(f.c.w, wgt, Dacc);
         last_contributor = __builtin_amdgcn_inverse_ballot_w64(m & ~dead) ? f.pos1 : last_contributor;
         T = DPP_MOV(X, 0xFF);
         live_m &= ~__builtin_amdgcn_uicmp(q, 0u, ICMP_NE);
@@ -711,6 +731,11 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     }
 }
 
+#undef Cr
+#undef Cg
+#undef Cb
+#undef Dacc
+
 __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
                                                     const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
                                                     HeavyLdsBwd* L, const float* __restrict__ bg_color,
@@ -780,14 +805,14 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     // contributor: no integer conversion and no validity flag in the trip; this kernel is bound by vector-instruction issue)
     const float last_contributor_f = (float)last_contributor;
     const float nTb = -T_final * bg_dot;
+    const v2f pix2 = v2f{pixx, pixy}, gp_rg = v2f{gpr, gpg};
     // wave-uniform address of the block's slab as a buffer resource: a record store is one 32-bit offset + an immediate
     const __amdgpu_buffer_rsrc_t rs_grad = __builtin_amdgcn_make_buffer_rsrc((void*)my_grad, 0, 0xffffff00u, 0x00020000u);
     auto trip = [&](const Fetched& f) {
-        const float dx = f.a.x - pixx, dy = f.a.y - pixy;
-        // the pair's alpha exactly as the forward kernel decides it (eval_pair); the three skip tests (power > 0, alpha < 1/255:
-        // backward.cu:507-514; position behind the pixel's last contributor: backward.cu:499) as lane masks in scalar registers
-        const float qf = __fmaf_rn(f.b.x * dx, dx, (f.b.z * dy) * dy);
-        const float power = __fmaf_rn(-0.5f, qf, -(f.b.y * dx) * dy);
+        // the pair's alpha exactly as the forward kernel decides it (pair_power / eval_pair); the three skip tests (power > 0, alpha <
+        // 1/255: backward.cu:507-514; position behind the pixel's last contributor: backward.cu:499) as lane masks in scalar registers
+        const PairGeom pg = pair_power(f.a, f.b, pix2);
+        const float power = pg.power;
         const float G0 = __expf(power);
         const float ao = fminf(0.99f, f.b.w * G0);
         const unsigned long long contrib = __builtin_amdgcn_fcmpf(power, 0.0f, FCMP_OLE) & __builtin_amdgcn_fcmpf(ao, 1.0f / 255.0f, FCMP_OGE) &
@@ -817,19 +842,19 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         if (contrib != 0ull) {
             // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k.  G = 0 for a skipped pair zeroes
             // everything below but the colour terms, which carry alpha = 0.
-            // The record holds the sums WITHOUT their constant factors (the per-Gaussian kernel applies them once per Gaussian):
-            //   [3] sum w (A dx + B dy)   x -0.5 W = dL/dmean2D.x      [5] sum w dx dx   x -0.5 = dL/dconic.x
-            //   [4] sum w (C dy + B dx)   x -0.5 H = dL/dmean2D.y      [6] sum w dx dy   x -0.5 = dL/dconic.y   [7] sum w dy dy: .w
-            // with w = dL/dG * G (backward.cu:566-580 factored)
+            // The record holds the MOMENTS of w = dL/dG * G over the block's pixels; what is constant per Gaussian -- the conic
+            // (A, B, C) and the factors -- is applied by the per-Gaussian kernel, once (backward.cu:566-580 factored):
+            //   [3] sum w dx, [4] sum w dy:   dL/dmean2D = -0.5 (W (A [3] + B [4]), H (C [4] + B [3]))
+            //   [5] sum w dx dx, [6] sum w dx dy, [7] sum w dy dy:   dL/dconic = -0.5 ([5], [6], [7])
             const float dL_dopa = __fmaf_rn(u - Qi, To, nTb * rinv);
             const float v8 = G * dL_dopa;
             const float w = f.b.w * v8;
-            const float wx = w * dx, wy = w * dy;
-            const float v3 = __fmaf_rn(wx, f.b.x, wy * f.b.y);
-            const float v4 = __fmaf_rn(wy, f.b.z, wx * f.b.y);
-            const float v5 = wx * dx, v6 = wx * dy, v7 = wy * dy;
+            const v2f v34 = v2f{w, w} * pg.d;                                     // (packed: two products per instruction)
+            const v2f v56 = v2f{v34.x, v34.x} * pg.d;
+            const float v3 = v34.x, v4 = v34.y, v5 = v56.x, v6 = v56.y, v7 = v34.y * pg.d.y;
             const float dchannel_dcolor = al * To;
-            const float v0 = dchannel_dcolor * gpr, v1 = dchannel_dcolor * gpg, v2 = dchannel_dcolor * gpb;
+            const v2f v01 = v2f{dchannel_dcolor, dchannel_dcolor} * gp_rg;
+            const float v0 = v01.x, v1 = v01.y, v2 = dchannel_dcolor * gpb;
             // reduce-scatter over the wave's pixels, separately per slot: after fold32 the lower/upper half-waves hold
             // different values, after fold16 even/odd rows do; lane (row r, slot s) ends with values m0, m1 (and 8 in row 0)
             const float r0 = fold32(v0, v1), r1 = fold32(v2, v3), r2 = fold32(v4, v5), r3 = fold32(v6, v7), r4 = fold32(v8, 0.0f);

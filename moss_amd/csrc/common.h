@@ -7,7 +7,8 @@
 //     geo    4 x float4 = ONE 64-byte record per Gaussian (a per-instance gather in the sort touches one cache line, not five):
 //       [0] {pix.x, pix.y, cull_hx, cull_hy}      position + half-extents of the alpha >= 1/255 box
 //       [1] {conic.A, conic.B, conic.C, opacity}  } [0..2] are copied, in sorted order, into the per-instance stream the
-//       [2] {r, g, b, depth}                      } blend kernels read (inst_rec)
+//       [2] {r, g, b, depth}                      } blend kernels read (inst_rec; there [0] = {pix.x, pix.y, slot, list position + 1}
+//                                                   and [1] = {B, C, A, opacity}: blend.hip, pair_power)
 //       [3] bits {rect.min (x | y<<16), rect.max, point_offsets, tiles_touched}   tile rectangle (getRect result) + slot run
 //     tiles_touched u32, point_offsets u32 (also kept as plain arrays: the backward reads them coalesced), radius i32,
 //     clamped u8 (bit c = channel c),

@@ -4,7 +4,7 @@
 # alternates the two libraries on the same box (bench.py --steps 200, no callers) and prints value, ms/step and per-stage times.
 rounds=${1:-2}
 for r in $(seq 1 $rounds); do
-  for lib in lib_prev lib_diag; do
+  for lib in ${AB_LIBS:-lib_prev lib_diag}; do
     env MOSS_AMD_LIB_DIR=$lib python bench.py --no-callers --no-cpu-baseline --steps 200 > gpurun_out/ab_${lib}_$r.json 2> gpurun_out/ab_${lib}_$r.err
     python - "$lib" "$r" <<'PY'
 import json, sys

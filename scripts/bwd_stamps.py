@@ -36,5 +36,18 @@ for q in range(8):
     m = s[:, 10] == q
     if not m.any(): continue
     x = s[m]
-    print(" xcd", q, "waves", int(m.sum()), "segments", int(x[:, 3].sum()), "tails", int(x[:, 7].sum()), "| segment phase end median/max", us(np.median(x[:, 1])), us(x[:, 1].max()),
+    print(" xcd", q, "waves", int(m.sum()), "start median", us(np.median(x[:, 0])), "segments", int(x[:, 3].sum()), "tails", int(x[:, 7].sum()), "| segment phase end median/max", us(np.median(x[:, 1])), us(x[:, 1].max()),
           "| end median/max", us(np.median(x[:, 2])), us(x[:, 2].max()))
+# implied clock of s_memtime against the 100 MHz real-time counter: waves with exactly one segment, phase 1 = pops + the item
+one = s[s[:, 3] == 1]
+if len(one):
+    dur_us = (one[:, 1] - one[:, 0]) / 100.0
+    cyc = one[:, 4] + one[:, 5]
+    print("phase 1 of one-segment waves: median %.2f us, item+pop cycles median %.0f -> %.2f cycles per ns; item alone %.0f cycles, pop+table %.0f" % (
+        np.median(dur_us), np.median(cyc), np.median(cyc / dur_us) / 1000.0, np.median(one[:, 4]), np.median(one[:, 5])))
+tl = s[s[:, 7] > 0]
+if len(tl):
+    dur_us = (tl[:, 2] - tl[:, 1]) / 100.0
+    cyc = tl[:, 8] + tl[:, 9]
+    print("phase 2 of waves with tail items: median %.2f us for %.2f items, item+pop cycles median %.0f -> %.2f cycles per ns" % (
+        np.median(dur_us), np.median(tl[:, 7]), np.median(cyc), np.median(cyc / dur_us) / 1000.0))
