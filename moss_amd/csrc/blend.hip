@@ -302,13 +302,14 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 const float dL_dopa = __fmaf_rn(u - Q, To, nTb * rinv);              // (u - Q) = sum_k (x_k - accum_k) g_k
                 Q = __fmaf_rn(mm, Q, al * u);
                 T = To;
-                // (the record holds moments of w: see the heavy path's trip)
+                // (the record's geometry sums go without their constant factors: see the heavy path's trip)
                 const float dchannel_dcolor = al * To;
                 const float v8 = G * dL_dopa;                                       // G = 0 for a skipped pair
                 const float w = b.w * v8;
                 const float wx = w * dx, wy = w * dy;
                 v[k][0] = dchannel_dcolor * gpr; v[k][1] = dchannel_dcolor * gpg; v[k][2] = dchannel_dcolor * gpb;
-                v[k][3] = wx; v[k][4] = wy;
+                v[k][3] = __fmaf_rn(wx, b.z, wy * b.x);
+                v[k][4] = __fmaf_rn(wy, b.y, wx * b.x);
                 v[k][5] = wx * dx; v[k][6] = wx * dy; v[k][7] = wy * dy;
                 v[k][8] = v8;
                 pos4[k] = pos; slot4[k] = __float_as_uint(a.z);
@@ -842,16 +843,19 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         if (contrib != 0ull) {
             // To = T after the division (backward.cu:516); (u - Qi) = sum_k (x_k - accum_k) g_k.  G = 0 for a skipped pair zeroes
             // everything below but the colour terms, which carry alpha = 0.
-            // The record holds the MOMENTS of w = dL/dG * G over the block's pixels; what is constant per Gaussian -- the conic
-            // (A, B, C) and the factors -- is applied by the per-Gaussian kernel, once (backward.cu:566-580 factored):
-            //   [3] sum w dx, [4] sum w dy:   dL/dmean2D = -0.5 (W (A [3] + B [4]), H (C [4] + B [3]))
-            //   [5] sum w dx dx, [6] sum w dx dy, [7] sum w dy dy:   dL/dconic = -0.5 ([5], [6], [7])
+            // The record holds the sums WITHOUT their constant factors (the per-Gaussian kernel applies them once per Gaussian):
+            //   [3] sum w (A dx + B dy)   x -0.5 W = dL/dmean2D.x      [5] sum w dx dx   x -0.5 = dL/dconic.x
+            //   [4] sum w (C dy + B dx)   x -0.5 H = dL/dmean2D.y      [6] sum w dx dy   x -0.5 = dL/dconic.y   [7] sum w dy dy: .w
+            // with w = dL/dG * G (backward.cu:566-580 factored; the record's second word is {B, C, A, opacity}).  (Leaving the conic
+            // to the per-Gaussian kernel as well saved four instructions here and cost that kernel a cache line per Gaussian: +0.5 us.)
             const float dL_dopa = __fmaf_rn(u - Qi, To, nTb * rinv);
             const float v8 = G * dL_dopa;
             const float w = f.b.w * v8;
-            const v2f v34 = v2f{w, w} * pg.d;                                     // (packed: two products per instruction)
-            const v2f v56 = v2f{v34.x, v34.x} * pg.d;
-            const float v3 = v34.x, v4 = v34.y, v5 = v56.x, v6 = v56.y, v7 = v34.y * pg.d.y;
+            const v2f wd = v2f{w, w} * pg.d;                                      // (w dx, w dy); packed: two products per instruction
+            const v2f v56 = v2f{wd.x, wd.x} * pg.d;
+            const float v3 = __fmaf_rn(wd.x, f.b.z, wd.y * f.b.x);
+            const float v4 = __fmaf_rn(wd.y, f.b.y, wd.x * f.b.x);
+            const float v5 = v56.x, v6 = v56.y, v7 = wd.y * pg.d.y;
             const float dchannel_dcolor = al * To;
             const v2f v01 = v2f{dchannel_dcolor, dchannel_dcolor} * gp_rg;
             const float v0 = v01.x, v1 = v01.y, v2 = dchannel_dcolor * gpb;

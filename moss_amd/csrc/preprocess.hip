@@ -763,7 +763,6 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc] + g.group_base[idc >> 8], hdr_flags = header[2];
-    const float4 conic_o = g.geo[4 * (size_t)idc + 1];     // the conic the blend kernels used (written by the forward; read only for visible Gaussians)
     if (STAGE_SH) {
         // into LDS right away (row stride 49: conflict-free rows): the SH loads are the oldest outstanding ones, so this waits for
         // them only, and their 48 registers are free during the gather (holding them across it spilled to scratch)
@@ -1000,15 +999,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     PSTAMP(1);
     if (STAGE_SH) __syncthreads();                           // SH records are in LDS
     PSTAMP(2);
-    // The blend kernel's records carry moments of w = dL/dG * G: sum w dx, sum w dy, sum w dx dx, sum w dx dy, sum w dy dy (blend.hip,
-    // the backward trip).  What is constant per Gaussian is applied here: dG/ddel = -(A dx + B dy, C dy + B dx) with the conic the
-    // forward used (backward.cu:570-571), d pixel / d ndc = W/2, H/2 (:472-473, 574-575), the -1/2 of the exponent (:578-580).
-    if (visible) {
-        const float sx = gmx, sy = gmy;
-        gmx = (conic_o.x * sx + conic_o.y * sy) * mean2d_sx;
-        gmy = (conic_o.z * sy + conic_o.y * sx) * mean2d_sy;
-    }
-    gca *= -0.5f; gcb *= -0.5f; gcc *= -0.5f;
+    // the blend kernel's records carry the geometry sums without their constant factors (blend.hip, the backward trip):
+    // d pixel / d ndc = W/2, H/2 (backward.cu:472-473, 574-575) and the -1/2 of the exponent (backward.cu:578-580)
+    gmx *= mean2d_sx; gmy *= mean2d_sy; gca *= -0.5f; gcb *= -0.5f; gcc *= -0.5f;
     if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
