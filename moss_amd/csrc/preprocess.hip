@@ -453,7 +453,7 @@ __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb,
                                                   float tan_fovx, float tan_fovy, float h_x, float h_y,
                                                   const float* __restrict__ means3D, const float* __restrict__ cov3D_precomp, const GeomView& g,
                                                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
-                                                  float3& mean, float* dmean, float* dcov)
+                                                  float3& mean, float* dmean, float* dcov, float (&A_out)[2][3], float (&d2_out)[3])
 {
     // ================= per-Gaussian backward, in matrix form =================================================================
     // What is differentiated is the reference's forward (forward.cu:74-113, 118-152, 20-71, 196-237) with the conventions its
@@ -503,6 +503,9 @@ __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb,
     d2[1][1] = -w * (v1 * a2 - v0 * b2);
     d2[1][0] = d2[0][1];
     if (w == 0.0f) { d2[0][0] = 0.f; d2[0][1] = 0.f; d2[1][0] = 0.f; d2[1][1] = 0.f; }   // (denom2inv == 0 case of backward.cu:205)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A_out[0][k] = A[0][k]; A_out[1][k] = A[1][k]; }             // (for the scale / rotation gradient: step (6))
+    d2_out[0] = d2[0][0]; d2_out[1] = d2[0][1]; d2_out[2] = d2[1][1];
     // (2)  dS3 = A^T dS2 A,  dA = 2 dS2 (A S3)
     float DA[2][3];                                                                          // dS2 A
 #pragma unroll
@@ -544,20 +547,30 @@ __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb,
 
 }
 
-// ---- step (6): dL/dcov3D -> dL/dscale, dL/drot (and dL/dtransforms), chained through the raw-parameter getters if asked
-__device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, float scale_modifier, int raw,
+// ---- step (6): dL/dscale, dL/drot (and dL/dtransforms), chained through the raw-parameter getters if asked
+__device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, const float (&A)[2][3], const float (&d2)[3],
+                                                   float scale_modifier, int raw,
                                                    const float* __restrict__ scales, const float* __restrict__ rotations,
                                                    const float* __restrict__ transforms, float* dscale, float* drot, float* dtf)
 {
-    // (6) S3 = L L^T, L = R(q) diag(mod s) with the quaternion as given (forward.cu:118-152; with a transform: S3 = T (L L^T) T^T,
-    //     pulled back first).  dL/dL = 2 dS3 L (dS3 the symmetric matrix: off-diagonals are half the six-vector's entries);
-    //     dL/d(mod s_k) = sum_i dL_ik R_ik;  G = dL/dR, G_ik = dL_ik s_k;  and for R(q) = I + 2 [..] with q = (r, v):
+    // (6) S3 = L L^T, L = R(q) diag(mod s) with the quaternion as given (forward.cu:118-152; with a transform: L = T R diag(mod s)).
+    //     dL/dL = 2 dS3 L with dS3 = A^T dS2 A (step 2).  The reference forms the six-vector dS3 in float32 and multiplies it by L
+    //     (backward.cu:278-341); for a needle -- scales 300 : 1 : 1 -- whose thin axes point nearly along the viewing ray that is a
+    //     difference of terms 10^3 times its size TWICE over (dS3 r_k, then r_k . (dS3 r_k)): the gradient of the thin scales comes out
+    //     with 10^-7 x 10^3..10^4 of relative error, in the reference's arithmetic and in ours alike (the fuzz outliers of
+    //     tests/golden/fuzz_outlier_seeds.json).  Evaluated from the right instead,
+    //         u_k = A' r_k (A' = A T),   w_k = dS2 u_k,   column k of dL/dL = 2 m_k A'^T w_k,   dL/dm_k = 2 m_k u_k . w_k   (m = mod s),
+    //     the small vector u_k is formed ONCE and the quadratic form is taken of it: the cancellation enters once, not squared.
+    //     That is how dL/dm_k is evaluated here (seed 3163 of the fuzz: 5e-3 of the Gaussian's contribution mass from float64 -> 1.3e-6;
+    //     the float32 restatement of the reference: 4.5e-5).
+    //     G = dL/dR, G_ik = (dL/dL)_ik m_k;  and for R(q) = I + 2 [..] with q = (r, v):
     //       dq_r = 2 v . a,   dq_v = 2 (Soff v + r a) - 4 v * (tr G - diag G),   a = (G21-G12, G02-G20, G10-G01), Soff = offdiag(G + G^T).
     if (scales != nullptr) {
         float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
         float qr[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
         const float q_raw[4] = { qr[0], qr[1], qr[2], qr[3] };
         activate_scale_rot(raw, scr, qr);                    // raw mode: exp / normalize as in the forward
+        float Ap[2][3] = { { A[0][0], A[0][1], A[0][2] }, { A[1][0], A[1][1], A[1][2] } };   // A' = A T
         float d6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
         if (transforms != nullptr) {
             float Tm[9], pre[6], d6_pre[6];
@@ -567,6 +580,10 @@ __device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, f
             transform_cov3d_bw(Tm, pre, d6, d6_pre, dtf);
 #pragma unroll
             for (int i = 0; i < 6; i++) d6[i] = d6_pre[i];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) Ap[j][i] = A[j][0] * Tm[i] + A[j][1] * Tm[3 + i] + A[j][2] * Tm[6 + i];
         }
         const float qw = qr[0], qx = qr[1], qy = qr[2], qz = qr[3];
         const float R[3][3] = { { 1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy) },
@@ -577,10 +594,17 @@ __device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, f
         float G[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
+            // the scale gradient from the right (see above) ...
+            const float u0 = Ap[0][0] * R[0][k] + Ap[0][1] * R[1][k] + Ap[0][2] * R[2][k];
+            const float u1 = Ap[1][0] * R[0][k] + Ap[1][1] * R[1][k] + Ap[1][2] * R[2][k];
+            const float w0 = d2[0] * u0 + d2[1] * u1, w1 = d2[1] * u0 + d2[2] * u1;
+            dscale[k] = 2.0f * sm[k] * (u0 * w0 + u1 * w1);  // w.r.t. mod * s, reported as is (backward.cu:322-325: no factor mod)
+            // ... dL/dR from the symmetric dS3, as the reference does (its cancellation is single; and an exactly symmetric dS3 gives
+            // the quaternion of an isotropic, unrotated Gaussian -- MOSS's initialisation -- a gradient of exactly zero, like the
+            // reference: noise of 1e-7 there would still move it by a full learning rate per step under Adam)
             float col[3];                                    // column k of dL/dL = 2 dS3 L
 #pragma unroll
             for (int i = 0; i < 3; i++) col[i] = 2.0f * sm[k] * (D3[i][0] * R[0][k] + D3[i][1] * R[1][k] + D3[i][2] * R[2][k]);
-            dscale[k] = col[0] * R[0][k] + col[1] * R[1][k] + col[2] * R[2][k];      // w.r.t. mod * s, reported as is (backward.cu:322-325: no factor mod)
 #pragma unroll
             for (int i = 0; i < 3; i++) G[i][k] = col[i] * sm[k];
         }
@@ -777,6 +801,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
     float dtf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    float A_cov[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } }, d2_cov[3] = { 0, 0, 0 };   // the 2x3 projection A = J Rv and dL/dS2 of step (1): kept for step (6)
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
     // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
     const bool visible = n_inst > 0 && !(hdr_flags & ERRFLAG_OVERFLOW);
@@ -1017,7 +1042,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 
     if (visible) {
         float3 mean;
-        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, means3D, cov3D_precomp, g, viewmatrix, projmatrix, mean, dmean, dcov);
+        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, means3D, cov3D_precomp, g, viewmatrix, projmatrix, mean, dmean, dcov, A_cov, d2_cov);
 
         PSTAMP(3);
         // (5) colour = max(0, 0.5 + sum_k b_k(n) sh_k), n = (mean - campos)/|.| (forward.cu:20-71).  dL/dsh_k = b_k(n) g (g = colour
@@ -1072,7 +1097,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 
 
         PSTAMP(4);
-        scale_rot_backward(idx, dcov, scale_modifier, raw, scales, rotations, transforms, dscale, drot, dtf);
+        scale_rot_backward(idx, dcov, A_cov, d2_cov, scale_modifier, raw, scales, rotations, transforms, dscale, drot, dtf);
     } else if (dsh != nullptr) {
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
     }

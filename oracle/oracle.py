@@ -222,11 +222,16 @@ def _forward64(bg, means3D, colors_precomp, opacities, scales, rotations, scale_
 
 def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None,
-             f32_accumulators=False):
+             f32_accumulators=False, sum_noise_ulps=0.0, noise_seed=0):
     """``fw`` is the namespace returned by :func:`forward`.  Returns the reference's 8 gradient arrays
     (rasterize_points.cu:205) plus dL_dconic as a namespace.  A float64 ``fw`` (forward(f64=True)) runs the float64 build.
     ``f32_accumulators``: the blend backward adds its per-pixel terms in float32 in loop order -- one of the orders the reference's
-    atomicAdd can take -- instead of in double (the default: the centre of that distribution)."""
+    atomicAdd can take -- instead of in double (the default: the centre of that distribution).
+    ``sum_noise_ulps`` (a conditioning probe, meant for the float64 build): the per-Gaussian sums the blend backward hands to the
+    per-Gaussian stages (dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors -- BACKWARD::render's atomicAdd targets, backward.cu:566-588)
+    are multiplied by 1 + eta, eta uniform in +-sum_noise_ulps * 2^-24, before those stages run: what ANY float32 evaluation of the
+    sums does to them at the least.  The change of the final gradients against the unperturbed run is how far float32 rounding of
+    the sums alone is entitled to move them (a 300:1 anisotropic Gaussian amplifies it by 10^3-10^4 in its scale gradient)."""
     is64 = bool(getattr(fw, "f64", False))
     L = lib64() if is64 else lib()
     dt = np.float64 if is64 else np.float32
@@ -266,6 +271,10 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
                              _p(fw.means2D), _p(fw.conic_opacity), _p(np.ascontiguousarray(color_ptr)), _p(fw.depths),
                              _p(fw.final_T), _p(fw.n_contrib), _p(dpix), _p(ddep), _p(dalp),
                              _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors))
+    if sum_noise_ulps:
+        rng = np.random.default_rng(noise_seed)
+        for a in (g.dL_dmeans2D, g.dL_dconic, g.dL_dopacity, g.dL_dcolors):
+            a *= (1.0 + (rng.random(a.shape) * 2.0 - 1.0) * float(sum_noise_ulps) * 2.0 ** -24).astype(dt)
     cov3D_ptr = cov3D_precomp if cov3D_precomp is not None else fw.cov3D    # rasterizer_impl.cu:424
     if is64:
         focal_y = H / (2.0 * float(np.float32(tan_fovy))); focal_x = W / (2.0 * float(np.float32(tan_fovx)))

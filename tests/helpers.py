@@ -47,12 +47,12 @@ def oracle_forward(d):
                           c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
 
 
-def oracle_backward(d, fw, dc, dd, da, f32_accumulators=False):
+def oracle_backward(d, fw, dc, dd, da, f32_accumulators=False, sum_noise_ulps=0.0, noise_seed=0):
     c = d.cam
     return oracle.backward(fw, d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), _np(d.scales), _np(d.rotations),
                            d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(), c.tanfovx,
                            c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms),
-                           f32_accumulators=f32_accumulators)
+                           f32_accumulators=f32_accumulators, sum_noise_ulps=sum_noise_ulps, noise_seed=noise_seed)
 
 
 def _np(t):
