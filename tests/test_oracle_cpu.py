@@ -334,6 +334,32 @@ def test_float64_adjudicator_build_agrees_with_the_float32_oracle():
             assert hp.cosine_gap(a, b) < 1e-10, name
 
 
+def test_conditioning_probe_of_the_float64_backward():
+    """``sum_noise_ulps`` multiplies the blend backward's per-Gaussian sums by 1 + eta (|eta| <= k * 2^-24) before the per-Gaussian stages:
+    0 is the plain run bit for bit, and on a well-conditioned scene (cfg1) the final gradients move by about that much and no more --
+    what profiles/r03_notes.md finding 24 used to tell an ill-conditioned PROBLEM (the float64 answer moves) from an unstable
+    float32 EVALUATION (it does not: the scale gradient of a needle)."""
+    from tests import helpers as hp
+    d = hp.inputs_of(scenes.config1(), "scale_rot")
+    fw = hp.oracle_forward(d)
+    fw64 = hp.oracle_forward64(d, fw)
+    dc, dd, da = hp.image_grads(d.H, d.W)
+    g = hp.oracle_backward(d, fw64, dc, dd, da)
+    g0 = hp.oracle_backward(d, fw64, dc, dd, da, sum_noise_ulps=0.0)
+    g4 = hp.oracle_backward(d, fw64, dc, dd, da, sum_noise_ulps=4.0, noise_seed=1)
+    sc = hp.oracle_gradient_scales(d, fw, dc, dd, da)
+    moved = 0.0
+    for name, scale in sc.items():
+        a, b, c = getattr(g, name), getattr(g0, name), getattr(g4, name)
+        if not a.size:
+            continue
+        np.testing.assert_array_equal(a, b)
+        live, dead = hp.scaled_err(c, a, scale)
+        assert dead == 0.0 and live < 200 * 4.0 * 2.0 ** -24, (name, live)     # a few hundred times the noise at most, in mass units
+        moved = max(moved, live)
+    assert moved > 0.0                                                        # the probe did perturb something
+
+
 def test_contribution_mass_bounds_the_gradient_and_is_zero_where_nothing_contributes():
     from tests import helpers as hp
     d = hp.inputs_of(scenes.config1(), "scale_rot")
