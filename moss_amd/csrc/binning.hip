@@ -152,8 +152,10 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
                uint64_t* __restrict__ keys, int lds_hist, uint32_t* __restrict__ header, int fold_scan,
                const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
                uint32_t capacity, int light_log2, uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues,
-               uint4* __restrict__ work_table)
+               uint4* __restrict__ work_table, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */)
 {
+#define SSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()   /* 100 MHz, device-wide */
+    SSTAMP(0);
     extern __shared__ uint32_t s_mem[];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_max;
@@ -164,6 +166,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
         if ((int)blockIdx.x == n_blocks) {
             scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
                               (P + 255) / 256, g.group_tot, g.group_base, flags_acc, queues, work_table);
+            SSTAMP(5);
             return;
         }
     } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
@@ -198,6 +201,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
             wave_for_each_tile(r0, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
             wave_for_each_tile(r1, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
         }
+        SSTAMP(1);                                           // counted
         if (fold_scan) {
             uint32_t sum = 0u;
             if (per <= 4) { for (int u = 0; u < 4; u++) sum += tb + u < te ? cnt4[u] : 0u; }
@@ -209,6 +213,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
             else for (int i = tb; i < te; i++) { s_base[i] = off; off += tile_count[i]; }
         }
         __syncthreads();
+        SSTAMP(2);                                           // tile starts known
         // One returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket.  Four tiles per thread at a
         // time, as BUFFER atomics whose offset is out of range for an empty tile (dropped without a memory request, returns 0):
         // no branch around the atomic, so the four are in flight together -- inside `if (c)` each one was followed by a full
@@ -236,6 +241,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
             }
         }
         __syncthreads();
+        SSTAMP(3);                                           // runs reserved
     }
     for (int base = blockIdx.x * blockDim.x; base < P; base += 2 * n_blocks * blockDim.x) {
         int idx[2]; uint2 r[2]; uint64_t key[2];
@@ -260,6 +266,8 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
             });
         }
     }
+    SSTAMP(4);                                               // keys written
+#undef SSTAMP
 }
 
 // Which tile owns sort chunk c: the tile t with chunk_base[t] <= c < chunk_base[t] + ceil(n_t / CHUNK).  Every thread of the workgroup
@@ -698,7 +706,7 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     const int fold = (fold_scan && lds_hist) ? 1 : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks + fold), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
                        lds_hist, im.header, fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob(), im.flags_acc, im.queues,
-                       im.work_table);
+                       im.work_table, (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 16384 : nullptr);
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,

@@ -35,3 +35,13 @@ t0 = w[:, 0].min()
 print("preprocess_forward blocks", len(w), "(realtime us, relative to the first block's start)")
 for i, name in ((0, "start"), (1, "loads issued + SH staged"), (2, "geometry done + stored"), (4, "histogram + slot runs"), (5, "flushed, end")):
     print("   %-28s median %6.2f  p90 %6.2f  max %6.2f" % (name, np.median(w[:, i] - t0) / 100, np.percentile(w[:, i] - t0, 90) / 100, (w[:, i].max() - t0) / 100))
+
+w = s[16384: 16384 + 8 * 512].reshape(-1, 8).astype(np.float64)
+w = w[w[:, 0] > 0]
+t0 = w[:, 0].min()
+scan = w[w[:, 5] > 0]; blk = w[w[:, 4] > 0]
+print("scatter blocks", len(blk), "(realtime us, relative to the first block's start)")
+for i, name in ((0, "start"), (1, "own instances counted"), (2, "tile starts known"), (3, "runs reserved"), (4, "keys written, end")):
+    print("   %-28s median %6.2f  p90 %6.2f  max %6.2f" % (name, np.median(blk[:, i] - t0) / 100, np.percentile(blk[:, i] - t0, 90) / 100, (blk[:, i].max() - t0) / 100))
+if len(scan):
+    print("   the scan block: start %.2f end %.2f" % ((scan[0, 0] - t0) / 100, (scan[0, 5] - t0) / 100))
