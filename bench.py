@@ -34,9 +34,10 @@ MIN_TIMED_MS = 50.0                   # a timed region shorter than this is re-m
 LONG_STEPS = 200
 
 
-def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
-    """bytes that MUST cross HBM per fwd+bwd step, from the measured P, Pv, R, N."""
-    c = 28 if scale_rot_mode else 24
+def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode, transforms=False):
+    """bytes that MUST cross HBM per fwd+bwd step, from the measured P, Pv, R, N.  transforms: the in-op
+    LBS covariance (row n2) reads 36 B per Gaussian more in both directions and writes dL_dtransforms (36 B per Gaussian)."""
+    c = (28 if scale_rot_mode else 24) + (36 if transforms else 0)
     fwd = {
         "preprocess_fwd": P * (12 + c + 4) + Pv * 12 * K + P * 8 + Pv * 43,
         "scan": 8 * P,
@@ -47,7 +48,8 @@ def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode):
     }
     bwd = {
         "blend_bwd": 44 * R + 28 * N + 36 * Pv,
-        "preprocess_bwd": 36 * Pv + Pv * (12 + 4 + 24 + 12 * K + 3) + Pv * (12 + 24 + 12 * K + 4) + (28 * Pv if scale_rot_mode else 0) + P * 12,
+        "preprocess_bwd": 36 * Pv + Pv * (12 + 4 + 24 + 12 * K + 3) + Pv * (12 + 24 + 12 * K + 4) + (28 * Pv if scale_rot_mode else 0) + P * 12
+                          + (Pv * 36 + P * 36 if transforms else 0),
     }
     return fwd, bwd
 
@@ -58,8 +60,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--mode", default="scale_rot", choices=["precomp", "scale_rot", "lbs", "lbs_python"],
-                    help="scale_rot = cov3D computed inside the rasterizer from scales+rotations (the reference's "
+    ap.add_argument("--mode", default="lbs", choices=["precomp", "scale_rot", "lbs", "lbs_python"],
+                    help="lbs (default: MOSS's data flow, gaussian_renderer/__init__.py:88-93 -- scales, rotations and a per-Gaussian "
+                         "3x3 LBS transform that changes every frame -- with the covariance product inside the op); "
+                         "scale_rot = cov3D computed inside the rasterizer from scales+rotations (the reference's "
                          "compute_cov3D_python=False path, gaussian_renderer/__init__.py:92-93); precomp = cov3D computed by "
                          "torch ops and passed in (MOSS's shipped default, arguments/__init__.py:60); lbs = per-Gaussian 3x3 LBS-like "
                          "transforms applied to the covariance INSIDE the op (extension row n2) vs lbs_python = the same transforms "
@@ -87,10 +91,12 @@ def parse_args(argv=None):
                     help="index order of the synthetic Gaussians: as generated (uncorrelated with position -- the default, and the "
                          "least favourable) or re-indexed along a Morton curve (moss_amd.densify.spatial_order); a side experiment, "
                          "named in config.workload when used")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded"],
-                    help="N > 1 only. allreduce = one all-reduce (mean) of the flat gradient bucket, then the full AdamW on every rank; "
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded", "loss_only"],
+                    help="N > 1 only. loss_only = BASELINE configs[3] as written: every rank trains its OWN model on its own frames and "
+                         "RCCL all-reduces the 4-float loss block only; "
+                         "allreduce = one all-reduce (mean) of the flat gradient bucket, then the full AdamW on every rank; "
                          "sharded = reduce-scatter, AdamW on the rank's 1/N of the parameters (moments memory and update time / N), "
-                         "all-gather of the updated parameters (moss_amd.dist.ShardedStep).  The other variant is measured after the "
+                         "all-gather of the updated parameters (moss_amd.dist.ShardedStep).  The other variants are measured after the "
                          "timed region and reported beside the headline as `exchange_variants`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
@@ -165,6 +171,8 @@ class Harness:
             raster_context=self.ctx)
         self.lbs_T = lbs_T
         self.exchange_kind = exchange if (world > 1 and not torch_adamw) else "allreduce"
+        # loss_only: independent models -- the optimizer step is local to the rank (inside the captured step), like at N = 1
+        self.local_opt = world == 1 or self.exchange_kind == "loss_only"
         self.bucket = bucket = mdist.GradBucket(list(pc.parameters()), world=world if self.exchange_kind == "sharded" else 1)
         pipe.grad_bucket = bucket
         self.sharded = None
@@ -226,8 +234,14 @@ class Harness:
                 _ = out["visibility_filter"]
             if not torch_adamw and pipe.fused_activations:
                 bucket.collect()
-            if world == 1:
-                self.opt.step()
+            if self.local_opt:
+                # a frame that overflowed its capacity rendered nothing: the update kernel reads the frame's status word and skips
+                # itself (inside a captured step nobody else can; moss_adamw_flat_guarded)
+                img = None if torch_adamw else self.ctx.last_img_buffer
+                if img is not None and forward == "async":
+                    self.opt.step(skip_word=dgr._C.frame_status_word(img))
+                else:
+                    self.opt.step()
             # detached: holding an output with a grad_fn would keep this step's autograd graph (and its AccumulateGrad nodes,
             # bound to the stream they were created on) alive into the next step / into graph capture
             return {"radii": out["radii"]}
@@ -254,7 +268,10 @@ class Harness:
             self.n_exchange += 1
         e = self._ev
         e[0].record()
-        if self.sharded is None:
+        if self.exchange_kind == "loss_only":
+            self.bucket.all_reduce_loss_only(self.world)
+            e[1].record(); e[2].record(); e[3].record()
+        elif self.sharded is None:
             self.bucket.all_reduce_mean(None, self.world)
             e[1].record()
             self.opt.step()
@@ -275,6 +292,8 @@ class Harness:
         """{phase: ms per step} over the steps since the counters were reset."""
         n = max(self.n_exchange, 1)
         t = [round(x / n, 4) for x in self.t_phase]
+        if self.exchange_kind == "loss_only":
+            return {"loss_allreduce_ms": t[0], "bytes_reduced": 16, "adamw_elements": int(self.opt.count), "adamw": "inside the rank-local step"}
         if self.sharded is None:
             return {"allreduce_ms": t[0], "adamw_ms": t[1], "bytes_reduced": int(self.bucket.flat.numel() * 4), "adamw_elements": int(self.opt.count)}
         return {"reduce_scatter_ms": t[0], "adamw_ms": t[1], "all_gather_ms": t[2], "bytes_reduced": int(self.bucket.flat.numel() * 4),
@@ -306,7 +325,8 @@ class Harness:
             graph_step()
         self.torch.cuda.synchronize(self.dev)
         self.step = graph_step
-        self.graph_note = "one hipGraph replay per step" + ((" + eager RCCL all-reduce and AdamW" if self.sharded is None else
+        self.graph_note = "one hipGraph replay per step" + ((" + eager RCCL all-reduce of the 16-byte loss block" if self.exchange_kind == "loss_only" else
+                                                             " + eager RCCL all-reduce and AdamW" if self.sharded is None else
                                                              " + eager RCCL reduce-scatter, AdamW on the rank's shard, all-gather") if self.world > 1 else "")
 
     def time_steps(self, n, barrier=None):
@@ -464,7 +484,7 @@ def main(argv=None):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
         # frame-parallel replicas must hold bit-identical parameters after the same sequence of averaged gradients
-        if hasattr(opt, "flat_params"):
+        if hasattr(opt, "flat_params") and h.exchange_kind != "loss_only":     # (loss_only: independent models, nothing to compare)
             chk = opt.flat_params[:bucket.n_params].double().sum().reshape(1)
             lo, hi = chk.clone(), chk.clone()
             torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
@@ -487,28 +507,31 @@ def main(argv=None):
         exchange_variants = {h.exchange_kind: dict(exchange_rep or {}, value=round(world * args.steps / elapsed, 3),
                                                    ms_per_step=round(1e3 * elapsed / args.steps, 4), steps=args.steps,
                                                    replicas_identical=replicas_identical, headline=True)}
-        other = "sharded" if h.exchange_kind == "allreduce" else "allreduce"
-        h2 = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
-                     torch_activations=args.torch_activations, torch_adamw=False, forward=args.forward, graph=args.graph,
-                     lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=other)
-        for _ in range(max(args.warmup, 3)):
-            h2.step()
-        torch.cuda.synchronize(dev)
-        if h2.use_graph:
-            h2.capture()
-        h2.t_phase = [0.0, 0.0, 0.0]; h2.n_exchange = 0
-        n2 = max(args.steps, 50)
-        t2, _ = h2.time_steps(n2, barrier)
-        tt = torch.tensor([t2], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        t2 = float(tt.item())
-        chk = h2.opt.flat_params[:h2.bucket.n_params].double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        exchange_variants[other] = dict(h2.exchange_report(), value=round(world * n2 / t2, 3), ms_per_step=round(1e3 * t2 / n2, 4), steps=n2,
-                                        replicas_identical=bool((lo == hi).item()), headline=False)
-        del h2
-        torch.cuda.empty_cache()
+        for other in [k for k in ("allreduce", "sharded", "loss_only") if k != h.exchange_kind]:
+            h2 = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
+                         torch_activations=args.torch_activations, torch_adamw=False, forward=args.forward, graph=args.graph,
+                         lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=other)
+            for _ in range(max(args.warmup, 3)):
+                h2.step()
+            torch.cuda.synchronize(dev)
+            if h2.use_graph:
+                h2.capture()
+            h2.t_phase = [0.0, 0.0, 0.0]; h2.n_exchange = 0
+            n2 = max(args.steps, 50)
+            t2, _ = h2.time_steps(n2, barrier)
+            tt = torch.tensor([t2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t2 = float(tt.item())
+            same = None
+            if other != "loss_only":
+                chk = h2.opt.flat_params[:h2.bucket.n_params].double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
+                torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+                torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+                same = bool((lo == hi).item())
+            exchange_variants[other] = dict(h2.exchange_report(), value=round(world * n2 / t2, 3), ms_per_step=round(1e3 * t2 / n2, 4), steps=n2,
+                                            replicas_identical=same, headline=False)
+            del h2
+            torch.cuda.empty_cache()
 
     # ---- per-kernel device times: eager replay of the same K iterations with a hipEvent pair around every kernel of the op -------
     # (graph mode: events inside a replayed graph cannot be read back, so this replay is also where the dominant kernel's launch
@@ -538,7 +561,7 @@ def main(argv=None):
     R = int(h.ctx.last_needed if args.forward == "async" else h.ctx.last_num_rendered)
     N = H * W
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"))
+    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"), transforms=args.mode == "lbs")
     all_b = dict(fwd_b); all_b.update(bwd_b)
     if stage_ms.get("scan", 0.0) == 0.0:
         # asynchronous forward: the scan rides along with the scatter kernel (no launch of its own) -- its bytes count there
@@ -549,7 +572,7 @@ def main(argv=None):
     total_bytes = sum(all_b.values())
     iters_per_s = world * args.steps / elapsed
     raster_ms = sum(stage_ms.values())
-    headline = args.config == "cfg3" and args.mode == "scale_rot"
+    headline = args.config == "cfg3" and args.mode == "lbs"
     pmc = _pmc_traffic() if headline else {}
     # every stage against the roofline, not only the dominant one (durations: kernel-attached events of the eager replay)
     stages = {}
@@ -565,6 +588,10 @@ def main(argv=None):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {P} Gaussians on a synthetic capsule body, {W}x{H}, SH degree 3, "
                                f"step = render + L1 + 0.2(1-SSIM) + 0.5 maskL2 + backward + AdamW; one view per GPU per step"
+                               + ("; MOSS's data flow (scales + rotations + a per-Gaussian LBS transform per frame, gaussian_renderer/__init__.py:88-93) "
+                                  "with the covariance product, the getters, the loss and AdamW as this library's kernels and the step replayed as one "
+                                  "hipGraph: what a maintainer gets by applying patches/*.diff; `value_dropin` in this line = the same workload "
+                                  "through the UNCHANGED MOSS call pattern (only the three packages swapped)" if headline else "")
                    if args.config == "cfg3" else args.config,
                    "target": args.target, "input_mode": args.mode, "index_order": args.order,
                    "activations": "torch" if args.torch_activations else ("in_op" if h.pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
@@ -609,9 +636,10 @@ def main(argv=None):
         torch.cuda.empty_cache()
         result["callers"] = caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_transforms())
         result["value_dropin"] = result["callers"]["dropin_unchanged"].get("value")
+        result["value_patched_moss"] = result["callers"]["patched_moss_pattern"].get("value")
         if "spatial_order" in result["callers"]:
             result["value_spatial_order"] = result["callers"]["spatial_order"].get("value")
-        result["value_lbs_in_op"] = result["callers"]["lbs_in_op"].get("value")
+        result["value_no_transforms"] = result["callers"]["no_transforms"].get("value")
         result["value_precomp"] = result["callers"]["precomp_graph"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
@@ -629,7 +657,7 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
       dropin_fused_sides the same call pattern with the caller-side rows of SURVEY 8(f) switched to this repository's kernels: fused
                          L1+SSIM loss, DensifyStats, flat AdamW, fused activation kernels (still cov3D_precomp from Python, still
                          synchronous and eager)
-      lbs_in_op          the transforms applied inside the op (raw parameters, asynchronous forward, one hipGraph per step)
+      no_transforms      scales + rotations only (no LBS transform), otherwise as the headline: rounds 1-3's headline configuration
       precomp_graph      cov3D_precomp built in Python from the fused-activated parameters (MOSS's shipped compute_cov3D_python=True,
                          without LBS transforms), asynchronous forward, one hipGraph per step: `value_precomp`
       spatial_order      the HEADLINE configuration on the same Gaussians re-indexed along a Morton curve (densify.spatial_order, what
@@ -644,7 +672,12 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                                  fused_loss=False, caller_side="torch"),
         "dropin_fused_sides": dict(mode="lbs_python", activations="fused", torch_activations=False, torch_adamw=False, forward="sync", graph=0,
                                    fused_loss=True, caller_side="fused"),
-        "lbs_in_op": dict(mode="lbs", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
+        # exactly what patches/gaussian_renderer.diff + patches/train_ZJU.diff turn MOSS's call pattern into: transforms in the op,
+        # asynchronous forward, the statistics kernel -- MOSS's torch getters, torch loss and torch.optim.AdamW kept, eager launches
+        "patched_moss_pattern": dict(mode="lbs", activations="fused", torch_activations=True, torch_adamw=True, forward="async", graph=0,
+                                     fused_loss=False, caller_side="fused"),
+        # the op without per-Gaussian transforms (the reference's compute_cov3D_python=False path): rounds 1-3's headline
+        "no_transforms": dict(mode="scale_rot", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
         # MOSS's shipped input mode (compute_cov3D_python=True, arguments/__init__.py:60: the covariance built by torch ops from the
         # activated scales / rotations and handed over as cov3D_precomp) through the same graph path as the headline
         "precomp_graph": dict(mode="precomp", activations="fused", torch_activations=False, torch_adamw=False, forward="async", graph=1),
@@ -842,6 +875,7 @@ def dry_run_cpu(args):
         params = [torch.nn.Parameter(torch.zeros(1000, 3)), torch.nn.Parameter(torch.zeros(1000, 16, 3))]
         bucket = mdist.GradBucket(params, world=world if kind == "sharded" else 1)
         n = bucket.n_params
+        loss_only = kind == "loss_only"                      # independent models: only the loss block is exchanged
         if kind == "sharded" and world > 1:
             opt = _SgdShard(bucket, rank)
             sharded = mdist.ShardedStep(bucket, opt, rank, world)
@@ -856,6 +890,8 @@ def dry_run_cpu(args):
             t0 = time.perf_counter()
             if sharded is not None:
                 sharded.step()
+            elif loss_only:
+                bucket.all_reduce_loss_only(world)
             else:
                 bucket.all_reduce_mean(None, world)
             t_ar[0] += time.perf_counter() - t0
@@ -879,11 +915,12 @@ def dry_run_cpu(args):
             elapsed = float(tt.item())
             chk = flat_params[:n].double().sum().reshape(1); lo, hi = chk.clone(), chk.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            identical = bool((lo == hi).item())
+            identical = None if loss_only else bool((lo == hi).item())          # (loss_only: the ranks' models are their own)
             mean = (world + 1) / 2.0                                            # the mean of 1..world
             loss_seen = float((sharded.loss_terms if sharded is not None else bucket.loss_terms)[0])
             assert abs(loss_seen - mean) < 1e-6, (kind, loss_seen)
-            want = -0.1 * mean * (max(args.warmup, 1) + args.steps)
+            want = -0.1 * (float(rank + 1) if loss_only else mean) * (max(args.warmup, 1) + args.steps)
+            assert not loss_only or abs(float(bucket.flat[0]) - float(rank + 1)) < 1e-6        # its gradients never travelled
             assert abs(float(flat_params[0]) - want) < 1e-4 * abs(want) and abs(float(flat_params[n - 1]) - want) < 1e-4 * abs(want), kind
         return {"value": round(world * args.steps / elapsed, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                 "exchange_ms": round(1e3 * t_ar[0] / args.steps, 4), "replicas_identical": identical,
@@ -891,9 +928,9 @@ def dry_run_cpu(args):
 
     variants[args.exchange] = run(args.exchange)
     if world > 1:
-        other = "sharded" if args.exchange == "allreduce" else "allreduce"
-        variants[other] = run(other)
-        assert variants[other]["checksum"] == variants[args.exchange]["checksum"], "the two exchange paths left different parameters"
+        for other in [k for k in ("allreduce", "sharded", "loss_only") if k != args.exchange]:
+            variants[other] = run(other)
+        assert variants["allreduce"]["checksum"] == variants["sharded"]["checksum"], "the two gradient-exchange paths left different parameters"
     head = variants[args.exchange]
     if rank == 0:
         print(json.dumps({"metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)", "value": head["value"],
@@ -901,7 +938,7 @@ def dry_run_cpu(args):
                           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "DRY RUN: no GPU work (launcher / collective plumbing test)",
                           "config": {"workload": "dry run"}, "rccl_ranks": ranks, "backend": dist.get_backend() if world > 1 else None,
-                          "replicas_identical": all(v["replicas_identical"] for v in variants.values()), "exchange": args.exchange,
+                          "replicas_identical": all(v["replicas_identical"] for v in variants.values() if v["replicas_identical"] is not None), "exchange": args.exchange,
                           "allreduce_ms": head["exchange_ms"], "adamw_ms": 0.0, "exchange_variants": variants}))
 
 

@@ -32,7 +32,10 @@ extern "C" {
  * caller's knowledge of the device-step block's size (288 bytes in early version-1 builds, 9216 later); diagnostics
  * (environment knobs, stamp buffers) exist only in -DMOSS_DIAG builds.  A binding compiled against another version must refuse to
  * load: compare ITS compile-time MOSS_ABI_VERSION with moss_abi_version(). */
-#define MOSS_ABI_VERSION 2
+#define MOSS_ABI_VERSION 3
+/* Version 3 (round 4): EVERY forward / backward entry point takes the `debug` bit set (version 2: only moss_raster_forward /
+ * moss_raster_backward did, so MOSS_DEBUG_NO_BLOCK_CULL was silently dropped on the _async / _tf / _raw paths: last argument before
+ * `stream`); moss_adamw_flat_guarded (an optimizer step that a dropped frame turns into a no-op). */
 
 /* error codes (negative returns) */
 #define MOSS_ERR_INVALID_ARG   (-1)   /* bad shape / null where required (AT_ERROR in DGR/rasterize_points.cu:57-59) */
@@ -103,7 +106,7 @@ int moss_raster_forward(
  * device-side count.  Returns `capacity` (>= 0) -- pass that as R to moss_raster_backward -- or a negative error code.
  * If a frame needs more instances than `capacity`, nothing is rendered (outputs = background, gradients = 0) and the
  * overflow bit is set in the status words; poll them with moss_raster_read_status once the stream has advanced.
- * `debug` is not available in this mode (it synchronises by definition).
+ * `debug`: MOSS_DEBUG_NO_BLOCK_CULL is honoured; MOSS_DEBUG_SYNC is refused (MOSS_ERR_INVALID_ARG: it synchronises by definition).
  *
  * `frame_state` (optional, may be NULL; no counterpart in the reference, which memsets its buffers in every forward): a caller-owned
  * device block of moss_raster_frame_state_bytes(width, height) bytes, zero-initialised ONCE.  With it this call keeps the per-frame
@@ -129,7 +132,7 @@ int moss_raster_forward_async(
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, int debug, void* stream);
 
 /* Enqueue (on `stream`) a copy of the forward's 8 status words from the image buffer to pinned host memory:
  * [0] instances rendered  [1] longest tile list  [2] flags: bit0 prefiltered-point culled, bit1 capacity overflow
@@ -251,6 +254,19 @@ int moss_adamw_flat_range(long long first, long long count, float* params, const
                           const int* segment_period, const int* segment_split, const float* segment_lr2,
                           float beta1, float beta2, float eps, float weight_decay, int step, void* step_state, void* stream);
 
+/* moss_adamw_flat_range with a GUARD: if (*skip_word & skip_mask) != 0 when the kernel runs, the call is a no-op -- parameters,
+ * moments and the device-side step counter stay bit for bit what they were.  `skip_word`: a device word, e.g. the frame's status word
+ * (image buffer, 32-bit word 2; skip_mask = 2: the capacity-overflow bit of moss_raster_forward_async) -- a frame that overflowed
+ * its capacity rendered nothing and left zero gradients, and inside a captured step nobody is there to skip the optimizer: without
+ * the guard such a frame is a weight-decay-only step that also decays the moments.  Or a float that is non-zero when ANY rank
+ * dropped its frame (the flag averaged with the gradient bucket, skip_mask = 0x7fffffff) so that replicas skip together.
+ * Needs the device-side step counter (step_state != NULL): a host-side count cannot know about the skipped step. */
+int moss_adamw_flat_guarded(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                            int num_segments, const long long* segment_end, const float* segment_lr,
+                            const int* segment_period, const int* segment_split, const float* segment_lr2,
+                            float beta1, float beta2, float eps, float weight_decay, void* step_state,
+                            const uint32_t* skip_word, uint32_t skip_mask, void* stream);
+
 /*
  * k nearest reference points of every query point, 3-D, exact, k = 1..4: replaces the third-party
  * `knn_cuda.KNN(k, transpose_mode=True)(ref, query)` MOSS calls at scene/gaussian_model.py:85-86,586,657,759,827 (a CUDA-only
@@ -298,7 +314,8 @@ int moss_neighbour_kl(int P, int Nsrc, const float* xyz, const float* rotation, 
  * gaussian_renderer/__init__.py:88-91) because the LBS transform T of each Gaussian changes every frame; on MI355X that Python
  * path costs more than the whole rasterizer.  These two entry points take (scales, rotations, transforms (P,3,3) row-major)
  * instead and return gradients for all three.  Same semantics otherwise as moss_raster_forward[_async] (capacity < 0:
- * synchronous sizing of the binning buffer, >= 0: asynchronous with that capacity) and moss_raster_backward.
+ * synchronous sizing of the binning buffer, >= 0: asynchronous with that capacity) and moss_raster_backward; `debug` as there
+ * (MOSS_DEBUG_SYNC only with capacity < 0; MOSS_DEBUG_NO_BLOCK_CULL on the forward AND the matching backward call).
  *   dL_dcov3D (P,6): gradient w.r.t. the transformed covariance (what the op stores); dL_dscale / dL_drot include the transform;
  *   dL_dtransforms (P,9): written for every Gaussian (zeros for culled ones).
  */
@@ -308,7 +325,7 @@ int moss_raster_forward_tf(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, int debug, void* stream);
 int moss_raster_backward_tf(
     int P, int D, int M, int R,
     const float* background, int width, int height,
@@ -319,7 +336,7 @@ int moss_raster_backward_tf(
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, void* stream);
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int debug, void* stream);
 
 /*
  * Extension (caller side of the boundary): the GaussianModel getters applied INSIDE the op.
@@ -344,7 +361,7 @@ int moss_raster_forward_raw(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, int debug, void* stream);
 int moss_raster_backward_raw(
     int P, int D, int M, int R,
     const float* background, int width, int height,
@@ -355,7 +372,7 @@ int moss_raster_backward_raw(
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, void* stream);
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, int debug, void* stream);
 
 /*
  * Gaussian parameter activations, forward and backward, one launch each (the rasterizer-facing getters of MOSS's GaussianModel,

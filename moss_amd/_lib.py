@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(_HERE, os.environ.get("MOSS_AMD_LIB_DIR", "lib"))
 LIB_PATH = os.path.join(_LIB_DIR, "libmoss_raster.so")
 EXT_PATH = os.path.join(_LIB_DIR, "_moss_C.so")          # the compiled PyTorch extension (csrc/torch_binding.cpp) over the same C ABI
-ABI_VERSION = 2                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
+ABI_VERSION = 3                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -121,6 +121,8 @@ def _declare(lib):
     lib.moss_adamw_flat_devstep.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]
     lib.moss_adamw_flat_range.restype = _i
     lib.moss_adamw_flat_range.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p, _p]
+    lib.moss_adamw_flat_guarded.restype = _i
+    lib.moss_adamw_flat_guarded.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, C.c_uint32, _p]
     lib.moss_gaussian_activate_forward.restype = _i
     lib.moss_gaussian_activate_forward.argtypes = [_i, _i] + [_p] * 12
     lib.moss_gaussian_activate_backward.restype = _i

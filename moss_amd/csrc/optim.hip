@@ -14,8 +14,10 @@ struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; flo
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))   // (eight waves per SIMD: the scalar file admits six at 106 SGPRs)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
              Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
-             const float* __restrict__ step_state, long long first)
+             const float* __restrict__ step_state, long long first, const uint32_t* __restrict__ skip_word, uint32_t skip_mask)
 {
+    // guard (moss_adamw_flat_guarded): a dropped frame's step is a no-op -- nothing is read or written, the step counter stays
+    if (skip_word != nullptr && (*skip_word & skip_mask) != 0u) return;
     // `first`: the arrays are the elements [first, first + n) of the flat buffers the segment table indexes (a rank's shard of the
     // bucket, moss_adamw_flat_range); a multiple of 4, so that a thread's four elements never straddle it.
     int t_dev = 0;
@@ -128,7 +130,8 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
 int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
                  const long long* segment_end, const float* segment_lr, const int* segment_period, const int* segment_split,
                  const float* segment_lr2, float beta1, float beta2, float eps, float weight_decay,
-                 float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream, long long first = 0)
+                 float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream, long long first = 0,
+                 const uint32_t* skip_word = nullptr, uint32_t skip_mask = 0u)
 {
     Segs segs; segs.n = num_segments;
     for (int i = 0; i < 8; i++) {
@@ -141,7 +144,7 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
     if (blocks > max_blocks) blocks = max_blocks;            // (2048: eight 256-thread blocks per CU, all resident at once)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
-                       segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state, first);
+                       segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state, first, skip_word, skip_mask);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
 
@@ -192,4 +195,18 @@ extern "C" int moss_adamw_flat_range(long long first, long long count, float* pa
     return moss::launch_adamw(count, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
                               segment_split, segment_lr2, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
                               (const float*)step_state, (hipStream_t)stream, first);
+}
+
+extern "C" int moss_adamw_flat_guarded(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                       int num_segments, const long long* segment_end, const float* segment_lr,
+                                       const int* segment_period, const int* segment_split, const float* segment_lr2,
+                                       float beta1, float beta2, float eps, float weight_decay, void* step_state,
+                                       const uint32_t* skip_word, uint32_t skip_mask, void* stream)
+{
+    if (first < 0 || (first & 3) || count <= 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq ||
+        !segment_end || !segment_lr || !step_state || !skip_word)
+        return MOSS_ERR_INVALID_ARG;
+    return moss::launch_adamw(count, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
+                              segment_split, segment_lr2, beta1, beta2, eps, weight_decay, 1.f, 1.f, (const float*)step_state,
+                              (hipStream_t)stream, first, skip_word, skip_mask);
 }

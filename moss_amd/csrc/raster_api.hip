@@ -232,13 +232,14 @@ int moss_raster_forward_async(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, int debug, void* stream)
 {
     if (capacity < 0) return fail(MOSS_ERR_INVALID_ARG, "capacity must be >= 0");
+    if (debug & MOSS_DEBUG_SYNC) return fail(MOSS_ERR_INVALID_ARG, "MOSS_DEBUG_SYNC needs the synchronous forward");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity, nullptr, 0, frame_state);
+                        debug, stream, capacity, nullptr, 0, frame_state);
 }
 
 // n2 extension: like moss_raster_forward / _async (capacity < 0: synchronous, debug off) with a per-Gaussian 3x3
@@ -249,13 +250,14 @@ int moss_raster_forward_tf(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int capacity, char* frame_state, int debug, void* stream)
 {
     if (P > 0 && (!scales || !rotations || !transforms)) return fail(MOSS_ERR_INVALID_ARG, "scales, rotations and transforms are required");
+    if (capacity >= 0 && (debug & MOSS_DEBUG_SYNC)) return fail(MOSS_ERR_INVALID_ARG, "MOSS_DEBUG_SYNC needs the synchronous forward (capacity < 0)");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity < 0 ? -1 : capacity, transforms, 0, frame_state);
+                        debug, stream, capacity < 0 ? -1 : capacity, transforms, 0, frame_state);
 }
 
 int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out /* 8 words */, void* stream)
@@ -351,14 +353,14 @@ int moss_raster_backward_tf(
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, void* stream)
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int debug, void* stream)
 {
     if (P > 0 && (!scales || !rotations || !transforms || !dL_dtransforms))
         return fail(MOSS_ERR_INVALID_ARG, "scales, rotations, transforms and dL_dtransforms are required");
     return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,
                          nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
                          image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
-                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0, stream, transforms, dL_dtransforms);
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, transforms, dL_dtransforms);
 }
 
 // Raw-parameter variant (the getters of GaussianModel applied inside preprocess, see include/moss_raster.h).
@@ -368,14 +370,15 @@ int moss_raster_forward_raw(
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* transforms,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, void* stream)
+    float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, int debug, void* stream)
 {
     if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (!scales || !rotations)) return fail(MOSS_ERR_INVALID_ARG, "scales and rotations are required");
+    if (capacity >= 0 && (debug & MOSS_DEBUG_SYNC)) return fail(MOSS_ERR_INVALID_ARG, "MOSS_DEBUG_SYNC needs the synchronous forward (capacity < 0)");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        0, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags, frame_state);
+                        debug, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags, frame_state);
 }
 
 int moss_raster_backward_raw(
@@ -388,7 +391,7 @@ int moss_raster_backward_raw(
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, void* stream)
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, int debug, void* stream)
 {
     if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))
@@ -396,7 +399,7 @@ int moss_raster_backward_raw(
     return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,
                          nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
                          image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
-                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0, stream, transforms, transforms ? dL_dtransforms : nullptr, opacities,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, transforms, transforms ? dL_dtransforms : nullptr, opacities,
                          raw_flags);
 }
 

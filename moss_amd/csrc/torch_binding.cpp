@@ -97,11 +97,10 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     if (has_tf) {
         TORCH_CHECK(transforms->numel() == 9 * (int64_t)P && scales.numel() != 0 && rotations.numel() != 0 && cov3D_precomp.numel() == 0,
                     "transforms must be (P,3,3) and comes with scales and rotations (no cov3D_precomp)");
-        TORCH_CHECK(!debug, "debug mode is not available together with transforms");
     }
     if (raw_flags)
-        TORCH_CHECK(scales.numel() != 0 && rotations.numel() != 0 && cov3D_precomp.numel() == 0 && !debug,
-                    "raw_flags comes with scales and rotations (no cov3D_precomp, no debug mode)");
+        TORCH_CHECK(scales.numel() != 0 && rotations.numel() != 0 && cov3D_precomp.numel() == 0,
+                    "raw_flags comes with scales and rotations (no cov3D_precomp)");
     const c10::DeviceGuard guard(means3D.device());
     const auto fopts = means3D.options().dtype(torch::kFloat32);
     // every element is written by the kernels (or memset by the library when P == 0): no zero-fill pass (the reference: torch::full x4)
@@ -116,7 +115,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     std::vector<torch::Tensor> keep;
     keep.reserve(16);
     void* stream = c10::hip::getCurrentHIPStream(means3D.device().index()).stream();
-    const bool use_async = capacity >= 0 && !debug && P > 0;
+    const bool use_async = capacity >= 0 && !(debug & MOSS_DEBUG_SYNC) && P > 0;   // (the reference's debug flag synchronises after every launch)
     const float* p_bg = ptr(background, "background", keep);
     const float* p_means = ptr(means3D, "means3D", keep);
     const float* p_sh = ptr(sh, "sh", keep);
@@ -144,15 +143,15 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     if (raw_flags)
         rc = moss_raster_forward_raw(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
                                      p_scl, (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
-                                     prefiltered ? 1 : 0, oc, od, oa, p_radii, (int)raw_flags, cap, p_fs, stream);
+                                     prefiltered ? 1 : 0, oc, od, oa, p_radii, (int)raw_flags, cap, p_fs, (int)debug, stream);
     else if (has_tf)
         rc = moss_raster_forward_tf(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
                                     p_scl, (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
-                                    prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, p_fs, stream);
+                                    prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, p_fs, (int)debug, stream);
     else if (use_async)
         rc = moss_raster_forward_async(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col,
                                        p_opa, p_scl, (float)scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, (float)tan_fovx,
-                                       (float)tan_fovy, prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, p_fs, stream);
+                                       (float)tan_fovy, prefiltered ? 1 : 0, oc, od, oa, p_radii, cap, p_fs, (int)debug, stream);
     else
         rc = moss_raster_forward(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
                                  p_scl, (float)scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
@@ -227,12 +226,12 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                                           (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy, p_geom,
                                           p_bin, p_img, g_c, g_d, g_a, f(dL_dmeans2D), f(dL_dconic), f(dL_dopacity), f(dL_dcolors), f(dL_dmeans3D),
                                           f(dL_dcov3D), p_dsh, f(dL_dscales), f(dL_drotations), has_tf ? f(dL_dtransforms) : nullptr,
-                                          (int)raw_flags, stream);
+                                          (int)raw_flags, (int)debug, stream);
         } else if (has_tf) {
             rc = moss_raster_backward_tf(P, (int)degree, M, (int)R, p_bg, W, H, p_means, p_sh, p_col, p_scl, (float)scale_modifier, p_rot, p_tf,
                                          p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy, p_geom, p_bin, p_img, g_c, g_d, g_a,
                                          f(dL_dmeans2D), f(dL_dconic), f(dL_dopacity), f(dL_dcolors), f(dL_dmeans3D), f(dL_dcov3D), p_dsh,
-                                         f(dL_dscales), f(dL_drotations), f(dL_dtransforms), stream);
+                                         f(dL_dscales), f(dL_drotations), f(dL_dtransforms), (int)debug, stream);
         } else {
             rc = moss_raster_backward(P, (int)degree, M, (int)R, p_bg, W, H, p_means, p_sh, p_col, ptr(alphas, "alphas", keep), p_scl,
                                       (float)scale_modifier, p_rot, p_cov, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,

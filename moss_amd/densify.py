@@ -15,7 +15,7 @@ import torch
 
 from ._lib import check, lib
 
-__all__ = ["DensifyStats", "neighbour_kl", "cal_kl"]
+__all__ = ["DensifyStats", "densify_stats_update", "neighbour_kl", "cal_kl"]
 
 
 def _stream(device):
@@ -67,6 +67,19 @@ class DensifyStats:
 
     def reset(self) -> None:
         self.xyz_gradient_accum.zero_(); self.denom.zero_(); self.max_radii2D.zero_()
+
+
+def densify_stats_update(max_radii2D: torch.Tensor, xyz_gradient_accum: torch.Tensor, denom: torch.Tensor,
+                         radii: torch.Tensor, viewspace_grad: torch.Tensor) -> None:
+    """The per-step bookkeeping of train_ZJU.py:171-174 on the CALLER's tensors (MOSS's ``gaussians.max_radii2D (P)``,
+    ``gaussians.xyz_gradient_accum (P,1)``, ``gaussians.denom (P,1)``), in place, in one launch and without the mask -> index host
+    synchronisation: what ``patches/train_ZJU.diff`` puts in the place of those two lines."""
+    st = DensifyStats.__new__(DensifyStats)
+    st.max_radii2D, st.xyz_gradient_accum, st.denom = max_radii2D, xyz_gradient_accum, denom
+    for t in (max_radii2D, xyz_gradient_accum, denom):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("densify_stats_update: the statistics must be contiguous float32 GPU tensors")
+    st.add(radii, viewspace_grad)
 
 
 def neighbour_kl(xyz: torch.Tensor, rotation: torch.Tensor, scaling: torch.Tensor, pair_idx: torch.Tensor) -> torch.Tensor:

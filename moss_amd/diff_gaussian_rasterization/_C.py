@@ -61,6 +61,7 @@ class RasterContext:
         self.sinks = dict.fromkeys(_SINK_NAMES)
         self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
         self._retired_frame_states = []   # outgrown blocks: a captured hipGraph may still hold their address (see _frame_state)
+        self._raised_overflows = 0        # overflows of this context already raised as CapacityOverflow (not "dropped by a replay")
 
     # ---- asynchronous forward -------------------------------------------------------------------------------------------------
     def set_async(self, enabled: bool, capacity: int = 0, margin: float = 2.0):
@@ -86,6 +87,7 @@ class RasterContext:
         if needed * 1.25 > self.capacity:                       # drifting towards the limit: grow ahead of time
             self.capacity = int(needed * self.margin) + 1024
         if flags & 2:
+            self._raised_overflows += 1                         # the caller hears about this frame here: it is not a silently dropped one
             raise CapacityOverflow(needed, self.capacity)
         if flags & 1:
             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
@@ -119,26 +121,33 @@ class RasterContext:
         fs = self.frame_state
         if fs is None or fs.device != dev or fs.numel() < n:
             if fs is not None:
-                self._retired_frame_states.append(fs)
-                for old in self._retired_frame_states:       # an older block of this device that is large enough serves again
-                    if old.device == dev and old.numel() >= n:
-                        self.frame_state = old
-                        return old
+                self._retired_frame_states.append(fs)       # (the active block is never in the list: see below)
+            for i, old in enumerate(self._retired_frame_states):   # an older block of this device that is large enough serves again
+                if old.device == dev and old.numel() >= n:
+                    self.frame_state = self._retired_frame_states.pop(i)
+                    return self.frame_state
             fs = self.frame_state = torch.zeros(n, dtype=torch.uint8, device=dev)
         return fs
 
+    def _dropped_words(self):
+        return [fs.view(torch.int32)[FRAME_STATE_DROPPED_WORD:FRAME_STATE_DROPPED_WORD + 1]
+                for fs in [self.frame_state] + self._retired_frame_states if fs is not None and fs.is_cuda]
+
     def read_dropped_frames(self, reset: bool = True) -> int:
-        """How many asynchronous forwards of this context overflowed their capacity (each rendered NOTHING: zero gradients, while an
-        optimizer in the same captured step kept stepping) since the last reset: the sticky counter the library keeps in the frame
-        state.  Synchronises the device; call it outside graph capture (``GraphedStep.check`` does)."""
-        n = 0
-        for fs in [self.frame_state] + self._retired_frame_states:
-            if fs is not None and fs.is_cuda:
-                w = fs.view(torch.int32)[FRAME_STATE_DROPPED_WORD:FRAME_STATE_DROPPED_WORD + 1]
-                n += int(w.item())
-                if reset:
-                    w.zero_()
-        return n
+        """How many asynchronous forwards of this context overflowed their capacity (each rendered NOTHING: zero gradients; a guarded
+        optimizer step -- ``FlatAdamW.step(skip_word=frame_status_word(img))`` -- skips itself on such a frame) since the last reset:
+        the sticky counter the library keeps in the frame state.  Overflows that were already RAISED to the caller as
+        :class:`CapacityOverflow` are not counted again (``_consume_status`` takes them off).  One device sum, one host read;
+        synchronises the device: call it outside graph capture (``GraphedStep.check`` does)."""
+        words = self._dropped_words()
+        if not words:
+            return 0
+        n = int(torch.stack([w.to(words[0].device) for w in words]).sum().item()) - self._raised_overflows
+        if reset:
+            for w in words:
+                w.zero_()
+            self._raised_overflows = 0
+        return max(n, 0)
 
     # ---- gradient sinks ---------------------------------------------------------------------------------------------------------
     def set_grad_sink(self, sh=None, means3D=None, opacity=None, scales=None, rotations=None):
@@ -166,6 +175,12 @@ def check_async_status(img_buffer=None, context=None):
     (context or DEFAULT).check_status(img_buffer)
 
 
+def frame_status_word(img_buffer):
+    """The 32-bit status word of a forward's image buffer as a one-element int32 view (bit 0: a prefiltered point was culled, bit 1:
+    the frame overflowed its capacity and rendered nothing): what ``FlatAdamW.step(skip_word=...)`` tests ON THE DEVICE."""
+    return img_buffer.view(torch.int32)[2:3]
+
+
 lib()   # fail at import time if the HIP library is missing: there is no fallback
 ext()   # ... or if the compiled torch extension is
 
@@ -183,7 +198,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     binningBuffer, imgBuffer)."""
     cx = context or DEFAULT
     P = int(means3D.size(0)) if means3D.ndimension() >= 1 else 0
-    use_async = cx.enabled and not debug and cx.capacity > 0 and P > 0 and means3D.is_cuda
+    use_async = cx.enabled and not (int(debug) & 1) and cx.capacity > 0 and P > 0 and means3D.is_cuda   # (bit 0 = the reference's debug: synchronous)
     capturing = use_async and torch.cuda.is_current_stream_capturing()
     if use_async and not capturing:
         cx._consume_status(block=False)

@@ -32,6 +32,29 @@ def init_from_env(backend: str | None = None):
     return rank, world, local_rank
 
 
+_AVG_OK = {}          # backend -> does the collective library average inside the collective (ncclAvg)?  Decided ONCE per process.
+
+
+def avg_supported(device=None) -> bool:
+    """Whether ``ReduceOp.AVG`` can be used (RCCL / NCCL >= 2.10: no separate divide pass over the bucket).  Decided once and
+    IDENTICALLY on every rank -- the same backend name, the same environment switch, the same torch build answering the same
+    one-element probe at the same point of the program (every rank's first exchange) -- and never revised afterwards: a rank that
+    caught an error from a DATA collective and issued a different one while its peers did not would hang the job instead of
+    reporting the failure.  The probe's refusal (an unsupported-op check in torch, raised before anything is launched)
+    is the only exception that is caught."""
+    backend = dist.get_backend()
+    if backend not in _AVG_OK:
+        ok = backend == "nccl" and os.environ.get("MOSS_ALLREDUCE_AVG", "1") != "0"
+        if ok:
+            try:
+                probe = torch.ones(1, dtype=torch.float32, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+            except (RuntimeError, ValueError):
+                ok = False
+        _AVG_OK[backend] = ok
+    return _AVG_OK[backend]
+
+
 def shard_layout(n: int, world: int):
     """(elements per shard, padded length) of a flat vector of `n` elements cut into `world` EQUAL shards: ceil(n / world) rounded up
     to a multiple of 4 elements (the update kernel works on float4 and every shard then starts 16-byte aligned; reduce-scatter /
@@ -73,7 +96,6 @@ class GradBucket:
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {}
         self._handed_out = set()
-        self._avg_ok = None
         o = 0
         for p, n in zip(self.params, self.sizes):
             self._offset[id(p)] = o
@@ -123,17 +145,25 @@ class GradBucket:
         world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
         if world > 1:
             # RCCL averages inside the collective (ncclAvg): no separate pass over the bucket to divide by the world size.
-            # gloo (CPU tests) has no AVG: sum, then divide.
-            if self._avg_ok is None:
-                self._avg_ok = dist.get_backend() == "nccl" and os.environ.get("MOSS_ALLREDUCE_AVG", "1") != "0"
-            if self._avg_ok:
-                try:
-                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-                    return self.loss_slot
-                except (RuntimeError, ValueError):             # a build without ncclAvg refuses before launching anything
-                    self._avg_ok = False
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(world)
+            # gloo (CPU tests) has no AVG: sum, then divide.  Which of the two is decided once, for all ranks alike (avg_supported).
+            if avg_supported(self.flat.device):
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.div_(world)
+        return self.loss_slot
+
+    def all_reduce_loss_only(self, world=None):
+        """BASELINE configs[3] as written -- "frames of six subjects sharded across 8 GPUs, RCCL loss all-reduce": every rank trains
+        its OWN model on its own frames (independent units, SURVEY 8e "pure task parallelism"), and the only thing that crosses xGMI
+        is the 4-float loss block, averaged for logging.  16 bytes per step instead of the 23.6 MB gradient bucket."""
+        world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
+        if world > 1:
+            if avg_supported(self.flat.device):
+                dist.all_reduce(self.loss_terms, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.loss_terms, op=dist.ReduceOp.SUM)
+                self.loss_terms.div_(world)
         return self.loss_slot
 
 
@@ -141,13 +171,12 @@ def _reduce_scatter_mean(out: torch.Tensor, inp: torch.Tensor, world: int):
     """out (per) = this rank's shard of the MEAN over ranks of inp (world * per).  RCCL: one reduce-scatter with ncclAvg.  gloo (the
     CPU tests) implements no reduce-scatter: all-reduce and keep the shard -- the same values, which is all those tests need."""
     if dist.get_backend() == "nccl":
-        try:
+        if avg_supported(inp.device):
             dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG)
-            return
-        except (RuntimeError, ValueError):                   # a build without ncclAvg refuses before launching anything
+        else:
             dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
             out.div_(world)
-            return
+        return
     dist.all_reduce(inp, op=dist.ReduceOp.SUM)
     r = dist.get_rank()
     out.copy_(inp[r * out.numel():(r + 1) * out.numel()])

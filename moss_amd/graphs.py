@@ -13,8 +13,11 @@ Rules the captured function must follow (``bench.py`` and tests/test_gpu_ops.py:
   the binning capacity is baked into the graph, and a scene whose instance count grows needs a re-capture before it overflows.
   EVERY frame that overflowed between two checks is counted in ``step.dropped_frames`` (the library keeps a sticky counter in the
   context's frame state; the status words alone describe only the last frame) and the step is re-captured with the grown capacity,
-  not raised.  Such a frame rendered nothing: its gradients were zero while the captured AdamW still advanced its step count and
-  decayed the moments and weights -- a dropped frame is a (weight-decay-only) optimizer step, not a skipped one.
+  not raised.  Such a frame rendered nothing and left zero gradients.  Give the captured optimizer the frame's status word --
+  ``opt.step(skip_word=frame_status_word(ctx.last_img_buffer))`` (``FlatAdamW``, C ABI ``moss_adamw_flat_guarded``) -- and a dropped
+  frame is a NO-OP: parameters, moments and the device-side step counter stay bit for bit
+  (tests/test_gpu_ops.py::test_dropped_frame_is_not_an_optimizer_step).  Without the guard the update kernel still runs on the
+  zero gradients: a weight-decay-only step that also decays the moments (what rounds 2-3 did).
 """
 from __future__ import annotations
 
@@ -51,6 +54,9 @@ class GraphedStep:
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn()
         torch.cuda.synchronize(dev)
+        # overflows of EAGER forwards on this context before (or during the warm-up of) this capture were raised to, or seen by, the
+        # caller: only what the replays drop from here on is counted in ``dropped_frames``
+        (self.context or _C.DEFAULT).read_dropped_frames(reset=True)
 
     def __call__(self):
         self.graph.replay()
@@ -68,7 +74,7 @@ class GraphedStep:
         except _C.CapacityOverflow:
             last_overflowed = True                           # the frame rendered nothing; check_status already grew the capacity
         # every overflowed frame since the last check, not only the last one (the sticky counter of the frame state)
-        self.dropped_frames += max(cx.read_dropped_frames(), 1 if last_overflowed else 0)
+        self.dropped_frames += cx.read_dropped_frames() + (1 if last_overflowed else 0)   # (the raised one is not in the count)
         if cx.capacity != self.captured_capacity:
             # no eager warm-up run: the step was running a moment ago, and an eager fn() would be one more (uncounted) training step.
             # NOTE self.outputs is re-bound: callers must read step.outputs / the return value of step() afresh after a check().

@@ -98,9 +98,30 @@ class FlatAdamW:
                         v.copy_(v[perm].clone())
                 off += n
 
-    def step(self):
-        self.t += 1
+    def step(self, skip_word=None, skip_mask=2):
+        """One update.  ``skip_word`` (capturable optimizers only): a one-element int32 / float32 DEVICE tensor; if
+        ``skip_word & skip_mask`` is non-zero when the kernel runs, the step is a no-op on the device -- parameters, moments and the
+        step counter stay bit for bit (C ABI ``moss_adamw_flat_guarded``).  ``frame_status_word(img_buffer)`` of a rasterizer forward
+        with the default mask 2 skips the step of a frame that overflowed its capacity and rendered nothing (inside a captured
+        hipGraph nobody else can)."""
         dev = self.flat_params.device
+        if skip_word is not None:
+            if self.step_state is None:
+                raise RuntimeError("a guarded step needs capturable=True: a host-side step count cannot know about the skipped step")
+            first, count = (0, self.n) if self.shard is None else (self.first, self.count)
+            if count == 0:
+                return
+            grads = self.bucket.flat if self.shard is None else self.grad_shard
+            with torch.cuda.device(dev):
+                rc = lib().moss_adamw_flat_guarded(first, count, self.flat_params[first:].data_ptr(), grads.data_ptr(),
+                                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
+                                                   self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]),
+                                                   float(self.eps), float(self.weight_decay), self.step_state.data_ptr(),
+                                                   skip_word.data_ptr(), int(skip_mask) & 0xffffffff,
+                                                   torch.cuda.current_stream(dev).cuda_stream)
+            check(rc, "adamw_flat_guarded")
+            return
+        self.t += 1
         if self.shard is not None:
             if self.count == 0:
                 return

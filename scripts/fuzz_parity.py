@@ -39,8 +39,7 @@ for seed in range(first, first + n_cases):
         if t.R > 0:
             g = tp._check_backward(d, dev, fw, t, e, zero_depth=bool(seed & 1), tol=2e-2, cos_gap=1e-3)
             # the block masks must be conservative: with culling off the decisions and every gradient equals up to rounding
-            # (MOSS_DEBUG_NO_BLOCK_CULL = 2 on both calls; the in-op transform / raw-parameter entry points take no debug argument)
-            nocull = 0 if d.transforms is not None else 2
+            nocull = 2                          # MOSS_DEBUG_NO_BLOCK_CULL on both calls (every entry point takes it since ABI 3)
             t0 = hp.hip_forward(d, dev, debug=nocull)
             dc, dd, da = hp.image_grads(d.H, d.W, zero_depth=bool(seed & 1))
             m = hp.stable_mask(d, fw, thr=1e-4)              # (the incoming gradients of tp._check_backward: stable pixels only)

@@ -422,10 +422,12 @@ def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode
     with pytest.raises(async_mode.CapacityOverflow, match="needed") as exc:
         async_mode.check_async_status()
     assert isinstance(exc.value, RuntimeError) and exc.value.needed > 2048
-    # the library's STICKY dropped-frame counter (frame state word MOSS_FRAME_STATE_DROPPED_WORD) saw exactly that frame; reading
-    # resets it, and then the overflowed frame has left every other counter clean too
-    assert async_mode._C.ASYNC.read_dropped_frames(reset=False) == 1 and async_mode._C.ASYNC.read_dropped_frames() == 1
-    assert async_mode._C.ASYNC.read_dropped_frames() == 0
+    # the library's STICKY dropped-frame counter (frame state word MOSS_FRAME_STATE_DROPPED_WORD) saw exactly that frame -- which was
+    # RAISED to the caller just now, so it does not count as a frame a replay dropped silently; reading resets the word,
+    # and then the overflowed frame has left every other counter clean too
+    cx = async_mode._C.ASYNC
+    assert int(cx.frame_state.view(torch.int32)[async_mode._C.FRAME_STATE_DROPPED_WORD]) == 1
+    assert cx.read_dropped_frames(reset=False) == 0 and cx.read_dropped_frames() == 0
     assert int(async_mode._C.ASYNC.frame_state.count_nonzero()) == 0
     assert async_mode._C.ASYNC.capacity > 2048
     got = _train_like_step(pc, cam, pipe, bg, w)               # the grown capacity fits
@@ -433,6 +435,73 @@ def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode
     assert torch.equal(got[0], ref[0])
     for a, c in zip(ref[3], got[3]):
         assert torch.equal(a, c)
+
+
+def test_dropped_frame_is_not_an_optimizer_step(gpu, hip_lib, async_mode):
+    """A frame that overflows its capacity renders nothing; a step captured in a hipGraph cannot skip its optimizer on the host.  With
+    the frame's status word as the guard (FlatAdamW.step(skip_word=...), C ABI moss_adamw_flat_guarded) the update kernel turns itself
+    into a no-op ON THE DEVICE: parameters, both moments and the step counter stay bit for bit across the dropped frame -- under graph
+    replay -- while a frame that fits steps as usual."""
+    from types import SimpleNamespace
+    from moss_amd.dist import GradBucket
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    from moss_amd.optim import FlatAdamW
+    from moss_amd.diff_gaussian_rasterization import _C
+    s = scenes.config2()
+    pc = GaussianSet(s, device=gpu)
+    cam = camera_view(s.camera, gpu)
+    cx = _C.RasterContext()
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raster_context=cx)
+    bg = torch.zeros(3, device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, device=gpu)
+    params = list(pc.parameters())
+    bucket = GradBucket(params)
+    opt = FlatAdamW([{"params": params, "lr": 1e-3}], bucket, capturable=True)
+
+    def compute():
+        bucket.attach()
+        out = render(cam, pc, pipe, bg)
+        ((out["render"] * w).sum() + out["render_alpha"].sum()).backward()
+        opt.step(skip_word=_C.frame_status_word(cx.last_img_buffer))
+        return out["render"].detach()
+
+    def state():
+        return [opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_state.clone()]
+
+    for capacity, dropped in ((2048, True), (4_000_000, False)):          # far below / above what config2 needs
+        cx.set_async(True, capacity=capacity)
+        side = torch.cuda.Stream(gpu)
+        side.wait_stream(torch.cuda.current_stream(gpu))
+        with torch.cuda.stream(side):
+            compute()
+        torch.cuda.current_stream(gpu).wait_stream(side)
+        torch.cuda.synchronize(gpu)
+        cx.pending = None                                                  # (the eager frame's status: not what this test is about)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            img = compute()
+        before = state()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize(gpu)
+        after = state()
+        if dropped:
+            assert torch.equal(img, torch.zeros_like(img))
+            for a, b in zip(before, after):
+                assert torch.equal(a, b)
+            assert cx.read_dropped_frames() >= 3
+        else:
+            assert float(img.abs().max()) > 0
+            assert int(after[3][0]) == int(before[3][0]) + 3
+            assert not torch.equal(before[0], after[0]) and not torch.equal(before[1], after[1])
+            assert cx.read_dropped_frames() == 0
+    # a retired frame-state block that serves again is not counted twice (ADVICE r3)
+    cx2 = _C.RasterContext()
+    a = cx2._frame_state(gpu, 64, 64); b = cx2._frame_state(gpu, 512, 512); c = cx2._frame_state(gpu, 64, 64)
+    assert c is b and len(cx2._retired_frame_states) == 1 and cx2._retired_frame_states[0] is a
+    b.view(torch.int32)[_C.FRAME_STATE_DROPPED_WORD] = 2
+    assert cx2.read_dropped_frames(reset=False) == 2 and cx2.read_dropped_frames() == 2 and cx2.read_dropped_frames() == 0
 
 
 def test_step_captured_in_hipgraph_replays_with_new_parameters(gpu, hip_lib, async_mode):
@@ -1039,7 +1108,8 @@ def test_raw_parameters_inside_the_op_equal_the_torch_getters(gpu, hip_lib, with
 def test_block_mask_culling_never_changes_a_result(gpu, hip_lib):
     """The per-instance block masks only SKIP (entry, block) pairs that cannot reach alpha >= 1/255 in that block.  With the masks
     switched off (``debug = MOSS_DEBUG_NO_BLOCK_CULL`` on the forward and the backward call -- an argument since ABI 2, a process-wide
-    switch before: every entry is blended against every block) the DECISIONS must be the same:
+    switch before; since ABI 3 on EVERY entry point, also the in-op transform / raw-parameter ones the bench and MOSS's data flow use:
+    every entry is blended against every block) the DECISIONS must be the same:
     final_T and n_contrib bit-identical; colour / depth / alpha equal up to fp32 summation order (a pixel's sums are kept as four
     per-slot partial sums, and which slot an entry lands in depends on how many entries were skipped before it); every gradient equal
     up to rounding -- since round 2 the forward cuts a block's list every 64 HITS into depth segments, the unculled run cuts elsewhere,
@@ -1047,7 +1117,7 @@ def test_block_mask_culling_never_changes_a_result(gpu, hip_lib):
     the body scene, on anisotropic random Gaussians with a precomputed (transformed) covariance, and with Gaussians that cover the
     whole image and opacities around the 1/255 threshold."""
     NO_BLOCK_CULL = 2                                                        # include/moss_raster.h MOSS_DEBUG_NO_BLOCK_CULL
-    cases = [hp.inputs_of(scenes.config2(), "scale_rot"), hp.inputs_of(scenes.config1(), "precomp")]
+    cases = [hp.inputs_of(scenes.config2(), "scale_rot"), hp.inputs_of(scenes.config1(), "precomp"), hp.inputs_of(scenes.config1(), "lbs")]
     big = scenes.config1(P=600, W=200, H=136, seed=77)
     big.scales[:12] *= 40.0
     big.opacities[:200] = torch.linspace(0.0, 0.02, 200)[:, None]            # around the 1/255 threshold
