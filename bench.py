@@ -167,6 +167,7 @@ class Harness:
         self.pipe = pipe = SimpleNamespace(
             convert_SHs_python=False, compute_cov3D_python=(mode in ("precomp", "lbs_python")), debug=False,
             fused_activations=not torch_activations, transforms_in_op=(mode == "lbs"),
+            pose_in_op=(mode == "lbs" and not torch_activations),    # the op poses the canonical positions itself (MOSS_RAW_POSE)
             raw_parameters_in_op=(not torch_activations and activations == "in_op" and unified and mode in ("scale_rot", "lbs")),
             raster_context=self.ctx)
         self.lbs_T = lbs_T
@@ -192,7 +193,7 @@ class Harness:
             if pipe.raw_parameters_in_op:                                     # ... and so are the raw-parameter gradients
                 sinks.update(opacity=lambda: bucket.sink_for(pc._opacity), scales=lambda: bucket.sink_for(pc._scaling),
                              rotations=lambda: bucket.sink_for(pc._rotation))
-                if lbs_T is None:                                             # (with a transform the means are not the parameter)
+                if lbs_T is None or pipe.pose_in_op:                          # (posed OUTSIDE the op, the means are not the parameter)
                     sinks["means3D"] = lambda: bucket.sink_for(pc._xyz)
             self.ctx.set_grad_sink(**sinks)
         training_loss = mloss.training_loss_fused if fused_loss else mloss.training_loss

@@ -35,7 +35,8 @@ extern "C" {
 #define MOSS_ABI_VERSION 3
 /* Version 3 (round 4): EVERY forward / backward entry point takes the `debug` bit set (version 2: only moss_raster_forward /
  * moss_raster_backward did, so MOSS_DEBUG_NO_BLOCK_CULL was silently dropped on the _async / _tf / _raw paths: last argument before
- * `stream`); moss_adamw_flat_guarded (an optimizer step that a dropped frame turns into a no-op). */
+ * `stream`); moss_adamw_flat_guarded (an optimizer step that a dropped frame turns into a no-op); MOSS_RAW_POSE and the
+ * `translation` / `dL_dtranslation` arguments of the _raw entry points (the canonical positions are posed inside the op). */
 
 /* error codes (negative returns) */
 #define MOSS_ERR_INVALID_ARG   (-1)   /* bad shape / null where required (AT_ERROR in DGR/rasterize_points.cu:57-59) */
@@ -350,29 +351,36 @@ int moss_raster_backward_tf(
  *   MOSS_HINT_SPATIAL_ORDER may be OR-ed in: "neighbours in index are neighbours in space" (the caller re-indexed its Gaussians along
  *   a space-filling curve, e.g. moss_amd.densify.spatial_order).  It changes no result beyond the order of some float32 sums, only how the per-Gaussian backward deals
  *   Gaussians to its workgroups (groups of 16 from places spread over the index range, so that no workgroup is all-heavy).
+ *   MOSS_RAW_POSE (needs `transforms`): means3D are the CANONICAL positions x and the op poses them itself, p = T x (+ translation
+ *   (P,3), may be NULL), rows of T times x summed left to right -- what MOSS's caller does with torch ops before the call
+ *   (gaussian_renderer/__init__.py:74-77: torch.matmul(transforms, means3D[..., None]).squeeze(-1) + translation).  dL_dmean3D is
+ *   then the gradient w.r.t. x (= T^T dL/dp: it can be written straight into the position parameter's gradient), dL_dtransforms
+ *   gains dL/dp x^T, and dL_dtranslation (P,3; may be NULL) = dL/dp.
  */
 #define MOSS_RAW_OPACITY 1
 #define MOSS_RAW_SCALE 2
 #define MOSS_RAW_ROTATION 4
 #define MOSS_HINT_SPATIAL_ORDER 8
+#define MOSS_RAW_POSE 16
 int moss_raster_forward_raw(
     moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
     moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms, const float* translation,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
     float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, int debug, void* stream);
 int moss_raster_backward_raw(
     int P, int D, int M, int R,
     const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms, const float* translation,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tan_fovx, float tan_fovy,
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, int debug, void* stream);
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
+    int raw_flags, int debug, void* stream);
 
 /*
  * Gaussian parameter activations, forward and backward, one launch each (the rasterizer-facing getters of MOSS's GaussianModel,

@@ -252,6 +252,7 @@ struct BinView {
 constexpr int RAW_OPACITY = 1;      // opacities are logits:            get_opacity  = sigmoid(_opacity)          (scene/gaussian_model.py:160-161)
 constexpr int RAW_SCALE = 2;        // scales are logarithms:           get_scaling  = exp(_scaling)              (:142-143)
 constexpr int HINT_SPATIAL_ORDER = 8; // (not a raw-parameter bit) index neighbours are spatial neighbours: include/moss_raster.h
+constexpr int RAW_POSE = 16;        // means3D are CANONICAL positions: posed inside the op, p = T x (+ translation)   (gaussian_renderer/__init__.py:74-77)
 constexpr int RAW_ROTATION = 4;     // rotations are not normalised:    get_rotation = normalize(_rotation)       (:146-147)
 struct FrameParams {
     int P, D, M, W, H, gx, gy;
@@ -265,14 +266,14 @@ struct FrameParams {
 // ---- launchers (each defined in exactly one .hip file; all enqueue on `s`, none synchronises) -------------
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                               const float* transforms, GeomView g, ImageView im, int* radii_out, hipStream_t s);
+                               const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s);
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* opacities /* only read in raw mode */,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 GeomView g, BinView b, const uint32_t* header, uint32_t* queues /* backward heads are rewound here */,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                                const float* transforms, float* dL_dtransforms, hipStream_t s);
+                                const float* transforms, float* dL_dtransforms, const float* translation, float* dL_dtranslation, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
 
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);

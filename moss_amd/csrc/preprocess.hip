@@ -164,6 +164,14 @@ __device__ __forceinline__ void transform_cov3d_bw(const float* T, const float* 
     d6_pre[3] = Gp[1][1]; d6_pre[4] = 2.0f * Gp[1][2]; d6_pre[5] = Gp[2][2];
 }
 
+// p = T x + t, T row-major (one rounding per operation, left to right: -ffp-contract=off); the oracle-side tests pose their means
+// with the same expression
+__device__ __forceinline__ float3 pose_point(const float* T, float3 x, float3 t)
+{
+    return make_float3(T[0] * x.x + T[1] * x.y + T[2] * x.z + t.x, T[3] * x.x + T[4] * x.y + T[5] * x.z + t.y,
+                       T[6] * x.x + T[7] * x.y + T[8] * x.z + t.z);
+}
+
 struct Cov2DSetup { float3 t; float txtz, tytz; M3 W, T, Vrk; };
 
 __device__ __forceinline__ Cov2DSetup cov2d_setup(float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
@@ -206,7 +214,8 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                           GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header /* the error-flag word */,
                           int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms, int raw,
-                          unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */)
+                          unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */,
+                          const float* __restrict__ translation /* RAW_POSE only, may be NULL */)
 {
 #define FSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
     FSTAMP(0);
@@ -268,10 +277,14 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
         }
         float3 col_ld = make_float3(0.f, 0.f, 0.f);
         if (colors_precomp != nullptr) col_ld = make_float3(colors_precomp[3 * ic], colors_precomp[3 * ic + 1], colors_precomp[3 * ic + 2]);
+        float3 tr_ld = make_float3(0.f, 0.f, 0.f);
+        if ((raw & RAW_POSE) && translation != nullptr) tr_ld = make_float3(translation[3 * ic], translation[3 * ic + 1], translation[3 * ic + 2]);
         FSTAMP(1);
         int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
         if (idx < P) do {
-            const float3 p_orig = p_ld;
+            // RAW_POSE: the canonical position is posed here, p = T x + t (the reference's caller does it with torch ops,
+            // gaussian_renderer/__init__.py:74-77); rows of T times x summed left to right, then the translation
+            const float3 p_orig = (raw & RAW_POSE) ? pose_point(tm_ld, p_ld, tr_ld) : p_ld;
             const float3 p_view = xform4x3(p_orig, view);
             if (p_view.z <= 0.2f) {                                   // in_frustum, auxiliary.h:154
                 if (prefiltered) atomicOr(header, ERRFLAG_PREFILTERED);
@@ -451,9 +464,9 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 // screen-position paths).  gca/gcb/gcc = dL/dconic (A, B per off-diagonal entry, C), gmx/gmy = dL/dmean2D in NDC units.
 __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb, float gcc, float gmx, float gmy,
                                                   float tan_fovx, float tan_fovy, float h_x, float h_y,
-                                                  const float* __restrict__ means3D, const float* __restrict__ cov3D_precomp, const GeomView& g,
+                                                  const float* __restrict__ cov3D_precomp, const GeomView& g,
                                                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
-                                                  float3& mean, float* dmean, float* dcov, float (&A_out)[2][3], float (&d2_out)[3])
+                                                  const float3 mean /* the (posed) mean the forward projected */, float* dmean, float* dcov, float (&A_out)[2][3], float (&d2_out)[3])
 {
     // ================= per-Gaussian backward, in matrix form =================================================================
     // What is differentiated is the reference's forward (forward.cu:74-113, 118-152, 20-71, 196-237) with the conventions its
@@ -469,7 +482,6 @@ __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb,
     //     dJ00/dtz = -J00/tz, dJ02/dtx = -J00/tz, dJ02/dtz = -2 J02/tz (same for the y row); dL/dmean = Rv^T dL/dt.
     const float Rv[3][3] = { { viewmatrix[0], viewmatrix[4], viewmatrix[8] }, { viewmatrix[1], viewmatrix[5], viewmatrix[9] },
                              { viewmatrix[2], viewmatrix[6], viewmatrix[10] } };            // t = Rv p + (view[12..14])
-    mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
     const float* c6 = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
     const float S3[3][3] = { { c6[0], c6[1], c6[2] }, { c6[1], c6[3], c6[4] }, { c6[2], c6[4], c6[5] } };
     float t[3];
@@ -745,7 +757,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ transforms, float* __restrict__ dL_dtransforms,
                            const float* __restrict__ opacities /* raw mode only */, int raw,
                            unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */,
-                           uint32_t* __restrict__ queues)
+                           uint32_t* __restrict__ queues,
+                           const float* __restrict__ translation /* RAW_POSE only, may be NULL */, float* __restrict__ dL_dtranslation /* may be NULL */)
 {
     // Rewind the work-queue heads of the blend-backward kernel that ran just before this one on the stream, so that another backward
     // over the same forward state (retain_graph) starts from zero again.  (The forward clears them per frame; doing it HERE instead
@@ -800,7 +813,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     const uint32_t n_inst = in_range ? tt_raw : 0u;
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
-    float dtf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    float dtf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dpose_t[3] = { 0, 0, 0 };
     float A_cov[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } }, d2_cov[3] = { 0, 0, 0 };   // the 2x3 projection A = J Rv and dL/dS2 of step (1): kept for step (6)
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
     // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
@@ -1041,8 +1054,17 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                           : ((M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr);
 
     if (visible) {
-        float3 mean;
-        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, means3D, cov3D_precomp, g, viewmatrix, projmatrix, mean, dmean, dcov, A_cov, d2_cov);
+        const float3 xc = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+        float3 mean = xc;
+        if (raw & RAW_POSE) {                                // the forward's posed mean, same expression
+            float Tm[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+            const float3 tr = translation != nullptr ? make_float3(translation[3 * (size_t)idx], translation[3 * (size_t)idx + 1], translation[3 * (size_t)idx + 2])
+                                                     : make_float3(0.f, 0.f, 0.f);
+            mean = pose_point(Tm, xc, tr);
+        }
+        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, cov3D_precomp, g, viewmatrix, projmatrix, mean, dmean, dcov, A_cov, d2_cov);
 
         PSTAMP(3);
         // (5) colour = max(0, 0.5 + sum_k b_k(n) sh_k), n = (mean - campos)/|.| (forward.cu:20-71).  dL/dsh_k = b_k(n) g (g = colour
@@ -1098,6 +1120,20 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 
         PSTAMP(4);
         scale_rot_backward(idx, dcov, A_cov, d2_cov, scale_modifier, raw, scales, rotations, transforms, dscale, drot, dtf);
+        if (raw & RAW_POSE) {
+            // p = T x + t:  dL/dt = g,  dL/dT += g x^T,  dL/dx = T^T g   (g = dL/dp collected above; reported in place of it)
+            const float gp[3] = { dmean[0], dmean[1], dmean[2] }, xv[3] = { xc.x, xc.y, xc.z };
+            float Tm[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) dtf[3 * a + c] += gp[a] * xv[c];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dmean[c] = Tm[c] * gp[0] + Tm[3 + c] * gp[1] + Tm[6 + c] * gp[2];
+            dpose_t[0] = gp[0]; dpose_t[1] = gp[1]; dpose_t[2] = gp[2];
+        }
     } else if (dsh != nullptr) {
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
     }
@@ -1115,6 +1151,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     if (dL_dtransforms != nullptr) {
 #pragma unroll
         for (int i = 0; i < 9; i++) dL_dtransforms[9 * (size_t)idx + i] = dtf[i];
+    }
+    if (dL_dtranslation != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) dL_dtranslation[3 * (size_t)idx + i] = dpose_t[i];
     }
     }   // in_range
     PSTAMP(5);
@@ -1183,7 +1223,7 @@ static int device_cus()
 
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                               const float* transforms, GeomView g, ImageView im, int* radii_out, hipStream_t s)
+                               const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
@@ -1200,7 +1240,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.flags_acc, radii_out, lds_hist, stage_sh,
                        transforms, fp.raw | ((knob("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0),
-                       (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr);
+                       (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr, translation);
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
@@ -1208,7 +1248,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 GeomView g, BinView b, const uint32_t* header, uint32_t* queues,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                                const float* transforms, float* dL_dtransforms, hipStream_t s)
+                                const float* transforms, float* dL_dtransforms, const float* translation, float* dL_dtranslation, hipStream_t s)
 {
     (void)colors_precomp;
     static const int threads = std::max(64, knob("MOSS_PREBWD_THREADS", 64) & ~63);
@@ -1237,7 +1277,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, -0.5f * (float)fp.W, -0.5f * (float)fp.H, fp.scale_modifier, \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues, translation, dL_dtranslation)
     if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
 }

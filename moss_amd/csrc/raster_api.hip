@@ -114,7 +114,7 @@ static int forward_impl(
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, int prefiltered,
     float* out_color, float* out_depth, float* out_alpha, int* radii, int debug_flags, void* stream, long long capacity,
-    const float* transforms, int raw_flags = 0, char* frame_state = nullptr)
+    const float* transforms, int raw_flags = 0, char* frame_state = nullptr, const float* translation = nullptr)
 {
     g_err[0] = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -160,7 +160,7 @@ static int forward_impl(
     // (a forward that ends before its sort kernel has run leaves the frame state dirty: clean it on those paths)
     auto abandon_frame_state = [&]() { if (frame_state) clear_frame_state(frame_state, fs_bytes, s); };
     { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
-      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, g, im, radii, s); }
+      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, translation, g, im, radii, s); }
     STAGE_CHECK("preprocess");
     // Asynchronous forward: the scan rides along with the scatter kernel (no launch of its own).
     const bool fold_scan = capacity > 0 && scatter_folds_scan(fp);
@@ -288,7 +288,8 @@ static int backward_impl(
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug_flags, void* stream,
-    const float* transforms, float* dL_dtransforms, const float* opacities = nullptr, int raw_flags = 0)
+    const float* transforms, float* dL_dtransforms, const float* opacities = nullptr, int raw_flags = 0,
+    const float* translation = nullptr, float* dL_dtranslation = nullptr)
 {
     (void)alphas; (void)radii;
     const int debug = debug_flags & MOSS_DEBUG_SYNC;
@@ -318,7 +319,7 @@ static int backward_impl(
     { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
       launch_preprocess_backward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, im.header, im.queues,
                                  dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                                 transforms, dL_dtransforms, s); }
+                                 transforms, dL_dtransforms, translation, dL_dtranslation, s); }
     STAGE_CHECK("preprocess_backward");
     return 0;
 }
@@ -368,39 +369,44 @@ int moss_raster_forward_raw(
     moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
     moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms, const float* translation,
     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
     float* out_color, float* out_depth, float* out_alpha, int* radii, int raw_flags, int capacity, char* frame_state, int debug, void* stream)
 {
-    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (!scales || !rotations)) return fail(MOSS_ERR_INVALID_ARG, "scales and rotations are required");
+    if (P > 0 && (raw_flags & RAW_POSE) && !transforms) return fail(MOSS_ERR_INVALID_ARG, "MOSS_RAW_POSE needs the transforms");
+    if (translation && !(raw_flags & RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "a translation comes with MOSS_RAW_POSE");
     if (capacity >= 0 && (debug & MOSS_DEBUG_SYNC)) return fail(MOSS_ERR_INVALID_ARG, "MOSS_DEBUG_SYNC needs the synchronous forward (capacity < 0)");
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
                         width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, nullptr,
                         viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii,
-                        debug, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags, frame_state);
+                        debug, stream, capacity < 0 ? -1 : capacity, transforms, raw_flags, frame_state, translation);
 }
 
 int moss_raster_backward_raw(
     int P, int D, int M, int R,
     const float* background, int width, int height,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations, const float* transforms,
+    const float* scales, float scale_modifier, const float* rotations, const float* transforms, const float* translation,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     float tan_fovx, float tan_fovy,
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, int raw_flags, int debug, void* stream)
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
+    int raw_flags, int debug, void* stream)
 {
-    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (P > 0 && (raw_flags & RAW_POSE) && !transforms) return fail(MOSS_ERR_INVALID_ARG, "MOSS_RAW_POSE needs the transforms");
+    if ((translation || dL_dtranslation) && !(raw_flags & RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "a translation comes with MOSS_RAW_POSE");
     if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))
         return fail(MOSS_ERR_INVALID_ARG, "scales and rotations (and dL_dtransforms with transforms) are required");
     return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,
                          nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
                          image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
                          dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, transforms, transforms ? dL_dtransforms : nullptr, opacities,
-                         raw_flags);
+                         raw_flags, translation, dL_dtranslation);
 }
 
 int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -88,7 +88,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
                     double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const torch::Tensor& sh,
                     int64_t degree, const torch::Tensor& campos, bool prefiltered, int64_t debug /* bool in the reference; MOSS_DEBUG_* bits */,
                     const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, int64_t capacity,
-                    const c10::optional<torch::Tensor>& frame_state)
+                    const c10::optional<torch::Tensor>& frame_state, const c10::optional<torch::Tensor>& translation)
 {
     TORCH_CHECK(means3D.ndimension() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");   // :57-59
     TORCH_CHECK(means3D.is_cuda(), "means3D must live on the GPU; this op has no CPU path");
@@ -125,6 +125,9 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     const float* p_rot = ptr(rotations, "rotations", keep);
     const float* p_cov = ptr(cov3D_precomp, "cov3D_precomp", keep);
     const float* p_tf = has_tf ? ptr(*transforms, "transforms", keep) : nullptr;
+    const bool has_tl = translation.has_value() && translation->defined() && translation->numel() != 0;
+    if (has_tl) TORCH_CHECK((raw_flags & MOSS_RAW_POSE) && translation->numel() == 3 * (int64_t)P, "translation must be (P,3) and comes with MOSS_RAW_POSE");
+    const float* p_tl = has_tl ? ptr(*translation, "translation", keep) : nullptr;
     const float* p_view = ptr(viewmatrix, "viewmatrix", keep);
     const float* p_proj = ptr(projmatrix, "projmatrix", keep);
     const float* p_cam = ptr(campos, "campos", keep);
@@ -142,7 +145,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     int rc;
     if (raw_flags)
         rc = moss_raster_forward_raw(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
-                                     p_scl, (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
+                                     p_scl, (float)scale_modifier, p_rot, p_tf, p_tl, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy,
                                      prefiltered ? 1 : 0, oc, od, oa, p_radii, (int)raw_flags, cap, p_fs, (int)debug, stream);
     else if (has_tf)
         rc = moss_raster_forward_tf(grow, &geom, grow, &binning, grow, &img, P, (int)degree, M, p_bg, W, H, p_means, p_sh, p_col, p_opa,
@@ -174,7 +177,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                              const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, const c10::optional<torch::Tensor>& opacities,
                              const c10::optional<torch::Tensor>& sink_means3D, const c10::optional<torch::Tensor>& sink_opacity,
                              const c10::optional<torch::Tensor>& sink_sh, const c10::optional<torch::Tensor>& sink_scales,
-                             const c10::optional<torch::Tensor>& sink_rotations)
+                             const c10::optional<torch::Tensor>& sink_rotations, const c10::optional<torch::Tensor>& translation)
 {
     const int P = static_cast<int>(means3D.size(0));
     const int H = static_cast<int>(alphas.size(-2)), W = static_cast<int>(alphas.size(-1));   // incoming gradients may be absent (= zeros)
@@ -196,6 +199,8 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     torch::Tensor dL_dscales = out_or_sink(sink_scales, {P, 3}, fopts, z);
     torch::Tensor dL_drotations = out_or_sink(sink_rotations, {P, 4}, fopts, z);
     torch::Tensor dL_dtransforms = has_tf ? mk({P, 3, 3}) : torch::Tensor();
+    const bool has_tl = translation.has_value() && translation->defined() && translation->numel() != 0;
+    torch::Tensor dL_dtranslation = has_tl ? mk({P, 3}) : torch::Tensor();
     if (P != 0) {
         std::vector<torch::Tensor> keep;
         keep.reserve(20);
@@ -223,10 +228,11 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
         if (raw_flags) {
             TORCH_CHECK(opacities.has_value() && opacities->defined(), "the raw-parameter backward needs the raw opacities");
             rc = moss_raster_backward_raw(P, (int)degree, M, (int)R, p_bg, W, H, p_means, p_sh, p_col, ptr(*opacities, "opacity", keep), p_scl,
-                                          (float)scale_modifier, p_rot, p_tf, p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy, p_geom,
+                                          (float)scale_modifier, p_rot, p_tf, has_tl ? ptr(*translation, "translation", keep) : nullptr,
+                                          p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy, p_geom,
                                           p_bin, p_img, g_c, g_d, g_a, f(dL_dmeans2D), f(dL_dconic), f(dL_dopacity), f(dL_dcolors), f(dL_dmeans3D),
                                           f(dL_dcov3D), p_dsh, f(dL_dscales), f(dL_drotations), has_tf ? f(dL_dtransforms) : nullptr,
-                                          (int)raw_flags, (int)debug, stream);
+                                          has_tl ? f(dL_dtranslation) : nullptr, (int)raw_flags, (int)debug, stream);
         } else if (has_tf) {
             rc = moss_raster_backward_tf(P, (int)degree, M, (int)R, p_bg, W, H, p_means, p_sh, p_col, p_scl, (float)scale_modifier, p_rot, p_tf,
                                          p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy, p_geom, p_bin, p_img, g_c, g_d, g_a,
@@ -243,6 +249,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     }
     std::vector<torch::Tensor> res = {dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations};
     if (has_tf) res.push_back(dL_dtransforms);
+    if (has_tl) res.push_back(dL_dtranslation);                // (only with MOSS_RAW_POSE, which needs transforms: always the tenth)
     return res;
 }
 
@@ -270,7 +277,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"),
           py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("image_height"), py::arg("image_width"), py::arg("sh"),
           py::arg("degree"), py::arg("campos"), py::arg("prefiltered"), py::arg("debug"), py::arg("transforms") = py::none(),
-          py::arg("raw_flags") = 0, py::arg("capacity") = -1, py::arg("frame_state") = py::none());
+          py::arg("raw_flags") = 0, py::arg("capacity") = -1, py::arg("frame_state") = py::none(), py::arg("translation") = py::none());
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"),
           py::arg("colors"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
           py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"),
@@ -278,7 +285,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"), py::arg("alphas"), py::arg("debug"),
           py::arg("transforms") = py::none(), py::arg("raw_flags") = 0, py::arg("opacities") = py::none(),
           py::arg("sink_means3D") = py::none(), py::arg("sink_opacity") = py::none(), py::arg("sink_sh") = py::none(),
-          py::arg("sink_scales") = py::none(), py::arg("sink_rotations") = py::none());
+          py::arg("sink_scales") = py::none(), py::arg("sink_rotations") = py::none(), py::arg("translation") = py::none());
     m.def("mark_visible", &mark_visible);
     // the version of the header THIS module was compiled against (not the library's answer: moss_amd/_lib.py compares the two, so a
     // stale _moss_C.so next to a rebuilt libmoss_raster.so refuses to load instead of passing arguments in the old layout)

@@ -19,6 +19,7 @@ NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/conf
 
 RAW_OPACITY, RAW_SCALE, RAW_ROTATION = 1, 2, 4       # include/moss_raster.h MOSS_RAW_*
 HINT_SPATIAL_ORDER = 8                               # MOSS_HINT_SPATIAL_ORDER: OR-ed into raw_flags, changes no result
+RAW_POSE = 16                                        # MOSS_RAW_POSE: means3D are canonical positions, posed inside the op (T x + translation)
 
 last_num_rendered = 0   # num_rendered of the most recent forward call of ANY context (kept for callers that predate contexts)
 
@@ -187,13 +188,15 @@ ext()   # ... or if the compiled torch extension is
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, transforms=None, raw_flags=0, context=None):
+                        prefiltered, debug, transforms=None, raw_flags=0, context=None, translation=None):
     """RasterizeGaussiansCUDA, rasterize_points.cu:35-119.
     ``raw_flags`` (an addition): RAW_OPACITY | RAW_SCALE | RAW_ROTATION -- those inputs are MOSS's raw parameters and the getters
     (sigmoid / exp / normalize) run inside the op (C ABI moss_raster_forward_raw); needs scales and rotations, no cov3D_precomp.
     ``transforms`` (an addition): (P,3,3) per-Gaussian matrices applied to the scale/rotation covariance
     inside the op (Sigma' = T Sigma T^T, what MOSS's Python get_covariance builds); needs scales and rotations, no cov3D_precomp.
     ``context`` (an addition): the :class:`RasterContext` whose asynchronous-forward policy applies (default: the shared one).
+    ``raw_flags & RAW_POSE`` / ``translation`` (additions): means3D are the canonical positions; the op poses them with the transforms
+    (and the optional (P,3) translation) itself -- gaussian_renderer/__init__.py:74-77 without the torch ops.
     Returns (num_rendered, out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P,), geomBuffer,
     binningBuffer, imgBuffer)."""
     cx = context or DEFAULT
@@ -206,7 +209,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                     viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), sh,
                                     int(degree), campos, bool(prefiltered), int(debug), transforms, int(raw_flags),
                                     int(cx.capacity) if use_async else -1,
-                                    cx._frame_state(means3D.device, image_width, image_height) if use_async else None)
+                                    cx._frame_state(means3D.device, image_width, image_height) if use_async else None, translation)
     rendered, img = res[0], res[7]
     if use_async:
         cx.last_img_buffer = img
@@ -223,11 +226,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
                                  sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, transforms=None,
-                                 raw_flags=0, opacities=None, context=None):
+                                 raw_flags=0, opacities=None, context=None, translation=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:121-206.
     ``raw_flags`` / ``opacities``: backward of the raw-parameter forward (gradients w.r.t. the raw parameters).
     Returns (dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P,1), dL_dmeans3D (P,3), dL_dcov3D (P,6),
-    dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4)) -- plus dL_dtransforms (P,3,3) when ``transforms`` was given."""
+    dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4)) -- plus dL_dtransforms (P,3,3) when ``transforms`` was given, plus
+    dL_dtranslation (P,3) when ``translation`` was (RAW_POSE: dL_dmeans3D is then w.r.t. the canonical positions)."""
     cx = context or DEFAULT
     if int(raw_flags) and opacities is None and means3D.size(0) != 0:
         raise RuntimeError("the raw-parameter backward needs the raw opacities")
@@ -235,7 +239,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
         float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, int(degree), campos, geomBuffer, int(R),
         binningBuffer, imageBuffer, alphas, int(debug), transforms, int(raw_flags), opacities,
-        cx._sink("means3D"), cx._sink("opacity"), cx._sink("sh"), cx._sink("scales"), cx._sink("rotations")))
+        cx._sink("means3D"), cx._sink("opacity"), cx._sink("sh"), cx._sink("scales"), cx._sink("rotations"), translation))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

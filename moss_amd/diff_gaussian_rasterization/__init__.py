@@ -64,7 +64,8 @@ def _call_native(fn, args, debug, dump_name, what):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                transforms=None, raw_flags=0, context=None):
+                transforms=None, raw_flags=0, context=None, translation=None):
+        # (the thirteenth input, with raw_flags & RAW_POSE: means3D are the canonical positions and the op poses them itself, T x + translation)
         # (the tenth input is an addition: per-Gaussian 3x3 transforms applied to the covariance inside the op, SURVEY 8f row n2;
         #  the eleventh too: which of opacities / scales / rotations are RAW parameters whose getter runs inside the op;
         #  the twelfth: the RasterContext -- asynchronous-forward policy and gradient sinks -- of the rasterizer that calls)
@@ -73,7 +74,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
-            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, transforms, raw_flags, context)
+            sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, transforms, raw_flags, context, translation)
         ctx.context = context
         (num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_native(
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
@@ -83,10 +84,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         # zero-filled image; the values computed are the same as with the reference's materialised zeros
         ctx.set_materialize_grads(False)
         ctx.has_transforms = transforms is not None
+        ctx.has_translation = translation is not None
         ctx.raw_flags = raw_flags
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, alpha, *(() if transforms is None else (transforms,)),
-                              *((opacities,) if raw_flags else ()))
+                              *(() if translation is None else (translation,)), *((opacities,) if raw_flags else ()))
         return color, radii, depth, alpha
 
     @staticmethod
@@ -96,27 +98,29 @@ class _RasterizeGaussians(torch.autograd.Function):
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, alpha) = saved[:11]
         transforms = saved[11] if ctx.has_transforms else None
+        translation = saved[12] if ctx.has_translation else None
         raw_opacities = saved[-1] if ctx.raw_flags else None
         if grad_out_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 12
+            return (None,) * 13
         native_args = (
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,
             sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug,
-            transforms, ctx.raw_flags, raw_opacities, ctx.context)
+            transforms, ctx.raw_flags, raw_opacities, ctx.context, translation)
         grads = _call_native(_C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = grads[:8]
         grad_transforms = grads[8] if transforms is not None else None
+        grad_translation = grads[9] if translation is not None else None
         # one gradient per forward() input, in forward()'s order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
-                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms, None, None)
+                grad_rotations, None if transforms is not None else grad_cov3Ds_precomp, None, grad_transforms, None, None, grad_translation)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        transforms=None, raw_flags=0, context=None):
+                        transforms=None, raw_flags=0, context=None, translation=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, transforms, raw_flags, context)
+                                     cov3Ds_precomp, raster_settings, transforms, raw_flags, context, translation)
 
 
 class GaussianRasterizer(nn.Module):
@@ -134,12 +138,15 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, transforms=None, raw_flags=0):
+                cov3D_precomp=None, transforms=None, raw_flags=0, translation=None):
         """``transforms`` (an addition): (P,3,3) per-Gaussian matrices; with scales and rotations the op then builds
         T (R S S^T R^T) T^T itself -- MOSS's Python get_covariance -- and returns a gradient for the transforms too.
         ``raw_flags`` (an addition): ``_C.RAW_OPACITY | _C.RAW_SCALE | _C.RAW_ROTATION`` -- those inputs are GaussianModel's raw
         parameters (``_opacity``, ``_scaling``, ``_rotation``); sigmoid / exp / normalize run inside the op and the gradients
-        come back w.r.t. the raw parameters (no activation kernels either side)."""
+        come back w.r.t. the raw parameters (no activation kernels either side).  With ``_C.RAW_POSE`` OR-ed in (needs ``transforms``),
+        ``means3D`` are the CANONICAL positions and the op poses them itself, T x + ``translation`` ((P,3), optional): the reference's
+        caller does that with torch ops (gaussian_renderer/__init__.py:74-77); gradients come back for the canonical positions, the
+        transforms and the translation."""
         rs = self.raster_settings
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -157,5 +164,7 @@ class GaussianRasterizer(nn.Module):
             raise Exception('transforms need the scale/rotation pair (and no precomputed 3D covariance)!')
         if raw_flags and (scales.numel() == 0 or cov3D_precomp.numel() != 0):
             raise Exception('raw_flags need the scale/rotation pair (and no precomputed 3D covariance)!')
+        if (translation is not None or (int(raw_flags) & _C.RAW_POSE)) and (transforms is None or not (int(raw_flags) & _C.RAW_POSE)):
+            raise Exception('a translation / RAW_POSE needs the transforms and the RAW_POSE flag!')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, transforms,
-                                   raw_flags, self.context)
+                                   raw_flags, self.context, translation)

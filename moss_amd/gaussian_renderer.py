@@ -89,7 +89,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     means3D = xyz
     bweights = correct_Rs = pose_out = None
-    if transforms is not None:
+    # ``pipe.pose_in_op`` (an addition; with ``pipe.transforms_in_op``): the op poses the canonical positions itself, T x + translation
+    # (C ABI MOSS_RAW_POSE) -- the reference does it here with torch ops (:74-77) -- and returns the gradients of x, T and the translation
+    pose_in_op = (transforms is not None and getattr(pipe, "pose_in_op", False) and getattr(pipe, "transforms_in_op", False)
+                  and not pipe.compute_cov3D_python and not pipe.convert_SHs_python)
+    op_translation = None
+    if pose_in_op:
+        raw_flags |= 16                                      # _C.RAW_POSE
+        op_translation = None if translation is None else translation.squeeze()
+    elif transforms is not None:
         # = torch.matmul(transforms, means3D[..., None]).squeeze(-1) (reference :74-75), written as an elementwise product + row sum:
         # a batched GEMM over 100k 3x3 matrices goes through hipBLASLt on MI355X and costs ~0.9 ms per call (and twice more backward)
         means3D = (transforms * means3D[..., None, :]).sum(-1) + (0 if translation is None else translation)
@@ -127,7 +135,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rendered_image, radii, depth, alpha = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
-        **({} if op_transforms is None else {"transforms": op_transforms}), **({"raw_flags": raw_flags} if raw_flags else {}))
+        **({} if op_transforms is None else {"transforms": op_transforms}), **({"raw_flags": raw_flags} if raw_flags else {}),
+        **({} if op_translation is None else {"translation": op_translation}))
 
     return RenderOutput({"render": rendered_image, "render_depth": depth, "render_alpha": alpha,
                          "viewspace_points": screenspace_points, "radii": radii,

@@ -898,6 +898,76 @@ def test_transforms_inside_the_op_equal_python_covariance(gpu, hip_lib):
         rast(means3D=means, means2D=m2d, opacities=opa, shs=shs, cov3D_precomp=cov, transforms=T)
 
 
+def test_means_posed_inside_the_op_equal_the_torch_posing(gpu, hip_lib):
+    """MOSS_RAW_POSE: rasterizer(means3D = canonical x, transforms = T, translation = t, raw_flags |= RAW_POSE) is the reference caller's
+    `means3D = torch.matmul(transforms, means3D[..., None]).squeeze(-1) + translation` (gaussian_renderer/__init__.py:74-77) followed
+    by the op, without the torch kernels:
+      * every integer stage (radii, sorted keys, ranges) is BIT-EXACT against the CPU oracle run on means posed with the kernel's
+        expression (rows of T times x summed left to right, then t: float32, one rounding per operation);
+      * the gradients of x, T and t equal those autograd sends back through the torch posing."""
+    import moss_amd.diff_gaussian_rasterization as dgr
+    from moss_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    s = scenes.config1(P=500, W=112, H=96)
+    c = s.camera
+    g = torch.Generator().manual_seed(21)
+    T = (torch.eye(3) + 0.1 * torch.randn(s.P, 3, 3, generator=g)).float()
+    t = (0.05 * torch.randn(s.P, 3, generator=g)).float()
+    x = s.means3D.float()
+    Tn, xn, tn = T.numpy(), x.numpy(), t.numpy()
+    posed = np.empty_like(xn)
+    for r in range(3):
+        posed[:, r] = ((Tn[:, r, 0] * xn[:, 0] + Tn[:, r, 1] * xn[:, 1]) + Tn[:, r, 2] * xn[:, 2]) + tn[:, r]
+    assert posed.dtype == np.float32
+    # ---- integer stages against the oracle on the posed means (through the raw C-level entry: hp.hip_forward has no pose argument)
+    d = hp.inputs_of(s, "lbs")
+    d.transforms = T
+    d_oracle = hp.inputs_of(s, "lbs"); d_oracle.transforms = T; d_oracle.means3D = torch.from_numpy(posed)
+    fw = hp.oracle_forward(d_oracle)
+    a = dict(bg=d.bg.to(gpu), means3D=x.to(gpu), opacity=d.opacities.to(gpu), scales=d.scales.to(gpu), rotations=d.rotations.to(gpu),
+             view=c.viewmatrix.to(gpu), proj=c.projmatrix.to(gpu), sh=d.shs.to(gpu), campos=c.campos.to(gpu))
+    empty = torch.Tensor([])
+    from types import SimpleNamespace
+    tt = SimpleNamespace()
+    (tt.R, tt.color, tt.depth, tt.alpha, tt.radii, tt.geom, tt.binning, tt.img) = _C.rasterize_gaussians(
+        a["bg"], a["means3D"], empty, a["opacity"], a["scales"], a["rotations"], 1.0, empty, a["view"], a["proj"], c.tanfovx, c.tanfovy,
+        c.H, c.W, a["sh"], d.degree, a["campos"], False, False, transforms=T.to(gpu), raw_flags=_C.RAW_POSE, translation=t.to(gpu))
+    e = hp.hip_export(d, tt, gpu)
+    assert np.array_equal(e.radii, fw.radii) and tt.R == fw.num_rendered
+    assert np.array_equal(e.point_list_keys, fw.point_list_keys) and np.array_equal(e.point_list, fw.point_list)
+    assert np.array_equal(e.ranges, fw.ranges) and np.array_equal(e.n_contrib, fw.n_contrib)
+    assert hp.rel_err(e.color, fw.color) < 2e-5 and hp.rel_err(e.alpha, fw.alpha) < 2e-5
+    # ---- gradients against the torch posing
+    rs = GaussianRasterizationSettings(image_height=c.H, image_width=c.W, tanfovx=c.tanfovx, tanfovy=c.tanfovy,
+                                       bg=torch.tensor([0.1, 0.2, 0.3], device=gpu), scale_modifier=1.0, viewmatrix=c.viewmatrix.to(gpu),
+                                       projmatrix=c.projmatrix.to(gpu), sh_degree=3, campos=c.campos.to(gpu), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(rs)
+    w = torch.rand(3, c.H, c.W, device=gpu)
+    leaf = lambda v: v.clone().to(gpu).requires_grad_(True)
+    res = []
+    for variant in ("torch", "in_op", "in_op_no_translation"):
+        xs, opa, shs, scl, rot, Tl, tl = leaf(x), leaf(s.opacities), leaf(s.shs), leaf(s.scales), leaf(s.rotations), leaf(T), leaf(t)
+        m2d = torch.zeros_like(xs, requires_grad=True)
+        if variant == "torch":
+            means = (Tl * xs[:, None, :]).sum(-1) + tl
+            img, radii, depth, alpha = rast(means3D=means, means2D=m2d, opacities=opa, shs=shs, scales=scl, rotations=rot, transforms=Tl)
+        elif variant == "in_op":
+            img, radii, depth, alpha = rast(means3D=xs, means2D=m2d, opacities=opa, shs=shs, scales=scl, rotations=rot, transforms=Tl,
+                                            raw_flags=_C.RAW_POSE, translation=tl)
+        else:
+            img, radii, depth, alpha = rast(means3D=xs, means2D=m2d, opacities=opa, shs=shs, scales=scl, rotations=rot, transforms=Tl,
+                                            raw_flags=_C.RAW_POSE)
+        ((img * w).sum() + alpha.sum() + 0.1 * depth.sum()).backward()
+        res.append((img.detach(), radii, xs.grad, Tl.grad, tl.grad, scl.grad, rot.grad, opa.grad, shs.grad, m2d.grad))
+    ref, op, op0 = res
+    assert hp.rel_err(ref[0].cpu().numpy(), op[0].cpu().numpy()) < 1e-5
+    assert float((ref[1] != op[1]).float().mean()) < 0.01       # (torch may sum the three products in another order: a radius can move by one)
+    for k in range(2, 10):
+        assert hp.rel_err(op[k].cpu().numpy(), ref[k].cpu().numpy()) < 2e-4, k
+    assert op0[4] is None and float((op0[0] - op[0]).abs().max()) > 1e-3      # without a translation: another image, no translation gradient
+    with pytest.raises(Exception):
+        rast(means3D=xs, means2D=m2d, opacities=opa, shs=shs, scales=scl, rotations=rot, raw_flags=_C.RAW_POSE)      # no transforms
+
+
 # ---------------------------------------------------------------- k-NN query (replacement for the knn_cuda wheel, row n3)
 @pytest.mark.parametrize("Nr,Nq,k", [(6890, 20000, 1), (3000, 3000, 2), (5, 17, 4), (1025, 300, 3)])
 def test_knn_query_matches_exhaustive_search(gpu, hip_lib, Nr, Nq, k):
