@@ -20,10 +20,13 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libmoss_raster.so")
 EXT = os.path.join(OUT_DIR, "_moss_C.so")                # PyTorch-ROCm extension module over the C ABI (csrc/torch_binding.cpp)
+# The C-ABI header: include/moss_raster.h of the source tree; an INSTALLED copy of the package carries its own (setup.py copies it to
+# moss_amd/include/), so that `python -m moss_amd.build --force` -- what the loader's error messages recommend -- works there too.
+INCLUDE_DIR = os.path.join(ROOT, "include") if os.path.exists(os.path.join(ROOT, "include", "moss_raster.h")) else os.path.join(HERE, "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE_DIR, "-I", CSRC,
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
 # translation unit -> extra flags.  The per-Gaussian kernels decide integers (radius, tile rectangle, sort key) and must
 # round exactly like the CPU oracle: no FMA contraction there.  The blend kernels spell their FMAs explicitly.
@@ -63,11 +66,14 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
 def _build_into(out_dir: str, defines, force: bool, verbose: bool) -> str:
     os.makedirs(out_dir, exist_ok=True)
     lib_path = os.path.join(out_dir, "libmoss_raster.so")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "moss_raster.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE_DIR, "moss_raster.h"), os.path.abspath(__file__)]
     objs = []
     procs = []
     sources = [(os.path.join(CSRC, src), extra) for src, extra in SOURCES.items()]
     if defines:
+        if not os.path.exists(DIAG_EXTRA_SOURCE):
+            raise RuntimeError("the diagnostic build (--diag) needs scripts/diag/knobs.cpp of the SOURCE tree; an installed package "
+                               "carries the product build only")
         sources.append((DIAG_EXTRA_SOURCE, ["-x", "hip"]))
     for s, extra in sources:
         src = os.path.basename(s)
@@ -99,14 +105,14 @@ def build_torch_extension(force: bool = False, verbose: bool = False, out_dir: s
     """<out_dir>/_moss_C.so: host-only C++ (g++), the torch glue of the reference's rasterize_points.cu over the C ABI."""
     src = os.path.join(CSRC, "torch_binding.cpp")
     EXT = os.path.join(out_dir, "_moss_C.so")
-    if not (force or _newer(EXT, [src, os.path.join(ROOT, "include", "moss_raster.h"), os.path.abspath(__file__)])):
+    if not (force or _newer(EXT, [src, os.path.join(INCLUDE_DIR, "moss_raster.h"), os.path.abspath(__file__)])):
         return EXT
     import sysconfig
     import torch
     from torch.utils import cpp_extension as ce
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include"),
-                                os.path.join(ROOT, "include")]
+                                INCLUDE_DIR]
     tmp = EXT + f".tmp{os.getpid()}"
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_moss_C",

@@ -222,7 +222,7 @@ def _forward64(bg, means3D, colors_precomp, opacities, scales, rotations, scale_
 
 def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, degree, campos, transforms=None,
-             f32_accumulators=False, sum_noise_ulps=0.0, noise_seed=0):
+             f32_accumulators=False, sum_noise_ulps=0.0, noise_seed=0, chain_noise_ulps=0.0):
     """``fw`` is the namespace returned by :func:`forward`.  Returns the reference's 8 gradient arrays
     (rasterize_points.cu:205) plus dL_dconic as a namespace.  A float64 ``fw`` (forward(f64=True)) runs the float64 build.
     ``f32_accumulators``: the blend backward adds its per-pixel terms in float32 in loop order -- one of the orders the reference's
@@ -231,7 +231,12 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     per-Gaussian stages (dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors -- BACKWARD::render's atomicAdd targets, backward.cu:566-588)
     are multiplied by 1 + eta, eta uniform in +-sum_noise_ulps * 2^-24, before those stages run: what ANY float32 evaluation of the
     sums does to them at the least.  The change of the final gradients against the unperturbed run is how far float32 rounding of
-    the sums alone is entitled to move them (a 300:1 anisotropic Gaussian amplifies it by 10^3-10^4 in its scale gradient)."""
+    the sums alone is entitled to move them (a 300:1 anisotropic Gaussian amplifies it by 10^3-10^4 in its scale gradient).
+    ``chain_noise_ulps`` (the same kind of probe, one stage further): the six-vector dL/dSigma3 that computeCov2DCUDA hands to
+    computeCov3D's backward (backward.cu:268-273 -> :278-341) is multiplied by 1 + eta likewise -- the reference STORES that vector in
+    float32 between its two kernels, so its own arithmetic rounds exactly there; for a needle whose long axis points along the
+    viewing ray the scale gradient r^T dSigma3 r is a difference of terms 10^3 times its size and that rounding is what it is
+    entitled to (round 3's finding 24)."""
     is64 = bool(getattr(fw, "f64", False))
     L = lib64() if is64 else lib()
     dt = np.float64 if is64 else np.float32
@@ -286,10 +291,17 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     L.oracle_compute_cov2d_backward(C.c_int(P), _p(means3D), _p(fw.radii), _p(np.ascontiguousarray(cov3D_ptr)),
                                     fx_c, fy_c, cf(tan_fovx), cf(tan_fovy),
                                     _p(viewmatrix), _p(g.dL_dconic), _p(g.dL_dmeans3D), _p(g.dL_dcov3D))
+    kept_cov3D = None
+    if chain_noise_ulps:
+        rng = np.random.default_rng(noise_seed + 7919)
+        kept_cov3D = g.dL_dcov3D.copy()                      # (the returned dL_dcov3D stays the unperturbed one: only its CONSUMER sees the noise)
+        g.dL_dcov3D *= (1.0 + (rng.random(g.dL_dcov3D.shape) * 2.0 - 1.0) * float(chain_noise_ulps) * 2.0 ** -24).astype(dt)
     L.oracle_preprocess_backward(C.c_int(P), C.c_int(degree), C.c_int(M), _p(means3D), _p(fw.radii), _p(sh),
                                  _p(fw.clamped), _p(scales), _p(rotations), cf(scale_modifier), _p(projmatrix),
                                  _p(campos), _p(g.dL_dmeans2D), _p(g.dL_dmeans3D), _p(g.dL_dcolors), _p(g.dL_dcov3D),
                                  _p(g.dL_dsh), _p(g.dL_dscales), _p(g.dL_drotations), _p(transforms), _p(g.dL_dtransforms))
+    if kept_cov3D is not None:
+        g.dL_dcov3D = kept_cov3D
     return g
 
 

@@ -21,6 +21,10 @@ def _build_native():
     try:
         from moss_amd import build as hip_build
         hip_build.build()
+        # the installed package carries the C-ABI header next to the kernel sources: it can rebuild itself (moss_amd/build.py INCLUDE_DIR)
+        import shutil
+        os.makedirs(os.path.join(ROOT, "moss_amd", "include"), exist_ok=True)
+        shutil.copy(os.path.join(ROOT, "include", "moss_raster.h"), os.path.join(ROOT, "moss_amd", "include", "moss_raster.h"))
     finally:
         sys.path.pop(0)
 
@@ -39,11 +43,11 @@ class DevelopWithNative(develop):
 
 setup(
     name="moss-amd",
-    version="0.3.0",
+    version="0.4.0",
     description="MI355X-native (gfx950) differentiable Gaussian-splatting rasterizer: drop-in for MOSS's diff_gaussian_rasterization, "
                 "simple_knn and knn_cuda",
     python_requires=">=3.10",
     packages=find_packages(include=["moss_amd*", "diff_gaussian_rasterization*", "simple_knn*", "knn_cuda*"]),
-    package_data={"moss_amd": ["lib/libmoss_raster.so", "lib/_moss_C.so", "csrc/*"]},
+    package_data={"moss_amd": ["lib/libmoss_raster.so", "lib/_moss_C.so", "csrc/*", "include/*.h"]},
     cmdclass={"build_py": BuildPyWithNative, "develop": DevelopWithNative},
 )

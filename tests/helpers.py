@@ -221,3 +221,75 @@ def adjudication_excess(got, refs32, ref64, scale, factor=2.0):
     e32 = max(float((np.abs(np.asarray(r, dtype=np.float64) - b64)[pos] / s[pos]).max()) for r in refs32)
     err = np.abs(a - b64)[pos] / s[pos]
     return float(err.max() - factor * e32), e32, float(err.max())
+
+
+# ---- ONE parity rule for the gradients (round 4) -----------------------------------------------------------------------------------
+# "Within a stated fp32 tolerance of the reference" needs a tolerance that follows from the INPUTS, per element, and holds for every
+# scene -- the BASELINE configurations and the random ones alike, with no list of exceptions.  What a float32 implementation of the
+# reference's algorithm is entitled to has two parts, and both are measured rather than estimated:
+#   * SUMMATION: an element is a sum over pixels of terms that may cancel; any float32 order of that sum errs in proportion to the
+#     sum of the ABSOLUTE terms, the element's contribution mass (oracle.gradient_scales);
+#   * the NOISE FLOOR OF THE REFERENCE'S OWN ARITHMETIC at that element.  The per-Gaussian chain conic -> cov2D -> cov3D -> scale /
+#     rotation / transform is riddled with cancellations (a 300:1 needle seen end-on: the scale gradient of its long axis is a
+#     difference of terms 10^3 times its size, several times over).  How much float32 rounding moves the result there is measured by
+#     stochastic arithmetic: the float32 restatement of the reference (oracle/moss_oracle.c: its statements, its operation order) is
+#     run PROBES times on inputs moved by -1 / 0 / +1 float32 ulp at random -- every internal rounding then falls differently -- with
+#     double and with float32 accumulators, over the same forward state; `spread` is the largest distance of those runs from the
+#     float64 result, element by element.  (The float64 oracle's own response to the same one-ulp perturbations -- the conditioning
+#     of the exact function -- is part of it by construction.)
+# The rule, for EVERY element of every gradient tensor:      |hip - f64|  <=  RULE_K * (spread + RULE_EPS * mass)
+# i.e. the kernels are never further from float64 than RULE_K times what the reference's arithmetic itself scatters by.
+RULE_EPS = 16 * U32          # the summation share: sixteen unit roundoffs of the contribution mass (lists of 10^2-10^3 terms, summed in trees)
+RULE_K = 8.0             # measured over 4 088 scenes (profiles/r04_fuzz_rule_*.log): median 0.5, 99th percentile 1.8, worst 6.1
+RULE_PROBES = 6
+
+
+def _ulp_perturbed(a, rng):
+    """float32 array -> every element moved by -1, 0 or +1 float32 ulp at random."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    step = rng.integers(-1, 2, size=a.shape)
+    up = np.nextafter(a, np.float32(np.inf)); dn = np.nextafter(a, np.float32(-np.inf))
+    return np.where(step > 0, up, np.where(step < 0, dn, a)).astype(np.float32)
+
+
+RULE_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dtransforms"]
+
+
+def reference_noise_floor(d, fw, fw64, dc, dd, da, probes=RULE_PROBES, seed=0):
+    """({name: spread}, float64 gradients): the float32 restatement run on one-ulp perturbed inputs `probes` times (alternating double /
+    float32 accumulators; probe 0 is the unperturbed run), each compared with the float64 oracle on the UNPERTURBED inputs."""
+    import copy
+    c = d.cam
+    ref64 = oracle_backward(d, fw64, dc, dd, da)
+    spread = {n: np.zeros(np.asarray(getattr(ref64, n)).shape, np.float64) for n in RULE_NAMES}
+    for s in range(probes):
+        rng = np.random.default_rng(1000 * seed + s)
+        P = (lambda a: None if a is None else np.ascontiguousarray(_np(a))) if s == 0 else (lambda a: None if a is None else _ulp_perturbed(_np(a), rng))
+        fwp = copy.copy(fw)
+        if s > 0:
+            # the forward's per-Gaussian results the backward reads: rounded differently by every float32 implementation
+            for name in ("cov3D", "means2D", "conic_opacity", "rgb", "depths"):
+                v = getattr(fw, name, None)
+                if v is not None and np.asarray(v).size:
+                    setattr(fwp, name, _ulp_perturbed(v, rng))
+        g = oracle.backward(fwp, d.bg.numpy(), P(d.means3D), _np(d.colors_precomp), P(d.scales), P(d.rotations), d.scale_modifier,
+                            P(d.cov3D_precomp), P(c.viewmatrix), P(c.projmatrix), c.tanfovx, c.tanfovy, _np(dc), _np(dd), _np(da),
+                            P(d.shs), d.degree, P(c.campos), transforms=P(d.transforms), f32_accumulators=bool(s & 1))
+        for n in RULE_NAMES:
+            spread[n] = np.maximum(spread[n], np.abs(np.asarray(getattr(g, n), np.float64) - np.asarray(getattr(ref64, n), np.float64)))
+    return spread, ref64
+
+
+def single_rule_ratio(got, ref64, mass, spread):
+    """max over the elements of |got - ref64| / (spread + RULE_EPS * mass) -- the rule holds iff this is <= RULE_K -- plus the index of
+    the worst element.  Elements with neither mass nor spread (nothing contributes to them) must agree exactly (asserted)."""
+    a = np.asarray(got, np.float64); b = np.asarray(ref64, np.float64)
+    den = np.asarray(spread, np.float64).reshape(a.shape) + RULE_EPS * np.asarray(mass, np.float64).reshape(a.shape)
+    err = np.abs(a - b)
+    pos = den > 0
+    assert not err[~pos].any(), "an element that nothing contributes to is not exactly zero"
+    if not pos.any():
+        return 0.0, -1
+    r = np.zeros_like(err); r[pos] = err[pos] / den[pos]
+    k = int(np.argmax(r))
+    return float(r.reshape(-1)[k]), k

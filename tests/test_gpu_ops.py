@@ -30,6 +30,45 @@ def test_fused_loss_matches_torch_reference(gpu, hip_lib, shape):
     assert hp.rel_err(al.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("shape,blobs", [((3, 160, 200), 2), ((3, 512, 512), 1), ((3, 96, 96), 0)])
+def test_fused_loss_on_masked_frames_with_empty_tiles(gpu, hip_lib, shape, blobs):
+    """MOSS's frames are masked people on black: most 32x32 tiles of a frame are exactly zero in BOTH images.  The loss kernels skip
+    the filters there (loss.hip, "EMPTY TILES") -- the values they leave must be the general path's: checked against the float64 torch
+    reference at the tolerances of the dense test, the gradient is exactly +0 wherever a tile and its neighbours are empty, and a frame
+    with NO content at all (blobs = 0) gives SSIM = 1 to rounding, L1 = 0 and a zero image gradient."""
+    from moss_amd.loss import training_loss, training_loss_fused
+    C, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    m = torch.zeros(H, W)
+    for k in range(blobs):                                   # irregular blobs that cross tile borders at odd offsets
+        cx, cy, r = (0.3 + 0.37 * k) * W, (0.45 + 0.2 * k) * H, 0.17 * min(H, W)
+        m = torch.maximum(m, ((xx - cx) ** 2 + ((yy - cy) * 0.8) ** 2 < r * r).float())
+    img = torch.rand(C, H, W, generator=g) * m
+    gt = torch.rand(C, H, W, generator=g) * torch.roll(m, shifts=(3, -5), dims=(0, 1))       # the target's silhouette is not the render's
+    alpha = torch.rand(1, H, W, generator=g) * m; mask = m[None].clone()
+    a = img.double().requires_grad_(True); b = alpha.double().requires_grad_(True)
+    ref = training_loss(a, b, gt.double(), mask.double())
+    ref.backward()
+    x = img.to(gpu).requires_grad_(True); al = alpha.to(gpu).requires_grad_(True)
+    terms = torch.zeros(4, device=gpu)
+    out = training_loss_fused(x, al, gt.to(gpu), mask.to(gpu), terms_out=terms)
+    (out * 1.0).backward()
+    assert abs(float(out) - float(ref)) < 1e-6
+    gx = x.grad.cpu()
+    assert hp.rel_err(gx.numpy(), a.grad.numpy()) < 2e-5 or (blobs == 0 and float(gx.abs().max()) == 0.0)
+    assert hp.rel_err(al.grad.cpu().numpy(), b.grad.numpy()) < 2e-5 or float(b.grad.abs().max()) == 0.0
+    # exactly +0 (not a tiny number, not -0) where nothing is within a tile + its neighbours of content
+    content = ((img.abs().sum(0) + gt.abs().sum(0)) > 0).float()[None, None]
+    near = torch.nn.functional.max_pool2d(content, kernel_size=2 * 64 + 1, stride=1, padding=64)[0, 0] > 0
+    far = ~near
+    if far.any():
+        vals = gx[:, far]
+        assert float(vals.abs().max()) == 0.0 and not bool(torch.signbit(vals).any())
+    if blobs == 0:
+        assert abs(float(terms[2]) - 1.0) < 1e-6 and float(terms[1]) == 0.0
+
+
 @pytest.mark.parametrize("i", [0, 1])
 def test_fused_loss_matches_reference_golden(gpu, hip_lib, i):
     """The HIP loss kernels against the REFERENCE'S OWN numbers, no restatement in between: tests/golden/loss.npz

@@ -4,14 +4,15 @@ adjudication, and the configurations / call modes the first suite did not reach.
 * END TO END: HIP forward+backward against oracle forward+backward (each with its own final_T / n_contrib), on the pixels where
   every implementation provably takes the same branches (``helpers.stable_mask``: all decision margins > 1e-4 in the float32
   AND the float64 oracle; the incoming image gradients are zeroed elsewhere), at the bars of tests/test_gpu_parity.py.
-* ADJUDICATION: the reference holds no vector for the blend / backward ("parity unpinned"), so where the HIP
-  kernels and the float32 restatement differ neither is right by definition.  The same C source compiled with float -> double
-  (oracle/Makefile) referees, element by element in units of the element's contribution mass (helpers.adjudication_excess):
-      |HIP - f64| <= ADJ_FACTOR * E32 + ADJ_FLOOR,   E32 = worst |float32 restatement - f64| of the tensor
-  over TWO float32 restatements: the oracle as it is (double accumulators = the centre of the distribution of the reference's
-  atomicAdd orders) and the oracle with float32 accumulators added in loop order (one admissible order: the reference's arithmetic
-  including the rounding of its atomics; the kernels sum in float32 too, hierarchically).  Run on cfg1-3, cfg5 and on the random
-  scenes the fuzz sweep of this round flagged (image-covering, 300:1 anisotropic Gaussians; tests/golden/fuzz_outlier_seeds.json).
+* ONE RULE FOR EVERY GRADIENT ELEMENT (round 4; rounds 2-3 had two tolerances selected by a hand-kept list of seeds): the reference
+  holds no vector for the blend / backward ("parity unpinned"), so where the HIP kernels and the float32
+  restatement differ neither is right by definition.  The same C source compiled with float -> double (oracle/Makefile) referees, and
+  the tolerance is what the reference's OWN float32 arithmetic scatters by at that element, measured by stochastic arithmetic
+  (helpers.reference_noise_floor: the float32 restatement re-run on inputs moved by one float32 ulp, double and float32 accumulators):
+      |HIP - f64|  <=  RULE_K * (spread + RULE_EPS * contribution mass)            per element, RULE_K = 8, RULE_EPS = 16 x 2^-24
+  asserted on cfg1-3, cfg5 AND on every random scene of tests/golden/fuzz_outlier_seeds.json -- the 147 seeds earlier sweeps flagged
+  (image-covering, 300:1 anisotropic Gaussians) are regression cases now, not exceptions: scripts/fuzz_rule.py applies the same
+  rule with the same constants to every seed of a sweep (profiles/r04_fuzz_rule_*.log: pass rate).
 * BASELINE configs[4] (300k Gaussians, 1024x1024) in cov3D_precomp mode and in the bench's raw-parameter scale/rotation mode;
   BASELINE configs[2] exactly the way bench.py calls the op (render(), raw parameters, gradient sinks into a GradBucket).
 """
@@ -28,9 +29,7 @@ from tests import test_gpu_parity as tp
 
 pytestmark = pytest.mark.gpu
 
-ADJ_FACTOR = 2.0
-ADJ_FACTOR_OUTLIERS = 8.0   # the fuzz outliers: measured worst 5.8 (seed 3235, dL_dscales of a Gaussian over 81 tiles), see their test
-ADJ_FLOOR = 2e-5
+ADJ_FACTOR = 2.0            # images only (colour, alpha, final_T against float64): no further than 2x the float32 oracle + 2e-6
 STABLE = 1e-4
 
 _REPORT = {}
@@ -82,23 +81,23 @@ def _end_to_end(d, gpu, key, adjudicate=True, per_gaussian=tp.PER_GAUSSIAN_TOL):
     dc, dd, da = dc * m, dd * m, da * m
     g = hp.hip_backward(d, t, dc, dd, da, gpu)
     ref = hp.oracle_backward(d, fw, dc, dd, da)             # the oracle's OWN forward state
-    ref64 = hp.oracle_backward(d, fw64, dc, dd, da)
-    ref_f32acc = hp.oracle_backward(d, fw, dc, dd, da, f32_accumulators=True)
     scales = hp.oracle_gradient_scales(d, fw, dc, dd, da)
     got = {n: getattr(g, n).cpu().numpy() for n in _names(d)}
     errs = tp.check_gradients(got, {n: getattr(ref, n) for n in _names(d)}, scales, per_gaussian=per_gaussian)
+    # the single rule: every element within RULE_K x (what the reference's own float32 arithmetic scatters by + the summation share)
+    spread, ref64 = hp.reference_noise_floor(d, fw, fw64, dc, dd, da)
     adj = {}
     for n in _names(d):
         if n not in scales or not got[n].size:
             continue
-        excess, e_orc, e_hip = hp.adjudication_excess(got[n], (getattr(ref, n), getattr(ref_f32acc, n)), getattr(ref64, n), scales[n], ADJ_FACTOR)
-        adj[n] = (e_hip, e_orc, excess)
+        ratio, k = hp.single_rule_ratio(got[n], getattr(ref64, n), scales[n], spread[n])
+        adj[n] = ratio
         if adjudicate:
-            assert excess <= ADJ_FLOOR, f"{n}: HIP is up to {e_hip:.3g} of the contribution mass from float64 (the float32 oracle {e_orc:.3g}); {excess:.3g} beyond the allowance"
+            assert ratio <= hp.RULE_K, f"{n}: element {k} is {ratio:.2f} x (spread + eps mass) from float64 (rule: {hp.RULE_K})"
     unmasked = tp.check_backward_unmasked(d, gpu, fw, t, e)   # incoming gradients on every pixel, whole-tensor bars
     _note(key, {"fragile_pixels": float(1.0 - m.mean()), "every_pixel": flips, "backward_unmasked (relmax, 1-cos)": unmasked,
                 "images_vs_f64 (hip, oracle32)": img_adj,
-                "grads_vs_oracle32 (relmax, 1-cos, per-Gaussian scaled)": errs, "grads_vs_f64 scaled (hip, float32 restatements, excess)": adj})
+                "grads_vs_oracle32 (relmax, 1-cos, per-Gaussian scaled)": errs, "single_rule_ratio (|hip - f64| / (spread + eps mass), <= RULE_K)": adj})
     return errs, adj
 
 
@@ -283,13 +282,13 @@ def _fuzz_outlier_seeds():
 
 
 @pytest.mark.parametrize("seed", _fuzz_outlier_seeds())
-def test_fuzz_outliers_adjudicated_by_float64(gpu, hip_lib, seed):
-    """Each of these seeds holds 50-600:1 anisotropic Gaussians over dozens to hundreds of tiles, whose scale / rotation gradient is a
-    difference of terms 100-1000x its size: the float32 summation noise of dL_dconic (the kernels', and just as much the reference's
-    atomics') comes out of the covariance chain amplified by that condition number.  The whole-tensor bar against the float32 oracle
-    is the sweep's (2e-2); what is asserted on top is the adjudication -- against float64 the kernels are no further than
-    ADJ_FACTOR_OUTLIERS x the float32 restatements, per element in mass units AND in the whole-tensor norm (measured worst: 5.8x and
-    2.4x; the BASELINE configurations are held to 2x, tests above)."""
+def test_fuzz_scenes_hold_the_single_rule(gpu, hip_lib, seed):
+    """Random scenes with 50-600:1 anisotropic Gaussians over dozens to hundreds of tiles -- the 147 seeds that rounds 2-3's sweeps
+    flagged against their plain bars and then passed under a looser, second tolerance.  Round 4 holds them to the SAME rule as the
+    BASELINE configurations (helpers.RULE_K, RULE_EPS; measured worst on these seeds: 3.9 of the allowed 8): the scale / rotation
+    gradient of such a needle is a difference of terms 100-1000x its size, the reference's own float32 arithmetic scatters there by
+    just that much, and the rule's tolerance is that scatter, measured per element.  Images: no further from float64 than 4x the
+    float32 oracle; n_contrib exact on the stable pixels; nothing NaN."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "fuzz_scenes", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_scenes.py"))
@@ -305,18 +304,9 @@ def test_fuzz_outliers_adjudicated_by_float64(gpu, hip_lib, seed):
     dc, dd, da = hp.image_grads(d.H, d.W, zero_depth=bool(seed & 1))
     dc, dd, da = dc * m, dd * m, da * m
     g = hp.hip_backward(d, t, dc, dd, da, gpu)
-    ref = hp.oracle_backward(d, fw, dc, dd, da); ref64 = hp.oracle_backward(d, fw64, dc, dd, da)
-    ref_f32acc = hp.oracle_backward(d, fw, dc, dd, da, f32_accumulators=True)
     scales = hp.oracle_gradient_scales(d, fw, dc, dd, da)
+    spread, ref64 = hp.reference_noise_floor(d, fw, fw64, dc, dd, da, seed=seed)
     got = {n: getattr(g, n).cpu().numpy() for n in _names(d)}
-    # whole-tensor bar as in the sweep that found them (2e-2 of the largest value against the float32 oracle) -- unless the oracle
-    # itself is the one that is off: since the per-Gaussian backward is written in matrix form (round 2) the kernels are CLOSER to
-    # float64 than the reference's expressions on the worst-conditioned Gaussians (seed 1891: 1.3e-3 against the oracle's 2.8e-2)
-    for n in _names(d):
-        if got[n].size:
-            assert np.isfinite(got[n]).all(), n
-            r32, r64, o64 = hp.rel_err(got[n], getattr(ref, n)), hp.rel_err(got[n], getattr(ref64, n)), hp.rel_err(getattr(ref, n), getattr(ref64, n))
-            assert r32 <= 2e-2 or r64 <= ADJ_FACTOR * o64, (n, r32, r64, o64)      # (seed 3170: both 1 % from float64, 2 % apart)
     e = hp.hip_export(d, t, gpu)
     ok = m.numpy().astype(bool)
     np.testing.assert_array_equal(e.n_contrib[ok.reshape(-1)], fw.n_contrib[ok.reshape(-1)])
@@ -327,14 +317,11 @@ def test_fuzz_outliers_adjudicated_by_float64(gpu, hip_lib, seed):
     for n in _names(d):
         if not got[n].size:
             continue
-        excess, e_orc, e_hip = hp.adjudication_excess(got[n], (getattr(ref, n), getattr(ref_f32acc, n)), getattr(ref64, n), scales[n], ADJ_FACTOR_OUTLIERS)
-        # and in the whole-tensor norm the sweep used
-        r_hip = hp.rel_err(got[n], getattr(ref64, n))
-        r_orc = max(hp.rel_err(getattr(ref, n), getattr(ref64, n)), hp.rel_err(getattr(ref_f32acc, n), getattr(ref64, n)))
-        adj[n] = (e_hip, e_orc, excess, r_hip, r_orc)
-        assert excess <= ADJ_FLOOR, (n, e_hip, e_orc, excess)
-        assert r_hip <= ADJ_FACTOR_OUTLIERS * r_orc + 2e-5, (n, r_hip, r_orc)
-    _note(f"fuzz{seed}", {"grads_vs_f64 (scaled hip, scaled float32 restatements, excess, relmax hip, relmax restatements)": adj})
+        assert np.isfinite(got[n]).all(), n
+        ratio, k = hp.single_rule_ratio(got[n], getattr(ref64, n), scales[n], spread[n])
+        adj[n] = ratio
+        assert ratio <= hp.RULE_K, (n, k, ratio)
+    _note(f"fuzz{seed}", {"single_rule_ratio": adj})
 
 
 @pytest.mark.gpu
