@@ -209,7 +209,14 @@ class Harness:
             stats = DensifyStats(scene.means3D.shape[0], device=dev)
         self.stats = stats
 
+        exp_side = os.environ.get("MOSS_EXP_SIDE_ADAM") == "1"
+        side_stream = torch.cuda.Stream(dev) if exp_side else None
+
         def compute():                      # everything of a step that is local to this rank
+            if exp_side:                    # TIMING EXPERIMENT: the update (of the previous gradients) beside the chain
+                side_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side_stream):
+                    self.opt.step()
             if torch_adamw:
                 self.opt.zero_grad(set_to_none=True)
             elif pipe.fused_activations:
@@ -235,7 +242,9 @@ class Harness:
                 _ = out["visibility_filter"]
             if not torch_adamw and pipe.fused_activations:
                 bucket.collect()
-            if self.local_opt:
+            if exp_side:
+                torch.cuda.current_stream(dev).wait_stream(side_stream)
+            elif self.local_opt:
                 # a frame that overflowed its capacity rendered nothing: the update kernel reads the frame's status word and skips
                 # itself (inside a captured step nobody else can; moss_adamw_flat_guarded)
                 img = None if torch_adamw else self.ctx.last_img_buffer
