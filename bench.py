@@ -34,9 +34,12 @@ MIN_TIMED_MS = 50.0                   # a timed region shorter than this is re-m
 LONG_STEPS = 200
 
 
-def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode, transforms=False):
+def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode, transforms=False, fused_adamw=False):
     """bytes that MUST cross HBM per fwd+bwd step, from the measured P, Pv, R, N.  transforms: the in-op
-    LBS covariance (row n2) reads 36 B per Gaussian more in both directions and writes dL_dtransforms (36 B per Gaussian)."""
+    LBS covariance (row n2) reads 36 B per Gaussian more in both directions and writes dL_dtransforms (36 B per Gaussian).
+    fused_adamw: the per-Gaussian backward also takes the optimizer step (moss_raster_backward_raw_adamw): per parameter (11 + 3K per
+    Gaussian, ALL P of them) both moments read, parameter and both moments written = 20 B, the parameters of the Gaussians that were
+    not rendered read as well, and the gradients of the updated tensors (position, SH, opacity, scale, rotation) no longer written."""
     c = (28 if scale_rot_mode else 24) + (36 if transforms else 0)
     fwd = {
         "preprocess_fwd": P * (12 + c + 4) + Pv * 12 * K + P * 8 + Pv * 43,
@@ -51,6 +54,9 @@ def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode, transforms=False):
         "preprocess_bwd": 36 * Pv + Pv * (12 + 4 + 24 + 12 * K + 3) + Pv * (12 + 24 + 12 * K + 4) + (28 * Pv if scale_rot_mode else 0) + P * 12
                           + (Pv * 36 + P * 36 if transforms else 0),
     }
+    if fused_adamw:
+        n_par = 11 + 3 * K
+        bwd["preprocess_bwd"] += P * n_par * 20 + (P - Pv) * n_par * 4 - Pv * (12 + 12 * K + 4 + 28)
     return fwd, bwd
 
 
@@ -91,6 +97,10 @@ def parse_args(argv=None):
                     help="index order of the synthetic Gaussians: as generated (uncorrelated with position -- the default, and the "
                          "least favourable) or re-indexed along a Morton curve (moss_amd.densify.spatial_order); a side experiment, "
                          "named in config.workload when used")
+    ap.add_argument("--fused-optimizer", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the per-Gaussian backward kernel takes the AdamW step of the parameters it differentiates "
+                         "(FlatAdamW.fuse_into_backward) wherever the step is local to the rank (N = 1, loss_only); 0: gradients into the "
+                         "bucket, then the flat AdamW kernel (always so for the gradient exchanges).  Same bits either way")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded", "loss_only"],
                     help="N > 1 only. loss_only = BASELINE configs[3] as written: every rank trains its OWN model on its own frames and "
                          "RCCL all-reduces the 4-float loss block only; "
@@ -151,7 +161,7 @@ class Harness:
     n_exchange = 0
 
     def __init__(self, args, dev, rank, world, scene, cam, gt, gt_mask, bg, *, mode, activations, torch_activations, torch_adamw,
-                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None, exchange="allreduce"):
+                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None, exchange="allreduce", fused_optimizer=True):
         import torch
         from types import SimpleNamespace
         from moss_amd import dist as mdist
@@ -196,6 +206,13 @@ class Harness:
                 if lbs_T is None or pipe.pose_in_op:                          # (posed OUTSIDE the op, the means are not the parameter)
                     sinks["means3D"] = lambda: bucket.sink_for(pc._xyz)
             self.ctx.set_grad_sink(**sinks)
+        # The optimizer step INSIDE the backward kernel (FlatAdamW.fuse_into_backward, C ABI moss_raster_backward_raw_adamw): whenever the
+        # step is local to the rank and the op is given the parameters themselves (raw, unified SH; positions posed inside the op)
+        self.fused_opt = bool(fused_optimizer and self.local_opt and not torch_adamw and pipe.raw_parameters_in_op and caller_side is None
+                              and (lbs_T is None or pipe.pose_in_op))
+        if self.fused_opt:
+            self.opt.fuse_into_backward(self.ctx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling,
+                                        rotations=pc._rotation)
         training_loss = mloss.training_loss_fused if fused_loss else mloss.training_loss
         self.caller_side = caller_side
         stats = None
@@ -209,14 +226,7 @@ class Harness:
             stats = DensifyStats(scene.means3D.shape[0], device=dev)
         self.stats = stats
 
-        exp_side = os.environ.get("MOSS_EXP_SIDE_ADAM") == "1"
-        side_stream = torch.cuda.Stream(dev) if exp_side else None
-
         def compute():                      # everything of a step that is local to this rank
-            if exp_side:                    # TIMING EXPERIMENT: the update (of the previous gradients) beside the chain
-                side_stream.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side_stream):
-                    self.opt.step()
             if torch_adamw:
                 self.opt.zero_grad(set_to_none=True)
             elif pipe.fused_activations:
@@ -240,10 +250,10 @@ class Harness:
             elif caller_side == "fused":
                 stats.add(out["radii"], out["viewspace_points"].grad)
                 _ = out["visibility_filter"]
-            if not torch_adamw and pipe.fused_activations:
+            if not torch_adamw and pipe.fused_activations and not self.fused_opt:
                 bucket.collect()
-            if exp_side:
-                torch.cuda.current_stream(dev).wait_stream(side_stream)
+            if self.fused_opt:
+                pass                        # the backward kernel took the step (and skipped it for a frame that overflowed)
             elif self.local_opt:
                 # a frame that overflowed its capacity rendered nothing: the update kernel reads the frame's status word and skips
                 # itself (inside a captured step nobody else can; moss_adamw_flat_guarded)
@@ -426,7 +436,8 @@ def main(argv=None):
 
     h = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
                 torch_activations=args.torch_activations, torch_adamw=args.torch_adamw, forward=args.forward, graph=args.graph,
-                lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=args.exchange)
+                lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=args.exchange,
+                fused_optimizer=bool(args.fused_optimizer))
     opt, bucket, pc = h.opt, h.bucket, h.pc
     pc.spatially_ordered = args.order == "morton"
 
@@ -520,7 +531,8 @@ def main(argv=None):
         for other in [k for k in ("allreduce", "sharded", "loss_only") if k != h.exchange_kind]:
             h2 = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
                          torch_activations=args.torch_activations, torch_adamw=False, forward=args.forward, graph=args.graph,
-                         lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=other)
+                         lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=other,
+                         fused_optimizer=bool(args.fused_optimizer))
             for _ in range(max(args.warmup, 3)):
                 h2.step()
             torch.cuda.synchronize(dev)
@@ -571,7 +583,8 @@ def main(argv=None):
     R = int(h.ctx.last_needed if args.forward == "async" else h.ctx.last_num_rendered)
     N = H * W
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"), transforms=args.mode == "lbs")
+    fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"), transforms=args.mode == "lbs",
+                                     fused_adamw=h.fused_opt)
     all_b = dict(fwd_b); all_b.update(bwd_b)
     if stage_ms.get("scan", 0.0) == 0.0:
         # asynchronous forward: the scan rides along with the scatter kernel (no launch of its own) -- its bytes count there
@@ -607,6 +620,8 @@ def main(argv=None):
                    "activations": "torch" if args.torch_activations else ("in_op" if h.pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
                    "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                    "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
+                   "optimizer": ("AdamW step taken by the per-Gaussian backward kernel (moss_raster_backward_raw_adamw); bit-identical to the flat "
+                                 "kernel, reported beside as callers.unfused_optimizer") if h.fused_opt else "flat AdamW kernel over the gradient bucket",
                    "glue": "compiled PyTorch-ROCm extension moss_amd/lib/_moss_C.so over the C ABI of libmoss_raster.so"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -650,6 +665,8 @@ def main(argv=None):
         if "spatial_order" in result["callers"]:
             result["value_spatial_order"] = result["callers"]["spatial_order"].get("value")
         result["value_no_transforms"] = result["callers"]["no_transforms"].get("value")
+        if "unfused_optimizer" in result["callers"]:
+            result["value_unfused_optimizer"] = result["callers"]["unfused_optimizer"].get("value")
         result["value_precomp"] = result["callers"]["precomp_graph"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
@@ -692,10 +709,14 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         # activated scales / rotations and handed over as cov3D_precomp) through the same graph path as the headline
         "precomp_graph": dict(mode="precomp", activations="fused", torch_activations=False, torch_adamw=False, forward="async", graph=1),
     }
+    if args.mode in ("scale_rot", "lbs") and args.forward == "async" and args.graph and not args.torch_adamw and args.fused_optimizer:
+        # the headline configuration with the optimizer as a kernel of its own (rounds 1-4's step): gradients into the bucket, flat AdamW
+        specs["unfused_optimizer"] = dict(mode=args.mode, activations=args.activations, torch_activations=args.torch_activations,
+                                          torch_adamw=False, forward="async", graph=1, fused_optimizer=False)
     if args.order == "as_generated" and args.mode in ("scale_rot", "lbs") and args.forward == "async" and args.graph:
         # (the pair is measured the same way -- same harness, same number of replays -- so that their RATIO is the effect of the order)
         same = dict(mode=args.mode, activations=args.activations, torch_activations=args.torch_activations,
-                    torch_adamw=args.torch_adamw, forward="async", graph=1)
+                    torch_adamw=args.torch_adamw, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer))
         specs["as_generated_order"] = dict(same)
         specs["spatial_order"] = dict(same)
     for name, kw in specs.items():

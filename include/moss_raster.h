@@ -32,7 +32,7 @@ extern "C" {
  * caller's knowledge of the device-step block's size (288 bytes in early version-1 builds, 9216 later); diagnostics
  * (environment knobs, stamp buffers) exist only in -DMOSS_DIAG builds.  A binding compiled against another version must refuse to
  * load: compare ITS compile-time MOSS_ABI_VERSION with moss_abi_version(). */
-#define MOSS_ABI_VERSION 3
+#define MOSS_ABI_VERSION 4
 /* Version 3 (round 4): EVERY forward / backward entry point takes the `debug` bit set (version 2: only moss_raster_forward /
  * moss_raster_backward did, so MOSS_DEBUG_NO_BLOCK_CULL was silently dropped on the _async / _tf / _raw paths: last argument before
  * `stream`); moss_adamw_flat_guarded (an optimizer step that a dropped frame turns into a no-op); MOSS_RAW_POSE and the
@@ -381,6 +381,50 @@ int moss_raster_backward_raw(
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
     int raw_flags, int debug, void* stream);
+
+/*
+ * Extension (ABI 4): the raw-parameter backward that also TAKES THE OPTIMIZER STEP.  The Gaussian parameters
+ * of MOSS receive their gradients from this op alone (every loss term of train_ZJU.py:111-131 goes through the rendered image; the
+ * exception is the position, which also feeds the LBS-weight network), and torch.optim.AdamW then streams parameter, gradient and
+ * both moments through the device once more (scene/gaussian_model.py:215-226, train_ZJU.py:204-205).  Here the per-Gaussian backward
+ * kernel, which holds a Gaussian's gradients in registers / LDS when it finishes, applies the AdamW update of the tensors named in
+ * opt->tensors itself: the parameters (= the op's inputs, hence not const here) are updated in place, the moments in
+ * opt->exp_avg / exp_avg_sq, and the gradient of an updated tensor need not be written at all (its dL_d* pointer may be NULL).
+ * Same arithmetic, bit for bit, as moss_adamw_flat_devstep on the same values (both use csrc/adamw.h); a frame that overflowed its
+ * capacity (asynchronous forward) takes no step, like moss_adamw_flat_guarded on the frame's status word.
+ *   Requirements: raw_flags contains MOSS_RAW_OPACITY | MOSS_RAW_SCALE | MOSS_RAW_ROTATION (the inputs must be the parameters
+ *   themselves, not activated copies); MOSS_OPT_SH needs M == 16 and 16-byte aligned shs / moments; MOSS_OPT_MEANS only if the
+ *   means the op sees are the parameter (no transforms, or MOSS_RAW_POSE) and nothing else contributes to its gradient.
+ *   opt->step_state: moss_adamw_state_bytes() zeroed device bytes owned by this optimizer (not shared with a moss_adamw_flat_* call
+ *   of the same step: each launch that is given the block advances the count).
+ * opt == NULL or opt->tensors == 0: exactly moss_raster_backward_raw.
+ */
+#define MOSS_OPT_MEANS 1
+#define MOSS_OPT_SH 2
+#define MOSS_OPT_OPACITY 4
+#define MOSS_OPT_SCALES 8
+#define MOSS_OPT_ROTATIONS 16
+typedef struct moss_fused_adamw {
+    uint32_t tensors;            /* MOSS_OPT_* bits: which parameters this call updates */
+    float* exp_avg[5];           /* first moments, same shapes as the parameters; order: means, sh, opacity, scales, rotations */
+    float* exp_avg_sq[5];        /* second moments */
+    float lr[5];                 /* learning rates, same order; sh: of a Gaussian's first 3 floats (MOSS's features_dc group) */
+    float lr_sh_rest;            /* sh: of the other 45 floats of a record (features_rest) */
+    float beta1, beta2, eps, weight_decay;
+    void* step_state;
+} moss_fused_adamw;
+int moss_raster_backward_raw_adamw(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    float* means3D, float* shs, const float* colors_precomp, float* opacities,
+    float* scales, float scale_modifier, float* rotations, const float* transforms, const float* translation,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
+    const moss_fused_adamw* opt, int raw_flags, int debug, void* stream);
 
 /*
  * Gaussian parameter activations, forward and backward, one launch each (the rasterizer-facing getters of MOSS's GaussianModel,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(_HERE, os.environ.get("MOSS_AMD_LIB_DIR", "lib"))
 LIB_PATH = os.path.join(_LIB_DIR, "libmoss_raster.so")
 EXT_PATH = os.path.join(_LIB_DIR, "_moss_C.so")          # the compiled PyTorch extension (csrc/torch_binding.cpp) over the same C ABI
-ABI_VERSION = 3                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
+ABI_VERSION = 4                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -94,6 +94,8 @@ def _declare(lib):
         _p, _p, _p, _p, _p, _p,
         _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]     # 10 gradient outputs, raw_flags, stream
     lib.moss_raster_mark_visible.restype = _i
+    lib.moss_raster_backward_raw_adamw.restype = _i
+    lib.moss_raster_backward_raw_adamw.argtypes = list(lib.moss_raster_backward_raw.argtypes[:-3]) + [_p] + list(lib.moss_raster_backward_raw.argtypes[-3:])
     lib.moss_raster_mark_visible.argtypes = [_i, _p, _p, _p, _p, _p]
     lib.moss_knn_workspace_bytes.restype = C.c_size_t
     lib.moss_knn_workspace_bytes.argtypes = [_i]
@@ -135,6 +137,16 @@ def _declare(lib):
     lib.moss_raster_export_geometry.argtypes = [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p]
     lib.moss_raster_export_binning.restype = _i
     lib.moss_raster_export_binning.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]
+
+
+class FusedAdamWStruct(C.Structure):
+    """``moss_fused_adamw`` of include/moss_raster.h (host struct handed to ``moss_raster_backward_raw_adamw``)."""
+    _fields_ = [("tensors", C.c_uint32), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_float * 5),
+                ("lr_sh_rest", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("step_state", C.c_void_p)]
+
+
+OPT_BITS = {"means3D": 1, "sh": 2, "opacity": 4, "scales": 8, "rotations": 16}      # MOSS_OPT_*; position = index in the struct's arrays
 
 
 def lib() -> C.CDLL:

@@ -1,0 +1,87 @@
+// adamw.h -- the AdamW element update and the device-resident step counter, shared by the flat update kernel (optim.hip) and by the
+// per-Gaussian backward kernel when it applies the update itself (preprocess.hip, moss_raster_backward_raw_adamw).  Both must give
+// the same bits for the same inputs whatever their translation unit's contraction flags, so every rounding is spelled out.
+// Semantics = torch.optim.AdamW (amsgrad=False, maximize=False): decoupled weight decay, bias-corrected moments
+// (MOSS: scene/gaussian_model.py:215-226).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace moss {
+
+// Words of the step-state block (int32 / float32 views of the same memory; moss_adamw_state_bytes()):
+//   [0] step count t, [8..11] cached bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} for the two parities of t,
+//   [64] global completion counter, [128 + 64 g] completion counter of block group g -- every counter on a 256-byte line of its own.
+constexpr int ADAMW_NGROUPS = 32;
+constexpr int ADAMW_STATE_WORDS = 128 + 64 * ADAMW_NGROUPS;
+
+// p, m, v <- one AdamW step with gradient g.  (Per element a hardware square root and reciprocal, ~1 ulp each: with correctly rounded
+// sqrt / divisions the update was ~40 vector instructions per element, as much issue time as the flat kernel's bytes are HBM time.)
+__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, float lr, float beta1, float beta2, float eps,
+                                              float weight_decay, float inv_bc1, float inv_bc2_sqrt)
+{
+    p = __fmul_rn(p, __fsub_rn(1.0f, __fmul_rn(lr, weight_decay)));
+    m = __fmaf_rn(beta1, m, __fmul_rn(__fsub_rn(1.0f, beta1), g));
+    v = __fmaf_rn(beta2, v, __fmul_rn(__fmul_rn(__fsub_rn(1.0f, beta2), g), g));
+    const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);
+    p = __fmaf_rn(-__fmul_rn(lr, inv_bc1), __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
+}
+
+// Start of a step with the counter on the device (graph replay): returns t (the step being taken) and its bias corrections.  The
+// reads are wave-uniform (scalar loads).  `writer` (ONE thread of the launch, at its start) caches the NEXT step's corrections in
+// the other slot, which nobody reads during this launch (two double pow() at the end of the last block were a 3-5 us serial tail);
+// a launch that may still turn out to be a no-op passes writer = false and calls adamw_cache_next once it knows (a skipped step
+// must leave the whole block bit for bit).
+__device__ __forceinline__ void adamw_cache_next(const float* step_state, float beta1, float beta2, int t)
+{
+    float* sf = const_cast<float*>(step_state);
+    sf[8 + 2 * ((t + 1) & 1)] = (float)(1.0 - pow((double)beta1, (double)(t + 1)));
+    sf[9 + 2 * ((t + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t + 1)));
+}
+
+__device__ __forceinline__ int adamw_step_begin(const float* step_state, float beta1, float beta2, bool writer, float& bc1, float& bc2_sqrt)
+{
+    const int t = reinterpret_cast<const int*>(step_state)[0] + 1;
+    if (t == 1) {                                            // first step ever: nothing cached yet
+        bc1 = (float)(1.0 - pow((double)beta1, 1.0));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, 1.0));
+    } else {                                                 // cached by the previous step (slot = parity of the step)
+        bc1 = step_state[8 + 2 * (t & 1)]; bc2_sqrt = step_state[9 + 2 * (t & 1)];
+    }
+    if (writer) adamw_cache_next(step_state, beta1, beta2, t);
+    return t;
+}
+
+// End of a step: called by ONE thread of every block after the block's last use of the step word.  The LAST block of the launch
+// stores t back (after every block has read the old value): no separate "tick" launch (a minimal launch costs 4-5 us here).
+// Two-level completion count, every counter on a 256-byte line of its own: atomics on words of ONE cache line execute one after the
+// other for the whole device (~11 ns each, profiles/r02_notes.md finding 1).
+__device__ __forceinline__ void adamw_step_end(const float* step_state, int t)
+{
+    int* st = reinterpret_cast<int*>(const_cast<float*>(step_state));
+    const int grp = (int)(blockIdx.x % (unsigned)ADAMW_NGROUPS);
+    const int grp_size = ((int)gridDim.x - grp + ADAMW_NGROUPS - 1) / ADAMW_NGROUPS;      // blocks with this group id
+    const int n_groups = min((int)gridDim.x, ADAMW_NGROUPS);
+    if (atomicAdd(&st[128 + 64 * grp], 1) == grp_size - 1) {
+        st[128 + 64 * grp] = 0;
+        if (atomicAdd(&st[64], 1) == n_groups - 1) {
+            st[0] = t; st[64] = 0;
+        }
+    }
+}
+
+// The update of the Gaussian parameters as the per-Gaussian backward kernel applies it (include/moss_raster.h: moss_fused_adamw).
+// Order of the five tensors: means, sh, opacity, scales, rotations.
+constexpr uint32_t OPT_MEANS = 1u, OPT_SH = 2u, OPT_OPACITY = 4u, OPT_SCALES = 8u, OPT_ROTATIONS = 16u;
+struct FusedAdam {
+    uint32_t tensors = 0u;                                   // which tensors the kernel updates (0: none, a plain backward)
+    float* p[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };       // the parameters themselves (= the op's inputs), written in place
+    float* m[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    float* v[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    float lr[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+    float lr_sh_rest = 0.f;                                  // sh: lr[1] for a Gaussian's first 3 floats (features_dc), this for the other 45
+    float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f, weight_decay = 0.f;
+    const float* step_state = nullptr;
+};
+
+}  // namespace moss

@@ -267,13 +267,15 @@ struct FrameParams {
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                                const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s);
+struct FusedAdam;
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* opacities /* only read in raw mode */,
                                 const float* scales, const float* rotations, const float* cov3D_precomp,
                                 GeomView g, BinView b, const uint32_t* header, uint32_t* queues /* backward heads are rewound here */,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                                const float* transforms, float* dL_dtransforms, const float* translation, float* dL_dtranslation, hipStream_t s);
+                                const float* transforms, float* dL_dtransforms, const float* translation, float* dL_dtranslation, hipStream_t s,
+                                const struct FusedAdam* fused = nullptr /* adamw.h: the kernel also applies the AdamW update */);
 void launch_mark_visible(int P, const float* means3D, const float* view16_dev, uint8_t* present, hipStream_t s);
 
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);

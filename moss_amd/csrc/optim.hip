@@ -5,6 +5,7 @@
 // groups differ only in learning rate, looked up from a small segment table.
 // Semantics = torch.optim.AdamW (amsgrad=False, maximize=False): decoupled weight decay, bias-corrected moments.
 #include "common.h"
+#include "adamw.h"
 
 namespace moss {
 namespace {
@@ -21,25 +22,8 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     // `first`: the arrays are the elements [first, first + n) of the flat buffers the segment table indexes (a rank's shard of the
     // bucket, moss_adamw_flat_range); a multiple of 4, so that a thread's four elements never straddle it.
     int t_dev = 0;
-    if (step_state) {
-        // Device-resident step counter (graph replay): the LAST block of a step to finish stores t back and caches the bias
-        // corrections of step t + 1 (double precision like the host path), which is after every block has read the old values.
-        // No separate "tick" launch (a minimal launch costs 4-5 us here).  The reads are wave-uniform (scalar loads): no barrier.
-        t_dev = reinterpret_cast<const int*>(step_state)[0] + 1;
-        if (t_dev == 1) {                                    // first step ever: nothing cached yet
-            bc1 = (float)(1.0 - pow((double)beta1, 1.0));
-            bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, 1.0));
-        } else {                                             // cached by the previous step (slot = parity of the step)
-            bc1 = step_state[8 + 2 * (t_dev & 1)]; bc2_sqrt = step_state[9 + 2 * (t_dev & 1)];
-        }
-        // the NEXT step's corrections go to the other slot, computed by one thread at the START of this launch (two double pow()
-        // at the end of the last block were a 3-5 us serial tail); nobody reads that slot during this launch
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            float* sf = const_cast<float*>(step_state);
-            sf[8 + 2 * ((t_dev + 1) & 1)] = (float)(1.0 - pow((double)beta1, (double)(t_dev + 1)));
-            sf[9 + 2 * ((t_dev + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t_dev + 1)));
-        }
-    }
+    if (step_state)                                          // device-resident step counter (graph replay): adamw.h
+        t_dev = adamw_step_begin(step_state, beta1, beta2, blockIdx.x == 0 && threadIdx.x == 0, bc1, bc2_sqrt);
     // (once per thread, correctly rounded; per ELEMENT: a hardware square root and reciprocal, ~1 ulp each -- with this file's correctly
     // rounded sqrt / divisions the update was ~40 vector instructions per element, ten million per step: as much issue time as the
     // kernel's 165 MB are HBM time)
@@ -92,14 +76,8 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float lr = lr4[k];
-            pv[k] *= 1.0f - lr * weight_decay;
-            mv[k] = beta1 * mv[k] + (1.0f - beta1) * gv[k];
-            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
-            const float denom = __builtin_amdgcn_sqrtf(vv[k]) * inv_bc2_sqrt + eps;
-            pv[k] -= (lr * inv_bc1) * (mv[k] * __builtin_amdgcn_rcpf(denom));
-        }
+        for (int k = 0; k < 4; k++)
+            adamw_element(pv[k], gv[k], mv[k], vv[k], lr4[k], beta1, beta2, eps, weight_decay, inv_bc1, inv_bc2_sqrt);
         if (full) {
             reinterpret_cast<float4*>(p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
             reinterpret_cast<float4*>(m)[i4] = make_float4(mv[0], mv[1], mv[2], mv[3]);
@@ -108,23 +86,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             for (int k = 0; k < 4; k++) if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
         }
     }
-    if (step_state && threadIdx.x == 0) {
-        int* st = reinterpret_cast<int*>(const_cast<float*>(step_state));
-        // Two-level completion count, EVERY counter on a 256-byte line of its own: 32 group counters (words 128 + 64 g), then one
-        // global counter (word 64).  Atomics on words of ONE cache line execute one after the other for the whole device (~11 ns
-        // each, profiles/r02_notes.md finding 1): round 2 kept 64 group counters in two lines, so the 4096 blocks' atomics were a
-        // ~6 us tail of this kernel (26 us with a host-side step count, 32 us with the device-side one).
-        constexpr int NGROUPS = 32;
-        const int grp = (int)(blockIdx.x % (unsigned)NGROUPS);
-        const int grp_size = ((int)gridDim.x - grp + NGROUPS - 1) / NGROUPS;      // blocks with this group id
-        const int n_groups = min((int)gridDim.x, NGROUPS);
-        if (atomicAdd(&st[128 + 64 * grp], 1) == grp_size - 1) {
-            st[128 + 64 * grp] = 0;
-            if (atomicAdd(&st[64], 1) == n_groups - 1) {
-                st[0] = t_dev; st[64] = 0;
-            }
-        }
-    }
+    if (step_state && threadIdx.x == 0) adamw_step_end(step_state, t_dev);
 }
 
 int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
@@ -178,6 +140,7 @@ extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* 
                               (hipStream_t)stream);
 }
 
+static_assert(moss::ADAMW_STATE_WORDS * 4 <= MOSS_ADAMW_STATE_BYTES, "the step-state block of adamw.h must fit the size the header promises");
 extern "C" size_t moss_adamw_state_bytes(void) { return MOSS_ADAMW_STATE_BYTES; }
 
 // A rank's SHARD of the flat bucket (reduce-scatter -> AdamW on 1/N of the elements -> all-gather of the parameters, moss_amd/dist.py):

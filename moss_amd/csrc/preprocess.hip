@@ -10,6 +10,7 @@
 //   conic / radius    forward.cu:218-237         SH -> RGB    forward.cu:20-71
 // These kernels stream ~100-300 B per Gaussian and are HBM-bound; contraction would buy nothing.
 #include "common.h"
+#include "adamw.h"
 
 namespace moss {
 
@@ -758,7 +759,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ opacities /* raw mode only */, int raw,
                            unsigned long long* __restrict__ g_stamps_dev /* diagnostics: 8 words per block, else NULL */,
                            uint32_t* __restrict__ queues,
-                           const float* __restrict__ translation /* RAW_POSE only, may be NULL */, float* __restrict__ dL_dtranslation /* may be NULL */)
+                           const float* __restrict__ translation /* RAW_POSE only, may be NULL */, float* __restrict__ dL_dtranslation /* may be NULL */,
+                           FusedAdam fa /* fa.tensors != 0: this kernel also applies the AdamW update of those parameters (adamw.h) */)
 {
     // Rewind the work-queue heads of the blend-backward kernel that ran just before this one on the stream, so that another backward
     // over the same forward state (retain_graph) starts from zero again.  (The forward clears them per frame; doing it HERE instead
@@ -767,6 +769,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         const int line = threadIdx.x < NUM_XCD_QUEUES ? Q_BWD + (int)threadIdx.x : Q_SEG_HEAD + (int)threadIdx.x - NUM_XCD_QUEUES;
         queues[(size_t)line * QLINE_WORDS] = 0u;
     }
+    // Fused AdamW (fa.tensors != 0): the step count and its bias corrections, read now (scalar loads, used at the very end)
+    float fa_bc1 = 1.0f, fa_bc2_sqrt = 1.0f;
+    int fa_t = 0;
+    if (fa.tensors != 0u) fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then dL_dsh out (in place)
 #define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
 #define PRSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime()
@@ -818,6 +824,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
     // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
     const bool visible = n_inst > 0 && !(hdr_flags & ERRFLAG_OVERFLOW);
+    // a frame that overflowed its capacity rendered nothing: its optimizer step is a no-op (parameters, moments and the step count
+    // stay bit for bit), like moss_adamw_flat_guarded on the frame's status word
+    const bool fa_on = fa.tensors != 0u && !(hdr_flags & ERRFLAG_OVERFLOW);
+    if (fa_on && blockIdx.x == 0 && threadIdx.x == 0) adamw_cache_next(fa.step_state, fa.beta1, fa.beta2, fa_t);   // (the next step's bias corrections)
 
     // Sum the per-instance partial records.  A Gaussian with few instances (the norm: 2-3) is summed by its own lane.  One that
     // covers much of the image owns up to gx*gy instances x `slabs` records -- a serial sum of thousands of 48-byte gathers -- so
@@ -1047,7 +1057,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         const float sg = sigmoid_act(opacities[idx]);
         gop = gop * ((1.0f - sg) * sg);
     }
-    dL_dopacity[idx] = gop;
+    if (dL_dopacity != nullptr) dL_dopacity[idx] = gop;
     dL_dcolor[3 * (size_t)idx] = gcol.x; dL_dcolor[3 * (size_t)idx + 1] = gcol.y; dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
 
     float* dsh = STAGE_SH ? &s_dsh[threadIdx.x * SH_ROW]
@@ -1141,13 +1151,18 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         for (int k = 0; k < 3 * M; k++) dsh[k] = 0.0f;
     }
 
+    // (with the fused update the gradients of the updated tensors need not leave the kernel: NULL = not wanted)
+    if (dL_dmean3D != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) dL_dmean3D[3 * (size_t)idx + i] = dmean[i];
+        for (int i = 0; i < 3; i++) dL_dmean3D[3 * (size_t)idx + i] = dmean[i];
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    if (dL_dscale != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
-    reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+        for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
+    }
+    if (dL_drot != nullptr) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
     if (dL_dtransforms != nullptr) {
 #pragma unroll
         for (int i = 0; i < 9; i++) dL_dtransforms[9 * (size_t)idx + i] = dtf[i];
@@ -1156,19 +1171,103 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
         for (int i = 0; i < 3; i++) dL_dtranslation[3 * (size_t)idx + i] = dpose_t[i];
     }
+    // ---- fused AdamW, the eleven per-Gaussian scalars (position, opacity, scale, rotation): this thread's own parameters, read
+    //      above by nobody else; every Gaussian takes the step, with zero gradients if it was not rendered (torch.optim.AdamW does
+    //      the same: the moments decay).  All loads first, then the arithmetic, then the stores.
+    if (fa_on && (fa.tensors & (OPT_MEANS | OPT_OPACITY | OPT_SCALES | OPT_ROTATIONS))) {
+        const float ib1 = 1.0f / fa_bc1, ib2 = 1.0f / fa_bc2_sqrt;
+        const size_t i3 = 3 * (size_t)idx, i4 = 4 * (size_t)idx;
+        const bool u_mean = fa.tensors & OPT_MEANS, u_opa = fa.tensors & OPT_OPACITY, u_scl = fa.tensors & OPT_SCALES, u_rot = fa.tensors & OPT_ROTATIONS;
+        float pv[11], mv[11], vv[11];
+#pragma unroll
+        for (int i = 0; i < 11; i++) { pv[i] = 0.f; mv[i] = 0.f; vv[i] = 0.f; }
+        if (u_mean) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pv[i] = fa.p[0][i3 + i]; mv[i] = fa.m[0][i3 + i]; vv[i] = fa.v[0][i3 + i]; }
+        }
+        if (u_opa) { pv[3] = fa.p[2][idx]; mv[3] = fa.m[2][idx]; vv[3] = fa.v[2][idx]; }
+        if (u_scl) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pv[4 + i] = fa.p[3][i3 + i]; mv[4 + i] = fa.m[3][i3 + i]; vv[4 + i] = fa.v[3][i3 + i]; }
+        }
+        if (u_rot) {
+            const float4 a = reinterpret_cast<const float4*>(fa.p[4])[idx], b = reinterpret_cast<const float4*>(fa.m[4])[idx], c = reinterpret_cast<const float4*>(fa.v[4])[idx];
+            pv[7] = a.x; pv[8] = a.y; pv[9] = a.z; pv[10] = a.w; mv[7] = b.x; mv[8] = b.y; mv[9] = b.z; mv[10] = b.w;
+            vv[7] = c.x; vv[8] = c.y; vv[9] = c.z; vv[10] = c.w;
+        }
+        const float gv[11] = { dmean[0], dmean[1], dmean[2], gop, dscale[0], dscale[1], dscale[2], drot[0], drot[1], drot[2], drot[3] };
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float lr = i < 3 ? fa.lr[0] : i == 3 ? fa.lr[2] : i < 7 ? fa.lr[3] : fa.lr[4];
+            adamw_element(pv[i], gv[i], mv[i], vv[i], lr, fa.beta1, fa.beta2, fa.eps, fa.weight_decay, ib1, ib2);
+        }
+        if (u_mean) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { fa.p[0][i3 + i] = pv[i]; fa.m[0][i3 + i] = mv[i]; fa.v[0][i3 + i] = vv[i]; }
+        }
+        if (u_opa) { fa.p[2][idx] = pv[3]; fa.m[2][idx] = mv[3]; fa.v[2][idx] = vv[3]; }
+        if (u_scl) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { fa.p[3][i3 + i] = pv[4 + i]; fa.m[3][i3 + i] = mv[4 + i]; fa.v[3][i3 + i] = vv[4 + i]; }
+        }
+        if (u_rot) {
+            reinterpret_cast<float4*>(fa.p[4])[idx] = make_float4(pv[7], pv[8], pv[9], pv[10]);
+            reinterpret_cast<float4*>(fa.m[4])[idx] = make_float4(mv[7], mv[8], mv[9], mv[10]);
+            reinterpret_cast<float4*>(fa.v[4])[idx] = make_float4(vv[7], vv[8], vv[9], vv[10]);
+        }
+        (void)i4;
+    }
     }   // in_range
     PSTAMP(5);
     if (STAGE_SH) {
         __syncthreads();                                     // every row now holds dL_dsh
-        float4* dst = reinterpret_cast<float4*>(dL_dsh);
-        for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
-            const int gi = gaussian_of_row(f / 12);
-            if (gi < P) {
-                const float* r = &s_dsh[(f / 12) * SH_ROW + (f % 12) * 4];
-                dst[(size_t)gi * 12 + (size_t)(f % 12)] = make_float4(r[0], r[1], r[2], r[3]);
+        if (dL_dsh != nullptr) {
+            float4* dst = reinterpret_cast<float4*>(dL_dsh);
+            for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
+                const int gi = gaussian_of_row(f / 12);
+                if (gi < P) {
+                    const float* r = &s_dsh[(f / 12) * SH_ROW + (f % 12) * 4];
+                    dst[(size_t)gi * 12 + (size_t)(f % 12)] = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+        // ---- fused AdamW, the SH records (48 of a Gaussian's 59 parameters): the gradient rows are in LDS; parameters and both
+        //      moments come and go as the block's 12 coalesced float4 per lane (the parameters were read by this block at its start:
+        //      cache hits mostly).  All 36 loads are requested before the first is used.  Learning rate: lr[1] for a record's first
+        //      three floats (MOSS's features_dc group), lr_sh_rest for the other 45 (features_rest, scene/gaussian_model.py:218-219).
+        if (fa_on && (fa.tensors & OPT_SH)) {
+            const float ib1 = 1.0f / fa_bc1, ib2 = 1.0f / fa_bc2_sqrt;
+            float4* const pw = reinterpret_cast<float4*>(fa.p[1]);
+            float4* const mw = reinterpret_cast<float4*>(fa.m[1]);
+            float4* const vw = reinterpret_cast<float4*>(fa.v[1]);
+            float4 p4[12], m4[12], v4[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const int f = (int)threadIdx.x + j * (int)blockDim.x;
+                const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
+                p4[j] = pw[a]; m4[j] = mw[a]; v4[j] = vw[a];
+            }
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const int f = (int)threadIdx.x + j * (int)blockDim.x, part = f % 12, gi = gaussian_of_row(f / 12);
+                const float* r = &s_dsh[(f / 12) * SH_ROW + part * 4];
+                float pe[4] = { p4[j].x, p4[j].y, p4[j].z, p4[j].w }, me[4] = { m4[j].x, m4[j].y, m4[j].z, m4[j].w };
+                float ve[4] = { v4[j].x, v4[j].y, v4[j].z, v4[j].w };
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    adamw_element(pe[k], r[k], me[k], ve[k], (part == 0 && k < 3) ? fa.lr[1] : fa.lr_sh_rest, fa.beta1, fa.beta2, fa.eps,
+                                  fa.weight_decay, ib1, ib2);
+                if (gi < P) {
+                    const size_t a = (size_t)gi * 12 + (size_t)part;
+                    pw[a] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+                    mw[a] = make_float4(me[0], me[1], me[2], me[3]);
+                    vw[a] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                }
             }
         }
     }
+    // the step word was read at this block's start: the last block to get here stores the new count (adamw.h)
+    if (fa_on && threadIdx.x == 0) adamw_step_end(fa.step_state, fa_t);
     PSTAMP(6); PRSTAMP(14);
 #undef PSTAMP
 #undef PRSTAMP
@@ -1248,9 +1347,11 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                                 GeomView g, BinView b, const uint32_t* header, uint32_t* queues,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                                const float* transforms, float* dL_dtransforms, const float* translation, float* dL_dtranslation, hipStream_t s)
+                                const float* transforms, float* dL_dtransforms, const float* translation, float* dL_dtranslation, hipStream_t s,
+                                const FusedAdam* fused)
 {
     (void)colors_precomp;
+    const FusedAdam fa = fused ? *fused : FusedAdam();
     static const int threads = std::max(64, knob("MOSS_PREBWD_THREADS", 64) & ~63);
     // Rows of a block = groups of 2^gl2 consecutive Gaussians (gaussian_of_row); 6 = the block's 64 rows are consecutive: the default.
     // When the caller says that index neighbours are spatial neighbours (MOSS_HINT_SPATIAL_ORDER) 64 consecutive Gaussians are all-heavy
@@ -1261,7 +1362,9 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     static const int gl2_env = knob("MOSS_PREBWD_GROUP_LOG2", 0);
     static const int gather_knob = knob("MOSS_GATHER", 0) == 1 ? 0x200 : knob("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     const int blocks = (fp.P + threads - 1) / threads;
-    const bool stage = fp.M == 16 && shs != nullptr && dL_dsh != nullptr && knob("MOSS_PREBWD_STAGE", 1) &&
+    // (the fused update of the SH records works on the staged rows: raster_api.hip refuses it unless M == 16 and the arrays are aligned)
+    const bool stage = fp.M == 16 && shs != nullptr && (dL_dsh != nullptr || (fa.tensors & OPT_SH)) &&
+                       (knob("MOSS_PREBWD_STAGE", 1) || (fa.tensors & OPT_SH)) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
     const size_t lds_bytes_staged = (size_t)threads * SH_ROW * sizeof(float) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4;
     static const int resident_per_cu = [&] {
@@ -1277,7 +1380,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, -0.5f * (float)fp.W, -0.5f * (float)fp.H, fp.scale_modifier, \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues, translation, dL_dtranslation)
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues, translation, dL_dtranslation, fa)
     if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
 #undef LAUNCH_PB
 }

@@ -2,6 +2,7 @@
 // Stage order follows CudaRasterizer::Rasterizer::forward / ::backward
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:198-341, :345-447); the stages themselves are this library's own.
 #include "common.h"
+#include "adamw.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -289,7 +290,7 @@ static int backward_impl(
     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug_flags, void* stream,
     const float* transforms, float* dL_dtransforms, const float* opacities = nullptr, int raw_flags = 0,
-    const float* translation = nullptr, float* dL_dtranslation = nullptr)
+    const float* translation = nullptr, float* dL_dtranslation = nullptr, const moss_fused_adamw* opt = nullptr)
 {
     (void)alphas; (void)radii;
     const int debug = debug_flags & MOSS_DEBUG_SYNC;
@@ -299,9 +300,37 @@ static int backward_impl(
     if (P == 0) return 0;                                                 // rasterize_points.cu:168
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(MOSS_ERR_INVALID_ARG, "null scratch buffer");
     if (!dL_dpix && !dL_ddepths && !dL_dalphas) return fail(MOSS_ERR_INVALID_ARG, "all three incoming gradients are NULL");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+    // (the gradient of a tensor whose AdamW update this call applies itself may stay inside the kernel)
+    const uint32_t fused = opt ? opt->tensors : 0u;
+    if (!dL_dmean2D || !dL_dconic || !dL_dcolor || !dL_dcov3D || (!dL_dopacity && !(fused & OPT_OPACITY)) || (!dL_dmean3D && !(fused & OPT_MEANS)) ||
+        (!dL_dscale && !(fused & OPT_SCALES)) || (!dL_drot && !(fused & OPT_ROTATIONS)))
         return fail(MOSS_ERR_INVALID_ARG, "null gradient output");
-    if (shs && !dL_dsh) return fail(MOSS_ERR_INVALID_ARG, "dL_dsh is NULL although shs is given");
+    if (shs && !dL_dsh && !(fused & OPT_SH)) return fail(MOSS_ERR_INVALID_ARG, "dL_dsh is NULL although shs is given");
+    FusedAdam fa;
+    if (fused) {
+        if (fused & ~(OPT_MEANS | OPT_SH | OPT_OPACITY | OPT_SCALES | OPT_ROTATIONS)) return fail(MOSS_ERR_INVALID_ARG, "unknown bits in moss_fused_adamw.tensors");
+        if ((raw_flags & (RAW_OPACITY | RAW_SCALE | RAW_ROTATION)) != (RAW_OPACITY | RAW_SCALE | RAW_ROTATION) || cov3D_precomp)
+            return fail(MOSS_ERR_INVALID_ARG, "the fused AdamW update works on the raw parameters: MOSS_RAW_OPACITY | MOSS_RAW_SCALE | MOSS_RAW_ROTATION");
+        if ((fused & OPT_MEANS) && transforms && !(raw_flags & RAW_POSE))
+            return fail(MOSS_ERR_INVALID_ARG, "MOSS_OPT_MEANS: with transforms the position parameter is only what the op sees under MOSS_RAW_POSE");
+        if (!opt->step_state) return fail(MOSS_ERR_INVALID_ARG, "moss_fused_adamw.step_state is NULL");
+        const float* params[5] = { means3D, shs, opacities, scales, rotations };
+        for (int i = 0; i < 5; i++) {
+            if (!(fused & (1u << i))) continue;
+            if (!params[i] || !opt->exp_avg[i] || !opt->exp_avg_sq[i]) return fail(MOSS_ERR_INVALID_ARG, "a tensor named in moss_fused_adamw.tensors has a NULL parameter or moment array");
+            fa.p[i] = const_cast<float*>(params[i]); fa.m[i] = opt->exp_avg[i]; fa.v[i] = opt->exp_avg_sq[i]; fa.lr[i] = opt->lr[i];
+        }
+        if (fused & OPT_SH) {
+            if (M != 16 || ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(opt->exp_avg[1]) | reinterpret_cast<uintptr_t>(opt->exp_avg_sq[1]) |
+                             reinterpret_cast<uintptr_t>(dL_dsh)) & 15u))
+                return fail(MOSS_ERR_INVALID_ARG, "MOSS_OPT_SH needs M == 16 and 16-byte aligned SH, moment and gradient arrays");
+        }
+        if ((fused & OPT_ROTATIONS) && ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(opt->exp_avg[4]) | reinterpret_cast<uintptr_t>(opt->exp_avg_sq[4])) & 15u))
+            return fail(MOSS_ERR_INVALID_ARG, "MOSS_OPT_ROTATIONS needs 16-byte aligned rotation and moment arrays");
+        fa.tensors = fused; fa.lr_sh_rest = opt->lr_sh_rest;
+        fa.beta1 = opt->beta1; fa.beta2 = opt->beta2; fa.eps = opt->eps; fa.weight_decay = opt->weight_decay;
+        fa.step_state = reinterpret_cast<const float*>(opt->step_state);
+    }
     if (!means3D || !viewmatrix || !projmatrix || !campos || !background) return fail(MOSS_ERR_INVALID_ARG, "null required input");
 
     GeomView g = GeomView::at(geom_buffer, P);
@@ -319,7 +348,7 @@ static int backward_impl(
     { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
       launch_preprocess_backward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, im.header, im.queues,
                                  dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                                 transforms, dL_dtransforms, translation, dL_dtranslation, s); }
+                                 transforms, dL_dtransforms, translation, dL_dtranslation, s, fused ? &fa : nullptr); }
     STAGE_CHECK("preprocess_backward");
     return 0;
 }
@@ -407,6 +436,32 @@ int moss_raster_backward_raw(
                          image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
                          dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, transforms, transforms ? dL_dtransforms : nullptr, opacities,
                          raw_flags, translation, dL_dtranslation);
+}
+
+// The raw-parameter backward that also takes the AdamW step of the parameters named in opt->tensors (include/moss_raster.h).
+int moss_raster_backward_raw_adamw(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    float* means3D, float* shs, const float* colors_precomp, float* opacities,
+    float* scales, float scale_modifier, float* rotations, const float* transforms, const float* translation,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
+    const moss_fused_adamw* opt, int raw_flags, int debug, void* stream)
+{
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (P > 0 && (raw_flags & RAW_POSE) && !transforms) return fail(MOSS_ERR_INVALID_ARG, "MOSS_RAW_POSE needs the transforms");
+    if ((translation || dL_dtranslation) && !(raw_flags & RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "a translation comes with MOSS_RAW_POSE");
+    if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))
+        return fail(MOSS_ERR_INVALID_ARG, "scales and rotations (and dL_dtransforms with transforms) are required");
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, nullptr, scales, scale_modifier, rotations,
+                         nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, nullptr, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, transforms, transforms ? dL_dtransforms : nullptr, opacities,
+                         raw_flags, translation, dL_dtranslation, (opt && opt->tensors) ? opt : nullptr);
 }
 
 int moss_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -177,9 +177,15 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                              const c10::optional<torch::Tensor>& transforms, int64_t raw_flags, const c10::optional<torch::Tensor>& opacities,
                              const c10::optional<torch::Tensor>& sink_means3D, const c10::optional<torch::Tensor>& sink_opacity,
                              const c10::optional<torch::Tensor>& sink_sh, const c10::optional<torch::Tensor>& sink_scales,
-                             const c10::optional<torch::Tensor>& sink_rotations, const c10::optional<torch::Tensor>& translation)
+                             const c10::optional<torch::Tensor>& sink_rotations, const c10::optional<torch::Tensor>& translation,
+                             int64_t fused_adamw /* address of a host moss_fused_adamw the caller keeps alive, or 0 */)
 {
     const int P = static_cast<int>(means3D.size(0));
+    // The tensors whose AdamW update the backward kernel applies itself (moss_raster_backward_raw_adamw): their gradients stay inside
+    // the kernel and come back as None.
+    const moss_fused_adamw* opt = reinterpret_cast<const moss_fused_adamw*>(static_cast<intptr_t>(fused_adamw));
+    const uint32_t fused = (opt != nullptr && P != 0) ? opt->tensors : 0u;
+    TORCH_CHECK(!fused || raw_flags, "the fused AdamW update needs the raw-parameter backward (raw_flags)");
     const int H = static_cast<int>(alphas.size(-2)), W = static_cast<int>(alphas.size(-1));   // incoming gradients may be absent (= zeros)
     const int M = sh.numel() != 0 ? static_cast<int>(sh.size(1)) : 0;
     const bool has_tf = transforms.has_value() && transforms->defined();
@@ -189,15 +195,15 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     // element exactly once, so plain allocations suffice.  P == 0 keeps the reference's zeros.
     const bool z = P == 0;
     auto mk = [&](at::IntArrayRef shape) { return z ? torch::zeros(shape, fopts) : torch::empty(shape, fopts); };
-    torch::Tensor dL_dmeans3D = out_or_sink(sink_means3D, {P, 3}, fopts, z);
+    torch::Tensor dL_dmeans3D = (fused & MOSS_OPT_MEANS) ? torch::Tensor() : out_or_sink(sink_means3D, {P, 3}, fopts, z);
     torch::Tensor dL_dmeans2D = mk({P, 3});
     torch::Tensor dL_dcolors = mk({P, NUM_CHANNELS});
     torch::Tensor dL_dconic = mk({P, 2, 2});
-    torch::Tensor dL_dopacity = out_or_sink(sink_opacity, {P, 1}, fopts, z);
+    torch::Tensor dL_dopacity = (fused & MOSS_OPT_OPACITY) ? torch::Tensor() : out_or_sink(sink_opacity, {P, 1}, fopts, z);
     torch::Tensor dL_dcov3D = mk({P, 6});
-    torch::Tensor dL_dsh = M != 0 ? out_or_sink(sink_sh, {P, M, 3}, fopts, z) : mk({P, M, 3});
-    torch::Tensor dL_dscales = out_or_sink(sink_scales, {P, 3}, fopts, z);
-    torch::Tensor dL_drotations = out_or_sink(sink_rotations, {P, 4}, fopts, z);
+    torch::Tensor dL_dsh = (fused & MOSS_OPT_SH) ? torch::Tensor() : M != 0 ? out_or_sink(sink_sh, {P, M, 3}, fopts, z) : mk({P, M, 3});
+    torch::Tensor dL_dscales = (fused & MOSS_OPT_SCALES) ? torch::Tensor() : out_or_sink(sink_scales, {P, 3}, fopts, z);
+    torch::Tensor dL_drotations = (fused & MOSS_OPT_ROTATIONS) ? torch::Tensor() : out_or_sink(sink_rotations, {P, 4}, fopts, z);
     torch::Tensor dL_dtransforms = has_tf ? mk({P, 3, 3}) : torch::Tensor();
     const bool has_tl = translation.has_value() && translation->defined() && translation->numel() != 0;
     torch::Tensor dL_dtranslation = has_tl ? mk({P, 3}) : torch::Tensor();
@@ -205,7 +211,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
         std::vector<torch::Tensor> keep;
         keep.reserve(20);
         void* stream = c10::hip::getCurrentHIPStream(means3D.device().index()).stream();
-        auto f = [](torch::Tensor& t) { return reinterpret_cast<float*>(t.data_ptr()); };
+        auto f = [](torch::Tensor& t) { return t.defined() ? reinterpret_cast<float*>(t.data_ptr()) : nullptr; };
         const float* p_bg = ptr(background, "background", keep);
         const float* p_means = ptr(means3D, "means3D", keep);
         const float* p_sh = ptr(sh, "sh", keep);
@@ -225,7 +231,19 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
         const float* g_a = ptr(dL_dout_alpha, "dL_dout_alpha", keep);
         float* p_dsh = M ? f(dL_dsh) : nullptr;
         int rc;
-        if (raw_flags) {
+        if (fused) {
+            // the parameters are updated IN PLACE: they must be the caller's own contiguous float32 tensors, not copies made here
+            TORCH_CHECK(opacities.has_value() && opacities->defined(), "the raw-parameter backward needs the raw opacities");
+            for (const torch::Tensor* t : { &means3D, &sh, &*opacities, &scales, &rotations })
+                TORCH_CHECK(t->is_contiguous() && t->scalar_type() == torch::kFloat32, "fused AdamW update: the parameters must be contiguous float32 tensors");
+            rc = moss_raster_backward_raw_adamw(P, (int)degree, M, (int)R, p_bg, W, H, const_cast<float*>(p_means), const_cast<float*>(p_sh), p_col,
+                                                const_cast<float*>(ptr(*opacities, "opacity", keep)), const_cast<float*>(p_scl),
+                                                (float)scale_modifier, const_cast<float*>(p_rot), p_tf, has_tl ? ptr(*translation, "translation", keep) : nullptr,
+                                                p_view, p_proj, p_cam, (float)tan_fovx, (float)tan_fovy, p_geom,
+                                                p_bin, p_img, g_c, g_d, g_a, f(dL_dmeans2D), f(dL_dconic), f(dL_dopacity), f(dL_dcolors), f(dL_dmeans3D),
+                                                f(dL_dcov3D), p_dsh, f(dL_dscales), f(dL_drotations), has_tf ? f(dL_dtransforms) : nullptr,
+                                                has_tl ? f(dL_dtranslation) : nullptr, opt, (int)raw_flags, (int)debug, stream);
+        } else if (raw_flags) {
             TORCH_CHECK(opacities.has_value() && opacities->defined(), "the raw-parameter backward needs the raw opacities");
             rc = moss_raster_backward_raw(P, (int)degree, M, (int)R, p_bg, W, H, p_means, p_sh, p_col, ptr(*opacities, "opacity", keep), p_scl,
                                           (float)scale_modifier, p_rot, p_tf, has_tl ? ptr(*translation, "translation", keep) : nullptr,
@@ -285,7 +303,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"), py::arg("alphas"), py::arg("debug"),
           py::arg("transforms") = py::none(), py::arg("raw_flags") = 0, py::arg("opacities") = py::none(),
           py::arg("sink_means3D") = py::none(), py::arg("sink_opacity") = py::none(), py::arg("sink_sh") = py::none(),
-          py::arg("sink_scales") = py::none(), py::arg("sink_rotations") = py::none(), py::arg("translation") = py::none());
+          py::arg("sink_scales") = py::none(), py::arg("sink_rotations") = py::none(), py::arg("translation") = py::none(),
+          py::arg("fused_adamw") = 0);
     m.def("mark_visible", &mark_visible);
     // the version of the header THIS module was compiled against (not the library's answer: moss_amd/_lib.py compares the two, so a
     // stale _moss_C.so next to a rebuilt libmoss_raster.so refuses to load instead of passing arguments in the old layout)

@@ -60,6 +60,7 @@ class RasterContext:
         self.last_img_buffer = None  # image buffer (holds the status header) of the most recent asynchronous forward
         self.last_num_rendered = 0
         self.sinks = dict.fromkeys(_SINK_NAMES)
+        self.fused_adamw = None                              # FlatAdamW.fuse_into_backward: the backward kernel takes the optimizer step
         self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
         self._retired_frame_states = []   # outgrown blocks: a captured hipGraph may still hold their address (see _frame_state)
         self._raised_overflows = 0        # overflows of this context already raised as CapacityOverflow (not "dropped by a replay")
@@ -235,11 +236,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     cx = context or DEFAULT
     if int(raw_flags) and opacities is None and means3D.size(0) != 0:
         raise RuntimeError("the raw-parameter backward needs the raw opacities")
+    fused = 0
+    if cx.fused_adamw is not None and means3D.size(0) != 0:
+        if not int(raw_flags):
+            raise RuntimeError("this context's optimizer step is fused into the backward (FlatAdamW.fuse_into_backward): the op must be "
+                               "given the raw parameters (raw_flags)")
+        cx.fused_adamw.check_inputs(means3D=means3D, sh=sh, opacity=opacities, scales=scales, rotations=rotations)
+        fused = cx.fused_adamw.address
     return tuple(ext().rasterize_gaussians_backward(
         background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
         float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, int(degree), campos, geomBuffer, int(R),
         binningBuffer, imageBuffer, alphas, int(debug), transforms, int(raw_flags), opacities,
-        cx._sink("means3D"), cx._sink("opacity"), cx._sink("sh"), cx._sink("scales"), cx._sink("rotations"), translation))
+        *(None if (fused and n in cx.fused_adamw.param_ptrs) else cx._sink(n) for n in ("means3D", "opacity", "sh", "scales", "rotations")),
+        translation, fused))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -72,34 +72,40 @@ def shard_views(num_views: int, rank: int, world: int):
 
 class GradBucket:
     """One flat fp32 buffer for all parameter gradients (+4 slots for the loss and its three terms); a single all-reduce
-    averages it.  Layout: [gradients, in parameter order | pad to a multiple of 4 | loss, L1, SSIM, mask L2 | pad]; ``world`` > 1
+    averages it.  Layout: [gradients, in parameter order, EVERY tensor starting at a multiple of 4 floats (16-byte aligned: the
+    kernels that read and write these slices -- SH staging, gradient sinks, the fused optimizer step -- work on float4; up to 3 unused
+    floats after a tensor, zero and never read; ``offsets`` / ``pack``) | pad to a multiple of 4 | loss, L1, SSIM, mask L2 | pad]; ``world`` > 1
     pads the buffer to `world` equal shards (``shard_layout``) so that the same buffer serves the reduce-scatter of the sharded
     optimizer path (``ShardedStep``); the 4-float loss block is 4-aligned, so it never straddles two shards."""
 
     def __init__(self, params, world: int = 1):
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
-        self.n_params = sum(self.sizes)
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            off = (off + 3) // 4 * 4
+            self.offsets.append(off)
+            off += n
+        self.n_params = off                                # length of the parameter region (inner padding included)
         self.tail = (self.n_params + 3) // 4 * 4           # offset of the loss block
         self.n_exchange = self.tail + 4                    # what has to travel: gradients + loss block
         self.world = max(int(world), 1)
         self.shard_len, padded = shard_layout(self.n_exchange, self.world)
         dev = self.params[0].device
         self.flat = torch.zeros(padded if self.world > 1 else self.n_exchange, dtype=torch.float32, device=dev)
-        self.views = []
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+        self.views = [self.flat[off:off + n].view_as(p) for p, n, off in zip(self.params, self.sizes, self.offsets)]
         off = self.tail
         self.loss_slot = self.flat[off:off + 1]
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
-        self._offset = {}
+        self._offset = {id(p): off for p, off in zip(self.params, self.offsets)}
         self._handed_out = set()
-        o = 0
-        for p, n in zip(self.params, self.sizes):
-            self._offset[id(p)] = o
-            o += n
+
+    def pack(self, tensors):
+        """The flat image (``n_params`` floats, zeros in the alignment gaps) of one tensor per parameter, in parameter order."""
+        out = torch.zeros(self.n_params, dtype=torch.float32, device=tensors[0].device)
+        for t, n, off in zip(tensors, self.sizes, self.offsets):
+            out[off:off + n] = t.reshape(-1)
+        return out
 
     def attach(self):
         """Make every parameter's .grad a view into the bucket, so backward ACCUMULATES straight into it (no pack copy)."""

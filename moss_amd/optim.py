@@ -12,6 +12,23 @@ import torch
 from ._lib import check, lib
 
 
+class _FusedAdamW:
+    """What ``FlatAdamW.fuse_into_backward`` leaves on a RasterContext: the host struct of the C ABI (kept alive here), the data
+    pointers of the parameters it describes (the backward refuses other inputs: the update is applied IN PLACE to what the op is given)."""
+
+    def __init__(self, struct, param_ptrs, owner):
+        self.struct, self.param_ptrs, self.owner = struct, dict(param_ptrs), owner
+        self.address = C.addressof(struct)
+
+    def check_inputs(self, **tensors):
+        for name, ptr in self.param_ptrs.items():
+            t = tensors.get(name)
+            if t is None or t.data_ptr() != ptr or not t.is_contiguous() or t.dtype != torch.float32:
+                raise RuntimeError(f"fused AdamW update: the rasterizer's `{name}` input is not the parameter tensor the optimizer was "
+                                   f"given (a copy, a cast or an activated value?) -- use pipe.raw_parameters_in_op or detach the "
+                                   f"optimizer from the context (context.fused_adamw = None)")
+
+
 class FlatAdamW:
     def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.01, capturable=False, shard=None):
         """capturable=True keeps the step counter on the device (``moss_adamw_flat_devstep``) so that a hipGraph capture of
@@ -29,7 +46,7 @@ class FlatAdamW:
                 lr_of[id(p)] = float(grp["lr"])
                 # optional periodic pattern (period, split, lr_rest): first `split` of every `period` elements use lr, the rest lr_rest
                 pat_of[id(p)] = grp.get("lr_pattern")
-        total = sum(bucket.sizes)
+        total = bucket.n_params                              # (every tensor starts 16-byte aligned: GradBucket.offsets)
         dev = params[0].device
         self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
         if self.shard is not None and self.shard[1] != bucket.world:
@@ -37,13 +54,13 @@ class FlatAdamW:
         # (sharded: the parameter buffer mirrors the bucket's padded layout -- parameters, loss block, padding -- so that the
         # all-gather of the updated shards is in place)
         self.flat_params = torch.zeros(bucket.flat.numel() if self.shard is not None else total, dtype=torch.float32, device=dev)
-        off = 0
         ends, lrs, periods, splits, lr2s = [], [], [], [], []
-        for p, n in zip(params, bucket.sizes):
+        for i, (p, n, off) in enumerate(zip(params, bucket.sizes, bucket.offsets)):
             self.flat_params[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_params[off:off + n].view_as(p)              # the parameter now lives in the flat buffer
-            off += n
-            ends.append(off); lrs.append(lr_of[id(p)])
+            # a segment runs to the (aligned) start of the next tensor: the <= 3 floats of padding behind a tensor are zeros with zero
+            # gradients, which the update leaves zero
+            ends.append(bucket.offsets[i + 1] if i + 1 < len(params) else total); lrs.append(lr_of[id(p)])
             pat = pat_of[id(p)]
             periods.append(int(pat[0]) if pat else 0); splits.append(int(pat[1]) if pat else 0); lr2s.append(float(pat[2]) if pat else 0.0)
         if len(ends) > 8:
@@ -67,8 +84,76 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.t = 0
+        self.fused = None                                    # set by fuse_into_backward
         # device-side step counter + completion counters, each on a cache line of its own: the LIBRARY says how large (csrc/optim.hip)
         self.step_state = torch.zeros(int(lib().moss_adamw_state_bytes()) // 4, dtype=torch.int32, device=dev) if capturable else None
+
+    # ---- the update applied by the rasterizer's backward kernel itself -----------------------------------------------------------
+    def fuse_into_backward(self, context, means3D=None, sh=None, opacity=None, scales=None, rotations=None):
+        """Hand the update of the named parameters to the per-Gaussian backward kernel of the rasterizer (C ABI
+        ``moss_raster_backward_raw_adamw``): the kernel that produces a Gaussian's gradients applies its AdamW step on the spot --
+        parameters in place, moments in this optimizer's buffers, same bits as ``step()`` would give -- and the gradients of those
+        tensors never leave it (autograd sees ``None`` for them).  Valid when the rasterizer is the ONLY source of their gradients
+        (MOSS: features, opacity, scaling, rotation -- every loss term of train_ZJU.py:111-131 goes through the image; the position only
+        where it does not also feed the LBS network) and the op takes the RAW parameters (``pipe.raw_parameters_in_op``).
+
+        Every parameter of the bucket must be named (give the rest to a second optimizer over its own bucket); needs
+        ``capturable=True`` and no shard.  Afterwards ``step()`` is a no-op: the step is taken inside ``loss.backward()``, and a frame
+        that overflowed its binning capacity takes none (the kernel reads the frame's status word itself).
+        ``context``: the :class:`RasterContext` of the rasterizer whose backward does it (None: the default one)."""
+        from ._lib import FusedAdamWStruct, OPT_BITS
+        from .diff_gaussian_rasterization import _C
+        if self.shard is not None or self.step_state is None:
+            raise RuntimeError("fuse_into_backward needs capturable=True and an unsharded optimizer")
+        named = {"means3D": means3D, "sh": sh, "opacity": opacity, "scales": scales, "rotations": rotations}
+        given = {k: v for k, v in named.items() if v is not None}
+        if {id(v) for v in given.values()} != {id(p) for p in self.bucket.params} or len(given) != len(self.bucket.params):
+            raise ValueError("fuse_into_backward: name every parameter of the bucket exactly once (other parameters belong to a "
+                             "second optimizer over their own bucket)")
+        st = FusedAdamWStruct()
+        offs = {id(p): (off, i) for i, (p, off) in enumerate(zip(self.bucket.params, self.bucket.offsets))}
+        ptrs = {}
+        for name, p in given.items():
+            slot = OPT_BITS[name].bit_length() - 1
+            off, seg = offs[id(p)]
+            st.tensors |= OPT_BITS[name]
+            st.exp_avg[slot] = self.exp_avg.data_ptr() + 4 * off
+            st.exp_avg_sq[slot] = self.exp_avg_sq.data_ptr() + 4 * off
+            st.lr[slot] = self.seg_lr[seg]
+            if name == "sh":
+                period, split = int(self.seg_period[seg]), int(self.seg_split[seg])
+                if period == 0:
+                    st.lr_sh_rest = self.seg_lr[seg]
+                elif (period, split) == (48, 3):
+                    st.lr_sh_rest = self.seg_lr2[seg]
+                else:
+                    raise ValueError("fuse_into_backward: the SH learning-rate pattern must be (48, 3, lr_rest) -- features_dc / features_rest")
+            elif int(self.seg_period[seg]) != 0:
+                raise ValueError(f"fuse_into_backward: a learning-rate pattern on {name} is not supported")
+            ptrs[name] = p.data_ptr()
+        st.beta1, st.beta2, st.eps, st.weight_decay = float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay)
+        st.step_state = self.step_state.data_ptr()
+        self.fused = _FusedAdamW(st, ptrs, self)
+        (context or _C.DEFAULT).fused_adamw = self.fused
+        return self.fused
+
+    def refresh_fused_learning_rates(self):
+        """After changing ``seg_lr`` / ``seg_lr2`` (a learning-rate schedule): copy them into the fused descriptor.  NOTE a captured
+        hipGraph has the old values baked in as kernel arguments: re-capture the step."""
+        if getattr(self, "fused", None) is None:
+            return
+        for i, p in enumerate(self.bucket.params):
+            for name, ptr in self.fused.param_ptrs.items():
+                if ptr == p.data_ptr():
+                    from ._lib import OPT_BITS
+                    slot = OPT_BITS[name].bit_length() - 1
+                    self.fused.struct.lr[slot] = self.seg_lr[i]
+                    if name == "sh":
+                        self.fused.struct.lr_sh_rest = self.seg_lr2[i] if int(self.seg_period[i]) else self.seg_lr[i]
+
+    def step_count(self) -> int:
+        """Steps taken so far (reads the device-side counter when there is one: it synchronises)."""
+        return int(self.step_state[0].item()) if self.step_state is not None else self.t
 
     def snapshot(self):
         """Copies of everything a step changes (parameters, both moments, step counters)."""
@@ -89,14 +174,12 @@ class FlatAdamW:
                                "permute and rebuild the optimizer instead")
         n_rows = int(perm.numel())
         perm = perm.to(self.flat_params.device)
-        off = 0
         with torch.no_grad():
-            for p, n in zip(self.bucket.params, self.bucket.sizes):
+            for p, n, off in zip(self.bucket.params, self.bucket.sizes, self.bucket.offsets):
                 if p.dim() >= 1 and p.shape[0] == n_rows:
                     for flat in (self.flat_params, self.exp_avg, self.exp_avg_sq):
                         v = flat[off:off + n].view_as(p)
                         v.copy_(v[perm].clone())
-                off += n
 
     def step(self, skip_word=None, skip_mask=2):
         """One update.  ``skip_word`` (capturable optimizers only): a one-element int32 / float32 DEVICE tensor; if
@@ -105,6 +188,8 @@ class FlatAdamW:
         with the default mask 2 skips the step of a frame that overflowed its capacity and rendered nothing (inside a captured
         hipGraph nobody else can)."""
         dev = self.flat_params.device
+        if getattr(self, "fused", None) is not None:
+            return                                           # the rasterizer's backward kernel took the step (fuse_into_backward)
         if skip_word is not None:
             if self.step_state is None:
                 raise RuntimeError("a guarded step needs capturable=True: a host-side step count cannot know about the skipped step")

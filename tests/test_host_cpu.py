@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for n in sorted(diag_names):
         assert not hasattr(hip_lib, n), f"{n} is a diagnostic entry point and must not be in the product build"
     assert hip_lib.moss_build_has_diagnostics() == 0
-    assert re.search(r"#define\s+MOSS_ABI_VERSION\s+3\b", text) and hip_lib.moss_abi_version() == 3
+    assert re.search(r"#define\s+MOSS_ABI_VERSION\s+4\b", text) and hip_lib.moss_abi_version() == 4
     assert hip_lib.moss_last_error() == b""
     assert hip_lib.moss_adamw_state_bytes() == int(re.search(r"#define\s+MOSS_ADAMW_STATE_BYTES\s+(\d+)", text).group(1))
 
@@ -289,14 +289,14 @@ def _exchange_rank_main(rank, world, port, q):
     from moss_amd import dist as mdist
     mdist.init_from_env(backend="gloo")
     g = torch.Generator().manual_seed(5)
-    shapes = [(37, 3), (37, 16, 3), (37, 1)]                                  # 37 * 52 = 1924 parameters (+ the 4-float loss block): two shards of 964
+    shapes = [(37, 3), (37, 16, 3), (37, 1)]                                  # 111 + 1776 + 37 parameters, every tensor 16-byte aligned: 1925 floats (+ pad + the 4-float loss block = 1932): two shards of 968
     init = [torch.randn(s, generator=g) for s in shapes]
     out = {}
     for kind in ("allreduce", "sharded"):
         params = [torch.nn.Parameter(x.clone()) for x in init]
         bucket = mdist.GradBucket(params, world=world if kind == "sharded" else 1)
         n = bucket.n_params
-        p0 = torch.cat([x.reshape(-1) for x in init])
+        p0 = bucket.pack(init)                                # (every tensor 16-byte aligned in the flat buffers)
         if kind == "sharded":
             opt = _TorchAdamWShard(bucket, p0, rank)
             ex = mdist.ShardedStep(bucket, opt, rank, world)
@@ -316,7 +316,7 @@ def _exchange_rank_main(rank, world, port, q):
             assert torch.allclose(terms, torch.tensor([1.0, 2.0, 3.0, 4.0]) * t * (world + 1) / 2) and float(loss) == float(terms[0])
         out[kind] = (opt.flat_params[:n] if kind == "sharded" else flat).numpy().copy()
         if kind == "sharded":
-            assert opt.count == (964 if rank == 0 else 960) and opt.m.numel() == opt.count     # (1924 + 4) / 2 = 964 per shard; moments for the shard only
+            assert opt.count == (968 if rank == 0 else 957) and opt.m.numel() == opt.count     # ceil(1932 / 2) rounded up to 4 = 968 per shard, 1925 of them parameters; moments for the shard only
     q.put((rank, out["allreduce"], out["sharded"]))
     dist.barrier()
     dist.destroy_process_group()
