@@ -51,7 +51,8 @@ def algorithmic_bytes(P, Pv, R, N, tiles, K, scale_rot_mode, transforms=False, f
     }
     bwd = {
         "blend_bwd": 44 * R + 28 * N + 36 * Pv,
-        "preprocess_bwd": 36 * Pv + Pv * (12 + 4 + 24 + 12 * K + 3) + Pv * (12 + 24 + 12 * K + 4) + (28 * Pv if scale_rot_mode else 0) + P * 12
+        # (dL_dcov3D, 24 B, is written only when the covariance was an input: cov3D_precomp)
+        "preprocess_bwd": 36 * Pv + Pv * (12 + 4 + 24 + 12 * K + 3) + Pv * (12 + (0 if scale_rot_mode else 24) + 12 * K + 4) + (28 * Pv if scale_rot_mode else 0) + P * 12
                           + (Pv * 36 + P * 36 if transforms else 0),
     }
     if fused_adamw:

@@ -151,6 +151,8 @@ int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out,
  *   dL_dmean3D (P,3), dL_dcov3D (P,6), dL_dsh (P,M,3) (may be NULL if M==0), dL_dscale (P,3), dL_drot (P,4).
  *   Every element of every output is written (zeros for culled Gaussians, for dL_dscale/dL_drot when
  *   scales==NULL and for SH coefficients above the active degree), so outputs need NOT be pre-zeroed.
+ *   dL_dconic (an intermediate), dL_dcolor and dL_dcov3D (gradients of the optional inputs colors_precomp / cov3D_precomp) may be
+ *   NULL = not wanted (ABI 4): 52 bytes per Gaussian a caller working from SH and scales / rotations never reads.
  *   `alphas` and `radii` are accepted for signature parity and ignored (the reference ignores alphas too,
  *   DGR/cuda_rasterizer/backward.cu:410).
  * Gradients are bitwise reproducible run to run (no float atomics), unlike the reference.

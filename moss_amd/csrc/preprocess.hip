@@ -1052,13 +1052,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     gmx *= mean2d_sx; gmy *= mean2d_sy; gca *= -0.5f; gcb *= -0.5f; gcc *= -0.5f;
     if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
-    reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);
+    if (dL_dconic != nullptr) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);   // (NULL = not wanted)
     if (raw & RAW_OPACITY) {                                 // d sigmoid(v) = y (1 - y)
         const float sg = sigmoid_act(opacities[idx]);
         gop = gop * ((1.0f - sg) * sg);
     }
     if (dL_dopacity != nullptr) dL_dopacity[idx] = gop;
-    dL_dcolor[3 * (size_t)idx] = gcol.x; dL_dcolor[3 * (size_t)idx + 1] = gcol.y; dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
+    if (dL_dcolor != nullptr) { dL_dcolor[3 * (size_t)idx] = gcol.x; dL_dcolor[3 * (size_t)idx + 1] = gcol.y; dL_dcolor[3 * (size_t)idx + 2] = gcol.z; }
 
     float* dsh = STAGE_SH ? &s_dsh[threadIdx.x * SH_ROW]
                           : ((M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr);
@@ -1156,8 +1156,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
         for (int i = 0; i < 3; i++) dL_dmean3D[3 * (size_t)idx + i] = dmean[i];
     }
+    if (dL_dcov3D != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
     if (dL_dscale != nullptr) {
 #pragma unroll
         for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];

@@ -302,7 +302,9 @@ static int backward_impl(
     if (!dL_dpix && !dL_ddepths && !dL_dalphas) return fail(MOSS_ERR_INVALID_ARG, "all three incoming gradients are NULL");
     // (the gradient of a tensor whose AdamW update this call applies itself may stay inside the kernel)
     const uint32_t fused = opt ? opt->tensors : 0u;
-    if (!dL_dmean2D || !dL_dconic || !dL_dcolor || !dL_dcov3D || (!dL_dopacity && !(fused & OPT_OPACITY)) || (!dL_dmean3D && !(fused & OPT_MEANS)) ||
+    // dL_dconic (an intermediate the reference also exposes), dL_dcolor and dL_dcov3D (gradients of the OPTIONAL inputs colors_precomp /
+    // cov3D_precomp) may be NULL = not wanted: 52 bytes per Gaussian that a caller working from SH and scales / rotations never reads
+    if (!dL_dmean2D || (!dL_dopacity && !(fused & OPT_OPACITY)) || (!dL_dmean3D && !(fused & OPT_MEANS)) ||
         (!dL_dscale && !(fused & OPT_SCALES)) || (!dL_drot && !(fused & OPT_ROTATIONS)))
         return fail(MOSS_ERR_INVALID_ARG, "null gradient output");
     if (shs && !dL_dsh && !(fused & OPT_SH)) return fail(MOSS_ERR_INVALID_ARG, "dL_dsh is NULL although shs is given");

@@ -178,7 +178,8 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                              const c10::optional<torch::Tensor>& sink_means3D, const c10::optional<torch::Tensor>& sink_opacity,
                              const c10::optional<torch::Tensor>& sink_sh, const c10::optional<torch::Tensor>& sink_scales,
                              const c10::optional<torch::Tensor>& sink_rotations, const c10::optional<torch::Tensor>& translation,
-                             int64_t fused_adamw /* address of a host moss_fused_adamw the caller keeps alive, or 0 */)
+                             int64_t fused_adamw /* address of a host moss_fused_adamw the caller keeps alive, or 0 */,
+                             bool all_outputs /* false: gradients nobody can receive are not computed into memory */)
 {
     const int P = static_cast<int>(means3D.size(0));
     // The tensors whose AdamW update the backward kernel applies itself (moss_raster_backward_raw_adamw): their gradients stay inside
@@ -197,10 +198,14 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     auto mk = [&](at::IntArrayRef shape) { return z ? torch::zeros(shape, fopts) : torch::empty(shape, fopts); };
     torch::Tensor dL_dmeans3D = (fused & MOSS_OPT_MEANS) ? torch::Tensor() : out_or_sink(sink_means3D, {P, 3}, fopts, z);
     torch::Tensor dL_dmeans2D = mk({P, 3});
-    torch::Tensor dL_dcolors = mk({P, NUM_CHANNELS});
-    torch::Tensor dL_dconic = mk({P, 2, 2});
+    // gradients nobody can receive are not computed into memory: dL_dcolors without colors_precomp, dL_dcov3D without cov3D_precomp
+    // (their inputs are absent: autograd drops whatever is returned for them), dL_dconic always (the reference allocates and fills it,
+    // rasterize_points.cu:160, and returns it to nobody)
+    // (all_outputs = false, what the autograd function asks for)
+    torch::Tensor dL_dcolors = (all_outputs || colors.numel() != 0 || z) ? mk({P, NUM_CHANNELS}) : torch::Tensor();
+    torch::Tensor dL_dconic = all_outputs ? mk({P, 2, 2}) : torch::Tensor();
     torch::Tensor dL_dopacity = (fused & MOSS_OPT_OPACITY) ? torch::Tensor() : out_or_sink(sink_opacity, {P, 1}, fopts, z);
-    torch::Tensor dL_dcov3D = mk({P, 6});
+    torch::Tensor dL_dcov3D = (all_outputs || cov3D_precomp.numel() != 0 || z) ? mk({P, 6}) : torch::Tensor();
     torch::Tensor dL_dsh = (fused & MOSS_OPT_SH) ? torch::Tensor() : M != 0 ? out_or_sink(sink_sh, {P, M, 3}, fopts, z) : mk({P, M, 3});
     torch::Tensor dL_dscales = (fused & MOSS_OPT_SCALES) ? torch::Tensor() : out_or_sink(sink_scales, {P, 3}, fopts, z);
     torch::Tensor dL_drotations = (fused & MOSS_OPT_ROTATIONS) ? torch::Tensor() : out_or_sink(sink_rotations, {P, 4}, fopts, z);
@@ -304,7 +309,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("transforms") = py::none(), py::arg("raw_flags") = 0, py::arg("opacities") = py::none(),
           py::arg("sink_means3D") = py::none(), py::arg("sink_opacity") = py::none(), py::arg("sink_sh") = py::none(),
           py::arg("sink_scales") = py::none(), py::arg("sink_rotations") = py::none(), py::arg("translation") = py::none(),
-          py::arg("fused_adamw") = 0);
+          py::arg("fused_adamw") = 0, py::arg("all_outputs") = true);
     m.def("mark_visible", &mark_visible);
     // the version of the header THIS module was compiled against (not the library's answer: moss_amd/_lib.py compares the two, so a
     // stale _moss_C.so next to a rebuilt libmoss_raster.so refuses to load instead of passing arguments in the old layout)

@@ -227,12 +227,16 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_alpha,
                                  sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, transforms=None,
-                                 raw_flags=0, opacities=None, context=None, translation=None):
+                                 raw_flags=0, opacities=None, context=None, translation=None, all_outputs=True):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:121-206.
     ``raw_flags`` / ``opacities``: backward of the raw-parameter forward (gradients w.r.t. the raw parameters).
     Returns (dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P,1), dL_dmeans3D (P,3), dL_dcov3D (P,6),
     dL_dsh (P,M,3), dL_dscales (P,3), dL_drotations (P,4)) -- plus dL_dtransforms (P,3,3) when ``transforms`` was given, plus
-    dL_dtranslation (P,3) when ``translation`` was (RAW_POSE: dL_dmeans3D is then w.r.t. the canonical positions)."""
+    dL_dtranslation (P,3) when ``translation`` was (RAW_POSE: dL_dmeans3D is then w.r.t. the canonical positions).
+    ``all_outputs=False`` (what the autograd function passes): gradients nobody can receive -- dL_dcolors without colors_precomp,
+    dL_dcov3D without cov3D_precomp, and the intermediate dL_dconic the reference fills and returns to nobody (rasterize_points.cu:160)
+    -- are not computed into memory and come back as None; so do the gradients of tensors whose AdamW update the kernel applied
+    itself (``context.fused_adamw``)."""
     cx = context or DEFAULT
     if int(raw_flags) and opacities is None and means3D.size(0) != 0:
         raise RuntimeError("the raw-parameter backward needs the raw opacities")
@@ -248,7 +252,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, int(degree), campos, geomBuffer, int(R),
         binningBuffer, imageBuffer, alphas, int(debug), transforms, int(raw_flags), opacities,
         *(None if (fused and n in cx.fused_adamw.param_ptrs) else cx._sink(n) for n in ("means3D", "opacity", "sh", "scales", "rotations")),
-        translation, fused))
+        translation, fused, bool(all_outputs)))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

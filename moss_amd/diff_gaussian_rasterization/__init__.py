@@ -106,7 +106,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha,
             sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug,
-            transforms, ctx.raw_flags, raw_opacities, ctx.context, translation)
+            transforms, ctx.raw_flags, raw_opacities, ctx.context, translation, False)
         grads = _call_native(_C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations) = grads[:8]
