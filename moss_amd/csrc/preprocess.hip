@@ -1050,6 +1050,42 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // the blend kernel's records carry the geometry sums without their constant factors (blend.hip, the backward trip):
     // d pixel / d ndc = W/2, H/2 (backward.cu:472-473, 574-575) and the -1/2 of the exponent (backward.cu:578-580)
     gmx *= mean2d_sx; gmy *= mean2d_sy; gca *= -0.5f; gcb *= -0.5f; gcc *= -0.5f;
+    // Fused AdamW: the eleven per-Gaussian scalars' parameters and moments are requested HERE, before the backward arithmetic, and
+    // used after it (stamps: loaded where they are used, the 33 strided loads were a round trip of 10k cycles on every block's path)
+    const bool fa_scalars = fa_on && in_range && (fa.tensors & (OPT_MEANS | OPT_OPACITY | OPT_SCALES | OPT_ROTATIONS));
+    float fa_p[11], fa_m[11], fa_v[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) { fa_p[i] = 0.f; fa_m[i] = 0.f; fa_v[i] = 0.f; }
+    if (fa_scalars) {
+        const size_t i3 = 3 * (size_t)idx;
+        if (fa.tensors & OPT_MEANS) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { fa_p[i] = fa.p[0][i3 + i]; fa_m[i] = fa.m[0][i3 + i]; fa_v[i] = fa.v[0][i3 + i]; }
+        }
+        if (fa.tensors & OPT_OPACITY) { fa_p[3] = fa.p[2][idx]; fa_m[3] = fa.m[2][idx]; fa_v[3] = fa.v[2][idx]; }
+        if (fa.tensors & OPT_SCALES) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { fa_p[4 + i] = fa.p[3][i3 + i]; fa_m[4 + i] = fa.m[3][i3 + i]; fa_v[4 + i] = fa.v[3][i3 + i]; }
+        }
+        if (fa.tensors & OPT_ROTATIONS) {
+            const float4 a = reinterpret_cast<const float4*>(fa.p[4])[idx], b = reinterpret_cast<const float4*>(fa.m[4])[idx], c = reinterpret_cast<const float4*>(fa.v[4])[idx];
+            fa_p[7] = a.x; fa_p[8] = a.y; fa_p[9] = a.z; fa_p[10] = a.w; fa_m[7] = b.x; fa_m[8] = b.y; fa_m[9] = b.z; fa_m[10] = b.w;
+            fa_v[7] = c.x; fa_v[8] = c.y; fa_v[9] = c.z; fa_v[10] = c.w;
+        }
+    }
+    // ... and so are the moments of the block's SH rows (24 float4 per lane): in flight during the arithmetic below
+    float4 fa_m4[12], fa_v4[12];
+    const bool fa_sh = STAGE_SH && fa_on && (fa.tensors & OPT_SH);
+    if (fa_sh) {
+        const float4* const mw = reinterpret_cast<const float4*>(fa.m[1]);
+        const float4* const vw = reinterpret_cast<const float4*>(fa.v[1]);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int f = (int)threadIdx.x + j * (int)blockDim.x;
+            const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
+            fa_m4[j] = mw[a]; fa_v4[j] = vw[a];
+        }
+    }
     if (in_range) {
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     if (dL_dconic != nullptr) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);   // (NULL = not wanted)
@@ -1175,49 +1211,30 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     }
     // ---- fused AdamW, the eleven per-Gaussian scalars (position, opacity, scale, rotation): this thread's own parameters, read
     //      above by nobody else; every Gaussian takes the step, with zero gradients if it was not rendered (torch.optim.AdamW does
-    //      the same: the moments decay).  All loads first, then the arithmetic, then the stores.
-    if (fa_on && (fa.tensors & (OPT_MEANS | OPT_OPACITY | OPT_SCALES | OPT_ROTATIONS))) {
+    //      the same: the moments decay).  (Loads: requested before the backward arithmetic, see above.)
+    if (fa_scalars) {
         const float ib1 = 1.0f / fa_bc1, ib2 = 1.0f / fa_bc2_sqrt;
-        const size_t i3 = 3 * (size_t)idx, i4 = 4 * (size_t)idx;
-        const bool u_mean = fa.tensors & OPT_MEANS, u_opa = fa.tensors & OPT_OPACITY, u_scl = fa.tensors & OPT_SCALES, u_rot = fa.tensors & OPT_ROTATIONS;
-        float pv[11], mv[11], vv[11];
-#pragma unroll
-        for (int i = 0; i < 11; i++) { pv[i] = 0.f; mv[i] = 0.f; vv[i] = 0.f; }
-        if (u_mean) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) { pv[i] = fa.p[0][i3 + i]; mv[i] = fa.m[0][i3 + i]; vv[i] = fa.v[0][i3 + i]; }
-        }
-        if (u_opa) { pv[3] = fa.p[2][idx]; mv[3] = fa.m[2][idx]; vv[3] = fa.v[2][idx]; }
-        if (u_scl) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) { pv[4 + i] = fa.p[3][i3 + i]; mv[4 + i] = fa.m[3][i3 + i]; vv[4 + i] = fa.v[3][i3 + i]; }
-        }
-        if (u_rot) {
-            const float4 a = reinterpret_cast<const float4*>(fa.p[4])[idx], b = reinterpret_cast<const float4*>(fa.m[4])[idx], c = reinterpret_cast<const float4*>(fa.v[4])[idx];
-            pv[7] = a.x; pv[8] = a.y; pv[9] = a.z; pv[10] = a.w; mv[7] = b.x; mv[8] = b.y; mv[9] = b.z; mv[10] = b.w;
-            vv[7] = c.x; vv[8] = c.y; vv[9] = c.z; vv[10] = c.w;
-        }
+        const size_t i3 = 3 * (size_t)idx;
         const float gv[11] = { dmean[0], dmean[1], dmean[2], gop, dscale[0], dscale[1], dscale[2], drot[0], drot[1], drot[2], drot[3] };
 #pragma unroll
         for (int i = 0; i < 11; i++) {
             const float lr = i < 3 ? fa.lr[0] : i == 3 ? fa.lr[2] : i < 7 ? fa.lr[3] : fa.lr[4];
-            adamw_element(pv[i], gv[i], mv[i], vv[i], lr, fa.beta1, fa.beta2, fa.eps, fa.weight_decay, ib1, ib2);
+            adamw_element(fa_p[i], gv[i], fa_m[i], fa_v[i], lr, fa.beta1, fa.beta2, fa.eps, fa.weight_decay, ib1, ib2);
         }
-        if (u_mean) {
+        if (fa.tensors & OPT_MEANS) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) { fa.p[0][i3 + i] = pv[i]; fa.m[0][i3 + i] = mv[i]; fa.v[0][i3 + i] = vv[i]; }
+            for (int i = 0; i < 3; i++) { fa.p[0][i3 + i] = fa_p[i]; fa.m[0][i3 + i] = fa_m[i]; fa.v[0][i3 + i] = fa_v[i]; }
         }
-        if (u_opa) { fa.p[2][idx] = pv[3]; fa.m[2][idx] = mv[3]; fa.v[2][idx] = vv[3]; }
-        if (u_scl) {
+        if (fa.tensors & OPT_OPACITY) { fa.p[2][idx] = fa_p[3]; fa.m[2][idx] = fa_m[3]; fa.v[2][idx] = fa_v[3]; }
+        if (fa.tensors & OPT_SCALES) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) { fa.p[3][i3 + i] = pv[4 + i]; fa.m[3][i3 + i] = mv[4 + i]; fa.v[3][i3 + i] = vv[4 + i]; }
+            for (int i = 0; i < 3; i++) { fa.p[3][i3 + i] = fa_p[4 + i]; fa.m[3][i3 + i] = fa_m[4 + i]; fa.v[3][i3 + i] = fa_v[4 + i]; }
         }
-        if (u_rot) {
-            reinterpret_cast<float4*>(fa.p[4])[idx] = make_float4(pv[7], pv[8], pv[9], pv[10]);
-            reinterpret_cast<float4*>(fa.m[4])[idx] = make_float4(mv[7], mv[8], mv[9], mv[10]);
-            reinterpret_cast<float4*>(fa.v[4])[idx] = make_float4(vv[7], vv[8], vv[9], vv[10]);
+        if (fa.tensors & OPT_ROTATIONS) {
+            reinterpret_cast<float4*>(fa.p[4])[idx] = make_float4(fa_p[7], fa_p[8], fa_p[9], fa_p[10]);
+            reinterpret_cast<float4*>(fa.m[4])[idx] = make_float4(fa_m[7], fa_m[8], fa_m[9], fa_m[10]);
+            reinterpret_cast<float4*>(fa.v[4])[idx] = make_float4(fa_v[7], fa_v[8], fa_v[9], fa_v[10]);
         }
-        (void)i4;
     }
     }   // in_range
     PSTAMP(5);
@@ -1242,12 +1259,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             float4* const pw = reinterpret_cast<float4*>(fa.p[1]);
             float4* const mw = reinterpret_cast<float4*>(fa.m[1]);
             float4* const vw = reinterpret_cast<float4*>(fa.v[1]);
-            float4 p4[12], m4[12], v4[12];
+            float4 p4[12];
+            float4 (&m4)[12] = fa_m4, (&v4)[12] = fa_v4;
 #pragma unroll
             for (int j = 0; j < 12; j++) {
                 const int f = (int)threadIdx.x + j * (int)blockDim.x;
                 const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
-                p4[j] = pw[a]; m4[j] = mw[a]; v4[j] = vw[a];
+                p4[j] = pw[a];
             }
 #pragma unroll
             for (int j = 0; j < 12; j++) {
