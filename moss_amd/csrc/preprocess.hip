@@ -465,7 +465,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 // screen-position paths).  gca/gcb/gcc = dL/dconic (A, B per off-diagonal entry, C), gmx/gmy = dL/dmean2D in NDC units.
 __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb, float gcc, float gmx, float gmy,
                                                   float tan_fovx, float tan_fovy, float h_x, float h_y,
-                                                  const float* __restrict__ cov3D_precomp, const GeomView& g,
+                                                  const float (&c6)[6] /* the 3-D covariance the forward used (given or stored by it) */,
                                                   const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                                                   const float3 mean /* the (posed) mean the forward projected */, float* dmean, float* dcov, float (&A_out)[2][3], float (&d2_out)[3])
 {
@@ -483,7 +483,7 @@ __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb,
     //     dJ00/dtz = -J00/tz, dJ02/dtx = -J00/tz, dJ02/dtz = -2 J02/tz (same for the y row); dL/dmean = Rv^T dL/dt.
     const float Rv[3][3] = { { viewmatrix[0], viewmatrix[4], viewmatrix[8] }, { viewmatrix[1], viewmatrix[5], viewmatrix[9] },
                              { viewmatrix[2], viewmatrix[6], viewmatrix[10] } };            // t = Rv p + (view[12..14])
-    const float* c6 = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idx : g.cov3D + 6 * (size_t)idx;
+    (void)idx;
     const float S3[3][3] = { { c6[0], c6[1], c6[2] }, { c6[1], c6[3], c6[4] }, { c6[2], c6[4], c6[5] } };
     float t[3];
 #pragma unroll
@@ -563,8 +563,8 @@ __device__ __forceinline__ void cov_proj_backward(int idx, float gca, float gcb,
 // ---- step (6): dL/dscale, dL/drot (and dL/dtransforms), chained through the raw-parameter getters if asked
 __device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, const float (&A)[2][3], const float (&d2)[3],
                                                    float scale_modifier, int raw,
-                                                   const float* __restrict__ scales, const float* __restrict__ rotations,
-                                                   const float* __restrict__ transforms, float* dscale, float* drot, float* dtf)
+                                                   bool has_scales, const float (&sc_in)[3], const float (&q_in)[4],
+                                                   bool has_transforms, const float (&Tm)[9], float* dscale, float* drot, float* dtf)
 {
     // (6) S3 = L L^T, L = R(q) diag(mod s) with the quaternion as given (forward.cu:118-152; with a transform: L = T R diag(mod s)).
     //     dL/dL = 2 dS3 L with dS3 = A^T dS2 A (step 2).  The reference forms the six-vector dS3 in float32 and multiplies it by L
@@ -578,17 +578,16 @@ __device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, c
     //     the float32 restatement of the reference: 4.5e-5).
     //     G = dL/dR, G_ik = (dL/dL)_ik m_k;  and for R(q) = I + 2 [..] with q = (r, v):
     //       dq_r = 2 v . a,   dq_v = 2 (Soff v + r a) - 4 v * (tr G - diag G),   a = (G21-G12, G02-G20, G10-G01), Soff = offdiag(G + G^T).
-    if (scales != nullptr) {
-        float scr[3] = { scales[3 * (size_t)idx], scales[3 * (size_t)idx + 1], scales[3 * (size_t)idx + 2] };
-        float qr[4] = { rotations[4 * (size_t)idx], rotations[4 * (size_t)idx + 1], rotations[4 * (size_t)idx + 2], rotations[4 * (size_t)idx + 3] };
+    (void)idx;
+    if (has_scales) {
+        float scr[3] = { sc_in[0], sc_in[1], sc_in[2] };
+        float qr[4] = { q_in[0], q_in[1], q_in[2], q_in[3] };
         const float q_raw[4] = { qr[0], qr[1], qr[2], qr[3] };
         activate_scale_rot(raw, scr, qr);                    // raw mode: exp / normalize as in the forward
         float Ap[2][3] = { { A[0][0], A[0][1], A[0][2] }, { A[1][0], A[1][1], A[1][2] } };   // A' = A T
         float d6[6] = { dcov[0], dcov[1], dcov[2], dcov[3], dcov[4], dcov[5] };
-        if (transforms != nullptr) {
-            float Tm[9], pre[6], d6_pre[6];
-#pragma unroll
-            for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+        if (has_transforms) {
+            float pre[6], d6_pre[6];
             cov3d_from_scale_rot(scr, scale_modifier, qr, pre);
             transform_cov3d_bw(Tm, pre, d6, d6_pre, dtf);
 #pragma unroll
@@ -806,6 +805,35 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc] + g.group_base[idc >> 8], hdr_flags = header[2];
+    // Every per-Gaussian input of the arithmetic at the end is requested HERE too, unconditionally (clamped index): the position, the
+    // transform, the covariance, scales / rotation, the raw opacity, the clamp flags -- none depends on the gather.  Loads complete
+    // in order: read where they are used -- behind the fused update's moment loads, which are requested before the arithmetic so that
+    // they are in flight during it -- each would wait for all of those.
+    float in_x[3], in_T[9] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, in_t[3] = { 0.f, 0.f, 0.f }, in_c6[6], in_sc[3] = { 0.f, 0.f, 0.f }, in_q[4] = { 0.f, 0.f, 0.f, 0.f };
+    float in_opa = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) in_x[i] = means3D[3 * (size_t)idc + i];
+    if (transforms != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) in_T[i] = transforms[9 * (size_t)idc + i];
+    }
+    if ((raw & RAW_POSE) && translation != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) in_t[i] = translation[3 * (size_t)idc + i];
+    }
+    {
+        const float* c6p = (cov3D_precomp != nullptr) ? cov3D_precomp + 6 * (size_t)idc : g.cov3D + 6 * (size_t)idc;
+#pragma unroll
+        for (int i = 0; i < 6; i++) in_c6[i] = c6p[i];
+    }
+    if (scales != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) in_sc[i] = scales[3 * (size_t)idc + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) in_q[i] = rotations[4 * (size_t)idc + i];
+    }
+    if (raw & RAW_OPACITY) in_opa = opacities[idc];
+    const uint8_t in_clamped = g.clamped[idc];
     if (STAGE_SH) {
         // into LDS right away (row stride 49: conflict-free rows): the SH loads are the oldest outstanding ones, so this waits for
         // them only, and their 48 registers are free during the gather (holding them across it spilled to scratch)
@@ -817,6 +845,17 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     const uint32_t n_inst = in_range ? tt_raw : 0u;
+    // (pinned: the values must be in registers HERE -- where the wave waits for its first-level loads anyway -- or the compiler sinks
+    // these loads of read-only data down to their uses, behind the moment loads)
+#pragma unroll
+    for (int i = 0; i < 3; i++) { asm volatile("" : "+v"(in_x[i])); asm volatile("" : "+v"(in_t[i])); asm volatile("" : "+v"(in_sc[i])); }
+#pragma unroll
+    for (int i = 0; i < 9; i++) asm volatile("" : "+v"(in_T[i]));
+#pragma unroll
+    for (int i = 0; i < 6; i++) asm volatile("" : "+v"(in_c6[i]));
+#pragma unroll
+    for (int i = 0; i < 4; i++) asm volatile("" : "+v"(in_q[i]));
+    asm volatile("" : "+v"(in_opa));
     float3 gcol = make_float3(0, 0, 0); float gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, drot[4] = { 0, 0, 0, 0 };
     float dtf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dpose_t[3] = { 0, 0, 0 };
@@ -1074,13 +1113,15 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         }
     }
     // ... and so are the moments of the block's SH rows (24 float4 per lane): in flight during the arithmetic below
+    // (FA_HOIST of the 12 slots: all 12 pairs are 96 registers held across the arithmetic -- 260 in all, one wave per SIMD)
+    constexpr int FA_HOIST = 10;
     float4 fa_m4[12], fa_v4[12];
     const bool fa_sh = STAGE_SH && fa_on && (fa.tensors & OPT_SH);
     if (fa_sh) {
         const float4* const mw = reinterpret_cast<const float4*>(fa.m[1]);
         const float4* const vw = reinterpret_cast<const float4*>(fa.v[1]);
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < FA_HOIST; j++) {
             const int f = (int)threadIdx.x + j * (int)blockDim.x;
             const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
             fa_m4[j] = mw[a]; fa_v4[j] = vw[a];
@@ -1090,7 +1131,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     dL_dmean2D[3 * (size_t)idx] = gmx; dL_dmean2D[3 * (size_t)idx + 1] = gmy; dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
     if (dL_dconic != nullptr) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gca, gcb, 0.0f, gcc);   // (NULL = not wanted)
     if (raw & RAW_OPACITY) {                                 // d sigmoid(v) = y (1 - y)
-        const float sg = sigmoid_act(opacities[idx]);
+        const float sg = sigmoid_act(in_opa);
         gop = gop * ((1.0f - sg) * sg);
     }
     if (dL_dopacity != nullptr) dL_dopacity[idx] = gop;
@@ -1100,17 +1141,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                           : ((M > 0 && dL_dsh != nullptr) ? dL_dsh + (size_t)idx * M * 3 : nullptr);
 
     if (visible) {
-        const float3 xc = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+        const float3 xc = make_float3(in_x[0], in_x[1], in_x[2]);
         float3 mean = xc;
-        if (raw & RAW_POSE) {                                // the forward's posed mean, same expression
-            float Tm[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
-            const float3 tr = translation != nullptr ? make_float3(translation[3 * (size_t)idx], translation[3 * (size_t)idx + 1], translation[3 * (size_t)idx + 2])
-                                                     : make_float3(0.f, 0.f, 0.f);
-            mean = pose_point(Tm, xc, tr);
-        }
-        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, cov3D_precomp, g, viewmatrix, projmatrix, mean, dmean, dcov, A_cov, d2_cov);
+        if (raw & RAW_POSE) mean = pose_point(in_T, xc, make_float3(in_t[0], in_t[1], in_t[2]));   // the forward's posed mean, same expression
+        cov_proj_backward(idx, gca, gcb, gcc, gmx, gmy, tan_fovx, tan_fovy, h_x, h_y, in_c6, viewmatrix, projmatrix, mean, dmean, dcov, A_cov, d2_cov);
 
         PSTAMP(3);
         // (5) colour = max(0, 0.5 + sum_k b_k(n) sh_k), n = (mean - campos)/|.| (forward.cu:20-71).  dL/dsh_k = b_k(n) g (g = colour
@@ -1121,7 +1155,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             const float vx = mean.x - cam_pos[0], vy = mean.y - cam_pos[1], vz = mean.z - cam_pos[2];
             const float vlen = sqrtf(vx * vx + vy * vy + vz * vz);
             const float x = vx / vlen, y = vy / vlen, z = vz / vlen;
-            const uint8_t cl = g.clamped[idx];
+            const uint8_t cl = in_clamped;
             const float gc[3] = { (cl & 1) ? 0.0f : gcol.x, (cl & 2) ? 0.0f : gcol.y, (cl & 4) ? 0.0f : gcol.z };
             float basis[16], gbx[16], gby[16], gbz[16];
             const int used = (D + 1) * (D + 1);
@@ -1165,13 +1199,11 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 
 
         PSTAMP(4);
-        scale_rot_backward(idx, dcov, A_cov, d2_cov, scale_modifier, raw, scales, rotations, transforms, dscale, drot, dtf);
+        scale_rot_backward(idx, dcov, A_cov, d2_cov, scale_modifier, raw, scales != nullptr, in_sc, in_q, transforms != nullptr, in_T, dscale, drot, dtf);
         if (raw & RAW_POSE) {
             // p = T x + t:  dL/dt = g,  dL/dT += g x^T,  dL/dx = T^T g   (g = dL/dp collected above; reported in place of it)
             const float gp[3] = { dmean[0], dmean[1], dmean[2] }, xv[3] = { xc.x, xc.y, xc.z };
-            float Tm[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) Tm[i] = transforms[9 * (size_t)idx + i];
+            const float (&Tm)[9] = in_T;
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -1266,6 +1298,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                 const int f = (int)threadIdx.x + j * (int)blockDim.x;
                 const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
                 p4[j] = pw[a];
+                if (j >= FA_HOIST) { m4[j] = mw[a]; v4[j] = vw[a]; }
             }
 #pragma unroll
             for (int j = 0; j < 12; j++) {
