@@ -741,7 +741,9 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
 constexpr int SH_ROW = 49;
 constexpr int GATHER_CAP = 320;                          // records of a wave gathered per pass (8 rows of 64)
 constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
-template <bool STAGE_SH>
+// FUSED: the kernel also takes the AdamW step of the parameters named in fa.tensors (moss_raster_backward_raw_adamw) -- an
+// instantiation of its own, so that the plain backward keeps its code and registers and a kernel trace tells the two apart.
+template <bool STAGE_SH, bool FUSED>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float mean2d_sx, float mean2d_sy,
                            float scale_modifier,
@@ -771,7 +773,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // Fused AdamW (fa.tensors != 0): the step count and its bias corrections, read now (scalar loads, used at the very end)
     float fa_bc1 = 1.0f, fa_bc2_sqrt = 1.0f;
     int fa_t = 0;
-    if (fa.tensors != 0u) fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
+    if (FUSED) fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then dL_dsh out (in place)
 #define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
 #define PRSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime()
@@ -865,7 +867,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     const bool visible = n_inst > 0 && !(hdr_flags & ERRFLAG_OVERFLOW);
     // a frame that overflowed its capacity rendered nothing: its optimizer step is a no-op (parameters, moments and the step count
     // stay bit for bit), like moss_adamw_flat_guarded on the frame's status word
-    const bool fa_on = fa.tensors != 0u && !(hdr_flags & ERRFLAG_OVERFLOW);
+    const bool fa_on = FUSED && !(hdr_flags & ERRFLAG_OVERFLOW);
     if (fa_on && blockIdx.x == 0 && threadIdx.x == 0) adamw_cache_next(fa.step_state, fa.beta1, fa.beta2, fa_t);   // (the next step's bias corrections)
 
     // Sum the per-instance partial records.  A Gaussian with few instances (the norm: 2-3) is summed by its own lane.  One that
@@ -1422,19 +1424,20 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     const size_t lds_bytes_staged = (size_t)threads * SH_ROW * sizeof(float) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4;
     static const int resident_per_cu = [&] {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, preprocess_backward_kernel<true>, threads, lds_bytes_staged) != hipSuccess || occ < 1) occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, preprocess_backward_kernel<true, false>, threads, lds_bytes_staged) != hipSuccess || occ < 1) occ = 1;
         return occ;
     }();
     const int gl2 = gl2_env ? std::max(4, std::min(6, gl2_env))
                             : (((fp.raw & HINT_SPATIAL_ORDER) && blocks <= resident_per_cu * device_cus()) ? 4 : 6);
-#define LAUNCH_PB(STAGE)                                                                                                        \
-    MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE>), dim3(blocks), dim3(threads),                                        \
+#define LAUNCH_PB(STAGE, FUSE)                                                                                                  \
+    MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE, FUSE>), dim3(blocks), dim3(threads),                                  \
                        ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, -0.5f * (float)fp.W, -0.5f * (float)fp.H, fp.scale_modifier, \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues, translation, dL_dtranslation, fa)
-    if (stage) LAUNCH_PB(true); else LAUNCH_PB(false);
+    if (fa.tensors != 0u) { if (stage) LAUNCH_PB(true, true); else LAUNCH_PB(false, true); }
+    else if (stage) LAUNCH_PB(true, false); else LAUNCH_PB(false, false);
 #undef LAUNCH_PB
 }
 
