@@ -488,3 +488,15 @@ def test_moss_side_patches_apply(tmp_path):
     assert "context" in inspect.signature(GaussianRasterizer.__init__).parameters
     assert "transforms" in inspect.signature(GaussianRasterizer.forward).parameters
     assert list(inspect.signature(densify.densify_stats_update).parameters) == ["max_radii2D", "xyz_gradient_accum", "denom", "radii", "viewspace_grad"]
+
+
+def test_graft_entry_build_passes(hip_lib):
+    """__graft_entry__.build() is what the driver runs as its "does it build" check: it must succeed on a tree whose libraries are
+    current (it re-checks the three ABI numbers -- library, compiled glue, Python binding -- against each other, never against a literal:
+    the literal survived two ABI bumps unnoticed in round 4)."""
+    import importlib
+    import re
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    src = open(ge.__file__).read()
+    assert not re.search(r"abi_version\(\)\s*==\s*\d", src)
