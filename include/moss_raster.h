@@ -240,8 +240,16 @@ int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_a
  * (32-bit words: [0] = int step, advanced by one per call by the update kernel itself; [8..11] = the bias corrections of the
  * current / next step, double-buffered by step parity; [64] and [128 + 64 g], g < 32 = its two-level block-completion counters,
  * each on a 256-byte line of its own).  n must be > 0.  Nothing in the call depends on a host-side
- * counter, so a captured hipGraph of a training step replays correctly. */
+ * counter, so a captured hipGraph of a training step replays correctly.
+ * LEARNING RATES ON THE DEVICE (ABI 4): when word MOSS_ADAMW_LR_VALID_WORD of the block is non-zero, every kernel that is given the
+ * block (the _devstep / _range / _guarded updates and moss_raster_backward_raw_adamw) takes segment s's learning rate from float
+ * word MOSS_ADAMW_LR_WORD0 + s and its second rate (periodic pattern) from MOSS_ADAMW_LR2_WORD0 + s instead of from segment_lr /
+ * segment_lr2: a schedule -- MOSS decays the position rate every iteration, scene/gaussian_model.py:263-268 -- is then a 64-byte
+ * host-to-device copy between two replays of a captured step, not a re-capture. */
 #define MOSS_ADAMW_STATE_BYTES 9216
+#define MOSS_ADAMW_LR_VALID_WORD 12
+#define MOSS_ADAMW_LR_WORD0 16
+#define MOSS_ADAMW_LR2_WORD0 24
 size_t moss_adamw_state_bytes(void);
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
@@ -414,6 +422,9 @@ typedef struct moss_fused_adamw {
     float lr_sh_rest;            /* sh: of the other 45 floats of a record (features_rest) */
     float beta1, beta2, eps, weight_decay;
     void* step_state;
+    int32_t lr_segment[5];       /* per tensor: its entry s (0..7) in the step-state block's learning-rate table, or -1; when word
+                                  * MOSS_ADAMW_LR_VALID_WORD of step_state is non-zero the kernel reads lr from float word
+                                  * MOSS_ADAMW_LR_WORD0 + s (sh: lr_sh_rest from MOSS_ADAMW_LR2_WORD0 + s) instead of from this struct */
 } moss_fused_adamw;
 int moss_raster_backward_raw_adamw(
     int P, int D, int M, int R,

@@ -143,7 +143,7 @@ class FusedAdamWStruct(C.Structure):
     """``moss_fused_adamw`` of include/moss_raster.h (host struct handed to ``moss_raster_backward_raw_adamw``)."""
     _fields_ = [("tensors", C.c_uint32), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_float * 5),
                 ("lr_sh_rest", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
-                ("step_state", C.c_void_p)]
+                ("step_state", C.c_void_p), ("lr_segment", C.c_int32 * 5)]
 
 
 OPT_BITS = {"means3D": 1, "sh": 2, "opacity": 4, "scales": 8, "rotations": 16}      # MOSS_OPT_*; position = index in the struct's arrays

@@ -12,6 +12,10 @@ namespace moss {
 // Words of the step-state block (int32 / float32 views of the same memory; moss_adamw_state_bytes()):
 //   [0] step count t, [8..11] cached bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} for the two parities of t,
 //   [64] global completion counter, [128 + 64 g] completion counter of block group g -- every counter on a 256-byte line of its own.
+//   [12] != 0: the learning rates are read from the block too -- [16 + s] = lr of optimizer segment s, [24 + s] = its second rate
+//   (periodic pattern) -- instead of from the launch arguments: a schedule (MOSS decays the position rate every iteration,
+//   scene/gaussian_model.py:263-268, train_ZJU.py:82) then needs no re-capture of a hipGraph that has the arguments baked in.
+constexpr int ADAMW_LR_VALID_WORD = 12, ADAMW_LR_WORD0 = 16, ADAMW_LR2_WORD0 = 24;
 constexpr int ADAMW_NGROUPS = 32;
 constexpr int ADAMW_STATE_WORDS = 128 + 64 * ADAMW_NGROUPS;
 
@@ -80,6 +84,7 @@ struct FusedAdam {
     float* v[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     float lr[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     float lr_sh_rest = 0.f;                                  // sh: lr[1] for a Gaussian's first 3 floats (features_dc), this for the other 45
+    int lr_segment[5] = { -1, -1, -1, -1, -1 };              // each tensor's entry in the step-state block's learning-rate table (-1: none)
     float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f, weight_decay = 0.f;
     const float* step_state = nullptr;
 };

@@ -21,6 +21,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     if (skip_word != nullptr && (*skip_word & skip_mask) != 0u) return;
     // `first`: the arrays are the elements [first, first + n) of the flat buffers the segment table indexes (a rank's shard of the
     // bucket, moss_adamw_flat_range); a multiple of 4, so that a thread's four elements never straddle it.
+    const bool lr_table = step_state != nullptr && reinterpret_cast<const int*>(step_state)[ADAMW_LR_VALID_WORD] != 0;
     int t_dev = 0;
     if (step_state)                                          // device-resident step counter (graph replay): adamw.h
         t_dev = adamw_step_begin(step_state, beta1, beta2, blockIdx.x == 0 && threadIdx.x == 0, bc1, bc2_sqrt);
@@ -45,12 +46,13 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
         // thread, stepped for the other elements.  A thread whose 4 elements straddle a segment end takes the general lookup.
         float lr4[4];
         {
-            long long seg_start = 0, seg_end = first + n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0;
+            long long seg_start = 0, seg_end = first + n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0, seg_i = 0;
 #pragma unroll
             for (int s = 7; s >= 0; s--) if (s < segs.n && gi < segs.end[s]) {
                 seg_end = segs.end[s]; seg_start = s > 0 ? segs.end[s - 1] : 0;
-                lr_a = segs.lr[s]; lr_b = segs.lr2[s]; period = segs.period[s]; split = segs.split[s];
+                lr_a = segs.lr[s]; lr_b = segs.lr2[s]; period = segs.period[s]; split = segs.split[s]; seg_i = s;
             }
+            if (lr_table) { lr_a = step_state[ADAMW_LR_WORD0 + seg_i]; lr_b = step_state[ADAMW_LR2_WORD0 + seg_i]; }   // (device-resident rates)
             if (gi + 3 < seg_end) {
                 unsigned ph = period > 0 ? (unsigned)(gi - seg_start) % (unsigned)period : 0u;
 #pragma unroll
@@ -65,10 +67,10 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
                     float lr = 0.f;
 #pragma unroll
                     for (int s = 7; s >= 0; s--) if (s < segs.n && idx < segs.end[s]) {
-                        lr = segs.lr[s];
+                        lr = lr_table ? step_state[ADAMW_LR_WORD0 + s] : segs.lr[s];
                         if (segs.period[s] > 0) {
                             const unsigned local = (unsigned)(idx - (s > 0 ? segs.end[s - 1] : 0));
-                            if ((int)(local % (unsigned)segs.period[s]) >= segs.split[s]) lr = segs.lr2[s];
+                            if ((int)(local % (unsigned)segs.period[s]) >= segs.split[s]) lr = lr_table ? step_state[ADAMW_LR2_WORD0 + s] : segs.lr2[s];
                         }
                     }
                     lr4[k] = lr;
@@ -140,6 +142,7 @@ extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* 
                               (hipStream_t)stream);
 }
 
+static_assert(moss::ADAMW_LR_VALID_WORD == MOSS_ADAMW_LR_VALID_WORD && moss::ADAMW_LR_WORD0 == MOSS_ADAMW_LR_WORD0 && moss::ADAMW_LR2_WORD0 == MOSS_ADAMW_LR2_WORD0, "adamw.h and the header disagree");
 static_assert(moss::ADAMW_STATE_WORDS * 4 <= MOSS_ADAMW_STATE_BYTES, "the step-state block of adamw.h must fit the size the header promises");
 extern "C" size_t moss_adamw_state_bytes(void) { return MOSS_ADAMW_STATE_BYTES; }
 

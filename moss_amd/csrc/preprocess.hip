@@ -773,7 +773,15 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // Fused AdamW (fa.tensors != 0): the step count and its bias corrections, read now (scalar loads, used at the very end)
     float fa_bc1 = 1.0f, fa_bc2_sqrt = 1.0f;
     int fa_t = 0;
-    if (FUSED) fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
+    if (FUSED) {
+        fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
+        // learning rates kept in the step-state block (a schedule without re-capturing the step): scalar loads, like the step count
+        if (reinterpret_cast<const int*>(fa.step_state)[ADAMW_LR_VALID_WORD] != 0) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (fa.lr_segment[i] >= 0) fa.lr[i] = fa.step_state[ADAMW_LR_WORD0 + fa.lr_segment[i]];
+            if (fa.lr_segment[1] >= 0) fa.lr_sh_rest = fa.step_state[ADAMW_LR2_WORD0 + fa.lr_segment[1]];
+        }
+    }
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then dL_dsh out (in place)
 #define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
 #define PRSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime()

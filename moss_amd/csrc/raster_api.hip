@@ -321,6 +321,8 @@ static int backward_impl(
             if (!(fused & (1u << i))) continue;
             if (!params[i] || !opt->exp_avg[i] || !opt->exp_avg_sq[i]) return fail(MOSS_ERR_INVALID_ARG, "a tensor named in moss_fused_adamw.tensors has a NULL parameter or moment array");
             fa.p[i] = const_cast<float*>(params[i]); fa.m[i] = opt->exp_avg[i]; fa.v[i] = opt->exp_avg_sq[i]; fa.lr[i] = opt->lr[i];
+            if (opt->lr_segment[i] < -1 || opt->lr_segment[i] > 7) return fail(MOSS_ERR_INVALID_ARG, "moss_fused_adamw.lr_segment must be -1 or 0..7");
+            fa.lr_segment[i] = opt->lr_segment[i];
         }
         if (fused & OPT_SH) {
             if (M != 16 || ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(opt->exp_avg[1]) | reinterpret_cast<uintptr_t>(opt->exp_avg_sq[1]) |

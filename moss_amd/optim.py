@@ -111,6 +111,8 @@ class FlatAdamW:
             raise ValueError("fuse_into_backward: name every parameter of the bucket exactly once (other parameters belong to a "
                              "second optimizer over their own bucket)")
         st = FusedAdamWStruct()
+        for i in range(5):
+            st.lr_segment[i] = -1
         offs = {id(p): (off, i) for i, (p, off) in enumerate(zip(self.bucket.params, self.bucket.offsets))}
         ptrs = {}
         for name, p in given.items():
@@ -120,6 +122,7 @@ class FlatAdamW:
             st.exp_avg[slot] = self.exp_avg.data_ptr() + 4 * off
             st.exp_avg_sq[slot] = self.exp_avg_sq.data_ptr() + 4 * off
             st.lr[slot] = self.seg_lr[seg]
+            st.lr_segment[slot] = seg
             if name == "sh":
                 period, split = int(self.seg_period[seg]), int(self.seg_split[seg])
                 if period == 0:
@@ -137,19 +140,49 @@ class FlatAdamW:
         (context or _C.DEFAULT).fused_adamw = self.fused
         return self.fused
 
-    def refresh_fused_learning_rates(self):
-        """After changing ``seg_lr`` / ``seg_lr2`` (a learning-rate schedule): copy them into the fused descriptor.  NOTE a captured
-        hipGraph has the old values baked in as kernel arguments: re-capture the step."""
-        if getattr(self, "fused", None) is None:
-            return
-        for i, p in enumerate(self.bucket.params):
-            for name, ptr in self.fused.param_ptrs.items():
-                if ptr == p.data_ptr():
-                    from ._lib import OPT_BITS
-                    slot = OPT_BITS[name].bit_length() - 1
-                    self.fused.struct.lr[slot] = self.seg_lr[i]
-                    if name == "sh":
-                        self.fused.struct.lr_sh_rest = self.seg_lr2[i] if int(self.seg_period[i]) else self.seg_lr[i]
+    def set_learning_rates(self, rates):
+        """A learning-rate schedule.  ``rates``: {parameter (or its index in the bucket): lr, or (lr, lr_rest) for a tensor with a
+        periodic pattern}.  MOSS decays the position rate every iteration (``GaussianModel.update_learning_rate``,
+        scene/gaussian_model.py:263-268, train_ZJU.py:82).
+
+        With ``capturable=True`` the rates also go into the optimizer's device-side state block (one small asynchronous copy on the
+        current stream) and every update kernel -- the flat ones and the rasterizer backward that takes the step itself -- reads them
+        from there: call this BETWEEN replays of a captured step; no re-capture (the launch arguments baked into the graph are then
+        ignored)."""
+        index = {id(p): i for i, p in enumerate(self.bucket.params)}
+        for key, val in rates.items():
+            i = key if isinstance(key, int) else index[id(key)]
+            lr, lr2 = (val if isinstance(val, (tuple, list)) else (val, None))
+            self.seg_lr[i] = float(lr)
+            if lr2 is not None:
+                self.seg_lr2[i] = float(lr2)
+        if self.fused is not None:
+            st = self.fused.struct
+            for slot in range(5):
+                seg = st.lr_segment[slot]
+                if seg >= 0:
+                    st.lr[slot] = self.seg_lr[seg]
+                    if slot == 1:
+                        st.lr_sh_rest = self.seg_lr2[seg] if int(self.seg_period[seg]) else self.seg_lr[seg]
+        if self.step_state is not None:
+            # a small ring of pinned staging buffers: the copy is asynchronous and the device may be several steps behind the host, so a
+            # buffer is rewritten only after the copy that last read it has completed (its event)
+            if getattr(self, "_lr_ring", None) is None:
+                self._lr_ring = [[torch.zeros(20, dtype=torch.float32).pin_memory(), None] for _ in range(8)]
+                self._lr_next = 0
+            slot = self._lr_ring[self._lr_next]
+            self._lr_next = (self._lr_next + 1) % len(self._lr_ring)
+            if slot[1] is not None:
+                slot[1].synchronize()
+            h = slot[0]
+            hi = h.view(torch.int32)
+            hi[0] = 1                                        # word 12: the table is valid; words 13-15 unused
+            for s_ in range(8):
+                h[4 + s_] = self.seg_lr[s_] if s_ < self.nseg else 0.0
+                h[12 + s_] = (self.seg_lr2[s_] if int(self.seg_period[s_]) else self.seg_lr[s_]) if s_ < self.nseg else 0.0
+            self.step_state.view(torch.float32)[12:32].copy_(h, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(self.step_state.device))
 
     def step_count(self) -> int:
         """Steps taken so far (reads the device-side counter when there is one: it synchronises)."""

@@ -614,6 +614,83 @@ def test_backward_kernel_takes_the_adamw_step(gpu, hip_lib, async_mode, mode):
     assert b.opt.step_count() == 3
 
 
+def test_learning_rate_schedule_without_recapture(gpu, hip_lib, async_mode):
+    """MOSS changes the position learning rate every iteration (scene/gaussian_model.py:263-268).  FlatAdamW.set_learning_rates puts the
+    rates into the optimizer's device-side state block, where the update kernels read them: a captured step follows the schedule
+    without being captured again -- the fused form (the rasterizer backward takes the step) and the flat kernel alike, and both
+    equal eager steps that were given the rates as launch arguments."""
+    from types import SimpleNamespace
+    from moss_amd.dist import GradBucket
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    from moss_amd.optim import FlatAdamW
+    from moss_amd.diff_gaussian_rasterization import _C
+    s = scenes.config2()
+    cam = camera_view(s.camera, gpu)
+    bg = torch.zeros(3, device=gpu)
+    w = torch.rand(3, s.camera.H, s.camera.W, generator=torch.Generator().manual_seed(9)).to(gpu)
+    schedule = [1.6e-4, 1.1e-4, 7e-5, 3e-5]                   # the position rate, step by step; the SH pair changes too
+
+    def make(fused, device_table):
+        pc = GaussianSet(s, sh_degree=3, device=gpu, unified_features=True)
+        cx = _C.RasterContext()
+        cx.set_async(True, capacity=4_000_000)
+        pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raster_context=cx, raw_parameters_in_op=True)
+        bucket = GradBucket(list(pc.parameters()))
+        opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=device_table)
+        if fused:
+            opt.fuse_into_backward(cx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling, rotations=pc._rotation)
+
+        def step():
+            if not fused:
+                bucket.attach()
+            out = render(cam, pc, pipe, bg)
+            ((out["render"] * w).sum() + out["render_alpha"].sum()).backward()
+            opt.step()
+            return out["render"].detach()
+        return SimpleNamespace(pc=pc, opt=opt, step=step)
+
+    def rates(m, k):
+        return {m.pc._xyz: schedule[k], m.pc._features: (0.0025 * (1 + k), 0.0025 / 20.0 * (1 + k))}
+
+    # reference: eager steps of the flat kernel with the rates as LAUNCH ARGUMENTS (the host tables, no device table)
+    ref = make(False, True)
+    index = {id(p): i for i, p in enumerate(ref.opt.bucket.params)}
+    for k in range(len(schedule)):
+        for prm, val in rates(ref, k).items():
+            i = index[id(prm)]
+            ref.opt.seg_lr[i] = val[0] if isinstance(val, tuple) else val
+            if isinstance(val, tuple):
+                ref.opt.seg_lr2[i] = val[1]
+        ref.step()
+    assert int(ref.opt.step_state[12]) == 0
+    torch.cuda.synchronize(gpu)
+    for fused in (False, True):
+        m = make(fused, True)
+        m.opt.set_learning_rates(rates(m, 0))
+        side = torch.cuda.Stream(gpu)
+        side.wait_stream(torch.cuda.current_stream(gpu))
+        with torch.cuda.stream(side):
+            snap = m.opt.snapshot()
+            m.step()                                           # warm-up (allocator), then rewind
+            m.opt.restore(snap)
+        torch.cuda.current_stream(gpu).wait_stream(side)
+        torch.cuda.synchronize(gpu)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            m.step()
+        m.opt.restore(snap)                                    # the capture itself ran nothing, but keep the state explicit
+        torch.cuda.synchronize(gpu)
+        for k in range(len(schedule)):
+            m.opt.set_learning_rates(rates(m, k))              # between replays: a 80-byte copy, no re-capture
+            graph.replay()
+        torch.cuda.synchronize(gpu)
+        assert m.opt.step_count() == len(schedule)
+        for name in ("flat_params", "exp_avg", "exp_avg_sq"):
+            a, b = getattr(ref.opt, name), getattr(m.opt, name)
+            assert torch.equal(a, b), f"{name} (fused={fused}): max difference {float((a - b).abs().max())}"
+
+
 def test_step_captured_in_hipgraph_replays_with_new_parameters(gpu, hip_lib, async_mode):
     """With the asynchronous forward nothing in render+backward talks to the host, so the step is capturable in a hipGraph.
     Replays must track the CURRENT parameter values (not the captured ones) and agree bit-for-bit with eager launches."""
