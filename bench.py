@@ -102,9 +102,11 @@ def parse_args(argv=None):
                     help="1 (default): the per-Gaussian backward kernel takes the AdamW step of the parameters it differentiates "
                          "(FlatAdamW.fuse_into_backward) wherever the step is local to the rank (N = 1, loss_only); 0: gradients into the "
                          "bucket, then the flat AdamW kernel (always so for the gradient exchanges).  Same bits either way")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded", "loss_only"],
-                    help="N > 1 only. loss_only = BASELINE configs[3] as written: every rank trains its OWN model on its own frames and "
-                         "RCCL all-reduces the 4-float loss block only; "
+    ap.add_argument("--exchange", default="loss_only", choices=["allreduce", "sharded", "loss_only"],
+                    help="N > 1 only. loss_only (the default since round 4) = BASELINE configs[3] as written -- \"frames of six subjects "
+                         "sharded across 8 GPUs, RCCL loss all-reduce\": per-view / per-subject training is embarrassingly parallel "
+                         "(north_star), so every rank trains its OWN model on its own frames, exactly the N = 1 step, and RCCL all-reduces "
+                         "the 4-float loss block only (no data-path collective); "
                          "allreduce = one all-reduce (mean) of the flat gradient bucket, then the full AdamW on every rank; "
                          "sharded = reduce-scatter, AdamW on the rank's 1/N of the parameters (moments memory and update time / N), "
                          "all-gather of the updated parameters (moss_amd.dist.ShardedStep).  The other variants are measured after the "
@@ -314,7 +316,8 @@ class Harness:
         n = max(self.n_exchange, 1)
         t = [round(x / n, 4) for x in self.t_phase]
         if self.exchange_kind == "loss_only":
-            return {"loss_allreduce_ms": t[0], "bytes_reduced": 16, "adamw_elements": int(self.opt.count), "adamw": "inside the rank-local step"}
+            return {"loss_allreduce_ms": t[0], "bytes_reduced": 16, "adamw_elements": int(self.opt.count),
+                    "adamw": "inside the rank-local step" + (": taken by the per-Gaussian backward kernel" if self.fused_opt else "")}
         if self.sharded is None:
             return {"allreduce_ms": t[0], "adamw_ms": t[1], "bytes_reduced": int(self.bucket.flat.numel() * 4), "adamw_elements": int(self.opt.count)}
         return {"reduce_scatter_ms": t[0], "adamw_ms": t[1], "all_gather_ms": t[2], "bytes_reduced": int(self.bucket.flat.numel() * 4),
@@ -619,7 +622,9 @@ def main(argv=None):
                    if args.config == "cfg3" else args.config,
                    "target": args.target, "input_mode": args.mode, "index_order": args.order,
                    "activations": "torch" if args.torch_activations else ("in_op" if h.pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
-                   "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+                   "parallelism": ("single GPU" if world == 1 else
+                                   f"frames / subjects sharded over {world} GPUs, one model per GPU, RCCL all-reduce of the loss block (configs[3])"
+                                   if h.exchange_kind == "loss_only" else f"frame-parallel x{world} (replicas, gradient exchange: {h.exchange_kind})"),
                    "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
                    "optimizer": ("AdamW step taken by the per-Gaussian backward kernel (moss_raster_backward_raw_adamw); bit-identical to the flat "
                                  "kernel, reported beside as callers.unfused_optimizer") if h.fused_opt else "flat AdamW kernel over the gradient bucket",

@@ -447,11 +447,11 @@ def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
     assert len(lines) == 1, p.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
-    assert res["replicas_identical"] is True and res["backend"] == "gloo"
+    assert res["replicas_identical"] is True and res["backend"] == "gloo"            # (of the two gradient exchanges measured beside)
     assert res["allreduce_ms"] >= 0.0 and "adamw_ms" in res and res["value"] > 0
-    # both exchange paths were run, each reports its numbers, and they left identical parameters (asserted inside the ranks too)
+    # all three exchanges were run, each reports its numbers; the headline is BASELINE configs[3] as written (loss-only)
     ev = res["exchange_variants"]
-    assert set(ev) == {"allreduce", "sharded", "loss_only"} and res["exchange"] == "allreduce"
+    assert set(ev) == {"allreduce", "sharded", "loss_only"} and res["exchange"] == "loss_only" and res["value"] == ev["loss_only"]["value"]
     assert ev["allreduce"]["checksum"] == ev["sharded"]["checksum"] and ev["allreduce"]["replicas_identical"] and ev["sharded"]["replicas_identical"]
     # BASELINE configs[3] as written: independent models, only the loss block travels (asserted inside the ranks: every rank kept its
     # own gradients and saw the mean loss); nothing to compare between replicas
