@@ -629,12 +629,20 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         p_prev = p_cur;
         n_cuts++;
     };
-    // after a trip that consumed four real hits and left `hits_done` behind it: cut if that count is a multiple of the segment length
-    auto maybe_cut = [&](const Fetched& f, int hits_done, bool last_of_all) {
-        if ((hits_done & (se.seg_hits - 1)) != 0 || last_of_all) return;
-        // (only the item's LAST trip can hold padding slots, and it never cuts: last_of_all)
-        const int last_pos1 = (int)__builtin_amdgcn_readlane(__float_as_int(f.pos1), 3);      // slot 3 of pixel 0: the trip's last hit
-        emit_cut((int)__int_as_float(last_pos1));
+    // After a trip that left `hits_done` hits behind it, a multiple of the segment length: a cut is DUE there -- and made when the
+    // NEXT trip starts, i.e. only if the list goes on (the state at a trip's start is the state at the previous trip's end).  Round 3
+    // cut right after the trip unless it knew the trip to be the item's last, which it learned from the scanner's "list complete"
+    // flag: whether that flag had arrived when a list of exactly k x 64 hits ran its last trip was a matter of timing, so the same
+    // frame was now and then partitioned differently (one more piece, an empty remainder) -- the same gradients up to rounding, but not
+    // the same bits (found in round 4: two identical trainings, a handful of last-bit differences every ~20 steps).
+    int pend_pos = -1;
+    auto note_cut_due = [&](const Fetched& f, int hits_done) {
+        if ((hits_done & (se.seg_hits - 1)) != 0) return;
+        // (only the item's LAST trip can hold padding slots, and no trip follows it: its cut is never made)
+        pend_pos = (int)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.pos1), 3));   // slot 3 of pixel 0: the trip's last hit
+    };
+    auto cut_if_due = [&]() {
+        if (pend_pos >= 0) { emit_cut(pend_pos); pend_pos = -1; }
     };
 
     int C = 0;                                               // list entries [0, C) are blended
@@ -670,12 +678,14 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
             Fetched f0 = get(0);
             for (int t = 0; t < ntrip; t += 2) {
                 const Fetched f1 = get(t + 1);                                             // next trip's LDS reads under this trip
+                cut_if_due();
                 if (trip(f0)) { finished = true; break; }
-                maybe_cut(f0, C + 4 * (t + 1), final_round && t + 1 >= ntrip);
+                note_cut_due(f0, C + 4 * (t + 1));
                 if (t + 1 >= ntrip) break;
                 f0 = get(t + 2);
+                cut_if_due();
                 if (trip(f1)) { finished = true; break; }
-                maybe_cut(f1, C + 4 * (t + 2), final_round && t + 2 >= ntrip);
+                note_cut_due(f1, C + 4 * (t + 2));
             }
             d_trip += STAMP() - t4;
         }

@@ -1,0 +1,134 @@
+"""Debug aid: flat AdamW after the backward vs the step inside the backward kernel, same start, eager or graph; reports the first step
+after which parameters / moments differ and where.  Usage: python scripts/dbg_fused_vs_flat.py [steps] [graph 0|1] [config]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from types import SimpleNamespace
+from moss_amd import scenes, dist as mdist
+from moss_amd.gaussian_model import GaussianSet
+from moss_amd.gaussian_renderer import render, camera_view
+from moss_amd.loss import training_loss_fused, backward_from_loss
+from moss_amd.optim import FlatAdamW
+from moss_amd import diff_gaussian_rasterization as dgr
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+use_graph = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+scene = getattr(scenes, sys.argv[3] if len(sys.argv) > 3 else "config3")()
+dev = torch.device("cuda:0")
+cam = camera_view(scene.camera, dev)
+bg = torch.zeros(3, device=dev)
+with torch.no_grad():
+    o = render(cam, GaussianSet(getattr(scenes, sys.argv[3] if len(sys.argv) > 3 else "config3")(seed=scenes.SEED + 7), sh_degree=3, device=dev),
+               SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False), bg)
+gt = o["render"].detach().clamp(0, 1).contiguous(); gt_mask = (o["render_alpha"].detach() > 0.5).float().contiguous()
+
+
+def make(fused):
+    pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=True)
+    bucket = mdist.GradBucket(list(pc.parameters()))
+    cx = dgr.RasterContext()
+    cx.set_async(True, **({} if os.environ.get("DBG_LEARN_CAPACITY") else {"capacity": int(os.environ.get("DBG_CAPACITY", "8000000"))}))   # (learned: the first forward is synchronous)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True, grad_bucket=bucket, raster_context=cx)
+    opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)
+    if fused:
+        opt.fuse_into_backward(cx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling, rotations=pc._rotation)
+    else:
+        cx.set_grad_sink(sh=lambda: bucket.sink_for(pc._features), means3D=lambda: bucket.sink_for(pc._xyz), opacity=lambda: bucket.sink_for(pc._opacity),
+                         scales=lambda: bucket.sink_for(pc._scaling), rotations=lambda: bucket.sink_for(pc._rotation))
+
+    def compute():
+        bucket.detach_grads()
+        out = render(cam, pc, pipe, bg)
+        loss = training_loss_fused(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
+        backward_from_loss(loss)
+        if not fused:
+            bucket.collect()
+            opt.step()
+        return out["render"].detach()
+    return SimpleNamespace(pc=pc, opt=opt, compute=compute, bucket=bucket)
+
+
+a = make(False)
+if os.environ.get("DBG_POISON"):
+    # hand the second model RECYCLED memory full of a bit pattern (fresh hipMalloc pages read as zeros: a kernel that relies on that
+    # passes every test that allocates its buffers once)
+    pat = {"nan": float("nan"), "ones": 1.0, "big": 3.0e38}[os.environ["DBG_POISON"]]
+    junk = [torch.full((1 << 26,), pat, device=dev) for _ in range(12)]       # 3 GiB
+    torch.cuda.synchronize(); del junk
+b = make(bool(int(os.environ.get("DBG_SECOND_FUSED", "1"))))
+names = [n for n, _ in zip(("xyz", "features", "opacity", "scaling", "rotation"), a.bucket.params)]
+if use_graph:
+    for m in (a, b):
+        side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev))
+        snap = m.opt.snapshot()
+        with torch.cuda.stream(side):
+            m.compute()
+        torch.cuda.current_stream(dev).wait_stream(side); torch.cuda.synchronize()
+        m.opt.restore(snap)
+        m.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(m.graph, stream=side):
+            m.img = m.compute()
+        m.opt.restore(snap)
+        torch.cuda.synchronize()
+if os.environ.get("DBG_FREEZE"):
+    # train model a for `steps`, then FREEZE the parameters and repeat forward + loss + backward: the gradient bucket must not change
+    for it in range(steps):
+        a.compute()
+    torch.cuda.synchronize()
+    real_step = a.opt.step
+    a.opt.step = lambda *x, **k: None
+    ref_img = a.compute().clone(); torch.cuda.synchronize(); ref = a.bucket.flat.clone()
+    bad = 0
+    for it in range(int(os.environ["DBG_FREEZE"])):
+        img = a.compute(); torch.cuda.synchronize()
+        g = a.bucket.flat
+        if not torch.equal(g, ref) or not torch.equal(img, ref_img):
+            bad += 1
+            dd = (g != ref).nonzero().flatten()
+            where = []
+            for p_, n_, off in zip(names, a.bucket.sizes, a.bucket.offsets):
+                m_ = (dd >= off) & (dd < off + n_)
+                if int(m_.sum()):
+                    per = n_ // scene.P
+                    rows = torch.unique((dd[m_] - off) // per)
+                    where.append(f"{p_}: {int(m_.sum())} el in Gaussians {rows[:8].tolist()}")
+            print(f"repeat {it}: image identical {bool(torch.equal(img, ref_img))}; " + "; ".join(where))
+    print(f"frozen after {steps} steps: {bad} of {os.environ['DBG_FREEZE']} repeats differ")
+    sys.exit(0)
+if os.environ.get("DBG_NOSYNC"):
+    # each model on its own, `steps` replays queued without a host synchronisation in between (how a training loop runs)
+    for m in (a, b):
+        for it in range(steps):
+            if use_graph:
+                m.graph.replay()
+            else:
+                m.compute()
+        torch.cuda.synchronize()
+    for nm in ("flat_params", "exp_avg", "exp_avg_sq"):
+        x, y = getattr(a.opt, nm), getattr(b.opt, nm)
+        print(nm, "identical" if torch.equal(x, y) else f"DIFFERENT in {int((x != y).sum())} elements, max {float((x - y).abs().max()):.3e}")
+    print("steps counted", a.opt.step_count(), b.opt.step_count())
+    sys.exit(0)
+for it in range(1, steps + 1):
+    if use_graph:
+        a.graph.replay(); b.graph.replay(); ia, ib = a.img, b.img
+    else:
+        ia, ib = a.compute(), b.compute()
+    torch.cuda.synchronize()
+    bad = []
+    if not torch.equal(ia, ib):
+        bad.append("image")
+    for nm in ("flat_params", "exp_avg", "exp_avg_sq"):
+        x, y = getattr(a.opt, nm), getattr(b.opt, nm)
+        if not torch.equal(x, y):
+            d = (x != y).nonzero().flatten()
+            where = []
+            for p_, n_, off in zip(names, a.bucket.sizes, a.bucket.offsets):
+                k = int(((d >= off) & (d < off + n_)).sum())
+                if k:
+                    first = int(d[(d >= off) & (d < off + n_)][0]) - off
+                    where.append(f"{p_}: {k} elements (first at flat index {first}: {float(x[off + first])!r} vs {float(y[off + first])!r})")
+            bad.append(f"{nm}: " + "; ".join(where))
+    print(f"step {it}: steps counted {a.opt.step_count()} / {b.opt.step_count()}  " + ("IDENTICAL" if not bad else " | ".join(bad)))
+    if bad and it > 3:
+        break

@@ -2,7 +2,7 @@
 trajectory, checks every 500 steps that nothing overflowed and everything is finite.  Run TWICE from the same start -- with the
 flat AdamW kernel after the backward, then with the step taken inside the backward kernel (FlatAdamW.fuse_into_backward) -- and the
 parameters and moments after the last step must be equal bit for bit.
-Usage: python scripts/long_run.py [steps]"""
+Usage: python scripts/long_run.py [steps] [order, one digit per run: 0 = flat, 1 = fused; default 01]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,7 +30,7 @@ def run(fused):
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True, grad_bucket=bucket)
     opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)
     cx = dgr.RasterContext()
-    cx.set_async(True)
+    cx.set_async(True, **({"capacity": int(os.environ["LR_CAPACITY"])} if os.environ.get("LR_CAPACITY") else {}))
     pipe.raster_context = cx
     if fused:
         opt.fuse_into_backward(cx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling, rotations=pc._rotation)
@@ -45,7 +45,8 @@ def run(fused):
         backward_from_loss(loss)
         if not fused:
             bucket.collect()
-            opt.step(skip_word=dgr._C.frame_status_word(cx.last_img_buffer))
+            img = cx.last_img_buffer                         # (None after the first, synchronous forward that sizes the capacity)
+            opt.step(skip_word=None if (img is None or os.environ.get("LR_NOGUARD")) else dgr._C.frame_status_word(img))
         return {"radii": out["radii"]}
 
     for _ in range(3):
@@ -69,11 +70,16 @@ def run(fused):
     return opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count(), step.dropped_frames
 
 
-print("--- flat AdamW kernel after the backward")
-a = run(False)
-print("--- AdamW step inside the per-Gaussian backward kernel")
-b = run(True)
-same = [bool(torch.equal(x, y)) for x, y in zip(a[:3], b[:3])]
-print(f"steps taken {a[3]} / {b[3]}, dropped frames {a[4]} / {b[4]}; parameters, exp_avg, exp_avg_sq bit-identical: {same}")
-assert all(same) and a[3] == b[3]
+import itertools
+order = [bool(int(c)) for c in (sys.argv[2] if len(sys.argv) > 2 else "01")]
+res = []
+for f in order:
+    print("--- " + ("AdamW step inside the per-Gaussian backward kernel" if f else "flat AdamW kernel after the backward"))
+    res.append(run(f))
+ok = True
+for (i, x), (j, y) in itertools.combinations(enumerate(res), 2):
+    same = [bool(torch.equal(u, v)) for u, v in zip(x[:3], y[:3])]
+    print(f"run {i} (fused={order[i]}) vs run {j} (fused={order[j]}): steps {x[3]} / {y[3]}, dropped {x[4]} / {y[4]}; parameters, exp_avg, exp_avg_sq bit-identical: {same}")
+    ok = ok and all(same) and x[3] == y[3]
+assert ok
 print("ok")

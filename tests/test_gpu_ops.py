@@ -614,6 +614,61 @@ def test_backward_kernel_takes_the_adamw_step(gpu, hip_lib, async_mode, mode):
     assert b.opt.step_count() == 3
 
 
+def test_identical_trainings_end_bit_identical_on_the_bench_frame(gpu, hip_lib, async_mode):
+    """150 training steps on the bench frame (config3: 100k Gaussians, depth segments active), twice with the flat AdamW kernel and once
+    with the step inside the backward kernel, each queued without host synchronisation: parameters and moments must be equal bit for
+    bit.  (Round 3's forward made the cut after a list's k x 64-th hit depend on whether the scanner's "list complete" flag had arrived
+    yet: the same frame was now and then partitioned differently -- a handful of last-bit differences every ~20 steps, found in round 4
+    by exactly this comparison.  The single-frame reproducibility test never saw it.)"""
+    from types import SimpleNamespace
+    from moss_amd.dist import GradBucket
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render, camera_view
+    from moss_amd.loss import training_loss_fused, backward_from_loss
+    from moss_amd.optim import FlatAdamW
+    from moss_amd.diff_gaussian_rasterization import _C
+    s = scenes.config3()
+    cam = camera_view(s.camera, gpu)
+    bg = torch.zeros(3, device=gpu)
+    with torch.no_grad():
+        o = render(cam, GaussianSet(scenes.config3(seed=scenes.SEED + 7), sh_degree=3, device=gpu),
+                   SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False), bg)
+    gt = o["render"].detach().clamp(0, 1).contiguous()
+    gt_mask = (o["render_alpha"].detach() > 0.5).float().contiguous()
+
+    def run(fused, steps=150):
+        pc = GaussianSet(s, sh_degree=3, device=gpu, unified_features=True)
+        bucket = GradBucket(list(pc.parameters()))
+        cx = _C.RasterContext()
+        cx.set_async(True, capacity=480_000)                  # (2 x the frame's instances: what the capacity policy would pick)
+        pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True,
+                               grad_bucket=bucket, raster_context=cx)
+        opt = FlatAdamW(pc.param_groups(), bucket, eps=1e-15, capturable=True)
+        if fused:
+            opt.fuse_into_backward(cx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling, rotations=pc._rotation)
+        else:
+            cx.set_grad_sink(sh=lambda: bucket.sink_for(pc._features), means3D=lambda: bucket.sink_for(pc._xyz),
+                             opacity=lambda: bucket.sink_for(pc._opacity), scales=lambda: bucket.sink_for(pc._scaling),
+                             rotations=lambda: bucket.sink_for(pc._rotation))
+        for _ in range(steps):
+            bucket.detach_grads()
+            out = render(cam, pc, pipe, bg)
+            backward_from_loss(training_loss_fused(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms))
+            if not fused:
+                bucket.collect()
+                opt.step(skip_word=_C.frame_status_word(cx.last_img_buffer))
+        torch.cuda.synchronize(gpu)
+        cx.check_status()
+        assert cx.read_dropped_frames() == 0
+        return opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count()
+
+    a, b, c = run(False), run(False), run(True)
+    assert a[3] == b[3] == c[3] == 150
+    for x, y, z, name in zip(a[:3], b[:3], c[:3], ("parameters", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(x, y), f"{name}: two identical trainings differ"
+        assert torch.equal(x, z), f"{name}: the step inside the backward kernel differs from the flat kernel"
+
+
 def test_learning_rate_schedule_without_recapture(gpu, hip_lib, async_mode):
     """MOSS changes the position learning rate every iteration (scene/gaussian_model.py:263-268).  FlatAdamW.set_learning_rates puts the
     rates into the optimizer's device-side state block, where the update kernels read them: a captured step follows the schedule
