@@ -46,9 +46,9 @@ __device__ __forceinline__ void adamw_cache_next(const float* step_state, float 
 __device__ __forceinline__ int adamw_step_begin(const float* step_state, float beta1, float beta2, bool writer, float& bc1, float& bc2_sqrt)
 {
     const int t = reinterpret_cast<const int*>(step_state)[0] + 1;
-    if (t == 1) {                                            // first step ever: nothing cached yet
-        bc1 = (float)(1.0 - pow((double)beta1, 1.0));
-        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, 1.0));
+    if (t == 1) {                                            // first step ever: nothing cached yet (pow(x, 1) = x exactly)
+        bc1 = (float)(1.0 - (double)beta1);
+        bc2_sqrt = (float)sqrt(1.0 - (double)beta2);
     } else {                                                 // cached by the previous step (slot = parity of the step)
         bc1 = step_state[8 + 2 * (t & 1)]; bc2_sqrt = step_state[9 + 2 * (t & 1)];
     }

@@ -770,18 +770,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         const int line = threadIdx.x < NUM_XCD_QUEUES ? Q_BWD + (int)threadIdx.x : Q_SEG_HEAD + (int)threadIdx.x - NUM_XCD_QUEUES;
         queues[(size_t)line * QLINE_WORDS] = 0u;
     }
-    // Fused AdamW (fa.tensors != 0): the step count and its bias corrections, read now (scalar loads, used at the very end)
+    // Fused AdamW: the step count and its bias corrections (read below, used at the very end)
     float fa_bc1 = 1.0f, fa_bc2_sqrt = 1.0f;
     int fa_t = 0;
-    if (FUSED) {
-        fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
-        // learning rates kept in the step-state block (a schedule without re-capturing the step): scalar loads, like the step count
-        if (reinterpret_cast<const int*>(fa.step_state)[ADAMW_LR_VALID_WORD] != 0) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) if (fa.lr_segment[i] >= 0) fa.lr[i] = fa.step_state[ADAMW_LR_WORD0 + fa.lr_segment[i]];
-            if (fa.lr_segment[1] >= 0) fa.lr_sh_rest = fa.step_state[ADAMW_LR2_WORD0 + fa.lr_segment[1]];
-        }
-    }
     extern __shared__ float s_sh[];                          // when STAGE_SH: [blockDim.x][SH_ROW] SH in, then dL_dsh out (in place)
 #define PSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime()
 #define PRSTAMP(i) if (g_stamps_dev && threadIdx.x == 0) g_stamps_dev[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime()
@@ -876,7 +867,6 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // a frame that overflowed its capacity rendered nothing: its optimizer step is a no-op (parameters, moments and the step count
     // stay bit for bit), like moss_adamw_flat_guarded on the frame's status word
     const bool fa_on = FUSED && !(hdr_flags & ERRFLAG_OVERFLOW);
-    if (fa_on && blockIdx.x == 0 && threadIdx.x == 0) adamw_cache_next(fa.step_state, fa.beta1, fa.beta2, fa_t);   // (the next step's bias corrections)
 
     // Sum the per-instance partial records.  A Gaussian with few instances (the norm: 2-3) is summed by its own lane.  One that
     // covers much of the image owns up to gx*gy instances x `slabs` records -- a serial sum of thousands of 48-byte gathers -- so
@@ -1099,6 +1089,20 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // the blend kernel's records carry the geometry sums without their constant factors (blend.hip, the backward trip):
     // d pixel / d ndc = W/2, H/2 (backward.cu:472-473, 574-575) and the -1/2 of the exponent (backward.cu:578-580)
     gmx *= mean2d_sx; gmy *= mean2d_sy; gca *= -0.5f; gcb *= -0.5f; gcc *= -0.5f;
+    // (the step count, its bias corrections and the learning rates: chains of dependent SCALAR loads, requested HERE -- behind the
+    // gather, in front of the arithmetic -- and used after it.  At the top of the kernel they delayed every block's first vector load
+    // by three to four scalar round trips (2.3 us of the kernel, measured); between the first requests and the first wait their
+    // registers, live across the gather, cost the second wave per SIMD (260 VGPRs: 51 us))
+    if (FUSED) {
+        fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
+        // learning rates kept in the step-state block (a schedule without re-capturing the step): scalar loads, like the step count
+        if (reinterpret_cast<const int*>(fa.step_state)[ADAMW_LR_VALID_WORD] != 0) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (fa.lr_segment[i] >= 0) fa.lr[i] = fa.step_state[ADAMW_LR_WORD0 + fa.lr_segment[i]];
+            if (fa.lr_segment[1] >= 0) fa.lr_sh_rest = fa.step_state[ADAMW_LR2_WORD0 + fa.lr_segment[1]];
+        }
+    }
+    if (fa_on && blockIdx.x == 0 && threadIdx.x == 0) adamw_cache_next(fa.step_state, fa.beta1, fa.beta2, fa_t);   // (the next step's bias corrections)
     // Fused AdamW: the eleven per-Gaussian scalars' parameters and moments are requested HERE, before the backward arithmetic, and
     // used after it (stamps: loaded where they are used, the 33 strided loads were a round trip of 10k cycles on every block's path)
     const bool fa_scalars = fa_on && in_range && (fa.tensors & (OPT_MEANS | OPT_OPACITY | OPT_SCALES | OPT_ROTATIONS));
