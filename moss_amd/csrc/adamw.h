@@ -43,9 +43,11 @@ __device__ __forceinline__ void adamw_cache_next(const float* step_state, float 
     sf[9 + 2 * ((t + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t + 1)));
 }
 
-__device__ __forceinline__ int adamw_step_begin(const float* step_state, float beta1, float beta2, bool writer, float& bc1, float& bc2_sqrt)
+// (t_prev: word 0 of the block if the caller has loaded it already -- together with other words, so that the loads share one round trip)
+__device__ __forceinline__ int adamw_step_begin(const float* step_state, float beta1, float beta2, bool writer, float& bc1, float& bc2_sqrt,
+                                                int t_prev = -1)
 {
-    const int t = reinterpret_cast<const int*>(step_state)[0] + 1;
+    const int t = (t_prev >= 0 ? t_prev : reinterpret_cast<const int*>(step_state)[0]) + 1;
     if (t == 1) {                                            // first step ever: nothing cached yet (pow(x, 1) = x exactly)
         bc1 = (float)(1.0 - (double)beta1);
         bc2_sqrt = (float)sqrt(1.0 - (double)beta2);

@@ -21,10 +21,13 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     if (skip_word != nullptr && (*skip_word & skip_mask) != 0u) return;
     // `first`: the arrays are the elements [first, first + n) of the flat buffers the segment table indexes (a rank's shard of the
     // bucket, moss_adamw_flat_range); a multiple of 4, so that a thread's four elements never straddle it.
-    const bool lr_table = step_state != nullptr && reinterpret_cast<const int*>(step_state)[ADAMW_LR_VALID_WORD] != 0;
+    // (the step count and the learning-rate flag are requested together: one scalar round trip at the kernel's start, not two)
+    int t_prev = 0, lr_flag = 0;
+    if (step_state) { t_prev = reinterpret_cast<const int*>(step_state)[0]; lr_flag = reinterpret_cast<const int*>(step_state)[ADAMW_LR_VALID_WORD]; }
+    const bool lr_table = lr_flag != 0;
     int t_dev = 0;
     if (step_state)                                          // device-resident step counter (graph replay): adamw.h
-        t_dev = adamw_step_begin(step_state, beta1, beta2, blockIdx.x == 0 && threadIdx.x == 0, bc1, bc2_sqrt);
+        t_dev = adamw_step_begin(step_state, beta1, beta2, blockIdx.x == 0 && threadIdx.x == 0, bc1, bc2_sqrt, t_prev);
     // (once per thread, correctly rounded; per ELEMENT: a hardware square root and reciprocal, ~1 ulp each -- with this file's correctly
     // rounded sqrt / divisions the update was ~40 vector instructions per element, ten million per step: as much issue time as the
     // kernel's 165 MB are HBM time)

@@ -1094,9 +1094,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // by three to four scalar round trips (2.3 us of the kernel, measured); between the first requests and the first wait their
     // registers, live across the gather, cost the second wave per SIMD (260 VGPRs: 51 us))
     if (FUSED) {
-        fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt);
+        const int t_prev = reinterpret_cast<const int*>(fa.step_state)[0], lr_flag = reinterpret_cast<const int*>(fa.step_state)[ADAMW_LR_VALID_WORD];
+        fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt, t_prev);
         // learning rates kept in the step-state block (a schedule without re-capturing the step): scalar loads, like the step count
-        if (reinterpret_cast<const int*>(fa.step_state)[ADAMW_LR_VALID_WORD] != 0) {
+        if (lr_flag != 0) {
 #pragma unroll
             for (int i = 0; i < 5; i++) if (fa.lr_segment[i] >= 0) fa.lr[i] = fa.step_state[ADAMW_LR_WORD0 + fa.lr_segment[i]];
             if (fa.lr_segment[1] >= 0) fa.lr_sh_rest = fa.step_state[ADAMW_LR2_WORD0 + fa.lr_segment[1]];
