@@ -500,3 +500,26 @@ def test_graft_entry_build_passes(hip_lib):
     ge.build()
     src = open(ge.__file__).read()
     assert not re.search(r"abi_version\(\)\s*==\s*\d", src)
+
+
+def test_gradient_bucket_tensors_are_16_byte_aligned():
+    """Every tensor of the flat gradient / parameter / moment buffers starts at a multiple of 4 floats whatever the sizes (P is
+    arbitrary after a densification): the kernels that read and write those slices work on float4, and with P % 4 != 0 the SH slice of
+    rounds 1-3's packed layout was misaligned (the staged paths silently fell back to per-lane loads)."""
+    from moss_amd.dist import GradBucket
+    P = 1237
+    params = [torch.nn.Parameter(torch.randn(P, 3)), torch.nn.Parameter(torch.randn(P, 16, 3)), torch.nn.Parameter(torch.randn(P, 1)),
+              torch.nn.Parameter(torch.randn(P, 3)), torch.nn.Parameter(torch.randn(P, 4))]
+    b = GradBucket(params)
+    assert all(off % 4 == 0 for off in b.offsets) and b.offsets[0] == 0
+    assert all(b.offsets[i] + b.sizes[i] <= b.offsets[i + 1] < b.offsets[i] + b.sizes[i] + 4 for i in range(4))
+    assert b.n_params == b.offsets[-1] + b.sizes[-1] and b.tail % 4 == 0 and b.tail >= b.n_params
+    for v, p in zip(b.views, params):
+        assert v.shape == p.shape and v.data_ptr() % 16 == b.flat.data_ptr() % 16
+    flat = b.pack([p.data for p in params])
+    for p, n, off in zip(params, b.sizes, b.offsets):
+        assert torch.equal(flat[off:off + n], p.data.reshape(-1))
+    gaps = torch.ones(b.n_params, dtype=torch.bool)
+    for n, off in zip(b.sizes, b.offsets):
+        gaps[off:off + n] = False
+    assert float(flat[gaps].abs().sum()) == 0.0 and int(gaps.sum()) == b.n_params - sum(b.sizes)
