@@ -543,7 +543,7 @@ def test_dropped_frame_is_not_an_optimizer_step(gpu, hip_lib, async_mode):
     assert cx2.read_dropped_frames(reset=False) == 2 and cx2.read_dropped_frames() == 2 and cx2.read_dropped_frames() == 0
 
 
-@pytest.mark.parametrize("mode", ["scale_rot", "lbs"])
+@pytest.mark.parametrize("mode", ["scale_rot", "lbs", "scale_rot_spatial_hint"])
 def test_backward_kernel_takes_the_adamw_step(gpu, hip_lib, async_mode, mode):
     """FlatAdamW.fuse_into_backward (C ABI moss_raster_backward_raw_adamw): the per-Gaussian backward kernel applies the AdamW update of
     the parameters it has just differentiated.  Against the two-kernel form (backward -> gradients in the bucket -> flat AdamW) on
@@ -567,6 +567,8 @@ def test_backward_kernel_takes_the_adamw_step(gpu, hip_lib, async_mode, mode):
 
     def make(fused):
         pc = GaussianSet(s, sh_degree=3, device=gpu, unified_features=True)
+        # (MOSS_HINT_SPATIAL_ORDER: a block's rows are then groups of 16 Gaussians from four places of the index range)
+        pc.spatially_ordered = mode == "scale_rot_spatial_hint"
         cx = _C.RasterContext()
         cx.set_async(True, capacity=4_000_000)
         pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raster_context=cx,
