@@ -216,7 +216,11 @@ class Harness:
         if self.fused_opt:
             self.opt.fuse_into_backward(self.ctx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling,
                                         rotations=pc._rotation)
-        training_loss = mloss.training_loss_fused if fused_loss else mloss.training_loss
+        # fused_loss: True = the whole loss as the two HIP kernels; "ssim" = MOSS's torch loss expression with ONLY its ssim() call
+        # replaced (moss_amd.loss.ssim_fused: what patches/train_ZJU.diff does); False = the reference's torch functions throughout
+        import functools
+        training_loss = (mloss.training_loss_fused if fused_loss is True else
+                         functools.partial(mloss.training_loss, ssim_fn=mloss.ssim_fused) if fused_loss == "ssim" else mloss.training_loss)
         self.caller_side = caller_side
         stats = None
         if caller_side == "torch":
@@ -237,7 +241,7 @@ class Harness:
             else:
                 bucket.attach()             # zero the bucket; autograd accumulates into it
             out = render(cam, pc, pipe, bg, transforms=lbs_T)
-            if fused_loss:
+            if fused_loss is True:
                 # the loss kernels write [loss, L1, SSIM, mask] into the bucket's tail: it travels with the gradients, no copy
                 loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
                 mloss.backward_from_loss(loss)
@@ -706,9 +710,10 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         "dropin_fused_sides": dict(mode="lbs_python", activations="fused", torch_activations=False, torch_adamw=False, forward="sync", graph=0,
                                    fused_loss=True, caller_side="fused"),
         # exactly what patches/gaussian_renderer.diff + patches/train_ZJU.diff turn MOSS's call pattern into: transforms in the op,
-        # asynchronous forward, the statistics kernel -- MOSS's torch getters, torch loss and torch.optim.AdamW kept, eager launches
+        # asynchronous forward, the statistics kernel, ssim() from the HIP kernels inside MOSS's own torch loss expression -- MOSS's
+        # torch getters, the rest of its torch loss and torch.optim.AdamW kept, eager launches
         "patched_moss_pattern": dict(mode="lbs", activations="fused", torch_activations=True, torch_adamw=True, forward="async", graph=0,
-                                     fused_loss=False, caller_side="fused"),
+                                     fused_loss="ssim", caller_side="fused"),
         # the op without per-Gaussian transforms (the reference's compute_cov3D_python=False path): rounds 1-3's headline
         "no_transforms": dict(mode="scale_rot", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
         # MOSS's shipped input mode (compute_cov3D_python=True, arguments/__init__.py:60: the covariance built by torch ops from the

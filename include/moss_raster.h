@@ -221,6 +221,13 @@ size_t moss_loss_workspace_bytes(int C, int H, int W);
 int moss_photometric_loss(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
                           float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage, float* dL_dalpha,
                           char* workspace, size_t workspace_bytes, void* stream);
+/* The same with a weight on the L1 term too (ABI 4): total = lambda_l1 L1 + lambda_mask maskL2 + lambda_dssim (1 - SSIM); lambda_l1 = 1
+ * gives moss_photometric_loss bit for bit.  With lambda_l1 = 0, lambda_dssim = 1 and no alpha, loss_out[2] is the reference's
+ * ssim(img1, img2) (utils/loss_utils.py:47-87: 11x11 window, zero padding, mean over all elements) and -dL_dimage its gradient:
+ * a drop-in for MOSS's own ssim() call (train_ZJU.py:119) without changing its loss expression. */
+int moss_photometric_loss_weighted(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
+                                   float lambda_l1, float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage,
+                                   float* dL_dalpha, char* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Flat fused AdamW (torch.optim.AdamW semantics, amsgrad off) over `n` contiguous fp32 parameters with their gradients and

@@ -193,7 +193,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
                   const float* __restrict__ alpha, const float* __restrict__ mask, Win win,
                   const float* __restrict__ dmap, const float* __restrict__ partials, int nblocks,
                   float lambda_dssim, float lambda_mask, float* __restrict__ dL_dimg, float* __restrict__ dL_dalpha,
-                  const float* __restrict__ mask_partials, float* __restrict__ loss_out)
+                  const float* __restrict__ mask_partials, float* __restrict__ loss_out, float lambda_l1)
 {
     __shared__ float s_d[3][LP][LP + 1];
     __shared__ float s_h[3][LP][LT + 1];
@@ -271,7 +271,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const float dssim = f01[j].x + 2.f * x * f01[j].y + y * f2[j];     // d(sum SSIM)/dx
             const float d = x - y;
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            dL_dimg[o] = sgn / N - lambda_dssim * dssim / N;
+            dL_dimg[o] = (lambda_l1 * sgn) / N - lambda_dssim * dssim / N;     // (lambda_l1 = 1: the same bits as sgn / N)
         }
     }
     // Block (0,0,0) folds pass 1's partials into the four loss terms (no separate "finish" launch: a minimal launch costs 4-5 us).
@@ -292,7 +292,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const float mask_mean = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) / ((float)H * (float)W);
             const float lm = alpha != nullptr ? lambda_mask : 0.0f;
             loss_out[1] = l1_mean; loss_out[2] = ssim_mean; loss_out[3] = mask_mean;
-            loss_out[0] = l1_mean + lm * mask_mean + lambda_dssim * (1.0f - ssim_mean);
+            loss_out[0] = lambda_l1 * l1_mean + lm * mask_mean + lambda_dssim * (1.0f - ssim_mean);
         }
     }
 }
@@ -317,9 +317,24 @@ extern "C" size_t moss_loss_workspace_bytes(int C, int H, int W)
     return align_up(3 * (size_t)C * H * W * 4) + align_up(gx * gy * C * 2 * 4) + align_up(gx * gy * 4);
 }
 
+extern "C" int moss_photometric_loss_weighted(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
+                                              float lambda_l1, float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage,
+                                              float* dL_dalpha, char* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int moss_photometric_loss(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
                                      float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage, float* dL_dalpha,
                                      char* workspace, size_t workspace_bytes, void* stream)
+{
+    return moss_photometric_loss_weighted(C, H, W, image, gt, alpha, mask, 1.0f, lambda_dssim, lambda_mask, loss_out, dL_dimage, dL_dalpha,
+                                          workspace, workspace_bytes, stream);
+}
+
+// The same two kernels with a weight on the L1 term as well: total = lambda_l1 L1 + lambda_mask maskL2 + lambda_dssim (1 - SSIM).
+// lambda_l1 = 0, lambda_dssim = 1, no alpha: loss_out[2] is the reference's ssim(img1, img2) (utils/loss_utils.py:47-87) and
+// -dL_dimage its gradient -- what moss_amd.loss.ssim_fused hands MOSS's own loss expression in place of five MIOpen convolutions.
+extern "C" int moss_photometric_loss_weighted(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
+                                              float lambda_l1, float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage,
+                                              float* dL_dalpha, char* workspace, size_t workspace_bytes, void* stream)
 {
     if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !loss_out || !dL_dimage || !workspace) return MOSS_ERR_INVALID_ARG;
     if ((alpha == nullptr) != (mask == nullptr) || (alpha && !dL_dalpha)) return MOSS_ERR_INVALID_ARG;
@@ -334,6 +349,6 @@ extern "C" int moss_photometric_loss(int C, int H, int W, const float* image, co
     const dim3 grid(gx, gy, C);
     hipLaunchKernelGGL(ssim_pass1_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials);
     hipLaunchKernelGGL(ssim_pass2_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out);
+                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }

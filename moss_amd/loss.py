@@ -52,12 +52,58 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return ssim_map.mean(1).mean(1).mean(1)
 
 
-def training_loss(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5):
-    """L1 + lambda_mask * L2(alpha, mask) + lambda_dssim * (1 - SSIM)  (train_ZJU.py:111-112,119,131)."""
+def training_loss(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5, ssim_fn=None):
+    """L1 + lambda_mask * L2(alpha, mask) + lambda_dssim * (1 - SSIM)  (train_ZJU.py:111-112,119,131).  ``ssim_fn``: the SSIM used
+    (default: the torch restatement of the reference's; ``ssim_fused`` = the same value from the HIP kernels)."""
     ll1 = l1_loss(image, gt_image)
     mask_loss = l2_loss(alpha, gt_mask)
-    s = ssim(image.unsqueeze(0), gt_image.unsqueeze(0))
+    s = (ssim_fn or ssim)(image.unsqueeze(0), gt_image.unsqueeze(0))
     return ll1 + lambda_mask * mask_loss + lambda_dssim * (1.0 - s)
+
+
+class _FusedSSIM(torch.autograd.Function):
+    """mean SSIM(img1, img2) and its gradient w.r.t. img1 from the two loss kernels (C ABI moss_photometric_loss_weighted with
+    lambda_l1 = 0, lambda_dssim = 1, no mask term: total = 1 - SSIM, so d SSIM / d img1 = -dL_dimage)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        from ._lib import check, lib
+        L = lib()
+        C, H, W = img1.shape
+        a, b = img1.contiguous(), img2.contiguous()
+        out = torch.empty(4, dtype=torch.float32, device=a.device)
+        d_img = torch.empty((C, H, W), dtype=torch.float32, device=a.device)
+        nbytes = int(L.moss_loss_workspace_bytes(C, H, W))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            rc = L.moss_photometric_loss_weighted(C, H, W, a.data_ptr(), b.data_ptr(), None, None, 0.0, 1.0, 0.0, out.data_ptr(),
+                                                  d_img.data_ptr(), None, ws.data_ptr(), nbytes,
+                                                  torch.cuda.current_stream(a.device).cuda_stream)
+        check(rc, "photometric_loss_weighted")
+        ctx.save_for_backward(d_img)
+        return out[2]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (d_img,) = ctx.saved_tensors
+        return -grad_out * d_img, None
+
+
+def ssim_fused(img1, img2, window_size=11, size_average=True):
+    """Drop-in for the reference's ``utils.loss_utils.ssim`` (:47-87) as MOSS calls it (train_ZJU.py:119: two (1,3,h,w) crops, the
+    defaults): the same value, the gradient w.r.t. ``img1``, from two HIP kernels instead of five depthwise 11x11 convolutions and
+    ~20 elementwise kernels forward plus their autograd mirror (on MI355X through MIOpen: 8 x 177 us per step).  In MOSS:
+    ``from moss_amd.loss import ssim_fused as ssim`` (patches/train_ZJU.diff).  float32 GPU tensors, (C,H,W) or (1,C,H,W); the second
+    image gets no gradient (MOSS's is the ground truth)."""
+    if window_size != 11 or not size_average:
+        return ssim(img1, img2, window_size, size_average)       # (other windows / per-image means: the torch expressions)
+    if img1.dim() == 4:
+        if img1.shape[0] != 1:
+            return ssim(img1, img2, window_size, size_average)
+        img1, img2 = img1[0], img2[0]
+    if not img1.is_cuda or img1.dtype != torch.float32 or img2.dtype != torch.float32:
+        raise RuntimeError("ssim_fused needs float32 GPU tensors (the product path has no CPU fallback; moss_amd.loss.ssim is the torch form)")
+    return _FusedSSIM.apply(img1, img2.detach())
 
 
 class _FusedPhotometricLoss(torch.autograd.Function):

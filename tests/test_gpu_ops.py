@@ -95,6 +95,30 @@ def test_fused_loss_matches_reference_golden(gpu, hip_lib, i):
     assert float(alpha.grad.abs().max()) == 0.0               # lambda_mask = 0: no gradient reaches alpha
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_ssim_fused_is_a_drop_in_for_the_reference_ssim(gpu, hip_lib, i):
+    """moss_amd.loss.ssim_fused -- what patches/train_ZJU.diff binds to MOSS's name `ssim` -- against the REFERENCE'S OWN ssim values
+    (tests/golden/loss.npz, utils/loss_utils.py:47-87) and, for the gradient, against autograd through the torch restatement: called
+    the way train_ZJU.py:119 calls it, on (1,3,h,w) tensors, inside a larger torch expression."""
+    import os
+    from moss_amd.loss import ssim, ssim_fused
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss.npz"))
+    a0 = torch.from_numpy(g[f"l{i}_a"]).float().to(gpu)
+    b = torch.from_numpy(g[f"l{i}_b"]).float().to(gpu)
+    res = []
+    for fn in (ssim_fused, ssim):
+        a = a0.clone().requires_grad_(True)
+        v = fn((a * 1.0).unsqueeze(0), b.unsqueeze(0))
+        (0.2 * (1.0 - v) + 0.1 * a.mean()).backward()          # MOSS's 0.2 * (1 - ssim) beside another term
+        res.append((float(v), a.grad.clone()))
+    assert abs(res[0][0] - float(g[f"l{i}_ssim"])) < 2e-6 and abs(res[0][0] - res[1][0]) < 2e-6
+    assert hp.rel_err(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) < 2e-5
+    # other windows / batches fall back to the torch expressions; CPU tensors are refused (no CPU path)
+    assert abs(float(ssim_fused(a0.unsqueeze(0), b.unsqueeze(0), window_size=7)) - float(ssim(a0.unsqueeze(0), b.unsqueeze(0), window_size=7))) < 1e-7
+    with pytest.raises(RuntimeError):
+        ssim_fused(a0.cpu(), b.cpu())
+
+
 # ---------------------------------------------------------------- distCUDA2
 @pytest.mark.parametrize("P", [1, 3, 4, 5, 1000, 6890, 20000])
 def test_dist2_bit_exact_vs_bruteforce_oracle(gpu, hip_lib, P):
