@@ -164,7 +164,8 @@ class Harness:
     n_exchange = 0
 
     def __init__(self, args, dev, rank, world, scene, cam, gt, gt_mask, bg, *, mode, activations, torch_activations, torch_adamw,
-                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None, exchange="allreduce", fused_optimizer=True):
+                 forward, graph, fused_loss=True, caller_side=None, lbs_T=None, exchange="allreduce", fused_optimizer=True,
+                 raw_in_op=False):
         import torch
         from types import SimpleNamespace
         from moss_amd import dist as mdist
@@ -181,7 +182,10 @@ class Harness:
             convert_SHs_python=False, compute_cov3D_python=(mode in ("precomp", "lbs_python")), debug=False,
             fused_activations=not torch_activations, transforms_in_op=(mode == "lbs"),
             pose_in_op=(mode == "lbs" and not torch_activations),    # the op poses the canonical positions itself (MOSS_RAW_POSE)
-            raw_parameters_in_op=(not torch_activations and activations == "in_op" and unified and mode in ("scale_rot", "lbs")),
+            # (raw_in_op: MOSS's own parameter tensors -- separate f_dc / f_rest, torch.optim -- with only the three getters moved into
+            # the op: what `pipe.raw_parameters_in_op = True` in patches/train_ZJU.diff does)
+            raw_parameters_in_op=((not torch_activations and activations == "in_op" and unified and mode in ("scale_rot", "lbs"))
+                                  or (raw_in_op and mode in ("scale_rot", "lbs"))),
             raster_context=self.ctx)
         self.lbs_T = lbs_T
         self.exchange_kind = exchange if (world > 1 and not torch_adamw) else "allreduce"
@@ -710,10 +714,11 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         "dropin_fused_sides": dict(mode="lbs_python", activations="fused", torch_activations=False, torch_adamw=False, forward="sync", graph=0,
                                    fused_loss=True, caller_side="fused"),
         # exactly what patches/gaussian_renderer.diff + patches/train_ZJU.diff turn MOSS's call pattern into: transforms in the op,
-        # asynchronous forward, the statistics kernel, ssim() from the HIP kernels inside MOSS's own torch loss expression -- MOSS's
-        # torch getters, the rest of its torch loss and torch.optim.AdamW kept, eager launches
+        # asynchronous forward, the statistics kernel, ssim() from the HIP kernels inside MOSS's own torch loss expression, the
+        # opacity / scaling / rotation getters inside the op -- MOSS's parameter tensors, the rest of its torch loss and
+        # torch.optim.AdamW kept, eager launches
         "patched_moss_pattern": dict(mode="lbs", activations="fused", torch_activations=True, torch_adamw=True, forward="async", graph=0,
-                                     fused_loss="ssim", caller_side="fused"),
+                                     fused_loss="ssim", caller_side="fused", raw_in_op=True),
         # the op without per-Gaussian transforms (the reference's compute_cov3D_python=False path): rounds 1-3's headline
         "no_transforms": dict(mode="scale_rot", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
         # MOSS's shipped input mode (compute_cov3D_python=True, arguments/__init__.py:60: the covariance built by torch ops from the
