@@ -97,6 +97,9 @@ class FlatAdamW:
         (MOSS: features, opacity, scaling, rotation -- every loss term of train_ZJU.py:111-131 goes through the image; the position only
         where it does not also feed the LBS network) and the op takes the RAW parameters (``pipe.raw_parameters_in_op``).
 
+        ONE backward per forward: the parameters are updated IN PLACE by that backward (a second ``backward()`` over a retained
+        graph would differentiate at the old parameters and step again), and nothing else may add to these tensors' gradients.
+
         Every parameter of the bucket must be named (give the rest to a second optimizer over its own bucket); needs
         ``capturable=True`` and no shard.  Afterwards ``step()`` is a no-op: the step is taken inside ``loss.backward()``, and a frame
         that overflowed its binning capacity takes none (the kernel reads the frame's status word itself).
