@@ -66,7 +66,8 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
 def _build_into(out_dir: str, defines, force: bool, verbose: bool) -> str:
     os.makedirs(out_dir, exist_ok=True)
     lib_path = os.path.join(out_dir, "libmoss_raster.so")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE_DIR, "moss_raster.h"), os.path.abspath(__file__)]
+    # (every header of csrc/: common.h, adamw.h, ... -- a header left out of this list would not rebuild the objects that include it)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE_DIR, "moss_raster.h"), os.path.abspath(__file__)]
     objs = []
     procs = []
     sources = [(os.path.join(CSRC, src), extra) for src, extra in SOURCES.items()]
