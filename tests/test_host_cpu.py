@@ -523,3 +523,37 @@ def test_gradient_bucket_tensors_are_16_byte_aligned():
     for n, off in zip(b.sizes, b.offsets):
         gaps[off:off + n] = False
     assert float(flat[gaps].abs().sum()) == 0.0 and int(gaps.sum()) == b.n_params - sum(b.sizes)
+
+
+def test_per_gaussian_backward_keeps_two_waves_per_simd():
+    """The per-Gaussian backward kernels sit close to the register budget of two waves per SIMD (its 1 563 single-wave workgroups need
+    six per CU to be resident together): the fused form was measured at 38 us with 254 VGPRs and at 52 us with 260 -- one wave per SIMD --
+    when a block of scalar loads was placed where its registers stay live across the gather (profiles/r04_notes.md section 8).  The
+    compiler's own resource report for gfx950 must say 2 waves per SIMD and no more scratch than the 128 bytes per lane of rounds 2-4."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from moss_amd import build as hip_build
+    src = os.path.join(ROOT, "moss_amd", "csrc", "preprocess.hip")
+    with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "moss_amd", "lib")) as tmp:
+        cmd = [hipcc] + [a for a in hip_build.COMMON if a != "-Wall"] + hip_build.SOURCES["preprocess.hip"] + \
+              ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(tmp, "pp.o")]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    found = {}
+    blocks = re.split(r"remark: Function Name: ", p.stderr)
+    for b in blocks[1:]:
+        name = b.split()[0]
+        m = re.search(r"preprocess_backward_kernelILb(\d)ELb(\d)E", name)
+        if not m:
+            continue
+        vg = int(re.search(r"VGPRs: (\d+)", b).group(1)); ag = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)); scr = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        found[(int(m.group(1)), int(m.group(2)))] = (vg, ag, occ, scr)
+    assert set(found) == {(0, 0), (0, 1), (1, 0), (1, 1)}, found
+    for key, (vg, ag, occ, scr) in found.items():
+        assert occ >= 2 and vg + ag <= 256 and scr <= 128, f"preprocess_backward_kernel<STAGE_SH={key[0]}, FUSED={key[1]}>: {vg} VGPRs + {ag} AGPRs, {occ} waves per SIMD, {scr} B scratch"
