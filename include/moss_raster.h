@@ -241,7 +241,7 @@ int moss_photometric_loss_weighted(int C, int H, int W, const float* image, cons
 int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     int num_segments, const long long* segment_end, const float* segment_lr,
                     const int* segment_period, const int* segment_split, const float* segment_lr2,
-                    float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+                    double beta1, double beta2, float eps, float weight_decay, int step, void* stream);
 /* Same update with the step counter kept on the device: `step_state` is moss_adamw_state_bytes() (= MOSS_ADAMW_STATE_BYTES of the
  * header the library was built from; ask the library, a binding's copy of the constant can be stale) zero-initialised device bytes
  * (32-bit words: [0] = int step, advanced by one per call by the update kernel itself; [8..11] = the bias corrections of the
@@ -261,7 +261,7 @@ size_t moss_adamw_state_bytes(void);
 int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
                             const int* segment_period, const int* segment_split, const float* segment_lr2,
-                            float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream);
+                            double beta1, double beta2, float eps, float weight_decay, void* step_state, void* stream);
 
 /* The same update on a SHARD of the flat buffers: the arrays hold the elements [first, first + count) (first a multiple of 4) of the
  * buffers the segment table -- global indices, as above -- describes.  step_state != NULL: device-side step counter (then `step` is
@@ -270,7 +270,7 @@ int moss_adamw_flat_devstep(long long n, float* params, const float* grads, floa
 int moss_adamw_flat_range(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                           int num_segments, const long long* segment_end, const float* segment_lr,
                           const int* segment_period, const int* segment_split, const float* segment_lr2,
-                          float beta1, float beta2, float eps, float weight_decay, int step, void* step_state, void* stream);
+                          double beta1, double beta2, float eps, float weight_decay, int step, void* step_state, void* stream);
 
 /* moss_adamw_flat_range with a GUARD: if (*skip_word & skip_mask) != 0 when the kernel runs, the call is a no-op -- parameters,
  * moments and the device-side step counter stay bit for bit what they were.  `skip_word`: a device word, e.g. the frame's status word
@@ -282,7 +282,7 @@ int moss_adamw_flat_range(long long first, long long count, float* params, const
 int moss_adamw_flat_guarded(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             int num_segments, const long long* segment_end, const float* segment_lr,
                             const int* segment_period, const int* segment_split, const float* segment_lr2,
-                            float beta1, float beta2, float eps, float weight_decay, void* step_state,
+                            double beta1, double beta2, float eps, float weight_decay, void* step_state,
                             const uint32_t* skip_word, uint32_t skip_mask, void* stream);
 
 /*
@@ -427,7 +427,8 @@ typedef struct moss_fused_adamw {
     float* exp_avg_sq[5];        /* second moments */
     float lr[5];                 /* learning rates, same order; sh: of a Gaussian's first 3 floats (MOSS's features_dc group) */
     float lr_sh_rest;            /* sh: of the other 45 floats of a record (features_rest) */
-    float beta1, beta2, eps, weight_decay;
+    double beta1, beta2;         /* doubles (ABI 4): the kernels use float(beta) and float(1 - beta), rounded independently like torch's */
+    float eps, weight_decay;
     void* step_state;
     int32_t lr_segment[5];       /* per tensor: its entry s (0..7) in the step-state block's learning-rate table, or -1; when word
                                   * MOSS_ADAMW_LR_VALID_WORD of step_state is non-zero the kernel reads lr from float word

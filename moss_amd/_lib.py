@@ -25,6 +25,7 @@ _lock = threading.Lock()
 ERR_NAMES = {-1: "invalid argument", -2: "HIP error", -3: "allocation failed", -4: "prefiltered point culled", -5: "unsupported"}
 
 _f = C.c_float
+_d = C.c_double
 _i = C.c_int
 _p = C.c_void_p
 
@@ -120,13 +121,13 @@ def _declare(lib):
     lib.moss_photometric_loss_weighted.restype = _i
     lib.moss_photometric_loss_weighted.argtypes = [_i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
     lib.moss_adamw_flat.restype = _i
-    lib.moss_adamw_flat.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]
+    lib.moss_adamw_flat.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _i, _p]
     lib.moss_adamw_flat_devstep.restype = _i
-    lib.moss_adamw_flat_devstep.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]
+    lib.moss_adamw_flat_devstep.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _p, _p]
     lib.moss_adamw_flat_range.restype = _i
-    lib.moss_adamw_flat_range.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p, _p]
+    lib.moss_adamw_flat_range.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _i, _p, _p]
     lib.moss_adamw_flat_guarded.restype = _i
-    lib.moss_adamw_flat_guarded.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, C.c_uint32, _p]
+    lib.moss_adamw_flat_guarded.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _p, _p, C.c_uint32, _p]
     lib.moss_gaussian_activate_forward.restype = _i
     lib.moss_gaussian_activate_forward.argtypes = [_i, _i] + [_p] * 12
     lib.moss_gaussian_activate_backward.restype = _i
@@ -144,7 +145,7 @@ def _declare(lib):
 class FusedAdamWStruct(C.Structure):
     """``moss_fused_adamw`` of include/moss_raster.h (host struct handed to ``moss_raster_backward_raw_adamw``)."""
     _fields_ = [("tensors", C.c_uint32), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_float * 5),
-                ("lr_sh_rest", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("lr_sh_rest", C.c_float), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float),
                 ("step_state", C.c_void_p), ("lr_segment", C.c_int32 * 5)]
 
 

@@ -21,12 +21,22 @@ constexpr int ADAMW_STATE_WORDS = 128 + 64 * ADAMW_NGROUPS;
 
 // p, m, v <- one AdamW step with gradient g.  (Per element a hardware square root and reciprocal, ~1 ulp each: with correctly rounded
 // sqrt / divisions the update was ~40 vector instructions per element, as much issue time as the flat kernel's bytes are HBM time.)
-__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, float lr, float beta1, float beta2, float eps,
+// The betas arrive as DOUBLES at the C ABI and reach the kernels as two independently rounded floats each, beta and 1 - beta
+// (AdamBetas): torch's kernels round the Python doubles `beta2` and `1 - beta2` separately too, and float(1 - 0.999) = 0.001 is not
+// 1 - float(0.999) = 0.00099998713 -- a 1.3e-5 relative bias of the second moment with the rounds 1-3 form of this function.
+struct AdamBetas {
+    float b1 = 0.9f, b2 = 0.999f, omb1 = 0.1f, omb2 = 0.001f;
+    double b1_d = 0.9, b2_d = 0.999;
+    AdamBetas() = default;
+    AdamBetas(double beta1, double beta2) : b1((float)beta1), b2((float)beta2), omb1((float)(1.0 - beta1)), omb2((float)(1.0 - beta2)), b1_d(beta1), b2_d(beta2) {}
+};
+
+__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, float lr, const AdamBetas& B, float eps,
                                               float weight_decay, float inv_bc1, float inv_bc2_sqrt)
 {
     p = __fmul_rn(p, __fsub_rn(1.0f, __fmul_rn(lr, weight_decay)));
-    m = __fmaf_rn(beta1, m, __fmul_rn(__fsub_rn(1.0f, beta1), g));
-    v = __fmaf_rn(beta2, v, __fmul_rn(__fmul_rn(__fsub_rn(1.0f, beta2), g), g));
+    m = __fmaf_rn(B.b1, m, __fmul_rn(B.omb1, g));
+    v = __fmaf_rn(B.b2, v, __fmul_rn(__fmul_rn(B.omb2, g), g));
     const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, eps);
     p = __fmaf_rn(-__fmul_rn(lr, inv_bc1), __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
 }
@@ -36,25 +46,25 @@ __device__ __forceinline__ void adamw_element(float& p, float g, float& m, float
 // the other slot, which nobody reads during this launch (two double pow() at the end of the last block were a 3-5 us serial tail);
 // a launch that may still turn out to be a no-op passes writer = false and calls adamw_cache_next once it knows (a skipped step
 // must leave the whole block bit for bit).
-__device__ __forceinline__ void adamw_cache_next(const float* step_state, float beta1, float beta2, int t)
+__device__ __forceinline__ void adamw_cache_next(const float* step_state, const AdamBetas& B, int t)
 {
     float* sf = const_cast<float*>(step_state);
-    sf[8 + 2 * ((t + 1) & 1)] = (float)(1.0 - pow((double)beta1, (double)(t + 1)));
-    sf[9 + 2 * ((t + 1) & 1)] = (float)sqrt(1.0 - pow((double)beta2, (double)(t + 1)));
+    sf[8 + 2 * ((t + 1) & 1)] = (float)(1.0 - pow(B.b1_d, (double)(t + 1)));
+    sf[9 + 2 * ((t + 1) & 1)] = (float)sqrt(1.0 - pow(B.b2_d, (double)(t + 1)));
 }
 
 // (t_prev: word 0 of the block if the caller has loaded it already -- together with other words, so that the loads share one round trip)
-__device__ __forceinline__ int adamw_step_begin(const float* step_state, float beta1, float beta2, bool writer, float& bc1, float& bc2_sqrt,
+__device__ __forceinline__ int adamw_step_begin(const float* step_state, const AdamBetas& B, bool writer, float& bc1, float& bc2_sqrt,
                                                 int t_prev = -1)
 {
     const int t = (t_prev >= 0 ? t_prev : reinterpret_cast<const int*>(step_state)[0]) + 1;
     if (t == 1) {                                            // first step ever: nothing cached yet (pow(x, 1) = x exactly)
-        bc1 = (float)(1.0 - (double)beta1);
-        bc2_sqrt = (float)sqrt(1.0 - (double)beta2);
+        bc1 = (float)(1.0 - B.b1_d);
+        bc2_sqrt = (float)sqrt(1.0 - B.b2_d);
     } else {                                                 // cached by the previous step (slot = parity of the step)
         bc1 = step_state[8 + 2 * (t & 1)]; bc2_sqrt = step_state[9 + 2 * (t & 1)];
     }
-    if (writer) adamw_cache_next(step_state, beta1, beta2, t);
+    if (writer) adamw_cache_next(step_state, B, t);
     return t;
 }
 
@@ -87,7 +97,8 @@ struct FusedAdam {
     float lr[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     float lr_sh_rest = 0.f;                                  // sh: lr[1] for a Gaussian's first 3 floats (features_dc), this for the other 45
     int lr_segment[5] = { -1, -1, -1, -1, -1 };              // each tensor's entry in the step-state block's learning-rate table (-1: none)
-    float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f, weight_decay = 0.f;
+    AdamBetas betas;
+    float eps = 1e-15f, weight_decay = 0.f;
     const float* step_state = nullptr;
 };
 

@@ -14,7 +14,7 @@ struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; flo
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))   // (eight waves per SIMD: the scalar file admits six at 106 SGPRs)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-             Segs segs, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
+             Segs segs, AdamBetas betas, float eps, float weight_decay, float bc1, float bc2_sqrt,
              const float* __restrict__ step_state, long long first, const uint32_t* __restrict__ skip_word, uint32_t skip_mask)
 {
     // guard (moss_adamw_flat_guarded): a dropped frame's step is a no-op -- nothing is read or written, the step counter stays
@@ -27,7 +27,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     const bool lr_table = lr_flag != 0;
     int t_dev = 0;
     if (step_state)                                          // device-resident step counter (graph replay): adamw.h
-        t_dev = adamw_step_begin(step_state, beta1, beta2, blockIdx.x == 0 && threadIdx.x == 0, bc1, bc2_sqrt, t_prev);
+        t_dev = adamw_step_begin(step_state, betas, blockIdx.x == 0 && threadIdx.x == 0, bc1, bc2_sqrt, t_prev);
     // (once per thread, correctly rounded; per ELEMENT: a hardware square root and reciprocal, ~1 ulp each -- with this file's correctly
     // rounded sqrt / divisions the update was ~40 vector instructions per element, ten million per step: as much issue time as the
     // kernel's 165 MB are HBM time)
@@ -82,7 +82,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            adamw_element(pv[k], gv[k], mv[k], vv[k], lr4[k], beta1, beta2, eps, weight_decay, inv_bc1, inv_bc2_sqrt);
+            adamw_element(pv[k], gv[k], mv[k], vv[k], lr4[k], betas, eps, weight_decay, inv_bc1, inv_bc2_sqrt);
         if (full) {
             reinterpret_cast<float4*>(p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
             reinterpret_cast<float4*>(m)[i4] = make_float4(mv[0], mv[1], mv[2], mv[3]);
@@ -96,7 +96,7 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
 
 int launch_adamw(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int num_segments,
                  const long long* segment_end, const float* segment_lr, const int* segment_period, const int* segment_split,
-                 const float* segment_lr2, float beta1, float beta2, float eps, float weight_decay,
+                 const float* segment_lr2, double beta1, double beta2, float eps, float weight_decay,
                  float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream, long long first = 0,
                  const uint32_t* skip_word = nullptr, uint32_t skip_mask = 0u)
 {
@@ -111,7 +111,7 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
     if (blocks > max_blocks) blocks = max_blocks;            // (2048: eight 256-thread blocks per CU, all resident at once)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
-                       segs, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, step_state, first, skip_word, skip_mask);
+                       segs, AdamBetas(beta1, beta2), eps, weight_decay, bc1, bc2_sqrt, step_state, first, skip_word, skip_mask);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
 
@@ -121,12 +121,12 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
 extern "C" int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                int num_segments, const long long* segment_end, const float* segment_lr,
                                const int* segment_period, const int* segment_split, const float* segment_lr2,
-                               float beta1, float beta2, float eps, float weight_decay, int step, void* stream)
+                               double beta1, double beta2, float eps, float weight_decay, int step, void* stream)
 {
     if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || step < 1)
         return MOSS_ERR_INVALID_ARG;
     if (n == 0) return 0;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     return moss::launch_adamw(n, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
                               segment_split, segment_lr2, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), nullptr,
                               (hipStream_t)stream);
@@ -135,7 +135,7 @@ extern "C" int moss_adamw_flat(long long n, float* params, const float* grads, f
 extern "C" int moss_adamw_flat_devstep(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                        int num_segments, const long long* segment_end, const float* segment_lr,
                                        const int* segment_period, const int* segment_split, const float* segment_lr2,
-                                       float beta1, float beta2, float eps, float weight_decay, void* step_state, void* stream)
+                                       double beta1, double beta2, float eps, float weight_decay, void* step_state, void* stream)
 {
     if (n < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq || !segment_end || !segment_lr || !step_state)
         return MOSS_ERR_INVALID_ARG;
@@ -154,13 +154,13 @@ extern "C" size_t moss_adamw_state_bytes(void) { return MOSS_ADAMW_STATE_BYTES; 
 extern "C" int moss_adamw_flat_range(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                      int num_segments, const long long* segment_end, const float* segment_lr,
                                      const int* segment_period, const int* segment_split, const float* segment_lr2,
-                                     float beta1, float beta2, float eps, float weight_decay, int step, void* step_state, void* stream)
+                                     double beta1, double beta2, float eps, float weight_decay, int step, void* step_state, void* stream)
 {
     if (first < 0 || (first & 3) || count < 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq ||
         !segment_end || !segment_lr || (!step_state && step < 1))
         return MOSS_ERR_INVALID_ARG;
     if (count == 0) return step_state ? MOSS_ERR_INVALID_ARG : 0;
-    const double bc1 = step_state ? 1.0 : 1.0 - pow((double)beta1, step), bc2 = step_state ? 1.0 : 1.0 - pow((double)beta2, step);
+    const double bc1 = step_state ? 1.0 : 1.0 - pow(beta1, step), bc2 = step_state ? 1.0 : 1.0 - pow(beta2, step);
     return moss::launch_adamw(count, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
                               segment_split, segment_lr2, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
                               (const float*)step_state, (hipStream_t)stream, first);
@@ -169,7 +169,7 @@ extern "C" int moss_adamw_flat_range(long long first, long long count, float* pa
 extern "C" int moss_adamw_flat_guarded(long long first, long long count, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                        int num_segments, const long long* segment_end, const float* segment_lr,
                                        const int* segment_period, const int* segment_split, const float* segment_lr2,
-                                       float beta1, float beta2, float eps, float weight_decay, void* step_state,
+                                       double beta1, double beta2, float eps, float weight_decay, void* step_state,
                                        const uint32_t* skip_word, uint32_t skip_mask, void* stream)
 {
     if (first < 0 || (first & 3) || count <= 0 || num_segments < 1 || num_segments > 8 || !params || !grads || !exp_avg || !exp_avg_sq ||

@@ -1095,7 +1095,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // registers, live across the gather, cost the second wave per SIMD (260 VGPRs: 51 us))
     if (FUSED) {
         const int t_prev = reinterpret_cast<const int*>(fa.step_state)[0], lr_flag = reinterpret_cast<const int*>(fa.step_state)[ADAMW_LR_VALID_WORD];
-        fa_t = adamw_step_begin(fa.step_state, fa.beta1, fa.beta2, false, fa_bc1, fa_bc2_sqrt, t_prev);
+        fa_t = adamw_step_begin(fa.step_state, fa.betas, false, fa_bc1, fa_bc2_sqrt, t_prev);
         // learning rates kept in the step-state block (a schedule without re-capturing the step): scalar loads, like the step count
         if (lr_flag != 0) {
 #pragma unroll
@@ -1103,7 +1103,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             if (fa.lr_segment[1] >= 0) fa.lr_sh_rest = fa.step_state[ADAMW_LR2_WORD0 + fa.lr_segment[1]];
         }
     }
-    if (fa_on && blockIdx.x == 0 && threadIdx.x == 0) adamw_cache_next(fa.step_state, fa.beta1, fa.beta2, fa_t);   // (the next step's bias corrections)
+    if (fa_on && blockIdx.x == 0 && threadIdx.x == 0) adamw_cache_next(fa.step_state, fa.betas, fa_t);   // (the next step's bias corrections)
     // Fused AdamW: the eleven per-Gaussian scalars' parameters and moments are requested HERE, before the backward arithmetic, and
     // used after it (stamps: loaded where they are used, the 33 strided loads were a round trip of 10k cycles on every block's path)
     const bool fa_scalars = fa_on && in_range && (fa.tensors & (OPT_MEANS | OPT_OPACITY | OPT_SCALES | OPT_ROTATIONS));
@@ -1266,7 +1266,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
         for (int i = 0; i < 11; i++) {
             const float lr = i < 3 ? fa.lr[0] : i == 3 ? fa.lr[2] : i < 7 ? fa.lr[3] : fa.lr[4];
-            adamw_element(fa_p[i], gv[i], fa_m[i], fa_v[i], lr, fa.beta1, fa.beta2, fa.eps, fa.weight_decay, ib1, ib2);
+            adamw_element(fa_p[i], gv[i], fa_m[i], fa_v[i], lr, fa.betas, fa.eps, fa.weight_decay, ib1, ib2);
         }
         if (fa.tensors & OPT_MEANS) {
 #pragma unroll
@@ -1323,7 +1323,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                 float ve[4] = { v4[j].x, v4[j].y, v4[j].z, v4[j].w };
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    adamw_element(pe[k], r[k], me[k], ve[k], (part == 0 && k < 3) ? fa.lr[1] : fa.lr_sh_rest, fa.beta1, fa.beta2, fa.eps,
+                    adamw_element(pe[k], r[k], me[k], ve[k], (part == 0 && k < 3) ? fa.lr[1] : fa.lr_sh_rest, fa.betas, fa.eps,
                                   fa.weight_decay, ib1, ib2);
                 if (gi < P) {
                     const size_t a = (size_t)gi * 12 + (size_t)part;

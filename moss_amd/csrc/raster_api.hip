@@ -332,7 +332,7 @@ static int backward_impl(
         if ((fused & OPT_ROTATIONS) && ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(opt->exp_avg[4]) | reinterpret_cast<uintptr_t>(opt->exp_avg_sq[4])) & 15u))
             return fail(MOSS_ERR_INVALID_ARG, "MOSS_OPT_ROTATIONS needs 16-byte aligned rotation and moment arrays");
         fa.tensors = fused; fa.lr_sh_rest = opt->lr_sh_rest;
-        fa.beta1 = opt->beta1; fa.beta2 = opt->beta2; fa.eps = opt->eps; fa.weight_decay = opt->weight_decay;
+        fa.betas = AdamBetas(opt->beta1, opt->beta2); fa.eps = opt->eps; fa.weight_decay = opt->weight_decay;
         fa.step_state = reinterpret_cast<const float*>(opt->step_state);
     }
     if (!means3D || !viewmatrix || !projmatrix || !campos || !background) return fail(MOSS_ERR_INVALID_ARG, "null required input");

@@ -270,3 +270,66 @@ class FlatAdamW:
                                        self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                        self.t, torch.cuda.current_stream(dev).cuda_stream)
         check(rc, "adamw_flat")
+
+
+class AdamW(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.AdamW(params, lr, betas, eps, weight_decay)`` as MOSS builds it (scene/gaussian_model.py:226:
+    eight parameter groups, ``lr=0.0, eps=1e-15``): the same update rule, ONE kernel per parameter tensor (C ABI ``moss_adamw_flat``)
+    instead of torch's nine ``multi_tensor_apply`` launches per group -- with MOSS's six single-tensor Gaussian groups that is 54
+    launches of ~13 us per step, more than half of the patched call pattern's step (rocprofv3, ``profiles/r04_notes.md``).
+
+    Everything MOSS does to its optimizer keeps working: ``param_groups`` with per-group ``lr`` rewritten every iteration
+    (``update_learning_rate``), and the densification surgery on ``state[p]["exp_avg"] / ["exp_avg_sq"]`` (``cat_tensors_to_optimizer``,
+    ``_prune_optimizer``, ``replace_tensor_to_optimizer``, scene/gaussian_model.py:362-430) -- the state keys and meanings are torch's
+    (``step`` is kept as a Python int).  Parameters that are not contiguous float32 GPU tensors (or have no 16-byte aligned storage)
+    take torch's own functional AdamW.  Not capturable in a hipGraph (the step count is a launch argument): the graph path uses
+    :class:`FlatAdamW`."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._one = (C.c_longlong * 1)()
+        self._lr = (C.c_float * 1)()
+        self._zero_i = (C.c_int * 1)(0)
+        self._zero_f = (C.c_float * 1)(0.0)
+
+    @staticmethod
+    def _native_ok(*tensors):
+        return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in tensors)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = lib()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+                g, m, v = p.grad, st["exp_avg"], st["exp_avg_sq"]
+                n = p.numel()
+                if n == 0:
+                    continue
+                if self._native_ok(p, g, m, v):
+                    self._one[0] = n
+                    self._lr[0] = float(group["lr"])
+                    with torch.cuda.device(p.device):
+                        rc = L.moss_adamw_flat(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1, self._one, self._lr,
+                                               self._zero_i, self._zero_i, self._zero_f, float(beta1), float(beta2), float(group["eps"]),
+                                               float(group["weight_decay"]), int(st["step"]), torch.cuda.current_stream(p.device).cuda_stream)
+                    check(rc, "adamw_flat")
+                else:                                        # torch's expressions (CPU tensors, other dtypes, views with odd alignment)
+                    p.mul_(1 - group["lr"] * group["weight_decay"])
+                    m.lerp_(g, 1 - beta1)
+                    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+                    bc1, bc2 = 1 - beta1 ** st["step"], 1 - beta2 ** st["step"]
+                    p.addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(group["eps"]), value=-group["lr"] / bc1)
+        return loss

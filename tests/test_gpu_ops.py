@@ -640,6 +640,57 @@ def test_backward_kernel_takes_the_adamw_step(gpu, hip_lib, async_mode, mode):
     assert b.opt.step_count() == 3
 
 
+def test_adamw_drop_in_matches_torch_optim_adamw(gpu, hip_lib):
+    """moss_amd.optim.AdamW -- what patches/gaussian_model.diff puts in place of ``torch.optim.AdamW(l, lr=0.0, eps=1e-15)``
+    (scene/gaussian_model.py:226) -- against torch's own optimizer: MOSS's group structure (one tensor per group, a name, a per-group
+    lr rewritten between steps), five steps, then the densification surgery MOSS performs on the state (prune by mask, as
+    ``_prune_optimizer`` does, scene/gaussian_model.py:377-392) and three more steps.  Parameters and moments agree to 2e-6 of their
+    largest value (the kernel's square root and reciprocal are the hardware's, ~1 ulp)."""
+    from moss_amd.optim import AdamW
+    gen = torch.Generator().manual_seed(3)
+    shapes = {"xyz": (1237, 3), "f_dc": (1237, 1, 3), "f_rest": (1237, 15, 3), "opacity": (1237, 1), "scaling": (1237, 3), "rotation": (1237, 4)}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    init = {k: torch.randn(s, generator=gen) for k, s in shapes.items()}
+
+    def make(cls):
+        groups = [{"params": [torch.nn.Parameter(init[k].clone().to(gpu))], "lr": lrs[k], "name": k} for k in shapes]
+        return cls(groups, lr=0.0, eps=1e-15)
+
+    def close(a, b):
+        return float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-30)
+
+    ours, ref = make(AdamW), make(torch.optim.AdamW)
+    for it in range(8):
+        if it == 5:                                          # MOSS's _prune_optimizer, on both
+            mask = (torch.rand(1237, generator=gen) > 0.3).to(gpu)
+            for opt in (ours, ref):
+                for group in opt.param_groups:
+                    st = opt.state.get(group["params"][0], None)
+                    st["exp_avg"] = st["exp_avg"][mask]; st["exp_avg_sq"] = st["exp_avg_sq"][mask]
+                    del opt.state[group["params"][0]]
+                    group["params"][0] = torch.nn.Parameter(group["params"][0][mask].requires_grad_(True))
+                    opt.state[group["params"][0]] = st
+        for go, gr in zip(ours.param_groups, ref.param_groups):
+            if go["name"] == "xyz":
+                go["lr"] = gr["lr"] = lrs["xyz"] * (0.9 ** it)  # update_learning_rate (scene/gaussian_model.py:263-268)
+            g = torch.randn(go["params"][0].shape, generator=gen).to(gpu) * (0.0 if (it == 2 and go["name"] == "opacity") else 1.0)
+            go["params"][0].grad = g.clone(); gr["params"][0].grad = g.clone()
+        ours.step(); ref.step()
+        for go, gr in zip(ours.param_groups, ref.param_groups):
+            po, pr = go["params"][0], gr["params"][0]
+            assert close(po.data, pr.data), (it, go["name"])
+            assert close(ours.state[po]["exp_avg"], ref.state[pr]["exp_avg"]) and close(ours.state[po]["exp_avg_sq"], ref.state[pr]["exp_avg_sq"])
+    # a parameter the kernel cannot take (float64) goes through torch's expressions
+    p64 = torch.nn.Parameter(torch.randn(17, dtype=torch.float64, device=gpu))
+    r64 = torch.nn.Parameter(p64.detach().clone())
+    oa, ob = AdamW([p64], lr=1e-2), torch.optim.AdamW([r64], lr=1e-2)
+    for _ in range(3):
+        g = torch.randn(17, dtype=torch.float64, device=gpu)
+        p64.grad = g.clone(); r64.grad = g.clone()
+        oa.step(); ob.step()
+    assert float((p64 - r64).abs().max()) < 1e-12
+
+
 def test_partial_fusion_position_in_an_optimizer_of_its_own(gpu, hip_lib, async_mode):
     """The configuration INTEGRATION.md recommends for MOSS: features, opacity, scaling and rotation take their AdamW step inside the
     backward kernel; the POSITION -- whose gradient MOSS also feeds from its LBS network -- keeps its gradient (written by the op) and

@@ -473,7 +473,9 @@ def test_moss_side_patches_apply(tmp_path):
     os.makedirs(tmp_path / "gaussian_renderer")
     shutil.copy(os.path.join(ref, "gaussian_renderer", "__init__.py"), tmp_path / "gaussian_renderer" / "__init__.py")
     shutil.copy(os.path.join(ref, "train_ZJU.py"), tmp_path / "train_ZJU.py")
-    for name in ("gaussian_renderer.diff", "train_ZJU.diff"):
+    os.makedirs(tmp_path / "scene")
+    shutil.copy(os.path.join(ref, "scene", "gaussian_model.py"), tmp_path / "scene" / "gaussian_model.py")
+    for name in ("gaussian_renderer.diff", "train_ZJU.diff", "gaussian_model.diff"):
         with open(os.path.join(ROOT, "patches", name), "rb") as f:
             r = subprocess.run(["patch", "-p1", "--binary"], cwd=tmp_path, stdin=f, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -481,6 +483,13 @@ def test_moss_side_patches_apply(tmp_path):
         src = open(tmp_path / rel, newline="").read()
         compile(src, rel, "exec")
         assert "transforms_in_op" in src
+    src = open(tmp_path / "scene" / "gaussian_model.py", newline="").read()
+    compile(src, "scene/gaussian_model.py", "exec")
+    assert "from moss_amd.optim import AdamW as _AdamW" in src and "torch.optim.AdamW(l, lr=0.0, eps=1e-15)" not in src
+    assert "ssim_fused as ssim" in open(tmp_path / "train_ZJU.py", newline="").read()
+    from moss_amd import optim as moptim
+    import torch as _t
+    assert issubclass(moptim.AdamW, _t.optim.Optimizer)
     # what the patched lines call exists with the argument names they use
     import inspect
     from moss_amd import densify
