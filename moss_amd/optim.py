@@ -292,6 +292,42 @@ class AdamW(torch.optim.Optimizer):
         self._zero_i = (C.c_int * 1)(0)
         self._zero_f = (C.c_float * 1)(0.0)
 
+    # A group of MANY tensors (MOSS's two network groups, scene/gaussian_model.py:222-223: the parameters of `auto_regression` and
+    # `cross_attention_lbs`) is stepped with torch's multi-tensor primitives -- nine launches for the whole group, where one kernel per
+    # tensor would be dozens; the single-tensor Gaussian groups are where one kernel replaces nine.
+    FOREACH_ABOVE = 4
+
+    def _foreach_group(self, group) -> bool:
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return True
+        for p in ps:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        steps = {int(self.state[p]["step"]) for p in ps}
+        if len(steps) != 1 or len({(p.device, p.dtype) for p in ps}) != 1:
+            return False                                     # (tensors that joined later, mixed devices: one by one below)
+        t = steps.pop() + 1
+        beta1, beta2 = group["betas"]
+        lr, wd, eps = group["lr"], group["weight_decay"], group["eps"]
+        gs = [p.grad for p in ps]
+        ms = [self.state[p]["exp_avg"] for p in ps]
+        vs = [self.state[p]["exp_avg_sq"] for p in ps]
+        torch._foreach_mul_(ps, 1 - lr * wd)
+        torch._foreach_lerp_(ms, gs, 1 - beta1)
+        torch._foreach_mul_(vs, beta2)
+        torch._foreach_addcmul_(vs, gs, gs, 1 - beta2)
+        denom = torch._foreach_sqrt(vs)
+        torch._foreach_div_(denom, (1 - beta2 ** t) ** 0.5)
+        torch._foreach_add_(denom, eps)
+        torch._foreach_addcdiv_(ps, ms, denom, -lr / (1 - beta1 ** t))
+        for p in ps:
+            self.state[p]["step"] = t
+        return True
+
     @staticmethod
     def _native_ok(*tensors):
         return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in tensors)
@@ -305,6 +341,8 @@ class AdamW(torch.optim.Optimizer):
         L = lib()
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
+            if len(group["params"]) > self.FOREACH_ABOVE and self._foreach_group(group):
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue

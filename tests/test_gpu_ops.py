@@ -652,8 +652,12 @@ def test_adamw_drop_in_matches_torch_optim_adamw(gpu, hip_lib):
     lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
     init = {k: torch.randn(s, generator=gen) for k, s in shapes.items()}
 
+    net_init = [torch.randn(s_, generator=gen) for s_ in [(64, 32), (64,), (32, 64), (32,), (16, 32), (16,), (3, 16)]]
+
     def make(cls):
         groups = [{"params": [torch.nn.Parameter(init[k].clone().to(gpu))], "lr": lrs[k], "name": k} for k in shapes]
+        # MOSS's network groups (scene/gaussian_model.py:222-223): MANY small tensors in one group
+        groups.append({"params": [torch.nn.Parameter(t.clone().to(gpu)) for t in net_init], "lr": 1e-4, "name": "auto_regression"})
         return cls(groups, lr=0.0, eps=1e-15)
 
     def close(a, b):
@@ -665,6 +669,8 @@ def test_adamw_drop_in_matches_torch_optim_adamw(gpu, hip_lib):
             mask = (torch.rand(1237, generator=gen) > 0.3).to(gpu)
             for opt in (ours, ref):
                 for group in opt.param_groups:
+                    if group["name"] == "auto_regression":
+                        continue
                     st = opt.state.get(group["params"][0], None)
                     st["exp_avg"] = st["exp_avg"][mask]; st["exp_avg_sq"] = st["exp_avg_sq"][mask]
                     del opt.state[group["params"][0]]
@@ -673,13 +679,14 @@ def test_adamw_drop_in_matches_torch_optim_adamw(gpu, hip_lib):
         for go, gr in zip(ours.param_groups, ref.param_groups):
             if go["name"] == "xyz":
                 go["lr"] = gr["lr"] = lrs["xyz"] * (0.9 ** it)  # update_learning_rate (scene/gaussian_model.py:263-268)
-            g = torch.randn(go["params"][0].shape, generator=gen).to(gpu) * (0.0 if (it == 2 and go["name"] == "opacity") else 1.0)
-            go["params"][0].grad = g.clone(); gr["params"][0].grad = g.clone()
+            for po, pr in zip(go["params"], gr["params"]):
+                g = torch.randn(po.shape, generator=gen).to(gpu) * (0.0 if (it == 2 and go["name"] == "opacity") else 1.0)
+                po.grad = g.clone(); pr.grad = g.clone()
         ours.step(); ref.step()
         for go, gr in zip(ours.param_groups, ref.param_groups):
-            po, pr = go["params"][0], gr["params"][0]
-            assert close(po.data, pr.data), (it, go["name"])
-            assert close(ours.state[po]["exp_avg"], ref.state[pr]["exp_avg"]) and close(ours.state[po]["exp_avg_sq"], ref.state[pr]["exp_avg_sq"])
+            for po, pr in zip(go["params"], gr["params"]):
+                assert close(po.data, pr.data), (it, go["name"])
+                assert close(ours.state[po]["exp_avg"], ref.state[pr]["exp_avg"]) and close(ours.state[po]["exp_avg_sq"], ref.state[pr]["exp_avg_sq"])
     # a parameter the kernel cannot take (float64) goes through torch's expressions
     p64 = torch.nn.Parameter(torch.randn(17, dtype=torch.float64, device=gpu))
     r64 = torch.nn.Parameter(p64.detach().clone())
