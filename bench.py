@@ -310,7 +310,10 @@ class Harness:
             self.bucket.all_reduce_loss_only(self.world)
             e[1].record(); e[2].record(); e[3].record()
         elif self.sharded is None:
-            self.bucket.all_reduce_mean(None, self.world)
+            # (only the active SH coefficients travel while the degree is below its maximum: MOSS raises it every 1000 iterations; the
+            # bench trains at degree 3, where this is the plain all-reduce)
+            self.bucket.all_reduce_mean(None, self.world, sh_param=getattr(self.pc, "_features", None) if self.pc.unified_features else None,
+                                        active_sh_degree=self.pc.active_sh_degree)
             e[1].record()
             self.opt.step()
             e[2].record(); e[3].record()

@@ -145,10 +145,37 @@ class GradBucket:
                 v.copy_(p.grad)
             p.grad = v
 
-    def all_reduce_mean(self, loss=None, world=None):
+    def _mean_(self, t, world):
+        if avg_supported(t.device):
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(world)
+
+    def all_reduce_mean(self, loss=None, world=None, sh_param=None, active_sh_degree=None):
+        """One all-reduce (mean) of the whole bucket.  ``sh_param`` + ``active_sh_degree`` < its maximum: only the ACTIVE SH
+        coefficients travel -- MOSS starts at degree 0 and raises it every 1000 iterations (train_ZJU.py:85-86), and the backward
+        writes exact zeros above the active degree, so the mean of the rest is known: zero.  The SH record is coefficient-major PER
+        GAUSSIAN ((P, K, 3): the active part is the first 3 (d+1)^2 of every 3 K floats, not a prefix of the bucket), so the active
+        part is packed into a contiguous staging tensor (one copy kernel each way) and the bucket goes out as up to three pieces: what
+        precedes the SH slice, the packed coefficients, what follows it (with the loss block).  59 -> 14 / 23 / 38 floats per Gaussian
+        at degree 0 / 1 / 2 for the price of two more collective latencies: pays when the exchange is bandwidth-bound (DESIGN.md
+        section 5: it is, at every N)."""
         if loss is not None and loss.data_ptr() != self.loss_slot.data_ptr():
             self.loss_slot.copy_(loss.detach().reshape(1))
         world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
+        if world > 1 and sh_param is not None and active_sh_degree is not None and id(sh_param) in self._offset and sh_param.dim() == 3:
+            K = int(sh_param.shape[1]); k = (int(active_sh_degree) + 1) ** 2
+            if 0 < k < K:
+                off, n = self._offset[id(sh_param)], sh_param.numel()
+                sh = self.flat[off:off + n].view_as(sh_param)
+                packed = sh[:, :k, :].contiguous()
+                if off > 0:
+                    self._mean_(self.flat[:off], world)
+                self._mean_(packed, world)
+                self._mean_(self.flat[off + n:], world)      # (never empty: the loss block follows the parameters)
+                sh[:, :k, :].copy_(packed)
+                return self.loss_slot
         if world > 1:
             # RCCL averages inside the collective (ncclAvg): no separate pass over the bucket to divide by the world size.
             # gloo (CPU tests) has no AVG: sum, then divide.  Which of the two is decided once, for all ranks alike (avg_supported).

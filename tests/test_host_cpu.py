@@ -566,3 +566,49 @@ def test_per_gaussian_backward_keeps_two_waves_per_simd():
     assert set(found) == {(0, 0), (0, 1), (1, 0), (1, 1)}, found
     for key, (vg, ag, occ, scr) in found.items():
         assert occ >= 2 and vg + ag <= 256 and scr <= 128, f"preprocess_backward_kernel<STAGE_SH={key[0]}, FUSED={key[1]}>: {vg} VGPRs + {ag} AGPRs, {occ} waves per SIMD, {scr} B scratch"
+
+
+def _active_sh_rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from moss_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(40 + rank)
+    P = 37
+    out = {}
+    for degree in (0, 1, 2, 3):
+        res = []
+        for active in (None, degree):
+            xyz, sh, opa = (torch.nn.Parameter(torch.zeros(P, 3)), torch.nn.Parameter(torch.zeros(P, 16, 3)), torch.nn.Parameter(torch.zeros(P, 1)))
+            b = mdist.GradBucket([xyz, sh, opa])
+            gg = torch.Generator().manual_seed(100 * degree + rank)
+            b.attach()
+            xyz.grad.copy_(torch.randn(P, 3, generator=gg)); opa.grad.copy_(torch.randn(P, 1, generator=gg))
+            k = (degree + 1) ** 2
+            sh.grad[:, :k, :] = torch.randn(P, k, 3, generator=gg)               # the backward writes exact zeros above the active degree
+            b.loss_terms[:] = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
+            loss = b.all_reduce_mean(None, world, sh_param=sh if active is not None else None, active_sh_degree=active)
+            res.append((b.flat.clone(), float(loss)))
+        out[degree] = bool(torch.equal(res[0][0], res[1][0])) and res[0][1] == res[1][1] == 1.5
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_active_degree_sh_exchange_equals_the_full_all_reduce_gloo_world2():
+    """GradBucket.all_reduce_mean(sh_param=, active_sh_degree=): only the first 3 (d+1)^2 of every 48 SH floats travel (packed; the
+    rest of the bucket in two more pieces) -- round 3's review item 6.  The bucket afterwards is BIT-identical to the full all-reduce at
+    every degree (the coefficients above the active degree are exact zeros on every rank: their mean is zero), the loss block included."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_active_sh_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out == {0: True, 1: True, 2: True, 3: True}, (rank, out)
