@@ -58,23 +58,20 @@ for seed in range(first, first + n_cases):
             g0 = hp.hip_backward(d, t0, dc * m, dd * m, da * m, dev, debug=nocull)
             for a, b in ((t.color, t0.color), (t.alpha, t0.alpha), (t.depth, t0.depth)):     # equal up to the order of the per-slot sums
                 assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), "culling changed the image"
-            # The sums the kernels form themselves (means2D, colours, opacity, SH) equal to 1e-5 of the largest value: with culling
-            # off more (entry, block) pairs leave records, so the same terms are added in another order.  Everything derived from
-            # dL/dconic through the covariance chain (means3D, cov3D, scales, rotations, transforms) amplifies that 1e-7 reordering
-            # noise by the Gaussian's condition number (seed 838: 3e-7 on the sums, 1.6e-5 of the largest value on dL_dcov3D; needles
-            # seen end-on: 1e-2 of the contribution mass on dL_dscales, seeds 8036 / 8314 / 8388 / 8679), so the unculled run is held to
-            # the SAME single rule as the culled one -- |g0 - f64| <= RULE_K (spread + RULE_EPS mass), element by element -- instead of to
-            # a fixed distance from it (rounds 2-3: half the per-Gaussian bar, in mass units).
-            direct = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dsh")
+            # With culling off more (entry, block) pairs leave records, so the same terms are added in another order: the two runs differ
+            # by rounding, and what rounding may amount to depends on the element -- an opacity gradient of -3.3 whose contributions
+            # add up to a mass of 2e5 moves by 4e-5 (seed 14875: 1e-5 of the tensor's largest value, 2e-10 of its mass); everything
+            # derived from dL/dconic through the covariance chain is amplified by the Gaussian's condition number (needles seen end-on:
+            # 1e-2 of the mass on dL_dscales, seeds 8036 / 8314 / 8388 / 8679).  So the unculled run is held to the SAME single rule as
+            # the culled one -- |g0 - f64| <= RULE_K (spread + RULE_EPS mass), element by element, every tensor -- instead of to a
+            # fixed distance from it (rounds 2-3: 1e-5 of the largest value for the sums the kernels form themselves, half the
+            # per-Gaussian bar in mass units for the rest).
             for k, v in vars(g).items():
-                if v is not None and torch.is_tensor(v) and v.numel() > 0:
+                if v is not None and torch.is_tensor(v) and v.numel() > 0 and k in mass and k in hp.RULE_NAMES:
                     v0 = getattr(g0, k)                      # (segments are cut every 64 HITS: the unculled run cuts elsewhere -> rounding only)
-                    if k in direct:
-                        assert float((v - v0).abs().max()) <= 1e-5 * float(v0.abs().max()) + 1e-30, f"culling changed {k}"
-                    elif k in mass and k in hp.RULE_NAMES:
-                        ratio, el = hp.single_rule_ratio(v0.cpu().numpy(), getattr(ref64, k), mass[k], spread[k])
-                        worst_ratio = max(worst_ratio, ratio)
-                        assert ratio <= hp.RULE_K, f"culling off: {k} element {el} at {ratio:.2f} x (spread + eps mass) from float64 (allowed {hp.RULE_K})"
+                    ratio, el = hp.single_rule_ratio(v0.cpu().numpy(), getattr(ref64, k), mass[k], spread[k])
+                    worst_ratio = max(worst_ratio, ratio)
+                    assert ratio <= hp.RULE_K, f"culling off: {k} element {el} at {ratio:.2f} x (spread + eps mass) from float64 (allowed {hp.RULE_K})"
     except Exception as ex:                                      # keep going: report every failing seed
         bad += 1
         failures.append({"seed": seed, "P": s.P, "W": s.camera.W, "H": s.camera.H, "mode": mode, "degree": degree, "colors": colors,
