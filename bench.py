@@ -102,15 +102,15 @@ def parse_args(argv=None):
                     help="1 (default): the per-Gaussian backward kernel takes the AdamW step of the parameters it differentiates "
                          "(FlatAdamW.fuse_into_backward) wherever the step is local to the rank (N = 1, loss_only); 0: gradients into the "
                          "bucket, then the flat AdamW kernel (always so for the gradient exchanges).  Same bits either way")
-    ap.add_argument("--exchange", default="loss_only", choices=["allreduce", "sharded", "loss_only"],
-                    help="N > 1 only. loss_only (the default since round 4) = BASELINE configs[3] as written -- \"frames of six subjects "
-                         "sharded across 8 GPUs, RCCL loss all-reduce\": per-view / per-subject training is embarrassingly parallel "
-                         "(north_star), so every rank trains its OWN model on its own frames, exactly the N = 1 step, and RCCL all-reduces "
-                         "the 4-float loss block only (no data-path collective); "
-                         "allreduce = one all-reduce (mean) of the flat gradient bucket, then the full AdamW on every rank; "
-                         "sharded = reduce-scatter, AdamW on the rank's 1/N of the parameters (moments memory and update time / N), "
-                         "all-gather of the updated parameters (moss_amd.dist.ShardedStep).  The other variants are measured after the "
-                         "timed region and reported beside the headline as `exchange_variants`")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded", "loss_only"],
+                    help="N > 1 only: which form of the step `value` reports (ALL THREE are measured by every N > 1 run and reported at top "
+                         "level as value_allreduce / value_sharded / value_loss_only with their ms_per_step_* and replicas_identical_*). "
+                         "allreduce (the default: SURVEY 8e, the data-parallel form that exercises RCCL; rounds 1-3 and 5) = ONE model, "
+                         "frames sharded over the ranks, one all-reduce (mean) of the flat gradient bucket, then the full AdamW on every "
+                         "rank; sharded = reduce-scatter, AdamW on the rank's 1/N of the parameters (moments memory and update time / N), "
+                         "all-gather of the updated parameters (moss_amd.dist.ShardedStep); loss_only (round 4's headline) = BASELINE "
+                         "configs[3] as written -- \"frames of six subjects sharded across 8 GPUs, RCCL loss all-reduce\": every rank "
+                         "trains its OWN model on its own frames, exactly the N = 1 step, and RCCL all-reduces the 4-float loss block only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
     ap.add_argument("--callers-only", default="", help="comma-separated names: measure only these caller variants (profiling aid, e.g. "
@@ -225,8 +225,9 @@ class Harness:
         self.fused_opt = bool(fused_optimizer and self.local_opt and not torch_adamw and pipe.raw_parameters_in_op and caller_side is None
                               and (lbs_T is None or pipe.pose_in_op))
         if self.fused_opt:
+            # (N > 1: only ever with the loss-only exchange -- every rank trains a model of its own -- which is what local_only asserts)
             self.opt.fuse_into_backward(self.ctx, means3D=pc._xyz, sh=pc._features, opacity=pc._opacity, scales=pc._scaling,
-                                        rotations=pc._rotation)
+                                        rotations=pc._rotation, local_only=(world > 1 and self.exchange_kind == "loss_only"))
         # fused_loss: True = the whole loss as the two HIP kernels; "ssim" = MOSS's torch loss expression with ONLY its ssim() call
         # replaced (moss_amd.loss.ssim_fused: what patches/train_ZJU.diff does); False = the reference's torch functions throughout
         import functools
@@ -594,6 +595,23 @@ def main(argv=None):
     dom_ms = dom_ms / max(dom_n, 1)
 
     note(f"stage pass done {stage_ms}")
+    # ---- the RASTERIZER's own kernels: when the AdamW step rides inside the per-Gaussian backward, that kernel's time is not the
+    # rasterizer's.  The same K iterations once more with the step taken by the flat kernel (bit-identical parameters: the frames are the
+    # same), every kernel of the op timed: what `rasterizer_roofline` is computed from.
+    raster_stage_ms = stage_ms
+    was_fused = h.fused_opt
+    if h.fused_opt and snap is not None:
+        opt.restore(snap)
+        opt.unfuse()
+        h.fused_opt = False
+        _lib.profile_enable(None)
+        for _ in range(args.steps):
+            out = h.eager_step()
+        torch.cuda.synchronize(dev)
+        prof2 = _lib.profile_read()
+        _lib.profile_enable([])
+        raster_stage_ms = {k: round(v[0] / v[1], 5) if v[1] else 0.0 for k, v in prof2.items()}
+        note(f"rasterizer-only pass done {raster_stage_ms}")
     if rank != 0:
         return
 
@@ -606,17 +624,25 @@ def main(argv=None):
     N = H * W
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     fwd_b, bwd_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"), transforms=args.mode == "lbs",
-                                     fused_adamw=h.fused_opt)
+                                     fused_adamw=was_fused)
     all_b = dict(fwd_b); all_b.update(bwd_b)
+    # SURVEY 8(d) as written: the rasterizer's forward + backward, NO optimizer bytes
+    rf_b, rb_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"), transforms=args.mode == "lbs", fused_adamw=False)
+    raster_b = dict(rf_b); raster_b.update(rb_b)
     if stage_ms.get("scan", 0.0) == 0.0:
         # asynchronous forward: the scan rides along with the scatter kernel (no launch of its own) -- its bytes count there
         all_b["scatter"] += all_b.pop("scan")
+        raster_b["scatter"] += raster_b.pop("scan")
         stage_ms.pop("scan", None)
+        raster_stage_ms = {k: v for k, v in raster_stage_ms.items() if k != "scan"}
     dom_bytes = all_b[dominant]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     total_bytes = sum(all_b.values())
+    raster_bytes = sum(raster_b.values())
     iters_per_s = world * args.steps / elapsed
     raster_ms = sum(stage_ms.values())
+    raster_only_ms = sum(raster_stage_ms.values())
+    raster_gbs = raster_bytes / (raster_only_ms * 1e-3) / 1e9 if raster_only_ms > 0 else 0.0
     headline = args.config == "cfg3" and args.mode == "lbs"
     pmc = _pmc_traffic() if headline else {}
     # every stage against the roofline, not only the dominant one (durations: kernel-attached events of the eager replay)
@@ -641,8 +667,12 @@ def main(argv=None):
                    "target": args.target, "input_mode": args.mode, "index_order": args.order,
                    "activations": "torch" if args.torch_activations else ("in_op" if h.pipe.raw_parameters_in_op else "fused"), "P": P, "visible": Pv, "num_rendered": R, "pixels": N,
                    "parallelism": ("single GPU" if world == 1 else
-                                   f"frames / subjects sharded over {world} GPUs, one model per GPU, RCCL all-reduce of the loss block (configs[3])"
-                                   if h.exchange_kind == "loss_only" else f"frame-parallel x{world} (replicas, gradient exchange: {h.exchange_kind})"),
+                                   (f"`value` = loss_only: frames / subjects sharded over {world} GPUs, one model per GPU, RCCL all-reduce of the "
+                                    f"16-byte loss block (configs[3] as written)" if h.exchange_kind == "loss_only" else
+                                    f"`value` = {h.exchange_kind}: dp{world}, ONE model, frames sharded over {world} GPUs, replicas kept identical by "
+                                    + ("one RCCL all-reduce (mean) of the flat gradient bucket + the full AdamW per rank" if h.exchange_kind == "allreduce"
+                                       else "reduce-scatter + AdamW on the rank's shard + all-gather") + " (SURVEY 8e)")
+                                   + "; value_allreduce / value_sharded / value_loss_only in this line: the same step under each of the three exchanges"),
                    "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
                    "optimizer": ("AdamW step taken by the per-Gaussian backward kernel (moss_raster_backward_raw_adamw); bit-identical to the flat "
                                  "kernel, reported beside as callers.unfused_optimizer") if h.fused_opt else "flat AdamW kernel over the gradient bucket",
@@ -659,11 +689,26 @@ def main(argv=None):
                                 "replay of the SAME K iterations (parameters and optimizer state restored to the start of the "
                                 "graph-replay timed region)") if use_graph else
                                "hipEvents attached to the kernel (hipExtLaunchKernelGGL start/stop) on its launch stream, inside the timed region"},
+        # north_star: "rasterizer forward+backward ... as % of HBM roofline".  bytes = SURVEY 8(d)'s formula at the measured P, Pv, R, N
+        # with NO optimizer bytes; time = the SUM of the op's seven kernels (kernel-attached events, eager replay of the timed region's
+        # frames, the AdamW step taken by the flat kernel so that the per-Gaussian backward is the rasterizer's own kernel)
+        "rasterizer_roofline": {"bound": "hbm", "algorithmic_bytes": int(raster_bytes), "kernels_ms": round(raster_only_ms, 5),
+                                "achieved": round(raster_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(raster_gbs / HBM_PEAK_GBS, 5),
+                                "floor_ms_at_peak": round(raster_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 5),
+                                "frac_of_achievable": round(raster_gbs / HBM_ACHIEVABLE_GBS, 5),
+                                "stages_ms": raster_stage_ms,
+                                "what": "SURVEY 8(d) bytes of forward + backward (no optimizer, no loss) / summed kernel time of the op's "
+                                        "kernels; the AdamW step outside the per-Gaussian backward for this measurement"},
         "stages_ms": stage_ms,
         "stages": stages,
         "rasterizer_ms_per_step": round(raster_ms, 4),
-        "step_algorithmic_bytes": int(total_bytes),
-        "step_hbm_frac": round(total_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
+        "step_algorithmic_bytes": int(raster_bytes),
+        # ONE definition, the one of rounds 1-3 (comparable across rounds): SURVEY 8(d)'s rasterizer bytes (no optimizer, no loss) moved
+        # per WHOLE step time (loss kernels, optimizer and launch gaps included in the time) / 8 TB/s.  Round 4 counted the fused
+        # optimizer's 118 MB in the numerator: that figure is `step_hbm_frac_incl_optimizer`.
+        "step_hbm_frac": round(raster_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
+        "step_hbm_frac_incl_optimizer": round(total_bytes * (iters_per_s / world) / (HBM_PEAK_GBS * 1e9), 5),
+        "step_algorithmic_bytes_incl_optimizer": int(total_bytes),
     }
     if long_run is not None:
         result["long_run"] = long_run
@@ -678,6 +723,10 @@ def main(argv=None):
             result.update({k: v for k, v in exchange_rep.items() if k.endswith("_ms")})
             result["allreduce_bytes"] = exchange_rep["bytes_reduced"]
         result["exchange_variants"] = exchange_variants
+        for kind, rec in (exchange_variants or {}).items():      # every form of the step at top level, whichever one `value` is
+            result[f"value_{kind}"] = rec["value"]
+            result[f"ms_per_step_{kind}"] = rec["ms_per_step"]
+            result[f"replicas_identical_{kind}"] = rec["replicas_identical"]      # (loss_only: null -- the models are different by design)
     if world == 1:
         result["densify_side_ms"] = densify_side(pc, out)
     if world == 1 and not args.no_callers and headline:
@@ -994,11 +1043,15 @@ def dry_run_cpu(args):
         assert variants["allreduce"]["checksum"] == variants["sharded"]["checksum"], "the two gradient-exchange paths left different parameters"
     head = variants[args.exchange]
     if rank == 0:
-        print(json.dumps({"metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)", "value": head["value"],
+        per_kind = {}
+        for kind, rec in variants.items():
+            per_kind[f"value_{kind}"] = rec["value"]; per_kind[f"ms_per_step_{kind}"] = rec["ms_per_step"]
+            per_kind[f"replicas_identical_{kind}"] = rec["replicas_identical"]
+        print(json.dumps({**per_kind, "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)", "value": head["value"],
                           "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "DRY RUN: no GPU work (launcher / collective plumbing test)",
-                          "config": {"workload": "dry run"}, "rccl_ranks": ranks, "backend": dist.get_backend() if world > 1 else None,
+                          "config": {"workload": "dry run", "parallelism": f"`value` = {args.exchange}"}, "rccl_ranks": ranks, "backend": dist.get_backend() if world > 1 else None,
                           "replicas_identical": all(v["replicas_identical"] for v in variants.values() if v["replicas_identical"] is not None), "exchange": args.exchange,
                           "allreduce_ms": head["exchange_ms"], "adamw_ms": 0.0, "exchange_variants": variants}))
 

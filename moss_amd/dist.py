@@ -99,6 +99,10 @@ class GradBucket:
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {id(p): off for p, off in zip(self.params, self.offsets)}
         self._handed_out = set()
+        # whether the collective library averages inside the collective is decided HERE, once, on every rank alike -- not at the first
+        # exchange, which may sit inside a hipGraph capture or behind a rank-dependent branch (needs the process group)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            avg_supported(dev if dev.type == "cuda" else None)
 
     def pack(self, tensors):
         """The flat image (``n_params`` floats, zeros in the alignment gaps) of one tensor per parameter, in parameter order."""
@@ -160,7 +164,13 @@ class GradBucket:
         part is packed into a contiguous staging tensor (one copy kernel each way) and the bucket goes out as up to three pieces: what
         precedes the SH slice, the packed coefficients, what follows it (with the loss block).  59 -> 14 / 23 / 38 floats per Gaussian
         at degree 0 / 1 / 2 for the price of two more collective latencies: pays when the exchange is bandwidth-bound (DESIGN.md
-        section 5: it is, at every N)."""
+        section 5: it is, at every N).
+
+        The result is RANK-CONSISTENT (every rank ends with the same bits: what keeps replicas identical) and, with two ranks, also
+        bit-identical to the one-piece all-reduce (a + b has one order).  With more ranks a ring or tree adds in an order that depends
+        on how the buffer is chunked, so the three-piece form may differ from the one-piece form in the last bit -- never between ranks.
+        It RELIES on the inactive coefficients' gradients being exactly zero on every rank (the rasterizer's backward writes them so);
+        ``MOSS_DIST_DEBUG=1`` asserts it (one device reduction + a host read per exchange)."""
         if loss is not None and loss.data_ptr() != self.loss_slot.data_ptr():
             self.loss_slot.copy_(loss.detach().reshape(1))
         world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
@@ -169,6 +179,9 @@ class GradBucket:
             if 0 < k < K:
                 off, n = self._offset[id(sh_param)], sh_param.numel()
                 sh = self.flat[off:off + n].view_as(sh_param)
+                if os.environ.get("MOSS_DIST_DEBUG") == "1" and not (sh.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    assert not bool(sh[:, k:, :].any().item()), \
+                        "active-degree SH exchange: a gradient above the active degree is not zero on this rank (something besides the rasterizer adds to it?)"
                 packed = sh[:, :k, :].contiguous()
                 if off > 0:
                     self._mean_(self.flat[:off], world)

@@ -95,7 +95,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                   and not pipe.compute_cov3D_python and not pipe.convert_SHs_python)
     op_translation = None
     if pose_in_op:
-        raw_flags |= 16                                      # _C.RAW_POSE
+        raw_flags |= 16                                      # _C.RAW_POSE (composes with activated OR raw opacity / scales / rotations)
         op_translation = None if translation is None else translation.squeeze()
     elif transforms is not None:
         # = torch.matmul(transforms, means3D[..., None]).squeeze(-1) (reference :74-75), written as an elementwise product + row sum:
@@ -108,13 +108,16 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     if means3D.dim() != 2:
         means3D = means3D.squeeze()
     means2D = screenspace_points
-    opacity = pc._opacity if raw_flags else pc.get_opacity
+    # which tensors go in is decided by the three activation bits alone: RAW_POSE / HINT_SPATIAL_ORDER say nothing about them
+    # (round 4 tested `if raw_flags`: pose_in_op without raw_parameters_in_op handed the op logits as opacities)
+    raw_params = bool(raw_flags & 7)
+    opacity = pc._opacity if raw_params else pc.get_opacity
 
     scales = rotations = cov3D_precomp = op_transforms = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier, None if transforms is None else transforms.squeeze())
     else:
-        scales, rotations = (pc._scaling, pc._rotation) if raw_flags else (pc.get_scaling, pc.get_rotation)
+        scales, rotations = (pc._scaling, pc._rotation) if raw_params else (pc.get_scaling, pc.get_rotation)
         # an addition (pipe.transforms_in_op): the per-Gaussian LBS transform of the covariance is applied INSIDE the op instead of
         # by the torch ops of get_covariance (the reference ignores `transforms` in this branch, gaussian_renderer/__init__.py:92-93)
         if transforms is not None and getattr(pipe, "transforms_in_op", False):

@@ -25,8 +25,8 @@ class _FusedAdamW:
             t = tensors.get(name)
             if t is None or t.data_ptr() != ptr or not t.is_contiguous() or t.dtype != torch.float32:
                 raise RuntimeError(f"fused AdamW update: the rasterizer's `{name}` input is not the parameter tensor the optimizer was "
-                                   f"given (a copy, a cast or an activated value?) -- use pipe.raw_parameters_in_op or detach the "
-                                   f"optimizer from the context (context.fused_adamw = None)")
+                                   f"given (a copy, a cast or an activated value?) -- use pipe.raw_parameters_in_op, or take the step "
+                                   f"out of the backward again with optimizer.unfuse() (clears the context AND re-arms optimizer.step())")
 
 
 class FlatAdamW:
@@ -89,7 +89,7 @@ class FlatAdamW:
         self.step_state = torch.zeros(int(lib().moss_adamw_state_bytes()) // 4, dtype=torch.int32, device=dev) if capturable else None
 
     # ---- the update applied by the rasterizer's backward kernel itself -----------------------------------------------------------
-    def fuse_into_backward(self, context, means3D=None, sh=None, opacity=None, scales=None, rotations=None):
+    def fuse_into_backward(self, context, means3D=None, sh=None, opacity=None, scales=None, rotations=None, local_only=False):
         """Hand the update of the named parameters to the per-Gaussian backward kernel of the rasterizer (C ABI
         ``moss_raster_backward_raw_adamw``): the kernel that produces a Gaussian's gradients applies its AdamW step on the spot --
         parameters in place, moments in this optimizer's buffers, same bits as ``step()`` would give -- and the gradients of those
@@ -103,11 +103,22 @@ class FlatAdamW:
         Every parameter of the bucket must be named (give the rest to a second optimizer over its own bucket); needs
         ``capturable=True`` and no shard.  Afterwards ``step()`` is a no-op: the step is taken inside ``loss.backward()``, and a frame
         that overflowed its binning capacity takes none (the kernel reads the frame's status word itself).
-        ``context``: the :class:`RasterContext` of the rasterizer whose backward does it (None: the default one)."""
+        ``context``: the :class:`RasterContext` of the rasterizer whose backward does it (None: the default one).
+
+        In a process group of more than one rank the fused step is LOCAL: the gradients never reach the bucket, so no exchange can
+        average them and data-parallel replicas would drift apart without a word.  It is therefore refused there unless the caller
+        says ``local_only=True`` -- every rank trains a model of its own (the loss-only exchange of BASELINE configs[3]).
+        ``unfuse()`` takes the step out of the backward again."""
+        import torch.distributed as tdist
         from ._lib import FusedAdamWStruct, OPT_BITS
         from .diff_gaussian_rasterization import _C
         if self.shard is not None or self.step_state is None:
             raise RuntimeError("fuse_into_backward needs capturable=True and an unsharded optimizer")
+        if not local_only and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            raise RuntimeError("fuse_into_backward in a process group of %d ranks: the step inside the backward kernel is local to the rank "
+                               "(its gradients never reach the bucket, so nothing averages them and replicas diverge).  Pass "
+                               "local_only=True if every rank trains its OWN model (loss-only exchange); otherwise keep the flat "
+                               "step() behind the gradient exchange" % tdist.get_world_size())
         named = {"means3D": means3D, "sh": sh, "opacity": opacity, "scales": scales, "rotations": rotations}
         given = {k: v for k, v in named.items() if v is not None}
         if {id(v) for v in given.values()} != {id(p) for p in self.bucket.params} or len(given) != len(self.bucket.params):
@@ -140,8 +151,20 @@ class FlatAdamW:
         st.beta1, st.beta2, st.eps, st.weight_decay = float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay)
         st.step_state = self.step_state.data_ptr()
         self.fused = _FusedAdamW(st, ptrs, self)
-        (context or _C.DEFAULT).fused_adamw = self.fused
+        self._fused_context = context or _C.DEFAULT
+        self._fused_context.fused_adamw = self.fused
         return self.fused
+
+    def unfuse(self, context=None):
+        """Take the step out of the backward kernel again: clears the context's ``fused_adamw`` AND this optimizer's own flag, so that
+        the backward writes gradients to the bucket as before and ``step()`` applies them.  (Clearing only the context -- what round 4's
+        error message suggested -- left ``step()`` a no-op: parameters silently stopped updating.)  ``context``: the one given to
+        ``fuse_into_backward`` (default: that one).  A step captured in a hipGraph must be re-captured afterwards."""
+        cx = context or getattr(self, "_fused_context", None)
+        if cx is not None and cx.fused_adamw is self.fused:
+            cx.fused_adamw = None
+        self.fused = None
+        self._fused_context = None
 
     def set_learning_rates(self, rates):
         """A learning-rate schedule.  ``rates``: {parameter (or its index in the bucket): lr, or (lr, lr_rest) for a tensor with a
@@ -220,15 +243,26 @@ class FlatAdamW:
     def step(self, skip_word=None, skip_mask=2):
         """One update.  ``skip_word`` (capturable optimizers only): a one-element int32 / float32 DEVICE tensor; if
         ``skip_word & skip_mask`` is non-zero when the kernel runs, the step is a no-op on the device -- parameters, moments and the
-        step counter stay bit for bit (C ABI ``moss_adamw_flat_guarded``).  ``frame_status_word(img_buffer)`` of a rasterizer forward
+        step counter stay bit for bit (C ABI ``moss_adamw_flat_guarded``).  Not with ``shard``: the skip is a per-rank decision.  ``frame_status_word(img_buffer)`` of a rasterizer forward
         with the default mask 2 skips the step of a frame that overflowed its capacity and rendered nothing (inside a captured
         hipGraph nobody else can)."""
         dev = self.flat_params.device
         if getattr(self, "fused", None) is not None:
-            return                                           # the rasterizer's backward kernel took the step (fuse_into_backward)
+            cx = getattr(self, "_fused_context", None)
+            if cx is not None and cx.fused_adamw is self.fused:
+                return                                       # the rasterizer's backward kernel took the step (fuse_into_backward)
+            # somebody cleared the context by hand: the backward wrote gradients to the bucket again, and a silent no-op here would
+            # freeze the parameters (ADVICE r4)
+            raise RuntimeError("FlatAdamW.step(): this optimizer was fused into a rasterizer backward, but that context no longer "
+                               "carries it (context.fused_adamw was cleared by hand?) -- call optimizer.unfuse() to go back to step()")
         if skip_word is not None:
             if self.step_state is None:
                 raise RuntimeError("a guarded step needs capturable=True: a host-side step count cannot know about the skipped step")
+            if self.shard is not None:
+                # one rank's frame overflowed, its peers' did not: this rank would skip ITS shard's update while the others step theirs,
+                # and the all-gather would then spread a half-stepped parameter vector
+                raise RuntimeError("a guarded step (skip_word) on a SHARDED optimizer: the skip is a per-rank decision and would leave the "
+                                   "shards at different steps; guard the frame before the gradient exchange instead")
             first, count = (0, self.n) if self.shard is None else (self.first, self.count)
             if count == 0:
                 return
