@@ -111,6 +111,10 @@ def parse_args(argv=None):
                          "all-gather of the updated parameters (moss_amd.dist.ShardedStep); loss_only (round 4's headline) = BASELINE "
                          "configs[3] as written -- \"frames of six subjects sharded across 8 GPUs, RCCL loss all-reduce\": every rank "
                          "trains its OWN model on its own frames, exactly the N = 1 step, and RCCL all-reduces the 4-float loss block only")
+    ap.add_argument("--debug-bits", type=int, default=0,
+                    help="OR-ed into the op's `debug` argument (include/moss_raster.h MOSS_DEBUG_*): 8 = MOSS_DEBUG_TRACE, roctx ranges around "
+                         "every stage launcher (use with --graph 0 under `rocprofv3 --kernel-trace --marker-trace`); 4 = "
+                         "MOSS_DEBUG_EXACT_MATH (checking mode, slower blend kernels: not a valid `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
     ap.add_argument("--callers-only", default="", help="comma-separated names: measure only these caller variants (profiling aid, e.g. "
@@ -181,7 +185,7 @@ class Harness:
         unified = not torch_adamw and not torch_activations
         self.pc = pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
         self.pipe = pipe = SimpleNamespace(
-            convert_SHs_python=False, compute_cov3D_python=(mode in ("precomp", "lbs_python")), debug=False,
+            convert_SHs_python=False, compute_cov3D_python=(mode in ("precomp", "lbs_python")), debug=int(getattr(args, "debug_bits", 0)),
             fused_activations=not torch_activations, transforms_in_op=(mode == "lbs"),
             pose_in_op=(mode == "lbs" and not torch_activations),    # the op poses the canonical positions itself (MOSS_RAW_POSE)
             # (raw_in_op: MOSS's own parameter tensors -- separate f_dc / f_rest, torch.optim -- with only the three getters moved into
@@ -676,7 +680,8 @@ def main(argv=None):
                    "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
                    "optimizer": ("AdamW step taken by the per-Gaussian backward kernel (moss_raster_backward_raw_adamw); bit-identical to the flat "
                                  "kernel, reported beside as callers.unfused_optimizer") if h.fused_opt else "flat AdamW kernel over the gradient bucket",
-                   "glue": "compiled PyTorch-ROCm extension moss_amd/lib/_moss_C.so over the C ABI of libmoss_raster.so"},
+                   "glue": "compiled PyTorch-ROCm extension moss_amd/lib/_moss_C.so over the C ABI of libmoss_raster.so",
+                   **({"debug_bits": int(args.debug_bits)} if args.debug_bits else {})},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
                      # the best a plain streaming kernel reaches on this part (profiles/r01_hbm_bandwidth.json: triad over 1 GiB buffers)

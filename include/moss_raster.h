@@ -32,7 +32,9 @@ extern "C" {
  * caller's knowledge of the device-step block's size (288 bytes in early version-1 builds, 9216 later); diagnostics
  * (environment knobs, stamp buffers) exist only in -DMOSS_DIAG builds.  A binding compiled against another version must refuse to
  * load: compare ITS compile-time MOSS_ABI_VERSION with moss_abi_version(). */
-#define MOSS_ABI_VERSION 4
+/* ABI 5 (round 5): two more bits of `debug` -- MOSS_DEBUG_EXACT_MATH, MOSS_DEBUG_TRACE (below) -- and moss_raster_binning_bytes
+ * follows the slimmer gradient-record layout.  No signature changed. */
+#define MOSS_ABI_VERSION 5
 /* Version 3 (round 4): EVERY forward / backward entry point takes the `debug` bit set (version 2: only moss_raster_forward /
  * moss_raster_backward did, so MOSS_DEBUG_NO_BLOCK_CULL was silently dropped on the _async / _tf / _raw paths: last argument before
  * `stream`); moss_adamw_flat_guarded (an optimizer step that a dropped frame turns into a no-op); MOSS_RAW_POSE and the
@@ -70,9 +72,24 @@ const char* moss_last_error(void);
  * ignore the per-instance 4x4-block masks and test every list entry against every block.  The masks only SKIP (entry, block)
  * pairs that cannot reach alpha >= 1/255: final_T and n_contrib are bit-identical either way, images and gradients equal up to
  * float32 summation order (tests/test_gpu_ops.py::test_block_mask_culling_never_changes_a_result).  Per call, no global state.
+ * MOSS_DEBUG_EXACT_MATH (4; ABI 5; forward AND the matching backward call): the blend kernels evaluate what decides a pixel's list
+ * -- the exponent, exp(), alpha, the transmittance chain -- exactly as the reference's SOURCE reads (forward.cu:336-356,
+ * backward.cu:504-516): `power = -0.5f * (A dx dx + C dy dy) - B dx dy` with one rounding per operation (the fast path spells two
+ * of them as FMAs), exp() as a correctly defined function (the restatement of glibc's expf that oracle/moss_oracle.c carries as
+ * moss_expf_det: the same bits on CPU and GPU; the fast path uses v_exp_f32, ~1 ulp), and T = T / (1 - alpha) as a chain of IEEE
+ * divisions (the fast path: v_rcp_f32 and a prefix product).  Under it n_contrib and final_T equal the CPU oracle's (with the same
+ * exp) BIT FOR BIT on every pixel -- which turns "n_contrib may differ on <= 1e-4 of the pixels" of the fast path into a checked
+ * statement: fast and exact differ only where a decision sits within rounding of its threshold.  2-3x slower blend kernels; a
+ * checking mode, not a product path.
+ * MOSS_DEBUG_TRACE (8; ABI 5): every stage launcher is wrapped in a roctx range ("moss:preprocess_fwd", "moss:scatter", ...), so
+ * that a `rocprofv3 --kernel-trace --marker-trace` timeline of the CALLER's program shows the op's stages.  The
+ * roctx library (librocprofiler-sdk-roctx.so) is resolved with dlopen at the first traced call: no link-time dependency, nothing
+ * happens without the bit.  Ranges bracket the LAUNCH calls on the host (inside a captured hipGraph they are recorded once, at capture).
  */
 #define MOSS_DEBUG_SYNC          1
 #define MOSS_DEBUG_NO_BLOCK_CULL 2
+#define MOSS_DEBUG_EXACT_MATH    4
+#define MOSS_DEBUG_TRACE         8
 int moss_raster_forward(
     moss_alloc_fn geometry_alloc, void* geometry_user,
     moss_alloc_fn binning_alloc, void* binning_user,

@@ -47,24 +47,85 @@ typedef float v2f __attribute__((ext_vector_type(2)));        // an aligned regi
 // are done as PAIRS -- (B dx, C dy), then ((B dx) dy, (C dy) dy) -- which is why the record's second word is {B, C, A, opacity}
 // (merge_gather_kernel): (B, C) and (x, y) are aligned register pairs as they come out of the LDS read.  Six instructions for nine.
 struct PairGeom { v2f d; float power; };                      // d = (dx, dy)
+
+// ---- MOSS_DEBUG_EXACT_MATH (include/moss_raster.h): the arithmetic that DECIDES a pixel's list exactly as the reference's source reads
+// (forward.cu:336-356, backward.cu:504-516), i.e. as the CPU oracle evaluates it (gcc -ffp-contract=off): bit-identical n_contrib and
+// final_T on every pixel.  Template parameter EXACT of everything below; the product path (EXACT = false) is unchanged.
+// power = -0.5f * (A dx dx + C dy dy) - B dx dy, one rounding per operation, C's precedence (no contraction inside this function)
+__device__ __forceinline__ float power_exact(float dx, float dy, float A, float B, float C)
+{
+#pragma clang fp contract(off)
+    const float t1 = (A * dx) * dx, t2 = (C * dy) * dy;
+    const float sum = t1 + t2;
+    const float half = -0.5f * sum;
+    const float t3 = (B * dx) * dy;
+    return half - t3;
+}
+// exp(x), x <= 0: glibc's expf algorithm (sysdeps/ieee754/flt-32/e_expf.c: 2^(k/32) table + cubic, in double) with every double
+// operation one rounded operation -- oracle/moss_oracle.c: moss_expf_det is the SAME function, bit for bit (checked there against the
+// C library's expf on a grid of 11.5 M arguments)
+__device__ const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
+__device__ __forceinline__ float expf_det(float x)
+{
+#pragma clang fp contract(off)
+    if (!(x > -104.0f)) return 0.0f;
+    if (x > 0.0f) x = 0.0f;                                   // (never used for a decision: power > 0 is skipped; keeps the table index sane)
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double z = InvLn2N * (double)x;
+    double kd = z + SHIFT;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd = kd - SHIFT;
+    const double r = z - kd;
+    const uint64_t t = EXP2F_TAB[ki % 32u] + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double zz = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * sc;
+    return (float)y;
+}
+template <bool EXACT> __device__ __forceinline__ float blend_exp(float power) { if constexpr (EXACT) return expf_det(power); else return __expf(power); }
+// 1 / (1 - alpha): v_rcp_f32 (~1 ulp) on the product path, the IEEE quotient in the exact mode
+template <bool EXACT> __device__ __forceinline__ float blend_rcp(float v) { if constexpr (EXACT) return 1.0f / v; else return __builtin_amdgcn_rcpf(v); }
+
+template <bool EXACT = false>
 __device__ __forceinline__ PairGeom pair_power(const float4& a, const float4& b, v2f pix)
 {
     PairGeom r;
     r.d = v2f{a.x, a.y} - pix;
-    const v2f bc = v2f{b.x, b.y} * r.d;                       // (B dx, C dy)
-    const v2f t = bc * v2f{r.d.y, r.d.y};                     // ((B dx) dy, (C dy) dy)
-    const float q = __fmaf_rn(b.z * r.d.x, r.d.x, t.y);       // power = -0.5*(A dx^2 + C dy^2) - B dx dy
-    r.power = __fmaf_rn(-0.5f, q, -t.x);
+    if constexpr (EXACT) {
+        r.power = power_exact(r.d.x, r.d.y, b.z, b.x, b.y);      // (record word b = {B, C, A, opacity})
+    } else {
+        const v2f bc = v2f{b.x, b.y} * r.d;                       // (B dx, C dy)
+        const v2f t = bc * v2f{r.d.y, r.d.y};                     // ((B dx) dy, (C dy) dy)
+        const float q = __fmaf_rn(b.z * r.d.x, r.d.x, t.y);       // power = -0.5*(A dx^2 + C dy^2) - B dx dy
+        r.power = __fmaf_rn(-0.5f, q, -t.x);
+    }
     return r;
 }
 
 // alpha of one (pixel, entry) pair, 0 if the pair fails either skip test of forward.cu:340-350 / backward.cu:507-514
+template <bool EXACT = false>
 __device__ __forceinline__ PairEval eval_pair(float dx, float dy, float A, float B, float C, float opacity)
 {
     PairEval r;
-    const float q = __fmaf_rn(A * dx, dx, (C * dy) * dy);      // power = -0.5*(A dx^2 + C dy^2) - B dx dy
-    r.power = __fmaf_rn(-0.5f, q, -(B * dx) * dy);
-    r.G = __expf(r.power);
+    if constexpr (EXACT) {
+        r.power = power_exact(dx, dy, A, B, C);
+    } else {
+        const float q = __fmaf_rn(A * dx, dx, (C * dy) * dy);      // power = -0.5*(A dx^2 + C dy^2) - B dx dy
+        r.power = __fmaf_rn(-0.5f, q, -(B * dx) * dy);
+    }
+    r.G = blend_exp<EXACT>(r.power);
     float al = fminf(0.99f, opacity * r.G);
     al = (r.power <= 0.0f) ? al : 0.0f;
     r.alpha = (al >= 1.0f / 255.0f) ? al : 0.0f;
@@ -159,6 +220,7 @@ __device__ __forceinline__ Rec load_rec(const float4* __restrict__ inst_rec, int
 // backward kernel stops gaining (bench scene 37.0 -> 33.6 us, configs[1] 38.4 -> 26.0 us, configs[4] 88 -> 80 us; 8-16 the
 // same, 256 and up twice as slow), the forward kernel does not care.
 // ---------------------------------------------------------------------------------------------------------
+template <bool EXACT>
 __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
                                                    const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
                                                    float4 (*ring)[3], const float* __restrict__ bg_color, float* __restrict__ out_color,
@@ -191,7 +253,7 @@ __device__ __forceinline__ void light_forward_item(int W, int H, int gx, int til
             const int e = __ffsll((long long)m) - 1;         // wave-uniform: the records are LDS broadcasts
             m &= m - 1ull;
             const float4 a = ring[e][0], b = ring[e][1], c = ring[e][2];
-            const PairEval pe = eval_pair(a.x - pixx, a.y - pixy, b.z, b.x, b.y, b.w);   // (record word b = {B, C, A, opacity})
+            const PairEval pe = eval_pair<EXACT>(a.x - pixx, a.y - pixy, b.z, b.x, b.y, b.w);   // (record word b = {B, C, A, opacity})
             const float al = live ? pe.alpha : 0.0f;
             const float test_T = T * (1.0f - al);
             const bool stop = al > 0.0f && test_T < 0.0001f;                  // forward.cu:351-356: this entry is NOT blended
@@ -229,6 +291,7 @@ __device__ __forceinline__ float row_sum16(float v)
     return v;
 }
 
+template <bool EXACT>
 __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int tile, int q, int lane, const uint2 rg,
                                                     const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
                                                     float4 (*ring)[3], const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
@@ -292,13 +355,13 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 const int pos = n_eff - 1 - (base + e);
                 const float4 a = ring[e][0], b = ring[e][1], c = ring[e][2];
                 const float dx = a.x - pixx, dy = a.y - pixy;
-                const PairEval pe = eval_pair(dx, dy, b.z, b.x, b.y, b.w);                   // (record word b = {B, C, A, opacity})
+                const PairEval pe = eval_pair<EXACT>(dx, dy, b.z, b.x, b.y, b.w);            // (record word b = {B, C, A, opacity})
                 const float al = (valid && pos < last_contributor) ? pe.alpha : 0.0f;   // backward.cu:499-514
                 const float G = (al > 0.0f) ? pe.G : 0.0f;
                 const float mm = 1.0f - al;
-                const float rinv = __builtin_amdgcn_rcpf(mm);
+                const float rinv = blend_rcp<EXACT>(mm);
                 const float u = __fmaf_rn(c.x, gpr, __fmaf_rn(c.y, gpg, __fmaf_rn(c.z, gpb, __fmaf_rn(c.w, gpd, gpa))));
-                const float To = T * rinv;                                           // T after the division (backward.cu:516)
+                const float To = EXACT ? T / mm : T * rinv;                          // T after the division (backward.cu:516)
                 const float dL_dopa = __fmaf_rn(u - Q, To, nTb * rinv);              // (u - Q) = sum_k (x_k - accum_k) g_k
                 Q = __fmaf_rn(mm, Q, al * u);
                 T = To;
@@ -534,6 +597,7 @@ __device__ __forceinline__ void heavy_forward_scan(int blk, int lane, const uint
 }
 
 // BLENDER of a heavy item: trips over the landed entries, cuts, and the block's outputs.
+template <bool EXACT>
 __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
                                                     PairRing* L, PairCtl* ctl, uint32_t seq, const float* __restrict__ bg_color,
                                                     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
@@ -576,8 +640,8 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     // and the scalar unit has room: 51 -> 44 vector instructions per trip.  The arithmetic is eval_pair's, operation for operation.
     unsigned long long live_m = __ballot(live > 0.0f);
     auto trip = [&](const Fetched& f) -> bool {
-        const float power = pair_power(f.a, f.b, pix2).power;
-        const float ao = fminf(0.99f, f.b.w * __expf(power));
+        const float power = pair_power<EXACT>(f.a, f.b, pix2).power;
+        const float ao = fminf(0.99f, f.b.w * blend_exp<EXACT>(power));
         // pairs that blend: power <= 0, alpha >= 1/255 (forward.cu:340-350), pixel alive (padding slots hold zero records: alpha 0)
         const unsigned long long m = __builtin_amdgcn_fcmpf(power, 0.0f, FCMP_OLE) & __builtin_amdgcn_fcmpf(ao, 1.0f / 255.0f, FCMP_OGE) & live_m;
         // none of the four entries reaches any live pixel (the block masks are conservative): nothing changes -- T, the sums, the
@@ -747,6 +811,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
 #undef Cb
 #undef Dacc
 
+template <bool EXACT>
 __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int tile, int blk, int lane, const uint2 rg,
                                                     const float4* __restrict__ inst_rec, const uint16_t* __restrict__ inst_bmask,
                                                     HeavyLdsBwd* L, const float* __restrict__ bg_color,
@@ -822,9 +887,9 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     auto trip = [&](const Fetched& f) {
         // the pair's alpha exactly as the forward kernel decides it (pair_power / eval_pair); the three skip tests (power > 0, alpha <
         // 1/255: backward.cu:507-514; position behind the pixel's last contributor: backward.cu:499) as lane masks in scalar registers
-        const PairGeom pg = pair_power(f.a, f.b, pix2);
+        const PairGeom pg = pair_power<EXACT>(f.a, f.b, pix2);
         const float power = pg.power;
-        const float G0 = __expf(power);
+        const float G0 = blend_exp<EXACT>(power);
         const float ao = fminf(0.99f, f.b.w * G0);
         const unsigned long long contrib = __builtin_amdgcn_fcmpf(power, 0.0f, FCMP_OLE) & __builtin_amdgcn_fcmpf(ao, 1.0f / 255.0f, FCMP_OGE) &
                                            __builtin_amdgcn_fcmpf(f.pos1, last_contributor_f, FCMP_OLE);
@@ -833,16 +898,26 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         const float G = on ? G0 : 0.0f;
         // this entry's state transform:  T' = T / (1-alpha),  Q' = alpha*u + (1-alpha)*Q   (identity if skipped)
         const float mm = 1.0f - al;
-        const float rinv = __builtin_amdgcn_rcpf(mm);
+        const float rinv = blend_rcp<EXACT>(mm);
         const float u = __fmaf_rn(f.c.x, gpr, __fmaf_rn(f.c.y, gpg, __fmaf_rn(f.c.z, gpb, __fmaf_rn(f.c.w, gpd, gpa))));
         const float kq = al * u;
         // The four slots' transforms in visiting order.  T: slot s ends with T times the product of the slots' 1/(1-alpha) up to its
         // own -- a prefix product over the pixel's four lanes in two steps (the multiply takes its DPP operand directly).  Q: slot s
         // starts from the output of slot s-1, three dependent steps of one fused select and one FMA.
-        float P = rinv;
-        { const float y = DPP_MOV(P, 0x90) * P; P = slot >= 1 ? y : P; }     // quad_perm:[0,0,1,2]: r0, r0 r1, r1 r2, r2 r3
-        { const float y = DPP_MOV(P, 0x44) * P; P = slot >= 2 ? y : P; }     // quad_perm:[0,1,0,1]: r0, r0 r1, r0 r1 r2, r0 r1 r2 r3
-        const float To = T * P;
+        float To;
+        if constexpr (EXACT) {
+            // T = T / (1 - alpha), entry after entry, IEEE division (backward.cu:516): slot s divides what slot s-1 left
+            float X = T / mm, Y;
+            Y = DPP_MOV(X, 0x90); X = slot >= 1 ? Y / mm : X;                // quad_perm:[0,0,1,2]
+            Y = DPP_MOV(X, 0x90); X = slot >= 2 ? Y / mm : X;
+            Y = DPP_MOV(X, 0x90); X = slot >= 3 ? Y / mm : X;
+            To = X;
+        } else {
+            float P = rinv;
+            { const float y = DPP_MOV(P, 0x90) * P; P = slot >= 1 ? y : P; }     // quad_perm:[0,0,1,2]: r0, r0 r1, r1 r2, r2 r3
+            { const float y = DPP_MOV(P, 0x44) * P; P = slot >= 2 ? y : P; }     // quad_perm:[0,1,0,1]: r0, r0 r1, r0 r1 r2, r0 r1 r2 r3
+            To = T * P;
+        }
         float Qi = Q;
         float Qo = __fmaf_rn(mm, Qi, kq);
         Qi = take_prev_slot_unless(Qo, Qi, 0x1111111111111111ull); Qo = __fmaf_rn(mm, Qi, kq);
@@ -997,9 +1072,9 @@ __device__ __forceinline__ WaveItem pull_item(uint32_t* my_head, int lane, int n
 
 // PAIRS = wave pairs per workgroup: 2 (256 threads, four workgroups per CU: the product configuration) or 8 (ONE 1024-thread workgroup
 // per CU, all its pairs sharing LDS: the experimental form, diagnostic builds only, MOSS_FWD_PAIRS=8).
-template <int PAIRS>
+template <int PAIRS, bool EXACT>
 __global__ void __launch_bounds__(128 * PAIRS)
-blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ header,
+blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header,
                           uint32_t* __restrict__ queue_head, const uint4* __restrict__ work_table, const float4* __restrict__ inst_rec,
                           const uint16_t* __restrict__ inst_bmask,
                           const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -1032,6 +1107,9 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     const bool is_scanner = PAIRS == 2 ? (((wv ^ role_swap ^ (int)((blockIdx.x >> 3) / 32u)) & 1) == 0)
                                        : (((wv ^ role_swap ^ (pair >> 1)) & 1) == 0);
     if (threadIdx.x < PAIRS * (int)(sizeof(PairCtl) / 4)) reinterpret_cast<uint32_t*>(s_ctl)[threadIdx.x] = 0u;
+    // header[8] = this kernel's grid: the backward kernel numbers the cuts by it (how many pairs share a segment region), whatever
+    // instantiation -- product or MOSS_DEBUG_EXACT_MATH, with its own residency -- the forward call ran
+    if (blockIdx.x == 0 && threadIdx.x == 0) header[8] = gridDim.x;
     __syncthreads();                                         // (the only workgroup barrier of the kernel)
     PairRing* const L = &s_ring[pair];
     PairCtl* const ctl = &s_ctl[pair];
@@ -1119,7 +1197,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
             else if (prio_mode == 6) set_wave_prio(3);
             else if (prio_mode == 7) set_wave_prio(1 + ((int)blockIdx.x * 4 / (int)gridDim.x) / 2);
             else if (prio_mode != 0) set_wave_prio(prio_of_length(rg.y - rg.x));
-            heavy_forward_blend(W, H, gx, tile, blk, lane, rg, L, ctl, seq, bg_color, out_color, out_depth, out_alpha, final_T, n_contrib,
+            heavy_forward_blend<EXACT>(W, H, gx, tile, blk, lane, rg, L, ctl, seq, bg_color, out_color, out_depth, out_alpha, final_T, n_contrib,
                                 flags, stamps ? stamps + (size_t)(rank * WAVE_BLOCKS + blk) * 8 : nullptr, se, tail_start);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) lds_poke(&ctl->fin_seq, seq);
@@ -1134,7 +1212,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
         light_qi = -1;
         const WaveItem it = decode(qi);
         if (!it.valid) break;
-        light_forward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
+        light_forward_item<EXACT>(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, out_color, out_depth,
                            out_alpha, final_T, n_contrib, flags);
     }
 
@@ -1154,6 +1232,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
     }
 }
 
+template <bool EXACT>
 __global__ void __launch_bounds__(256, 4)      // (four waves per SIMD: at most 128 VGPRs)
 blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_table, const uint32_t* __restrict__ header,
                            uint32_t* __restrict__ queue_head, const float4* __restrict__ inst_rec,
@@ -1190,6 +1269,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
     if (!(flags & 16)) {
         // The forward waves of this XCD filled private slot ranges; their counts give every segment of the region a flat index.  Each
         // wave builds the prefix table itself (all four waves of the workgroup write the same values: no barrier needed).
+        { const int g8 = (int)header[8]; if (g8 > 0) fwd_grid = g8; }     // (the forward kernel's own record of its grid)
         const int fq = min(NUM_XCD_QUEUES, fwd_grid);
         const int f_waves = qx < fq ? fwd_pairs * ((fwd_grid - qx + fq - 1) / fq) : 0;          // forward pairs (blender waves) that fed this region
         uint32_t total = 0u;
@@ -1225,7 +1305,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
             c_pop += tp1 - tp0;
             n_seg++;
             // {tile | block << 28, first instance of the tile, first position, end position}: everything the item needs in ONE load
-            heavy_backward_item(W, H, gx, (int)(d.x & 0x0fffffffu), (int)(d.x >> 28), lane, make_uint2(d.y, d.y + d.w), inst_rec, inst_bmask,
+            heavy_backward_item<EXACT>(W, H, gx, (int)(d.x & 0x0fffffffu), (int)(d.x >> 28), lane, make_uint2(d.y, d.y + d.w), inst_rec, inst_bmask,
                                 &s_heavy[wv], bg_color, final_Ts, n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride,
                                 inst_mask, flags, (int)d.z, (int)d.w, (flags & 64) ? nullptr : seg_state + slot_idx * SEG_STATE_FLOATS);
             c_seg += WSTAMP() - tp1;
@@ -1248,12 +1328,12 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
         if (!it.valid) break;
         n_tail++;
         if (it.heavy)
-            heavy_backward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
+            heavy_backward_item<EXACT>(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
                                 n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags,
                                 (flags & 32) ? 0 : __builtin_amdgcn_readfirstlane((int)tail_start[(size_t)it.tile * WAVE_BLOCKS + it.sub]),
                                 0x7fffffff, nullptr);
         else
-            light_backward_item(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
+            light_backward_item<EXACT>(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
                                 dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
         c_tail += WSTAMP() - tq1;
     }
@@ -1304,18 +1384,21 @@ int forward_pairs()
     return FWD_PAIRS_PER_WG;
 #endif
 }
-int forward_grid(int T)
+// (exact: the MOSS_DEBUG_EXACT_MATH instantiation has its own register count, hence its own residency)
+int forward_grid(int T, bool exact = false)
 {
     static const int per_cu = [] {
 #ifdef MOSS_DIAG
         if (forward_pairs() == 8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blend_forward_wave_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdLds<8>::bytes);
-            return resident_wgs_per_cu(blend_forward_wave_kernel<8>, "MOSS_BLEND_WGS_PER_CU", 1, 1, 1024, FwdLds<8>::bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blend_forward_wave_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FwdLds<8>::bytes);
+            return resident_wgs_per_cu(blend_forward_wave_kernel<8, false>, "MOSS_BLEND_WGS_PER_CU", 1, 1, 1024, FwdLds<8>::bytes);
         }
 #endif
-        return resident_wgs_per_cu(blend_forward_wave_kernel<2>, "MOSS_BLEND_WGS_PER_CU", 4, 4, 256, FwdLds<2>::bytes);
+        return resident_wgs_per_cu(blend_forward_wave_kernel<2, false>, "MOSS_BLEND_WGS_PER_CU", 4, 4, 256, FwdLds<2>::bytes);
     }();
-    return min((8 / forward_pairs()) * T, device_cus() * per_cu);
+    static const int per_cu_exact = resident_wgs_per_cu(blend_forward_wave_kernel<2, true>, "MOSS_BLEND_WGS_PER_CU", 4, 4, 256, FwdLds<2>::bytes);
+    const bool ex = exact && forward_pairs() == FWD_PAIRS_PER_WG;
+    return min((8 / forward_pairs()) * T, device_cus() * (ex ? per_cu_exact : per_cu));
 }
 
 }  // anonymous namespace
@@ -1335,20 +1418,27 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
     static const int cull_knob = knob("MOSS_BLEND_CULL", 1);
     const int flags = fp.no_block_cull ? 0 : cull_knob;             // bit 0: use the per-instance block masks
     const int T = fp.gx * fp.gy;
-    const int wgs = forward_grid(T);                                   // 4 independent waves per workgroup, 16 items per tile
+    const bool exact = fp.exact_math != 0 && forward_pairs() == FWD_PAIRS_PER_WG;   // (MOSS_DEBUG_EXACT_MATH)
+    const int wgs = forward_grid(T, exact);                            // 4 independent waves per workgroup, 16 items per tile
     // hits per depth segment of the backward (0 = never cut: every block is ONE backward item, the round-1 behaviour)
     static const int seg_hits_env = [] { const int v = knob("MOSS_SEG_HITS", 64); return (v > 0 && (v & (v - 1)) == 0 && v >= 4) ? v : 0; }();
     const int seg_hits = T < (1 << 28) ? seg_hits_env : 0;             // (a descriptor packs the tile index into 28 bits)
     static const int role_swap = knob("MOSS_FWD_ROLE_SWAP", 0) & 1, prio_mode = knob("MOSS_FWD_PRIO", 0);
 #ifdef MOSS_DIAG
     if (forward_pairs() == 8)
-        MOSS_LAUNCH_TIMED(blend_forward_wave_kernel<8>, dim3(wgs), dim3(1024), FwdLds<8>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+        MOSS_LAUNCH_TIMED((blend_forward_wave_kernel<8, false>), dim3(wgs), dim3(1024), FwdLds<8>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
                           role_swap, prio_mode);
     else
 #endif
-        MOSS_LAUNCH_TIMED(blend_forward_wave_kernel<2>, dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+    if (exact)
+        MOSS_LAUNCH_TIMED((blend_forward_wave_kernel<2, true>), dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
+                          im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
+                          im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
+                          role_swap, prio_mode);
+    else
+        MOSS_LAUNCH_TIMED((blend_forward_wave_kernel<2, false>), dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
                           role_swap, prio_mode);
@@ -1364,14 +1454,24 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     static const int dbg = knob("MOSS_BWD_DEBUG", 0) & (16 | 32 | 64);
     const int flags = (fp.no_block_cull ? 0 : cull_knob) | dbg;
     const int T = fp.gx * fp.gy;
-    static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel, "MOSS_BWD_WGS_PER_CU", 4, 5);   // 27 KB of LDS each
-    const int wgs = min(4 * T, device_cus() * bwd_wgs_per_cu);
+    static const int bwd_wgs_per_cu = resident_wgs_per_cu(blend_backward_wave_kernel<false>, "MOSS_BWD_WGS_PER_CU", 4, 5);   // 27 KB of LDS each
+    static const int bwd_wgs_per_cu_exact = resident_wgs_per_cu(blend_backward_wave_kernel<true>, "MOSS_BWD_WGS_PER_CU", 4, 5);
+    // (MOSS_DEBUG_EXACT_MATH must be given to the forward AND the backward call: the forward's grid -- how its cuts are numbered -- follows it)
+    const bool exact = fp.exact_math != 0 && forward_pairs() == FWD_PAIRS_PER_WG;
+    const int wgs = min(4 * T, device_cus() * (exact ? bwd_wgs_per_cu_exact : bwd_wgs_per_cu));
     // the queue heads are zero here: cleared by the forward, rewound after each backward (preprocess_backward_kernel)
-    MOSS_LAUNCH_TIMED(blend_backward_wave_kernel, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.work_table, im.header,
-                       im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
-                       dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
-                       flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
-                       forward_grid(T) /* the forward kernel's grid */, forward_pairs());
+    if (exact)
+        MOSS_LAUNCH_TIMED(blend_backward_wave_kernel<true>, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.work_table, im.header,
+                           im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
+                           dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
+                           flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
+                           forward_grid(T, true) /* the forward kernel's grid */, forward_pairs());
+    else
+        MOSS_LAUNCH_TIMED(blend_backward_wave_kernel<false>, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.work_table, im.header,
+                           im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
+                           dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
+                           flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
+                           forward_grid(T, false) /* the forward kernel's grid */, forward_pairs());
 }
 
 }  // namespace moss

@@ -260,6 +260,7 @@ struct FrameParams {
     int prefiltered;
     int raw;                 // RAW_* bits: which of opacity / scales / rotations arrive as MOSS's raw parameters (activated inside the op)
     int no_block_cull;       // MOSS_DEBUG_NO_BLOCK_CULL of the call's `debug` argument: the blend kernels ignore the per-instance block masks
+    int exact_math;          // MOSS_DEBUG_EXACT_MATH: the blend kernels decide every pixel's list with the reference's source arithmetic (blend.hip)
     const float* view_dev; const float* proj_dev; const float* campos_dev; const float* bg_dev;
 };
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <vector>
 
@@ -81,6 +82,32 @@ struct StageTimer {
     }
 };
 
+// ---- MOSS_DEBUG_TRACE: roctx ranges around the stage launchers (the reference has torch.cuda.Event pairs around its
+// whole step only, train_ZJU.py:43-44).  rocprofv3 --marker-trace reads the ranges of the rocprofiler-sdk roctx library; it is
+// resolved with dlopen at the first traced call (no link-time dependency; the older libroctx64 as a fallback), and without the debug
+// bit nothing of this is touched.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        for (const char* name : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" }) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct TraceRange {
+    bool on;
+    TraceRange(bool enabled, const char* name) : on(enabled && roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+    ~TraceRange() { if (on) (void)roctx().pop(); }
+};
+
 // Small pinned host block for the header read-back, one per host thread.
 struct Pinned {
     uint32_t* p = nullptr;
@@ -97,7 +124,7 @@ FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
     fp.focal_y = H / (2.0f * tan_fovy);         // rasterizer_impl.cu:224-225
     fp.focal_x = W / (2.0f * tan_fovx);
-    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0; fp.no_block_cull = 0;
+    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0; fp.no_block_cull = 0; fp.exact_math = 0;
     fp.view_dev = view; fp.proj_dev = proj; fp.campos_dev = campos; fp.bg_dev = bg;
     return fp;
 }
@@ -151,6 +178,8 @@ static int forward_impl(
                                  viewmatrix, projmatrix, cam_pos, background);
     fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;     // scales / rotations are not read with a precomputed covariance
     fp.no_block_cull = (debug_flags & MOSS_DEBUG_NO_BLOCK_CULL) ? 1 : 0;
+    fp.exact_math = (debug_flags & MOSS_DEBUG_EXACT_MATH) ? 1 : 0;
+    const bool trace = (debug_flags & MOSS_DEBUG_TRACE) != 0;
     const int T = fp.gx * fp.gy;
 
     // The counters kernels ADD to (tile histogram, tile cursors, error flags) must be zero here.  With the caller's frame state
@@ -160,13 +189,14 @@ static int forward_impl(
     else launch_clear(im.header, im.clear_bytes(), s);                   // header + tile histogram + tile cursors
     // (a forward that ends before its sort kernel has run leaves the frame state dirty: clean it on those paths)
     auto abandon_frame_state = [&]() { if (frame_state) clear_frame_state(frame_state, fs_bytes, s); };
-    { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s);
+    TraceRange tr_all(trace, "moss:raster_forward");
+    { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s); TraceRange tr(trace, "moss:preprocess_fwd");
       launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, translation, g, im, radii, s); }
     STAGE_CHECK("preprocess");
     // Asynchronous forward: the scan rides along with the scatter kernel (no launch of its own).
     const bool fold_scan = capacity > 0 && scatter_folds_scan(fp);
     if (!fold_scan) {
-        { StageTimer tm(MOSS_STAGE_SCAN, s); launch_scan(P, g, im, T, capacity, s); }
+        { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s); }
         STAGE_CHECK("scan");
     }
 
@@ -194,7 +224,7 @@ static int forward_impl(
     BinView b = BinView::at(bin_ptr, R);
 
     if (R > 0) {
-        { StageTimer tm(MOSS_STAGE_SCATTER, s); launch_scatter(fp, g, im, b, fold_scan, capacity, s); }
+        { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, fold_scan ? "moss:scatter+scan" : "moss:scatter"); launch_scatter(fp, g, im, b, fold_scan, capacity, s); }
         STAGE_CHECK("scatter");
 #ifdef MOSS_DIAG
         {   // timing experiment (scripts/exp_atomics.py): with the scatter's reservation atomics off the keys are garbage -- stop here
@@ -202,11 +232,11 @@ static int forward_impl(
             if (stop) { abandon_frame_state(); return R; }
         }
 #endif
-        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 0); }
-        { StageTimer tm(MOSS_STAGE_MERGE_GATHER, s); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 1); }
+        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); TraceRange tr(trace, "moss:chunk_sort"); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 0); }
+        { StageTimer tm(MOSS_STAGE_MERGE_GATHER, s); TraceRange tr(trace, "moss:merge_gather"); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 1); }
         STAGE_CHECK("tile_sort");
     } else abandon_frame_state();                                        // (nothing rendered: no sort kernel to re-zero it)
-    { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }
+    { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); TraceRange tr(trace, "moss:blend_fwd"); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }
     STAGE_CHECK("blend_forward");
     return R;
 }
@@ -344,12 +374,15 @@ static int backward_impl(
                                  viewmatrix, projmatrix, campos, background);
     fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;
     fp.no_block_cull = (debug_flags & MOSS_DEBUG_NO_BLOCK_CULL) ? 1 : 0;
+    fp.exact_math = (debug_flags & MOSS_DEBUG_EXACT_MATH) ? 1 : 0;
+    const bool trace = (debug_flags & MOSS_DEBUG_TRACE) != 0;
     if ((fp.raw & RAW_OPACITY) && !opacities) return fail(MOSS_ERR_INVALID_ARG, "raw opacities are required to chain through the sigmoid");
+    TraceRange tr_all(trace, "moss:raster_backward");
     if (R > 0) {
-        { StageTimer tm(MOSS_STAGE_BLEND_BWD, s); launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s); }
+        { StageTimer tm(MOSS_STAGE_BLEND_BWD, s); TraceRange tr(trace, "moss:blend_bwd"); launch_blend_backward(fp, g, im, b, dL_dpix, dL_ddepths, dL_dalphas, s); }
         STAGE_CHECK("blend_backward");
     }
-    { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s);
+    { StageTimer tm(MOSS_STAGE_PREPROCESS_BWD, s); TraceRange tr(trace, fused ? "moss:preprocess_bwd+adamw" : "moss:preprocess_bwd");
       launch_preprocess_backward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, im.header, im.queues,
                                  dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                                  transforms, dL_dtransforms, translation, dL_dtranslation, s, fused ? &fa : nullptr); }

@@ -20,6 +20,8 @@ NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/conf
 RAW_OPACITY, RAW_SCALE, RAW_ROTATION = 1, 2, 4       # include/moss_raster.h MOSS_RAW_*
 HINT_SPATIAL_ORDER = 8                               # MOSS_HINT_SPATIAL_ORDER: OR-ed into raw_flags, changes no result
 RAW_POSE = 16                                        # MOSS_RAW_POSE: means3D are canonical positions, posed inside the op (T x + translation)
+# bits of the `debug` argument (GaussianRasterizationSettings.debug may be the reference's bool or an OR of these; include/moss_raster.h)
+DEBUG_SYNC, DEBUG_NO_BLOCK_CULL, DEBUG_EXACT_MATH, DEBUG_TRACE = 1, 2, 4, 8
 
 last_num_rendered = 0   # num_rendered of the most recent forward call of ANY context (kept for callers that predate contexts)
 

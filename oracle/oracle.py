@@ -81,6 +81,38 @@ def _opt(a):
     return None if a.size == 0 else _f32(a)
 
 
+class det_exp:
+    """``with oracle.det_exp(on):`` -- the blend forward / backward of the float32 oracle evaluate exp() with ``moss_expf_det`` (the
+    deterministic restatement of glibc's expf that csrc/blend.hip carries too, moss_oracle.c) instead of the C library's expf: the
+    oracle side of the EXACT-MATH parity mode (MOSS_DEBUG_EXACT_MATH).  The float64 adjudicator is not affected."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        lib().oracle_set_det_exp(C.c_int(1 if self.on else 0))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_det_exp(C.c_int(0))
+        return False
+
+
+def expf_det_mismatches(x) -> int:
+    """How many of the float32 values x have moss_expf_det(x) != expf(x) (the C library's), bit for bit."""
+    x = _f32(x).reshape(-1)
+    L = lib()
+    L.oracle_expf_det_mismatches.restype = C.c_int
+    return int(L.oracle_expf_det_mismatches(_p(x), C.c_int(x.size)))
+
+
+def expf_det(x):
+    x = _f32(x).reshape(-1)
+    y = np.zeros_like(x)
+    lib().oracle_expf_det_array(_p(x), C.c_int(x.size), _p(y))
+    return y
+
+
 def tile_grid(W, H):
     return (W + BLOCK_X - 1) // BLOCK_X, (H + BLOCK_Y - 1) // BLOCK_Y
 

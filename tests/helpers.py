@@ -40,15 +40,26 @@ def inputs_of(scene, mode="scale_rot", degree=None, colors=False, bg=None):
     return d
 
 
-def oracle_forward(d):
+def oracle_forward(d, det_exp=False):
+    """det_exp: the blend evaluates exp() with the deterministic expf the kernels' EXACT-MATH mode uses (oracle.det_exp)."""
     c = d.cam
+    with oracle.det_exp(det_exp):
+        return _oracle_forward(d, c)
+
+
+def _oracle_forward(d, c):
     return oracle.forward(d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), d.opacities.numpy(), _np(d.scales),
                           _np(d.rotations), d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(),
                           c.tanfovx, c.tanfovy, c.H, c.W, _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms))
 
 
-def oracle_backward(d, fw, dc, dd, da, f32_accumulators=False, sum_noise_ulps=0.0, noise_seed=0):
+def oracle_backward(d, fw, dc, dd, da, f32_accumulators=False, sum_noise_ulps=0.0, noise_seed=0, det_exp=False):
     c = d.cam
+    with oracle.det_exp(det_exp):
+        return _oracle_backward(d, c, fw, dc, dd, da, f32_accumulators, sum_noise_ulps, noise_seed)
+
+
+def _oracle_backward(d, c, fw, dc, dd, da, f32_accumulators, sum_noise_ulps, noise_seed):
     return oracle.backward(fw, d.bg.numpy(), d.means3D.numpy(), _np(d.colors_precomp), _np(d.scales), _np(d.rotations),
                            d.scale_modifier, _np(d.cov3D_precomp), c.viewmatrix.numpy(), c.projmatrix.numpy(), c.tanfovx,
                            c.tanfovy, _np(dc), _np(dd), _np(da), _np(d.shs), d.degree, c.campos.numpy(), transforms=_np(d.transforms),

@@ -373,3 +373,23 @@ def test_contribution_mass_bounds_the_gradient_and_is_zero_where_nothing_contrib
         assert (a[s == 0] == 0).all(), name
     untouched = sc["dL_dopacity"].reshape(-1) == 0            # Gaussians no stable pixel blends (cfg1 culls none)
     assert (sc["dL_dmeans3D"][untouched] == 0).all() and (sc["dL_dsh"][untouched] == 0).all()
+
+
+def test_deterministic_expf_is_the_c_librarys_expf():
+    """moss_expf_det (oracle/moss_oracle.c; csrc/blend.hip carries the same function for MOSS_DEBUG_EXACT_MATH) restates glibc's expf
+    with one rounding per double operation.  It must BE the C library's expf for every argument the blend can ask for: counted on a grid
+    of every 97th float of [-104, -0] (11.5 M arguments; the exhaustive run over all 1 120 927 745 of them finds ONE difference on this
+    image's glibc 2.35, at x = -0x1.f8cbb2p+5 where the result is 2^-92), plus the known answers exp(0) = 1 and exp(-ln 2) = 1/2."""
+    from oracle import oracle
+    bits = np.arange(0x80000000, 0xC2D00001, 97, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    assert x.min() >= -104.0 and x.max() <= 0.0 and x.size > 11_000_000
+    assert oracle.expf_det_mismatches(x) <= 2
+    y = oracle.expf_det(np.array([0.0, -0.0, -0.6931471805599453, -1.0, -200.0, -np.inf], np.float32))
+    assert y[0] == 1.0 and y[1] == 1.0 and y[2] == 0.5 and abs(float(y[3]) - 0.36787944117144233) < 3e-8 and y[4] == 0.0 and y[5] == 0.0
+    # switching the oracle's blend to it changes no decision of cfg1 (and is reset afterwards)
+    from moss_amd import scenes
+    from tests import helpers as hp
+    d = hp.inputs_of(scenes.config1(), "precomp")
+    a, b = hp.oracle_forward(d), hp.oracle_forward(d, det_exp=True)
+    assert np.array_equal(a.n_contrib, b.n_contrib) and np.array_equal(a.final_T, b.final_T)
