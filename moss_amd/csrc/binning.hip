@@ -10,7 +10,10 @@
 //      scan over the tiles gives every tile's [start,end) range directly -- no boundary search, and the tile id
 //      never has to be part of a sort key;
 //   2. scatter: each instance is dropped into its tile's bucket (slot order inside a bucket is arbitrary) as a
-//      64-bit key (depth_bits << 32 | gaussian_id);
+//      64-bit key (depth_bits << 32 | gaussian_id) -- by scatter_kernel into the tile's final range on the synchronous path; on the
+//      asynchronous path by the PREPROCESS kernel itself into fixed-stride buckets (preprocess.hip, scatter mode: no scan in front
+//      of the keys, one kernel and one pass over the Gaussians less), the sort workgroups then derive their chunk tables from the
+//      tile counts themselves and the scan rides along with the sort kernel as one extra block;
 //   3. each bucket is sorted on those 64-bit keys in two instance-parallel steps: 1024-key chunks are sorted in LDS
 //      (bitonic network, one workgroup per chunk), then every instance finds its final rank by binary search in its
 //      tile's other chunks.  (depth_bits, id) is a total order, so the result is unique and equals the reference's
@@ -55,7 +58,8 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
                                              uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
                                              uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */,
                                              int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
-                                             uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table)
+                                             uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table,
+                                             uint32_t key_stride = 0u /* != 0: the keys sit in per-tile buckets of this many slots (preprocess.hip, scatter mode) */)
 {
     const int tid = threadIdx.x;
     // every header word is WRITTEN here and the queue words are zeroed (the blend kernels pop from them): nothing in the image
@@ -74,7 +78,22 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
     // Asynchronous mode (no host read-back): the binning buffer was sized for `capacity` instances before R was known.
     // If this frame needs more, render NOTHING (all ranges empty, no queued work) and raise the overflow flag: the
     // following kernels stay inside the buffer and the host reports the error at its next check.
-    const bool overflow = total > capacity;
+    // (bucketed keys: a tile that outgrew its bucket lost keys -- the same answer, and `needed` is scaled so that the capacity the
+    // caller derives from it holds the longest list: the bucket size is proportional to the capacity)
+    bool overflow = total > capacity;
+    uint32_t needed = total;
+    if (key_stride != 0u) {
+        if (mx) atomicMax(s_max, mx);
+        __syncthreads();
+        const uint32_t longest = *s_max;
+        if (longest > key_stride) {
+            overflow = true;
+            const unsigned long long want = ((unsigned long long)longest * capacity + key_stride - 1u) / key_stride + 1ull;
+            needed = (uint32_t)(want > 0xfffffff0ull ? 0xfffffff0ull : want);
+            needed = max(needed, total);
+        }
+        // (s_max keeps the longest list: the atomicMax below repeats it for the lists that are kept, header[1] reports it either way)
+    }
     const uint32_t off_first = off;                      // where this thread's first tile starts (the loop below walks on from here)
     for (int i = b; i < e; i++) {
         const uint32_t v = overflow ? 0u : tile_count[i];
@@ -92,7 +111,7 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         for (int k = 0; k < 33; k++) { const uint32_t c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
         header[0] = overflow ? 0u : total; header[1] = *s_max; header[4] = overflow ? 0u : total_chunks;
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
-        header[6] = total;                             // instances this frame needs (for the host's capacity policy)
+        header[6] = needed;                            // instances this frame needs (for the host's capacity policy)
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
         header[3] = 0u;
         header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u);       // (the preprocess kernel's flags: it finished before this one)
@@ -357,22 +376,85 @@ __device__ __forceinline__ void network_phases(uint64_t& key, uint32_t tid, uint
 // (80 SGPRs: the CU admits waves per SIMD by the scalar file too -- 800 per SIMD in blocks of 16 + 16 -- and TWO 1024-thread workgroups,
 // eight waves per SIMD, only fit up to 80; with the 106 the unrolled network asked for, 84 of cfg3's 340 chunks waited for a first-round
 // workgroup to leave: scripts/sort_stamps.py, starts at 6.4 us)
+// SELF-SCAN (key_stride != 0: the asynchronous path, keys in per-tile buckets written by the preprocess kernel): there is no scan in
+// front of this kernel.  Every workgroup derives its chunk table from the tile counts itself -- thread i owns the tiles i PER ..
+// i PER + PER - 1 (PER = ceil(T / 1024) <= 8: T <= MAX_LDS_TILES), one block scan of their chunk counts, kept in registers for every
+// turn of the workgroup -- and ONE EXTRA BLOCK at the end of the grid writes what the later kernels need (ranges, chunk bases, tile
+// order, work table, header, group bases: scan_outputs), so the scan costs no launch of its own.  A frame that overflowed (more
+// instances than the capacity, or a tile that outgrew its bucket) is seen by every workgroup alike: nothing is sorted.
+// SORT_PER: tiles per thread of the self-scan, at most -- 1 (T <= 1024: a 512 x 512 frame; the instantiation that must keep its two
+// workgroups per CU: 64 VGPRs) or MAX_LDS_TILES / CHUNK = 8
+template <int SORT_PER>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
-chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
-                  const uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */,
-                  uint4* __restrict__ frame_state, uint32_t frame_state_n16)
+chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
+                  uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */,
+                  uint4* __restrict__ frame_state, uint32_t frame_state_n16,
+                  uint32_t key_stride, const uint32_t* __restrict__ tile_count, uint32_t capacity, int light_log2,
+                  uint32_t* __restrict__ tile_order, int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
+                  uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[2][CHUNK];
-    // the caller's frame state (tile histogram, cursors, flag word) is dead once the scatter kernel has ended: all-zero again for the
-    // next forward (every workgroup of the grid takes a slice, before anything can make it leave)
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frame_state_n16; i += gridDim.x * blockDim.x) frame_state[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ ChunkOwner s_own;
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bucket[34];
     const uint32_t tid = threadIdx.x;
+    const bool self_scan = key_stride != 0u;
+    uint32_t grid = gridDim.x, wg = blockIdx.x;              // workgroups that sort, and this one's index among them
+    if (self_scan) {
+        // (block 0: dispatched FIRST.  As the last block of a grid that fills every workgroup slot of the device it waited for a sort
+        // workgroup to leave and then ran alone: 12.1 -> 15.4 us)
+        grid--; wg--;
+        if (blockIdx.x == 0) {                               // the scan block
+            scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
+                               n_groups, group_tot, group_base, flags_acc, queues, work_table, key_stride);
+            return;
+        }
+    } else {
+        // the caller's frame state (tile histogram, cursors, flag word) is dead once the scatter kernel has ended: all-zero again for the
+        // next forward (every workgroup of the grid takes a slice, before anything can make it leave).  (Self-scan: this kernel still
+        // READS the counts -- merge_gather_kernel does the zeroing there.)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frame_state_n16; i += gridDim.x * blockDim.x) frame_state[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 #define KSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
 #define RSTAMP(i) if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()   /* 100 MHz, device-wide */
     KSTAMP(0); RSTAMP(5);
-    for (uint32_t c = blockIdx.x;; c += gridDim.x) {
-        find_chunk_tile(T, [&](uint32_t) { return c; }, ranges, chunk_base, header, &s_own);
+    // self-scan: this thread's tiles, their counts and chunk bases
+    uint32_t my_cnt[SORT_PER], my_cb[SORT_PER], n_chunks_dev = 0u;
+    const int per = (T + CHUNK - 1) / CHUNK;
+    if (self_scan) {
+        // (a count above the bucket size means the preprocess kernel dropped keys: the scan block flags the frame and empties every
+        // range; here the count is clamped so that whatever is sorted stays inside the bucket.  Likewise a frame with more instances
+        // than the capacity: the buckets themselves are always in bounds, only the compact arrays behind the scan are not -- and
+        // nobody writes those in a flagged frame.  ONE block scan, not three reductions: every barrier of 16 waves is ~0.3 us)
+        uint32_t nch = 0u;
+#pragma unroll
+        for (int u = 0; u < SORT_PER; u++) {
+            const int t = (int)tid * per + u;
+            my_cnt[u] = (u < per && t < T) ? min(tile_count[t], key_stride) : 0u;
+            nch += (my_cnt[u] + CHUNK - 1) / CHUNK;
+        }
+        uint32_t cb = block_scan<1024>(nch, s_wave, n_chunks_dev);
+        if (n_chunks_dev == 0u) return;                      // nothing rendered
+#pragma unroll
+        for (int u = 0; u < SORT_PER; u++) { my_cb[u] = cb; cb += (my_cnt[u] + CHUNK - 1) / CHUNK; }
+    }
+    for (uint32_t c = wg;; c += grid) {
+        if (self_scan) {
+            if (c >= n_chunks_dev) return;
+#pragma unroll
+            for (int u = 0; u < SORT_PER; u++) {
+                const uint32_t nch = (my_cnt[u] + CHUNK - 1) / CHUNK;
+                if (my_cb[u] <= c && c < my_cb[u] + nch) {
+                    const int t = (int)tid * per + u;
+                    s_own.tile = t; s_own.start = (uint32_t)t * key_stride; s_own.end = s_own.start + my_cnt[u]; s_own.cbase = my_cb[u];
+                }
+            }
+            if (tid == 0) { s_own.n_chunks = n_chunks_dev; s_own.c = c; }
+            __syncthreads();
+        } else {
+            find_chunk_tile(T, [&](uint32_t) { return c; }, ranges, chunk_base, header, &s_own);
+        }
         const uint32_t n_chunks = s_own.n_chunks;
         if (c >= n_chunks) return;
         KSTAMP(1);
@@ -381,7 +463,7 @@ chunk_sort_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __res
         uint64_t* gk = keys + first;
         uint32_t npad = 64;                                // at least one wave's worth: the intra-wave steps need no branches
         while (npad < n) npad <<= 1;
-        const bool last_turn = c + gridDim.x >= n_chunks;  // (no further lookup just to find that out: it is a memory round trip)
+        const bool last_turn = c + grid >= n_chunks;       // (no further lookup just to find that out: it is a memory round trip)
         if (tid >= npad) {
             // whole waves (npad is a multiple of 64) with nothing to sort.  On the workgroup's last turn they leave -- the barriers
             // below count the waves that are still alive (gfx9 s_barrier semantics; 16-wave barriers are what a short chunk's network
@@ -422,11 +504,16 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
                     const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ point_list,
                     float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask,
-                    unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup (after the sort's), else NULL */)
+                    unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup (after the sort's), else NULL */,
+                    uint32_t key_stride /* != 0: tile t's keys start at t * key_stride (buckets), else at its range */,
+                    uint4* __restrict__ frame_state, uint32_t frame_state_n16)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[MERGE_OC][CHUNK];
     __shared__ ChunkOwner s_own;
     const uint32_t tid = threadIdx.x;
+    // bucketed keys (asynchronous path): the sort kernel read the tile counts of the caller's frame state itself, so the state is
+    // re-zeroed for the next forward HERE (every workgroup of the grid takes a slice, before anything can make it leave)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frame_state_n16; i += gridDim.x * blockDim.x) frame_state[i] = make_uint4(0u, 0u, 0u, 0u);
     KSTAMP(0); RSTAMP(5);
     for (uint32_t it = blockIdx.x;; it += gridDim.x) {
     // XCD-aware chunk order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), chunks are in tile order, and neighbouring
@@ -447,10 +534,12 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     const uint32_t tile = (uint32_t)s_own.tile;
     const uint2 rg = make_uint2(s_own.start, s_own.end);
     const uint32_t n = rg.y - rg.x, nch = (n + CHUNK - 1) / CHUNK, own = c - s_own.cbase;
-    const uint32_t first = rg.x + own * CHUNK, n_own = min((uint32_t)CHUNK, rg.y - first);
+    const uint32_t n_own = min((uint32_t)CHUNK, n - own * CHUNK);
+    // where the tile's keys are: its bucket (asynchronous path) or its range; kq = the tile's key array, entries 0 .. n - 1
+    const uint64_t* const kq = keys + (key_stride != 0u ? (size_t)tile * key_stride : (size_t)rg.x);
     const uint32_t my = part * (uint32_t)MERGE_THREADS + tid; // this thread's instance of the chunk
     const bool mine = my < n_own;
-    const uint64_t key_ld = keys[min(first + my, rg.y - 1u)];
+    const uint64_t key_ld = kq[min(own * CHUNK + my, n - 1u)];
     uint32_t rank = my;                                       // rank inside the own (sorted) chunk
     // Sibling group s0: chunks s0 .. s0 + MERGE_OC - 1 of the tile's nch - 1 OTHER chunks (unconditional, clamped loads: all in
     // flight together).
@@ -461,11 +550,11 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         for (int q = 0; q < MERGE_OC; q++) {
             const uint32_t si = s0 + (uint32_t)q;             // sibling index: the tile's chunks without the own one
             const uint32_t oc = si + (si >= own ? 1u : 0u);
-            const uint32_t ofirst = rg.x + oc * CHUNK;
-            on[q] = si + 1 < nch ? min((uint32_t)CHUNK, rg.y - ofirst) : 0u;
+            const uint32_t ofirst = oc * CHUNK;
+            on[q] = si + 1 < nch ? min((uint32_t)CHUNK, n - ofirst) : 0u;
 #pragma unroll
             for (int u = 0; u < MERGE_PARTS; u++)
-                v[q][u] = keys[on[q] ? min(ofirst + (uint32_t)u * MERGE_THREADS + tid, rg.y - 1u) : first];
+                v[q][u] = kq[on[q] ? min(ofirst + (uint32_t)u * MERGE_THREADS + tid, n - 1u) : own * CHUNK];
         }
     };
     if (part * (uint32_t)MERGE_THREADS >= n_own) {            // (a short chunk has no second part: wave-uniform)
@@ -693,6 +782,16 @@ bool scatter_folds_scan(const FrameParams& fp)
     return on && fp.gx * fp.gy <= MAX_LDS_TILES;
 }
 
+// Bucketed keys (asynchronous path): the key area of the binning buffer -- the gradient-record slabs, dead until the backward -- cut
+// into one bucket per tile.  Proportional to the capacity the buffer was sized for, ~40x the average list at the usual 2x margin.
+uint32_t bucket_key_stride(const BinView& b, int num_tiles)
+{
+    const unsigned long long area = (unsigned long long)b.slabs * b.slab_stride_floats * 4ull / sizeof(uint64_t);    // keys the area holds
+    unsigned long long stride = num_tiles > 0 ? area / (unsigned long long)num_tiles : 0ull;
+    stride = std::min<unsigned long long>(stride, 0x7fffffffull / (unsigned long long)std::max(num_tiles, 1));    // 32-bit key indices
+    return (uint32_t)(stride & ~1ull);                       // (buckets start 16-byte aligned)
+}
+
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s)
 {
     const int T = fp.gx * fp.gy;
@@ -710,7 +809,7 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
-                      char* frame_state, size_t frame_state_bytes, int part)
+                      char* frame_state, size_t frame_state_bytes, int part, uint32_t key_stride, long long capacity)
 {
     const int T = fp.gx * fp.gy;
     // R / total_chunks are exact in synchronous mode and upper bounds (capacity) in asynchronous mode; the kernels bound
@@ -725,13 +824,23 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     // diagnostics (scripts/sort_stamps.py): the stamp buffer's words [131072, 131072 + 16384) -- behind the forward blend's item stamps
     static const int stamps_on = knob("MOSS_SORT_STAMPS", 0);
     unsigned long long* const sort_stamps = (stamps_on && g_stamps) ? g_stamps + 131072 : nullptr;
-    if (part == 0)
-    MOSS_LAUNCH_TIMED(chunk_sort_kernel, dim3(grid), dim3(CHUNK) /* one key per thread */, 0, s, T, im.ranges, im.chunk_base, b.keys, im.header,
-                       sort_stamps, reinterpret_cast<uint4*>(frame_state ? frame_state + FS_COUNTERS_OFFSET : nullptr),
-                       (uint32_t)(frame_state ? (frame_state_bytes - FS_COUNTERS_OFFSET) / 16 : 0));   // (the first line belongs to the scan block)
-    else
+    // (the first line of the frame state belongs to the scan block; the kernel that re-zeroes the rest: the sort on the synchronous
+    // path, the merge when the keys are bucketed -- the sort workgroups then still READ the tile counts)
+    uint4* const fs = reinterpret_cast<uint4*>(frame_state ? frame_state + FS_COUNTERS_OFFSET : nullptr);
+    const uint32_t fs_n16 = (uint32_t)(frame_state ? (frame_state_bytes - FS_COUNTERS_OFFSET) / 16 : 0);
+    const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
+#define SORT_ARGS T, im.ranges, im.chunk_base, b.keys, im.header, sort_stamps, key_stride ? nullptr : fs, key_stride ? 0u : fs_n16, key_stride,     \
+                  im.tile_count, cap, light_log2_knob(), im.tile_order, (fp.P + 255) / 256, g.group_tot, g.group_base, im.flags_acc, im.queues, im.work_table
+    if (part == 0) {
+        // (self-scan: one block more, the scan block -- inside the bound on resident workgroups, so that it never waits for a slot)
+        const int sort_grid = key_stride ? std::max(1, std::min(grid, max_grid - 1)) + 1 : grid;
+        if (T <= CHUNK) MOSS_LAUNCH_TIMED(chunk_sort_kernel<1>, dim3(sort_grid), dim3(CHUNK) /* one key per thread */, 0, s, SORT_ARGS);
+        else MOSS_LAUNCH_TIMED((chunk_sort_kernel<MAX_LDS_TILES / CHUNK>), dim3(sort_grid), dim3(CHUNK), 0, s, SORT_ARGS);
+    } else
     MOSS_LAUNCH_TIMED(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
-                       b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr);
+                       b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr,
+                       key_stride, key_stride ? fs : nullptr, key_stride ? fs_n16 : 0u);
+#undef SORT_ARGS
 }
 
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,

@@ -267,7 +267,9 @@ struct FrameParams {
 // ---- launchers (each defined in exactly one .hip file; all enqueue on `s`, none synchronises) -------------
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                               const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s);
+                               const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s,
+                               uint64_t* scatter_keys = nullptr /* scatter mode: the kernel also writes the sort keys into per-tile buckets */,
+                               uint32_t key_stride = 0);
 struct FusedAdam;
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                 const float* opacities /* only read in raw mode */,
@@ -286,7 +288,10 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
 bool scatter_folds_scan(const FrameParams& fp);                                                // asynchronous forward: no scan launch, see binning.hip
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, bool fold_scan, long long capacity, hipStream_t s);  // duplicateWithKeys (+ the scan)
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
-                      char* frame_state, size_t frame_state_bytes, int part);   // part 0: chunk sort (re-zeroes the frame state, if any), part 1: merge + emit
+                      char* frame_state, size_t frame_state_bytes, int part,   // part 0: chunk sort, part 1: merge + emit
+                      uint32_t key_stride = 0 /* != 0: bucketed keys written by the preprocess kernel; the sort scans the tile counts itself */,
+                      long long capacity = -1);
+uint32_t bucket_key_stride(const BinView& b, int num_tiles);  // slots per tile bucket the key area of this binning buffer holds (binning.hip)
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
                            uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);
 void launch_export_geometry(int P, GeomView g, float* depths, float* means2D, float* conic_opacity, float* rgb,

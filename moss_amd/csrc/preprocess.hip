@@ -216,13 +216,26 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                           GeomView g, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ header /* the error-flag word */,
                           int* __restrict__ radii_out, int lds_hist, int stage_sh, const float* __restrict__ transforms, int raw,
                           unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */,
-                          const float* __restrict__ translation /* RAW_POSE only, may be NULL */)
+                          const float* __restrict__ translation /* RAW_POSE only, may be NULL */,
+                          uint64_t* __restrict__ keys /* scatter mode (below): the tiles' key buckets, else NULL */, uint32_t key_stride)
 {
 #define FSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
     FSTAMP(0);
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_wsum[4];
     const int T = gx * gy;
+    // SCATTER MODE (keys != NULL; the asynchronous forward with the histogram in LDS): this kernel also does duplicateWithKeys
+    // (rasterizer_impl.cu:70-111).  The reference -- and rounds 1-4 here -- scan the tile counts first, so that every tile's keys land
+    // in its final, compact range: a device-wide dependency between "all Gaussians projected" and "first key written", i.e. a kernel
+    // boundary and a second pass over the Gaussians (scatter_kernel: 13.6 us on the bench frame, 14.9 us for configs[1]'s 6.9k Gaussians).
+    // Here every tile owns a BUCKET of key_stride slots in the key area (the binning buffer exists before this kernel in asynchronous
+    // mode: it is sized for the caller's capacity; key_stride = what that area holds / tiles, ~40x the average list): a block reserves
+    // its run in a tile's bucket with ONE returning atomic on the tile's counter -- the same atomic that builds the histogram -- and
+    // writes its keys there at once.  Nothing needs the scan before the sort, whose workgroups turn the counts into their own chunk
+    // tables (binning.hip, chunk_sort_kernel).  A tile that outgrows its bucket drops the frame like a capacity overflow (flagged by
+    // the scan block, `needed` scaled so that the caller's next capacity fits it).
+    const bool scatter = keys != nullptr;
+    uint32_t* const s_base = s_hist + ((T + 3) & ~3);        // scatter mode: where this block's run starts in each tile's bucket
     if (lds_hist) {
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
         __syncthreads();
@@ -237,7 +250,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
     // SH staging (M == 16 only): per thread a record is 48 floats at a 192-byte stride, i.e. each of the 48 scalar loads of a wave
     // touches 64 cache lines.  The block's 256 records of this iteration are instead read with coalesced 16-byte loads into LDS
     // (row stride 49 words: conflict-free) and evaluated from there -- same values, same arithmetic, so still bit-exact.
-    float* const s_shf = reinterpret_cast<float*>(s_hist + (lds_hist ? ((T + 3) & ~3) : 0));
+    float* const s_shf = reinterpret_cast<float*>(s_hist + (lds_hist ? ((T + 3) & ~3) * (scatter ? 2 : 1) : 0));
     for (int it = 0; it < iters; it++) {
         const int idx = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         if (stage_sh) {
@@ -282,6 +295,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
         if ((raw & RAW_POSE) && translation != nullptr) tr_ld = make_float3(translation[3 * ic], translation[3 * ic + 1], translation[3 * ic + 2]);
         FSTAMP(1);
         int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
+        float out_depth = 0.0f;
         if (idx < P) do {
             // RAW_POSE: the canonical position is posed here, p = T x + t (the reference's caller does it with torch ops,
             // gaussian_renderer/__init__.py:74-77); rows of T times x summed left to right, then the translation
@@ -408,6 +422,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             g.geo[4 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, p_view.z);
             g.clamped[idx] = clamp_bits;
             out_radius = rad;
+            out_depth = p_view.z;
             out_tiles = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
             out_rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
 
@@ -418,6 +433,44 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             if (lds_hist) atomicAdd(&s_hist[t], 1u);
             else atomicAdd(&tile_count[t], 1u);
         });
+        if (scatter) {
+            // One returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket and adds to the tile's
+            // count.  Four tiles per thread at a time, as BUFFER atomics whose offset is out of range for an empty tile (dropped
+            // without a memory request): no branch around the atomic, so the four are in flight together (a device-scope returning
+            // atomic is ~2 us; see scatter_kernel, which this replaces on the asynchronous path).
+            __syncthreads();                                 // this iteration's counts are complete
+            const __amdgpu_buffer_rsrc_t rs_cnt = __builtin_amdgcn_make_buffer_rsrc((void*)tile_count, 0, 0xffffff00u, 0x00020000u);
+            for (int b0 = 0; b0 < T; b0 += 4 * (int)blockDim.x) {
+                uint32_t c[4], old[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    c[u] = i < T ? s_hist[i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    old[u] = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)c[u], rs_cnt, c[u] ? (uint32_t)i * 4u : 0xfffffffcu /* out of range AND dword-aligned */, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                    if (c[u]) { s_base[i] = old[u]; s_hist[i] = 0u; }      // (the count word becomes the cursor of the pass below)
+                }
+            }
+            __syncthreads();
+            // the keys: (depth bits << 32 | Gaussian id), into the run this block reserved (slot order inside a bucket is arbitrary: the
+            // sort orders by the whole key)
+            const uint64_t key = out_tiles ? (((uint64_t)__float_as_uint(out_depth) << 32) | (uint32_t)idx) : 0ull;
+            wave_for_each_tile(out_rect, gx, key, [&](int t, uint64_t k) {
+                const uint32_t pos = s_base[t] + atomicAdd(&s_hist[t], 1u);
+                if (pos < key_stride) keys[(size_t)t * key_stride + pos] = k;      // (a bucket that overflows drops the frame: scan block)
+            });
+            if (it + 1 < iters) {                            // the next iteration counts from zero again
+                __syncthreads();
+                for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
+            }
+        }
         // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos (the reference: a device-wide inclusive
         // scan, rasterizer_impl.cu:279).  Here: the run's start RELATIVE to the block's group of 256 Gaussians (a block prefix sum) and
         // the group's total; the scan block that rides along with the scatter kernel turns the totals into group bases.  (Round 1-2
@@ -444,7 +497,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
         __syncthreads();
         FSTAMP(4);
     }
-    if (lds_hist) {
+    if (lds_hist && !scatter) {                              // (scatter mode added its counts with the reserving atomics)
         __syncthreads();
         for (int i = threadIdx.x; i < T; i += blockDim.x) {
             const uint32_t v = s_hist[i];
@@ -743,8 +796,10 @@ constexpr int GATHER_CAP = 320;                          // records of a wave ga
 constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
 // FUSED: the kernel also takes the AdamW step of the parameters named in fa.tensors (moss_raster_backward_raw_adamw) -- an
 // instantiation of its own, so that the plain backward keeps its code and registers and a kernel trace tells the two apart.
-template <bool STAGE_SH, bool FUSED>
-__global__ void __launch_bounds__(256)
+// (amdgpu_waves_per_eu(2): TWO waves per SIMD = at most 256 VGPRs.  The fused instantiation needs ~254 and the register allocator's own
+// choice flips between 254 and 280-330 -- one wave per SIMD: 38 -> 54 us -- with unrelated edits of this file; stated, it is a bound)
+template <bool STAGE_SH, bool FUSED, int LPG_L2 /* log2 of the lanes per Gaussian: 0, or 4 for small P (see below) */>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, float h_x, float h_y, float mean2d_sx, float mean2d_sy,
                            float scale_modifier,
                            const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -787,7 +842,24 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // all-light -- the kernel then lasted as long as its block in the densest part of the image (bench frame, Morton order: 28.8 us
     // against 25.0 in random order; interleaved: see profiles/r02_notes.md) -- while 16 consecutive ones still share their cache lines.
     const int gl2 = (raw >> 12) & 7;                       // log2 of the group size (launch_preprocess_backward)
-    auto gaussian_of_row = [&](int r) -> int { return (((r >> gl2) * (int)gridDim.x + (int)blockIdx.x) << gl2) + (r & ((1 << gl2) - 1)); };
+    // SMALL P (lanes-per-Gaussian, LPG = 2^lpg_l2 > 1): MOSS trains 6 890 ... 45 695 Gaussians (scene/dataset_readers.py:720,
+    // scene/gaussian_model.py:496).  One thread per Gaussian is then 108 waves for the whole device, each gathering dozens of records per
+    // lane one round trip after the other (configs[1]: 33 us for 6.9k Gaussians, 70 % of the 100k frame's time).  With LPG lanes per
+    // Gaussian only every LPG-th lane OWNS one; the others own nothing but take their share of the wave-balanced gather (which hands the
+    // wave's records to all 64 lanes whoever owns them), so a wave holds 64 / LPG Gaussians' records -- one pass -- and the frame has LPG
+    // times the waves, all resident at once.  The per-Gaussian arithmetic runs on the owner lanes (the wave issues it once either way).
+    // Chosen per launch (launch_preprocess_backward); the order of every sum is unchanged: bitwise the same results.
+    // (a template parameter: with the default, 0, every expression below folds to the one-thread-per-Gaussian kernel of rounds 2-4 --
+    // the fused instantiation sits at 254 of the 256 VGPRs two waves per SIMD allow, and a run-time parameter cost it 24 more: 38 -> 54 us)
+    // the block's SH rows: staged record q (0 .. rows_used - 1) belongs to thread-row q << lpg_l2.  (A MACRO, evaluated where it is used
+    // and only in the LPG instantiations: as a variable at the top of the kernel -- dead code when LPG_L2 = 0 -- the early read of
+    // blockDim moved the scheduler of the fused one-thread-per-Gaussian instantiation to 280 bytes more scratch per lane.)
+#define rows_used ((int)blockDim.x >> LPG_L2)
+    constexpr int lpg_l2 = LPG_L2;
+    auto gaussian_of_row = [&](int r) -> int {
+        if constexpr (LPG_L2 == 0) { return (((r >> gl2) * (int)gridDim.x + (int)blockIdx.x) << gl2) + (r & ((1 << gl2) - 1)); }
+        else { return (r & ((1 << LPG_L2) - 1)) ? 0x7fffffff : (int)blockIdx.x * rows_used + (r >> LPG_L2); }
+    };
     const int idx = gaussian_of_row((int)threadIdx.x);
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
     // All first-level loads are issued together and unconditionally (clamped indices): the 12 SH float4 of this thread's share of
@@ -801,8 +873,9 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         const float4* src = reinterpret_cast<const float4*>(shs);
 #pragma unroll
         for (int j = 0; j < 12; j++) {
-            const int f = (int)threadIdx.x + j * (int)blockDim.x;         // float4 f of the block's rows: row f / 12, part f % 12
-            shv[j] = src[min((size_t)gaussian_of_row(f / 12) * 12 + (size_t)(f % 12), total4 - 1)];
+            const int f = (int)threadIdx.x + j * (int)blockDim.x;         // float4 f of the block's rows: staged row f / 12, part f % 12
+            if constexpr (LPG_L2 == 0) shv[j] = src[min((size_t)gaussian_of_row(f / 12) * 12 + (size_t)(f % 12), total4 - 1)];
+            else shv[j] = src[f / 12 < rows_used ? min((size_t)min(gaussian_of_row((f / 12) << lpg_l2), P - 1) * 12 + (size_t)(f % 12), total4 - 1) : total4 - 1];
         }
     }
     const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc] + g.group_base[idc >> 8], hdr_flags = header[2];
@@ -841,8 +914,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int f = threadIdx.x + j * blockDim.x;
-            float* d = &s_sh[(f / 12) * SH_ROW + (f % 12) * 4];
-            d[0] = shv[j].x; d[1] = shv[j].y; d[2] = shv[j].z; d[3] = shv[j].w;
+            if (LPG_L2 == 0 || f / 12 < rows_used) {
+                float* d = &s_sh[((f / 12) << lpg_l2) * SH_ROW + (f % 12) * 4];
+                d[0] = shv[j].x; d[1] = shv[j].y; d[2] = shv[j].z; d[3] = shv[j].w;
+            }
         }
     }
     const uint32_t n_inst = in_range ? tt_raw : 0u;
@@ -885,7 +960,17 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         // stay bitwise reproducible.
         const bool mine = visible && n_inst <= COOP_INST;
         PSTAMP(8);
-        uint32_t wmax = mine ? n_inst : 0u;
+        // LPG = 16 (LPG_L2 == 4): the 16 lanes of a Gaussian's group take ONE instance each -- lane (g, j) the j-th of Gaussian g's
+        // <= 16 instances: one mask load per lane instead of sixteen per owner, and the filing loop below (serial over a lane's
+        // instances and their flagged slabs, the whole wave in step) runs <= 16 rounds for any wave: with four owners doing the
+        // filing of four Gaussians x 16 instances alone it was 16k of a block's 34k cycles (scripts/prebwd_fused_stamps.py, configs[1]).
+        const int lane_g = (int)(threadIdx.x & 63u);
+        uint32_t g_off = off, g_n = mine ? n_inst : 0u;
+        if constexpr (LPG_L2 == 4) {
+            g_off = (uint32_t)__shfl((int)g_off, lane_g & ~15); g_n = (uint32_t)__shfl((int)g_n, lane_g & ~15);
+        }
+        const bool has_inst = (uint32_t)(lane_g & 15) < g_n;         // (LPG = 16 only)
+        uint32_t wmax = LPG_L2 == 4 ? (has_inst ? 1u : 0u) : (mine ? n_inst : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
         // Loads are PREDICATED per lane (a lane without a k-th instance issues no request): the random 4- and 48-byte reads are
@@ -904,11 +989,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         // its records -- round 2 went Gaussian -> inst_pos -> inst_mask -> record, one more dependent round trip)
         uint32_t pp[COOP_INST], mm[COOP_INST];
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++) pp[k] = off + (uint32_t)k;
+        for (int k = 0; k < (int)COOP_INST; k++) pp[k] = LPG_L2 == 4 ? (k == 0 ? g_off + (uint32_t)(lane_g & 15) : 0u) : off + (uint32_t)k;
         PSTAMP(9);
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++)
-            mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_inst) ? pp[k] * 4u : OOB, 0, 0);
+        for (int k = 0; k < (int)COOP_INST; k++) {
+            if constexpr (LPG_L2 == 4) mm[k] = k == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs_msk, has_inst ? pp[0] * 4u : OOB, 0, 0) : 0u;
+            else mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_inst) ? pp[k] * 4u : OOB, 0, 0);
+        }
         PSTAMP(10);
         // ---- two ways to fetch the flagged records, chosen per wave.  How many records each lane owns:
         uint32_t cnt = 0u;
@@ -943,7 +1030,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         // (61 vs 24 us).
         const uint32_t passes = (W_all + (uint32_t)GATHER_CAP - 1u) / (uint32_t)GATHER_CAP;
         const uint32_t direct_trips = ((bmax & 0xffu) + 1u) / 2u + (((bmax >> 8) & 0xffu) + 1u) / 2u + (((bmax >> 16) & 0xffu) + 1u) / 2u + ((bmax >> 24) + 1u) / 2u;
-        const bool balanced = (raw & 0x200) ? false : (raw & 0x400) ? true : (passes == 1u ? direct_trips >= 5u : passes * 8u < direct_trips);     // (0x200 / 0x400: diagnostics, MOSS_GATHER=1 / 2)
+        const bool balanced = LPG_L2 == 4 ? true :           // (the group's lanes hold one instance each: only the list form sums a Gaussian's records)
+                              (raw & 0x200) ? false : (raw & 0x400) ? true : (passes == 1u ? direct_trips >= 5u : passes * 8u < direct_trips);     // (0x200 / 0x400: diagnostics, MOSS_GATHER=1 / 2)
         if (!balanced) {
 #pragma unroll
         for (int kb = 0; kb < (int)COOP_INST; kb += 4) {
@@ -991,6 +1079,15 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             float* const w_row = reinterpret_cast<float*>(w_desc + GATHER_CAP);          // [64][9]: a row's scanned values
             const int lane = (int)(threadIdx.x & 63u);
             const uint32_t base = incl - cnt, W = W_all;
+            // whose run a lane picks up: its own records -- or, LPG = 16, the owner lane its whole group's (the sixteen lanes' runs are
+            // consecutive in the list, in instance order: the same order of additions as one lane filing all of them)
+            uint32_t run_base = base, run_cnt = cnt;
+            bool head_ok = true;                                                          // the lane's first record starts a Gaussian's run
+            if constexpr (LPG_L2 == 4) {
+                const uint32_t gbase = (uint32_t)__shfl((int)base, lane & ~15), gend = (uint32_t)__shfl((int)incl, lane | 15);
+                head_ok = base == gbase;                                                  // no earlier lane of the group has a record
+                run_base = gbase; run_cnt = (lane & 15) == 0 ? gend - gbase : 0u;
+            }
             for (uint32_t w0 = 0u; w0 < W; w0 += (uint32_t)GATHER_CAP) {                 // (one pass unless the wave owns > GATHER_CAP records)
                 const uint32_t w1 = min(W, w0 + (uint32_t)GATHER_CAP);
                 // 1. every lane files its records' descriptors {head of the lane's run << 31 | slab << 27 | slot}
@@ -1005,7 +1102,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                                 if (bits != 0u) {
                                     const uint32_t sl = (uint32_t)(__ffs((int)bits) - 1);
                                     bits &= bits - 1u;
-                                    if (j >= w0 && j < w1) w_desc[j - w0] = (j == base ? 0x80000000u : 0u) | (sl << 27) | pp[k];
+                                    if (j >= w0 && j < w1) w_desc[j - w0] = ((j == base && head_ok) ? 0x80000000u : 0u) | (sl << 27) | pp[k];
                                     j++;
                                 }
                             }
@@ -1050,7 +1147,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                         for (int q = 0; q < 9; q++) w_row[lane * 9 + q] = v[q];
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t row0 = w0 + 64u * (uint32_t)r, row1 = min(w1, row0 + 64u);
-                        const uint32_t lo = max(base, row0), hi = min(base + cnt, row1);
+                        const uint32_t lo = max(run_base, row0), hi = min(run_base + run_cnt, row1);
                         if (lo < hi) {                                                   // this lane's run reaches into the row
                             const float* e = w_row + (hi - 1u - row0) * 9u;
                             gcol.x += e[0]; gcol.y += e[1]; gcol.z += e[2]; gmx += e[3];
@@ -1138,7 +1235,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
         for (int j = 0; j < FA_HOIST; j++) {
             const int f = (int)threadIdx.x + j * (int)blockDim.x;
-            const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
+            const size_t a = (size_t)min(gaussian_of_row(LPG_L2 == 0 ? f / 12 : (min(f / 12, rows_used - 1) << lpg_l2)), P - 1) * 12 + (size_t)(f % 12);
             fa_m4[j] = mw[a]; fa_v4[j] = vw[a];
         }
     }
@@ -1289,10 +1386,10 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         __syncthreads();                                     // every row now holds dL_dsh
         if (dL_dsh != nullptr) {
             float4* dst = reinterpret_cast<float4*>(dL_dsh);
-            for (int f = threadIdx.x; f < (int)blockDim.x * 12; f += blockDim.x) {
-                const int gi = gaussian_of_row(f / 12);
+            for (int f = threadIdx.x; f < (LPG_L2 == 0 ? (int)blockDim.x : rows_used) * 12; f += blockDim.x) {
+                const int gi = gaussian_of_row((f / 12) << lpg_l2);
                 if (gi < P) {
-                    const float* r = &s_dsh[(f / 12) * SH_ROW + (f % 12) * 4];
+                    const float* r = &s_dsh[((f / 12) << lpg_l2) * SH_ROW + (f % 12) * 4];
                     dst[(size_t)gi * 12 + (size_t)(f % 12)] = make_float4(r[0], r[1], r[2], r[3]);
                 }
             }
@@ -1311,14 +1408,16 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
 #pragma unroll
             for (int j = 0; j < 12; j++) {
                 const int f = (int)threadIdx.x + j * (int)blockDim.x;
-                const size_t a = (size_t)min(gaussian_of_row(f / 12), P - 1) * 12 + (size_t)(f % 12);
+                const size_t a = (size_t)min(gaussian_of_row(LPG_L2 == 0 ? f / 12 : (min(f / 12, rows_used - 1) << lpg_l2)), P - 1) * 12 + (size_t)(f % 12);
                 p4[j] = pw[a];
                 if (j >= FA_HOIST) { m4[j] = mw[a]; v4[j] = vw[a]; }
             }
 #pragma unroll
             for (int j = 0; j < 12; j++) {
-                const int f = (int)threadIdx.x + j * (int)blockDim.x, part = f % 12, gi = gaussian_of_row(f / 12);
-                const float* r = &s_dsh[(f / 12) * SH_ROW + part * 4];
+                const int f = (int)threadIdx.x + j * (int)blockDim.x, part = f % 12;
+                const int q = LPG_L2 == 0 ? f / 12 : min(f / 12, rows_used - 1);
+                const int gi = (LPG_L2 == 0 || f / 12 < rows_used) ? gaussian_of_row(q << lpg_l2) : 0x7fffffff;
+                const float* r = &s_dsh[(q << lpg_l2) * SH_ROW + part * 4];
                 float pe[4] = { p4[j].x, p4[j].y, p4[j].z, p4[j].w }, me[4] = { m4[j].x, m4[j].y, m4[j].z, m4[j].w };
                 float ve[4] = { v4[j].x, v4[j].y, v4[j].z, v4[j].w };
 #pragma unroll
@@ -1339,6 +1438,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     PSTAMP(6); PRSTAMP(14);
 #undef PSTAMP
 #undef PRSTAMP
+#undef rows_used
 }
 
 __global__ void __launch_bounds__(256)
@@ -1390,15 +1490,17 @@ static int device_cus()
 
 void launch_preprocess_forward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
                                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                               const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s)
+                               const float* transforms, const float* translation, GeomView g, ImageView im, int* radii_out, hipStream_t s,
+                               uint64_t* scatter_keys, uint32_t key_stride)
 {
     const int T = fp.gx * fp.gy;
     const int lds_hist = (T <= MAX_LDS_TILES) ? 1 : 0;
+    if (!lds_hist) scatter_keys = nullptr;                   // (scatter mode works on the LDS histogram: raster_api.hip asks for it only then)
     // Gaussians per thread: more -> better aggregation of the tile-histogram atomics, fewer -> more waves in flight.
     static const int per_thread = knob("MOSS_PREPROCESS_ITEMS", 1);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
-    const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
+    const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) * (scatter_keys ? 2 : 1) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
     const int stage_sh = (fp.M == 16 && shs != nullptr && colors_precomp == nullptr && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 &&
                           lds_h + lds_s <= 65536 /* default dynamic-LDS limit of a launch */ && knob("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
     const size_t lds = lds_h + (stage_sh ? lds_s : 0);
@@ -1407,7 +1509,19 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
                        fp.scale_modifier, fp.prefiltered, means3D, shs, colors_precomp, opacities, scales, rotations,
                        cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev, g, im.tile_count, im.flags_acc, radii_out, lds_hist, stage_sh,
                        transforms, fp.raw | ((knob("MOSS_EXPERIMENT", 0) & 1) ? 0x100 : 0),
-                       (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr, translation);
+                       (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 32768 : nullptr, translation, scatter_keys, key_stride);
+}
+
+// resident blocks per CU of the per-Gaussian backward (the fused instantiation: the larger one)
+static int prebwd_resident_per_cu(int threads)
+{
+    static const int occ = [&] {
+        const size_t lds_bytes_staged = (size_t)threads * SH_ROW * sizeof(float) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4;
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, preprocess_backward_kernel<true, true, 4>, threads, lds_bytes_staged) != hipSuccess || o < 1) o = 1;
+        return o;
+    }();
+    return occ;
 }
 
 void launch_preprocess_backward(const FrameParams& fp, const float* means3D, const float* shs, const float* colors_precomp,
@@ -1429,28 +1543,34 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     // does the balancing while the shared cache lines of 64 neighbours count for more (configs[4]: 81 us consecutive, 87-95 in groups).
     static const int gl2_env = knob("MOSS_PREBWD_GROUP_LOG2", 0);
     static const int gather_knob = knob("MOSS_GATHER", 0) == 1 ? 0x200 : knob("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
-    const int blocks = (fp.P + threads - 1) / threads;
     // (the fused update of the SH records works on the staged rows: raster_api.hip refuses it unless M == 16 and the arrays are aligned)
     const bool stage = fp.M == 16 && shs != nullptr && (dL_dsh != nullptr || (fa.tensors & OPT_SH)) &&
                        (knob("MOSS_PREBWD_STAGE", 1) || (fa.tensors & OPT_SH)) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
-    const size_t lds_bytes_staged = (size_t)threads * SH_ROW * sizeof(float) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4;
-    static const int resident_per_cu = [&] {
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, preprocess_backward_kernel<true, false>, threads, lds_bytes_staged) != hipSuccess || occ < 1) occ = 1;
-        return occ;
-    }();
+    // lanes per Gaussian (see the kernel): 16 while the whole grid is then still resident at once -- P <= 8192 with two waves per SIMD
+    // (instantiated for the staged-SH kernels -- MOSS's case, M = 16 -- only)
+    static const int lpg_env = knob("MOSS_PREBWD_LPG_LOG2", -1);
+    int lpg_l2 = 0;
+    if (stage) {
+        const long long resident = (long long)prebwd_resident_per_cu(threads) * device_cus();
+        if (((long long)fp.P + (threads >> 4) - 1) / (threads >> 4) <= resident) lpg_l2 = 4;
+        if (lpg_env >= 0) lpg_l2 = lpg_env >= 4 ? 4 : 0;
+    }
+    const int blocks = (fp.P + (threads >> lpg_l2) - 1) / (threads >> lpg_l2);
+    const int resident_per_cu = prebwd_resident_per_cu(threads);
     const int gl2 = gl2_env ? std::max(4, std::min(6, gl2_env))
                             : (((fp.raw & HINT_SPATIAL_ORDER) && blocks <= resident_per_cu * device_cus()) ? 4 : 6);
-#define LAUNCH_PB(STAGE, FUSE)                                                                                                  \
-    MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE, FUSE>), dim3(blocks), dim3(threads),                                  \
+#define LAUNCH_PB(STAGE, FUSE, LPG)                                                                                             \
+    MOSS_LAUNCH_TIMED((preprocess_backward_kernel<STAGE, FUSE, LPG>), dim3(blocks), dim3(threads),                             \
                        ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, -0.5f * (float)fp.W, -0.5f * (float)fp.H, fp.scale_modifier, \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
                        g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues, translation, dL_dtranslation, fa)
-    if (fa.tensors != 0u) { if (stage) LAUNCH_PB(true, true); else LAUNCH_PB(false, true); }
-    else if (stage) LAUNCH_PB(true, false); else LAUNCH_PB(false, false);
+    // (lanes per Gaussian: instantiated for the staged-SH kernels -- MOSS's case, M = 16 -- only)
+    if (stage && lpg_l2 == 4) { if (fa.tensors != 0u) LAUNCH_PB(true, true, 4); else LAUNCH_PB(true, false, 4); }
+    else if (fa.tensors != 0u) { if (stage) LAUNCH_PB(true, true, 0); else LAUNCH_PB(false, true, 0); }
+    else if (stage) LAUNCH_PB(true, false, 0); else LAUNCH_PB(false, false, 0);
 #undef LAUNCH_PB
 }
 

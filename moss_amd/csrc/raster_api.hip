@@ -183,57 +183,74 @@ static int forward_impl(
     const int T = fp.gx * fp.gy;
 
     // The counters kernels ADD to (tile histogram, tile cursors, error flags) must be zero here.  With the caller's frame state
-    // (the `frame_state` argument: all-zero between calls, re-zeroed by the sort kernel) nothing is launched for that; without it, a clear.
+    // (the `frame_state` argument: all-zero between calls, re-zeroed by the sort / merge kernel) nothing is launched for that; without it, a clear.
     const size_t fs_bytes = ImageView::frame_state_bytes(width, height);
     if (frame_state) im.use_frame_state(frame_state, width, height);
     else launch_clear(im.header, im.clear_bytes(), s);                   // header + tile histogram + tile cursors
     // (a forward that ends before its sort kernel has run leaves the frame state dirty: clean it on those paths)
     auto abandon_frame_state = [&]() { if (frame_state) clear_frame_state(frame_state, fs_bytes, s); };
-    TraceRange tr_all(trace, "moss:raster_forward");
-    { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s); TraceRange tr(trace, "moss:preprocess_fwd");
-      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, translation, g, im, radii, s); }
-    STAGE_CHECK("preprocess");
-    // Asynchronous forward: the scan rides along with the scatter kernel (no launch of its own).
-    const bool fold_scan = capacity > 0 && scatter_folds_scan(fp);
-    if (!fold_scan) {
-        { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s); }
-        STAGE_CHECK("scan");
-    }
-
-    int R, total_chunks;
-    if (capacity < 0) {
-        // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
-        if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
-        HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        R = (int)g_pinned.p[0];
-        total_chunks = (int)g_pinned.p[4];
-        if (g_pinned.p[2] & ERRFLAG_PREFILTERED) {
-            abandon_frame_state();
-            return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
-        }
-    } else {
-        // Asynchronous: no read-back.  Buffers and grids are sized for the caller's capacity; kernels bound themselves with the
-        // device-side R; a frame that needs more renders nothing and sets the overflow flag (moss_raster_read_status).
+    // Asynchronous forward with the tile histogram in LDS: the PREPROCESS kernel writes the sort keys itself, into per-tile buckets of the
+    // key area (preprocess.hip, scatter mode) -- the binning buffer is sized for the caller's capacity, so it exists before the first
+    // kernel -- the sort workgroups derive their chunk tables from the tile counts, and the scan rides along with the sort kernel as one
+    // extra block: preprocess, sort, merge, blend = FOUR launches (rounds 2-4: five, with a scatter kernel of its own; the reference: 7+).
+    // (a capacity so small that a bucket would hold no key at all keeps the scan -> scatter chain, whose only bound is the total)
+    uint32_t key_stride = (capacity > 0 && scatter_folds_scan(fp)) ? bucket_key_stride(BinView::at(nullptr, (int)capacity), T) : 0u;
+    if (key_stride < 2u) key_stride = 0u;
+    const bool bucketed = key_stride != 0u;
+    int R = 0, total_chunks = 0;
+    char* bin_ptr = nullptr;
+    BinView b;
+    if (bucketed) {
         R = (int)capacity;
         total_chunks = (int)(capacity / 1024) + T;
+        bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
+        if (!bin_ptr) { abandon_frame_state(); return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL"); }
+        b = BinView::at(bin_ptr, R);
+    }
+    { StageTimer tm(MOSS_STAGE_PREPROCESS_FWD, s); TraceRange tr(trace, bucketed ? "moss:preprocess_fwd+scatter" : "moss:preprocess_fwd");
+      launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, translation, g, im, radii, s,
+                                bucketed ? b.keys : nullptr, key_stride); }
+    STAGE_CHECK("preprocess");
+    if (!bucketed) {
+        { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s); }
+        STAGE_CHECK("scan");
+        if (capacity < 0) {
+            // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
+            if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
+            HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 32, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            R = (int)g_pinned.p[0];
+            total_chunks = (int)g_pinned.p[4];
+            if (g_pinned.p[2] & ERRFLAG_PREFILTERED) {
+                abandon_frame_state();
+                return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+            }
+        } else {
+            // Asynchronous: no read-back.  Buffers and grids are sized for the caller's capacity; kernels bound themselves with the
+            // device-side R; a frame that needs more renders nothing and sets the overflow flag (moss_raster_read_status).
+            R = (int)capacity;
+            total_chunks = (int)(capacity / 1024) + T;
+        }
+        bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
+        if (!bin_ptr) { abandon_frame_state(); return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL"); }
+        b = BinView::at(bin_ptr, R);
     }
 
-    char* bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
-    if (!bin_ptr) { abandon_frame_state(); return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL"); }
-    BinView b = BinView::at(bin_ptr, R);
-
     if (R > 0) {
-        { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, fold_scan ? "moss:scatter+scan" : "moss:scatter"); launch_scatter(fp, g, im, b, fold_scan, capacity, s); }
-        STAGE_CHECK("scatter");
+        if (!bucketed) {
+            { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, "moss:scatter"); launch_scatter(fp, g, im, b, false, capacity, s); }
+            STAGE_CHECK("scatter");
+        }
 #ifdef MOSS_DIAG
         {   // timing experiment (scripts/exp_atomics.py): with the scatter's reservation atomics off the keys are garbage -- stop here
             static const bool stop = (knob("MOSS_EXPERIMENT", 0) & 2) != 0;
             if (stop) { abandon_frame_state(); return R; }
         }
 #endif
-        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); TraceRange tr(trace, "moss:chunk_sort"); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 0); }
-        { StageTimer tm(MOSS_STAGE_MERGE_GATHER, s); TraceRange tr(trace, "moss:merge_gather"); launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 1); }
+        { StageTimer tm(MOSS_STAGE_TILE_SORT, s); TraceRange tr(trace, bucketed ? "moss:chunk_sort+scan" : "moss:chunk_sort");
+          launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 0, key_stride, capacity); }
+        { StageTimer tm(MOSS_STAGE_MERGE_GATHER, s); TraceRange tr(trace, "moss:merge_gather");
+          launch_tile_sort(fp, g, im, b, R, total_chunks, s, frame_state, fs_bytes, 1, key_stride, capacity); }
         STAGE_CHECK("tile_sort");
     } else abandon_frame_state();                                        // (nothing rendered: no sort kernel to re-zero it)
     { StageTimer tm(MOSS_STAGE_BLEND_FWD, s); TraceRange tr(trace, "moss:blend_fwd"); launch_blend_forward(fp, g, im, b, out_color, out_depth, out_alpha, s); }

@@ -14,7 +14,8 @@ dev = torch.device("cuda:0")
 L = _lib.lib()
 assert L.moss_build_has_diagnostics(), "run with MOSS_AMD_LIB_DIR=lib_diag (python -m moss_amd.build --diag)"
 L.moss_raster_debug_set_stamps.argtypes = [ctypes.c_void_p]
-s = scenes.config3()
+cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "cfg3"
+s = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[cfg]()
 cam = camera_view(s.camera, dev)
 bg = torch.zeros(3, device=dev)
 w = torch.rand(3, s.camera.H, s.camera.W, device=dev)
@@ -41,10 +42,12 @@ for fused in (False, True):
         loss.backward()
         torch.cuda.synchronize()
         L.moss_raster_debug_set_stamps(None)
-    st = buf.cpu().numpy().reshape(-1, 16)[:(s.P + 63) // 64]
+    st = buf.cpu().numpy().reshape(-1, 16); st = st[st[:, 0] > 0]
     ph = np.diff(st[:, :7], axis=1)
     print(f"--- fused = {fused}: blocks {len(st)}")
     print("mean cycles per phase [gather+SHload, barrier, pre-SH math+writes, SH, scale/rot, tail writes (+ the 11 scalars' update), copy-out / SH update]:", ph.mean(0).astype(int))
+    sub = np.diff(st[:, 8:13], axis=1)
+    print("inside phase 0 [.., masks requested, masks in + counted, records gathered, coop gather] mean:", sub.mean(0).astype(int), "p90:", np.percentile(sub, 90, axis=0).astype(int))
     print("p90:", np.percentile(ph, 90, axis=0).astype(int), " block total mean", int((st[:, 6] - st[:, 0]).mean()), "max", int((st[:, 6] - st[:, 0]).max()))
     r0 = st[:, 13].min()
     print("realtime (us): block starts median %.2f p90 %.2f last %.2f | block ends median %.2f p90 %.2f last %.2f" % (

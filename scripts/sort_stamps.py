@@ -9,6 +9,9 @@ dev = torch.device("cuda:0")
 d = hp.inputs_of(scenes.config3(), "scale_rot")
 L = _lib.lib()
 L.moss_raster_debug_set_stamps.argtypes = [ctypes.c_void_p]
+if "--async" in sys.argv:            # the capacity-bounded forward: keys bucketed by the preprocess kernel, the scan inside the sort kernel
+    from moss_amd.diff_gaussian_rasterization import _C
+    _C.set_async(True)
 buf = torch.zeros(131072 + 32768 + 8 * 4096 + 64, dtype=torch.int64, device=dev)
 for _ in range(3): hp.hip_forward(d, dev)
 torch.cuda.synchronize()
@@ -40,8 +43,8 @@ w = s[16384: 16384 + 8 * 512].reshape(-1, 8).astype(np.float64)
 w = w[w[:, 0] > 0]
 t0 = w[:, 0].min()
 scan = w[w[:, 5] > 0]; blk = w[w[:, 4] > 0]
-print("scatter blocks", len(blk), "(realtime us, relative to the first block's start)")
-for i, name in ((0, "start"), (1, "own instances counted"), (2, "tile starts known"), (3, "runs reserved"), (4, "keys written, end")):
+print("scatter blocks", len(blk), "(realtime us, relative to the first block's start)" if len(blk) else "(none: the preprocess kernel wrote the keys)")
+for i, name in [] if not len(blk) else ((0, "start"), (1, "own instances counted"), (2, "tile starts known"), (3, "runs reserved"), (4, "keys written, end")):
     print("   %-28s median %6.2f  p90 %6.2f  max %6.2f" % (name, np.median(blk[:, i] - t0) / 100, np.percentile(blk[:, i] - t0, 90) / 100, (blk[:, i].max() - t0) / 100))
 if len(scan):
     print("   the scan block: start %.2f end %.2f" % ((scan[0, 0] - t0) / 100, (scan[0, 5] - t0) / 100))

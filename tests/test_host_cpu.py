@@ -718,15 +718,16 @@ def test_per_gaussian_backward_keeps_two_waves_per_simd():
     blocks = re.split(r"remark: Function Name: ", p.stderr)
     for b in blocks[1:]:
         name = b.split()[0]
-        m = re.search(r"preprocess_backward_kernelILb(\d)ELb(\d)E", name)
+        m = re.search(r"preprocess_backward_kernelILb(\d)ELb(\d)ELi(\d)E", name)
         if not m:
             continue
         vg = int(re.search(r"VGPRs: (\d+)", b).group(1)); ag = int(re.search(r"AGPRs: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)); scr = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
-        found[(int(m.group(1)), int(m.group(2)))] = (vg, ag, occ, scr)
-    assert set(found) == {(0, 0), (0, 1), (1, 0), (1, 1)}, found
+        found[(int(m.group(1)), int(m.group(2)), int(m.group(3)))] = (vg, ag, occ, scr)
+    # (third parameter: log2 of the lanes per Gaussian -- the small-P instantiation, 4, exists for the staged-SH kernels only)
+    assert set(found) == {(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 0, 4), (1, 1, 4)}, found
     for key, (vg, ag, occ, scr) in found.items():
-        assert occ >= 2 and vg + ag <= 256 and scr <= 128, f"preprocess_backward_kernel<STAGE_SH={key[0]}, FUSED={key[1]}>: {vg} VGPRs + {ag} AGPRs, {occ} waves per SIMD, {scr} B scratch"
+        assert occ >= 2 and vg + ag <= 256 and scr <= 128, f"preprocess_backward_kernel<STAGE_SH={key[0]}, FUSED={key[1]}, LPG_L2={key[2]}>: {vg} VGPRs + {ag} AGPRs, {occ} waves per SIMD, {scr} B scratch"
 
 
 def _active_sh_rank_main(rank, world, port, q):
