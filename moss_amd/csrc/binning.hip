@@ -26,7 +26,16 @@ namespace moss {
 
 namespace {
 
-constexpr int CHUNK = 1024;           // keys sorted per workgroup by chunk_sort_kernel
+// Keys sorted per workgroup by chunk_sort_kernel: SORT_THREADS threads with KPT keys each (element i of a chunk in thread i / KPT,
+// register i % KPT).  KPT = 1: 1024-key chunks, as in rounds 1-4.  Round 5 measured larger chunks (round 4's review, item 4: "4 096-key
+// chunks with 4 keys per thread"): scripts/micro/chunk_sort_kpt.hip (profiles/r05_chunk_sort_kpt_microbench.log) sorts the bench frame's
+// 239k keys in 13.4 / 14.0 / 21.9 us as chunks of 1024 / 2048 / 4096 (a 4096-key chunk is 36k cycles on its own workgroup and the frame
+// then has 186 workgroups for 256 CUs); and with KPT = 2 in THIS file -- the network below is written for any KPT -- the frame's sort
+// stayed at 12.8 us while merge_gather, which the larger chunks were meant to relieve of sibling loads and searches, went 17.8 -> 19.0 us
+// (configs[1]: 6.9 -> 10.2 us, configs[4]: sort 27.6 -> 33.8 us): four 512-thread parts per chunk, most of them idle for tiles below
+// 2048 entries, and each part of a two-chunk tile still loads the whole sibling (profiles/r05_notes.md).  Not adopted.
+constexpr int SORT_THREADS = 1024, KPT = 1;
+constexpr int CHUNK = SORT_THREADS * KPT;
 
 // The scan's outputs for one block of `NT` threads (NT a multiple of 64, <= 1024): see scan_kernel.  Shared by scan_kernel (its own
 // launch: synchronous mode, where the host sizes the binning buffer from R before anything else can run) and by the LAST block of
@@ -342,26 +351,49 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane)
 }
 #undef MOSS_DPP
 
+// Element i of a chunk lives in thread i / KPT, register i % KPT: steps with partner distance J < KPT are compare-exchanges between a
+// thread's own registers; J / KPT < 64: the partner thread is in the same wave (lane_xor); larger: through LDS.
 template <int K, int J>
-__device__ __forceinline__ void network_steps(uint64_t& key, uint32_t tid, uint64_t (*s_buf)[CHUNK], int& p)
+__device__ __forceinline__ void network_steps(uint64_t (&key)[KPT], uint32_t tid, uint64_t (*s_buf)[CHUNK], int& p)
 {
-    uint64_t other;
-    if constexpr (J >= 64) {
-        s_buf[p][tid] = key;
+    if constexpr (J < KPT) {
+#pragma unroll
+        for (int e = 0; e < KPT; e++) {
+            if ((e & J) == 0) {
+                const bool asc = ((tid * (uint32_t)KPT + (uint32_t)e) & (uint32_t)K) == 0u;
+                const uint64_t a = key[e], b = key[e | J];
+                const bool sw = (a > b) == asc;
+                key[e] = sw ? b : a; key[e | J] = sw ? a : b;
+            }
+        }
+    } else if constexpr (J / KPT >= 64) {
+#pragma unroll
+        for (int e = 0; e < KPT; e++) s_buf[p][tid * KPT + e] = key[e];
         __syncthreads();
-        other = s_buf[p][tid ^ J];
+#pragma unroll
+        for (int e = 0; e < KPT; e++) {
+            const uint32_t i = tid * (uint32_t)KPT + (uint32_t)e;
+            const uint64_t other = s_buf[p][i ^ (uint32_t)J];
+            const bool take_min = ((i & (uint32_t)J) == 0u) == ((i & (uint32_t)K) == 0u);     // lower partner of an ascending run
+            const bool lt = key[e] < other;
+            key[e] = (lt == take_min) ? key[e] : other;
+        }
         p ^= 1;                                            // the next cross-wave step writes the other buffer: no second barrier
     } else {
-        const uint32_t lo = lane_xor<J>((uint32_t)key, tid), hi = lane_xor<J>((uint32_t)(key >> 32), tid);
-        other = ((uint64_t)hi << 32) | lo;
+#pragma unroll
+        for (int e = 0; e < KPT; e++) {
+            const uint32_t lo = lane_xor<J / KPT>((uint32_t)key[e], tid), hi = lane_xor<J / KPT>((uint32_t)(key[e] >> 32), tid);
+            const uint64_t other = ((uint64_t)hi << 32) | lo;
+            const uint32_t i = tid * (uint32_t)KPT + (uint32_t)e;
+            const bool take_min = ((i & (uint32_t)J) == 0u) == ((i & (uint32_t)K) == 0u);
+            const bool lt = key[e] < other;
+            key[e] = (lt == take_min) ? key[e] : other;
+        }
     }
-    const bool take_min = ((tid & (uint32_t)J) == 0u) == ((tid & (uint32_t)K) == 0u);     // lower partner of an ascending run
-    const bool lt = key < other;
-    key = (lt == take_min) ? key : other;
     if constexpr (J > 1) network_steps<K, J / 2>(key, tid, s_buf, p);
 }
 template <int K>
-__device__ __forceinline__ void network_phases(uint64_t& key, uint32_t tid, uint32_t npad, uint64_t (*s_buf)[CHUNK], int& p)
+__device__ __forceinline__ void network_phases(uint64_t (&key)[KPT], uint32_t tid, uint32_t npad, uint64_t (*s_buf)[CHUNK], int& p)
 {
     if constexpr (K > 2) network_phases<K / 2>(key, tid, npad, s_buf, p);
     if ((uint32_t)K <= npad) network_steps<K, K / 2>(key, tid, s_buf, p);          // (wave-uniform)
@@ -383,9 +415,9 @@ __device__ __forceinline__ void network_phases(uint64_t& key, uint32_t tid, uint
 // order, work table, header, group bases: scan_outputs), so the scan costs no launch of its own.  A frame that overflowed (more
 // instances than the capacity, or a tile that outgrew its bucket) is seen by every workgroup alike: nothing is sorted.
 // SORT_PER: tiles per thread of the self-scan, at most -- 1 (T <= 1024: a 512 x 512 frame; the instantiation that must keep its two
-// workgroups per CU: 64 VGPRs) or MAX_LDS_TILES / CHUNK = 8
+// workgroups per CU: 64 VGPRs) or MAX_LDS_TILES / SORT_THREADS = 8
 template <int SORT_PER>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(SORT_THREADS) __attribute__((amdgpu_num_sgpr(80)))
 chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base, uint64_t* __restrict__ keys,
                   uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */,
                   uint4* __restrict__ frame_state, uint32_t frame_state_n16,
@@ -421,7 +453,7 @@ chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chun
     KSTAMP(0); RSTAMP(5);
     // self-scan: this thread's tiles, their counts and chunk bases
     uint32_t my_cnt[SORT_PER], my_cb[SORT_PER], n_chunks_dev = 0u;
-    const int per = (T + CHUNK - 1) / CHUNK;
+    const int per = (T + SORT_THREADS - 1) / SORT_THREADS;
     if (self_scan) {
         // (a count above the bucket size means the preprocess kernel dropped keys: the scan block flags the frame and empties every
         // range; here the count is clamped so that whatever is sorted stays inside the bucket.  Likewise a frame with more instances
@@ -461,25 +493,28 @@ chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chun
         const uint32_t first = s_own.start + (c - s_own.cbase) * CHUNK;
         const uint32_t n = min((uint32_t)CHUNK, s_own.end - first);
         uint64_t* gk = keys + first;
-        uint32_t npad = 64;                                // at least one wave's worth: the intra-wave steps need no branches
+        uint32_t npad = 64 * KPT;                          // at least one wave's worth: the intra-wave steps need no branches
         while (npad < n) npad <<= 1;
         const bool last_turn = c + grid >= n_chunks;       // (no further lookup just to find that out: it is a memory round trip)
-        if (tid >= npad) {
-            // whole waves (npad is a multiple of 64) with nothing to sort.  On the workgroup's last turn they leave -- the barriers
+        if (tid * KPT >= npad) {
+            // whole waves (npad is a multiple of 64 KPT) with nothing to sort.  On the workgroup's last turn they leave -- the barriers
             // below count the waves that are still alive (gfx9 s_barrier semantics; 16-wave barriers are what a short chunk's network
             // would otherwise pay) -- on earlier turns they only keep the barrier count: one per cross-wave step.
             if (last_turn) return;
-            for (uint32_t k = 128; k <= npad; k <<= 1)
-                for (uint32_t j = k >> 1; j >= 64u; j >>= 1) __syncthreads();
+            for (uint32_t k = 128 * KPT; k <= npad; k <<= 1)
+                for (uint32_t j = k >> 1; j >= 64u * KPT; j >>= 1) __syncthreads();
             __syncthreads();
             continue;
         }
-        uint64_t key = tid < n ? gk[tid] : ~0ull;
-        if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = key ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = n; }
+        uint64_t key[KPT];                                 // (a thread's keys are neighbours in memory: one 16-byte load)
+#pragma unroll
+        for (int e = 0; e < KPT; e++) key[e] = tid * KPT + e < n ? gk[tid * KPT + e] : ~0ull;
+        if (stamps && tid == 0) { stamps[(size_t)blockIdx.x * 8 + 2] = key[0] ? __builtin_amdgcn_s_memtime() : 1ull; stamps[(size_t)blockIdx.x * 8 + 6] = n; }
         int p = 0;
         network_phases<CHUNK>(key, tid, npad, s_keys, p);
         KSTAMP(3);
-        if (tid < n) gk[tid] = key;
+#pragma unroll
+        for (int e = 0; e < KPT; e++) if (tid * KPT + e < n) gk[tid * KPT + e] = key[e];
         KSTAMP(4); RSTAMP(7);
         if (last_turn) return;
         __syncthreads();                                   // s_own is rewritten by the next round's lookup
@@ -495,6 +530,8 @@ chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chun
 // sorted id, the 48-byte record the blend kernels stream, the block mask, and the Gaussian -> instance back-pointer used by the
 // backward gather.
 constexpr int MERGE_OC = 6;                                // sibling chunks searched per round (48 KB of LDS)
+constexpr int SEARCH_STEPS = 11;                           // halvings of a binary search over one chunk: log2(CHUNK) + 1
+static_assert((1 << (SEARCH_STEPS - 1)) == CHUNK, "SEARCH_STEPS = log2(CHUNK) + 1");
 // MERGE_THREADS threads = a PART of a chunk's instances per workgroup (512: two workgroups per chunk).  One 1024-thread workgroup per
 // chunk put two workgroups on 84 of the 256 CUs for cfg3's 340 chunks and one on the rest: the kernel ended with the double-loaded CUs
 // (workgroup ends 8 us median, 17 us last).  Halves spread 680 workgroups three to a CU at most; each loads the sibling chunks itself.
@@ -591,7 +628,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         uint32_t lo[MERGE_OC], hi[MERGE_OC];
 #pragma unroll
         for (int q = 0; q < MERGE_OC; q++) { lo[q] = 0u; hi[q] = on[q]; }
-        for (int step = 0; step < 11; step++) {               // 2^10 keys: eleven halvings; the siblings' searches run side by side
+        for (int step = 0; step < SEARCH_STEPS; step++) {      // 2^10 keys: eleven halvings; the siblings' searches run side by side
 #pragma unroll
             for (int q = 0; q < MERGE_OC; q++) {
                 if (q < ns) {                                 // (scalar branch: absent siblings cost nothing)
@@ -834,8 +871,8 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     if (part == 0) {
         // (self-scan: one block more, the scan block -- inside the bound on resident workgroups, so that it never waits for a slot)
         const int sort_grid = key_stride ? std::max(1, std::min(grid, max_grid - 1)) + 1 : grid;
-        if (T <= CHUNK) MOSS_LAUNCH_TIMED(chunk_sort_kernel<1>, dim3(sort_grid), dim3(CHUNK) /* one key per thread */, 0, s, SORT_ARGS);
-        else MOSS_LAUNCH_TIMED((chunk_sort_kernel<MAX_LDS_TILES / CHUNK>), dim3(sort_grid), dim3(CHUNK), 0, s, SORT_ARGS);
+        if (T <= SORT_THREADS) MOSS_LAUNCH_TIMED(chunk_sort_kernel<1>, dim3(sort_grid), dim3(SORT_THREADS) /* KPT keys per thread */, 0, s, SORT_ARGS);
+        else MOSS_LAUNCH_TIMED((chunk_sort_kernel<MAX_LDS_TILES / SORT_THREADS>), dim3(sort_grid), dim3(SORT_THREADS), 0, s, SORT_ARGS);
     } else
     MOSS_LAUNCH_TIMED(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr,

@@ -24,6 +24,9 @@ pmc p1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_
 pmc p2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
 pmc p3 FETCH_SIZE
 pmc p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+# the scalar unit beside the vector unit (round 4's review, item 5: the forward blend executes as many SALU as VALU instructions)
+pmc p5 SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+pmc p6 SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SMEM SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS
 cd $GRAFT_REPO_ROOT
 python3 scripts/summarize_pmc.py $OUT/pmc $OUT/pmc_summary.json $OUT/pmc_stage_summary.json > $OUT/pmc_hbm_bytes.txt 2>&1
 python3 - <<PY
