@@ -72,6 +72,28 @@ for seed in range(first, first + n_cases):
                     ratio, el = hp.single_rule_ratio(v0.cpu().numpy(), getattr(ref64, k), mass[k], spread[k])
                     worst_ratio = max(worst_ratio, ratio)
                     assert ratio <= hp.RULE_K, f"culling off: {k} element {el} at {ratio:.2f} x (spread + eps mass) from float64 (allowed {hp.RULE_K})"
+            # round 5: the ASYNCHRONOUS forward (capacity-bounded: keys bucketed by the preprocess kernel, the scan inside the sort kernel,
+            # no scatter kernel) must render the same frame bit for bit, down to the sorted lists -- and so must the exact-math mode's
+            # integers (its blend decisions are checked against the oracle by tests/test_gpu_exact.py)
+            from moss_amd.diff_gaussian_rasterization import _C
+            cx = _C.RasterContext(); cx.set_async(True, capacity=2 * t.R + 1024)
+            a_ = t.args; c_ = d.cam
+            ra = _C.rasterize_gaussians(a_["bg"], a_["means3D"], a_["colors"], a_["opacity"], a_["scales"], a_["rotations"], d.scale_modifier,
+                                        a_["cov3D"], a_["view"], a_["proj"], c_.tanfovx, c_.tanfovy, c_.H, c_.W, a_["sh"], d.degree, a_["campos"],
+                                        False, 0, a_["transforms"], 0, cx)
+            cx.check_status()
+            assert cx.last_needed == t.R, ("async forward: instances", cx.last_needed, t.R)
+            for name_, u_, v_ in (("color", ra[1], t.color), ("depth", ra[2], t.depth), ("alpha", ra[3], t.alpha), ("radii", ra[4], t.radii)):
+                assert torch.equal(u_, v_), f"asynchronous forward: {name_} differs from the synchronous forward"
+            ta = SimpleNamespace(R=t.R, color=ra[1], depth=ra[2], alpha=ra[3], radii=ra[4], geom=ra[5], binning=ra[6], img=ra[7])
+            ea = hp.hip_export(d, ta, dev)
+            assert np.array_equal(ea.point_list, e.point_list) and np.array_equal(ea.ranges, e.ranges) and np.array_equal(ea.n_contrib, e.n_contrib)
+            ga = _C.rasterize_gaussians_backward(a_["bg"], a_["means3D"], ra[4], a_["colors"], a_["scales"], a_["rotations"], d.scale_modifier,
+                                                 a_["cov3D"], a_["view"], a_["proj"], c_.tanfovx, c_.tanfovy, (dc * m).to(dev), (dd * m).to(dev),
+                                                 (da * m).to(dev), a_["sh"], d.degree, a_["campos"], ra[5], ra[0], ra[6], ra[7], ra[3], 0,
+                                                 a_["transforms"], 0, None, cx)
+            for name_, u_ in zip(["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"], ga):
+                assert torch.equal(u_, getattr(g, name_)), f"asynchronous path: {name_} differs from the synchronous path's"
     except Exception as ex:                                      # keep going: report every failing seed
         bad += 1
         failures.append({"seed": seed, "P": s.P, "W": s.camera.W, "H": s.camera.H, "mode": mode, "degree": degree, "colors": colors,
