@@ -746,6 +746,8 @@ def main(argv=None):
         if "unfused_optimizer" in result["callers"]:
             result["value_unfused_optimizer"] = result["callers"]["unfused_optimizer"].get("value")
         result["value_precomp"] = result["callers"].get("precomp_graph", {}).get("value")
+        if "small_P_cfg2" in result["callers"]:
+            result["value_small_P_cfg2"] = result["callers"]["small_P_cfg2"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
         result["cpu_baseline_autograd"] = cpu_baseline_autograd()
@@ -800,12 +802,33 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                     torch_adamw=args.torch_adamw, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer))
         specs["as_generated_order"] = dict(same)
         specs["spatial_order"] = dict(same)
+    if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw:
+        # the regime MOSS actually trains in (6 890 SMPL-vertex Gaussians at the start, scene/dataset_readers.py:720; at most 45 695,
+        # scene/gaussian_model.py:496): BASELINE configs[1] through the headline's harness
+        specs["small_P_cfg2"] = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations,
+                                     torch_adamw=False, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer))
     only = [x for x in getattr(args, "callers_only", "").split(",") if x]
     for name, kw in specs.items():
         if only and name not in only:
             continue
         try:
             sc, T_ = scene, lbs_T
+            cam_, gt_, mask_ = cam, gt, gt_mask
+            if name == "small_P_cfg2":
+                from moss_amd import scenes as _scenes
+                from moss_amd.gaussian_model import GaussianSet as _GS
+                from moss_amd.gaussian_renderer import render as _render, camera_view as _camera_view
+                from types import SimpleNamespace as _NS
+                sc = _scenes.config2()
+                cam_ = _camera_view(sc.camera, dev)
+                gT = torch.Generator().manual_seed(1234)
+                T_ = (torch.eye(3) + 0.05 * torch.randn(sc.means3D.shape[0], 3, 3, generator=gT)).to(dev)
+                with torch.no_grad():
+                    o_ = _render(cam_, _GS(_scenes.config2(seed=_scenes.SEED + 7), sh_degree=3, device=dev),
+                                 _NS(convert_SHs_python=False, compute_cov3D_python=False, debug=False), bg)
+                gt_ = o_["render"].detach().clamp(0, 1).contiguous()
+                mask_ = (o_["render_alpha"].detach() > 0.5).float().contiguous()
+                del o_
             if name == "spatial_order":
                 from moss_amd.densify import spatial_order
                 perm = spatial_order(scene.means3D)
@@ -814,17 +837,17 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                     if torch.is_tensor(v_) and v_.dim() >= 1 and v_.shape[0] == scene.P:
                         setattr(sc, k_, v_[perm].contiguous())
                 T_ = lbs_T[perm.to(lbs_T.device)].contiguous()
-            h = Harness(args, dev, 0, 1, sc, cam, gt, gt_mask, bg, lbs_T=T_ if kw["mode"] in ("lbs", "lbs_python") else None, **kw)
+            h = Harness(args, dev, 0, 1, sc, cam_, gt_, mask_, bg, lbs_T=T_ if kw["mode"] in ("lbs", "lbs_python") else None, **kw)
             if name == "spatial_order":
                 h.pc.spatially_ordered = True                # what GaussianSet.reorder_spatially() leaves behind: render() hints the op
-            n_steps = 3 * steps if name in ("as_generated_order", "spatial_order") else steps
+            n_steps = 3 * steps if name in ("as_generated_order", "spatial_order", "small_P_cfg2") else steps
             for _ in range(warmup):
                 h.step()
             torch.cuda.synchronize(dev)
             if h.use_graph:
                 h.capture()
                 h.time_steps(warmup)                         # (replays: clocks and caches as in the timed region)
-            if name in ("as_generated_order", "spatial_order"):
+            if name in ("as_generated_order", "spatial_order", "small_P_cfg2"):
                 # three segments, the median one reported (with the segments beside it): late in a process that has built and dropped
                 # four harnesses a segment now and then takes a one-off host stall of tens of milliseconds, which is not what the
                 # pair is there to compare
@@ -837,6 +860,16 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                 h.ctx.check_status()
             res[name] = {"value": round(n_steps / dt, 2), "unit": "iters/s", "ms_per_step": round(1e3 * dt / n_steps, 4), "steps": n_steps,
                          "launch": h.graph_note if h.use_graph else "eager launches", "forward": kw["forward"]}
+            if name == "small_P_cfg2":
+                res[name]["workload"] = f"BASELINE configs[1]: {sc.means3D.shape[0]} Gaussians, 512x512, the headline's step (lbs, fused optimizer, one hipGraph)"
+                # its kernels, one by one (eager replay with the library's kernel-attached events)
+                _lib_ = sys.modules["moss_amd._lib"]
+                _lib_.profile_enable(None)
+                for _ in range(20):
+                    h.eager_step()
+                torch.cuda.synchronize(dev)
+                res[name]["stages_us"] = {k: round(1e3 * v[0] / v[1], 1) for k, v in _lib_.profile_read().items() if v[1]}
+                _lib_.profile_enable([])
             if segs is not None:
                 res[name]["segments_ms_per_step"] = [round(1e3 * x / steps, 4) for x in segs]
             del h

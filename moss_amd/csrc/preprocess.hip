@@ -433,11 +433,14 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             if (lds_hist) atomicAdd(&s_hist[t], 1u);
             else atomicAdd(&tile_count[t], 1u);
         });
+        // ---- scatter mode, first half: one returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket and
+        // adds to the tile's count.  Four tiles per thread at a time, as BUFFER atomics whose offset is out of range for an empty tile
+        // (dropped without a memory request): no branch around the atomic, so the four are in flight together (a device-scope
+        // returning atomic is ~2 us; see scatter_kernel, which this replaces on the asynchronous path).  The LAST batch's answers --
+        // for up to 1024 tiles the only one -- are waited for BEHIND the slot-run prefix sum and its stores below, not here.
+        uint32_t pend_c[4] = { 0u, 0u, 0u, 0u }, pend_old[4] = { 0u, 0u, 0u, 0u };
+        int pend_b0 = 0;
         if (scatter) {
-            // One returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket and adds to the tile's
-            // count.  Four tiles per thread at a time, as BUFFER atomics whose offset is out of range for an empty tile (dropped
-            // without a memory request): no branch around the atomic, so the four are in flight together (a device-scope returning
-            // atomic is ~2 us; see scatter_kernel, which this replaces on the asynchronous path).
             __syncthreads();                                 // this iteration's counts are complete
             const __amdgpu_buffer_rsrc_t rs_cnt = __builtin_amdgcn_make_buffer_rsrc((void*)tile_count, 0, 0xffffff00u, 0x00020000u);
             for (int b0 = 0; b0 < T; b0 += 4 * (int)blockDim.x) {
@@ -452,23 +455,17 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                     const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
                     old[u] = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)c[u], rs_cnt, c[u] ? (uint32_t)i * 4u : 0xfffffffcu /* out of range AND dword-aligned */, 0, 0);
                 }
+                if (b0 + 4 * (int)blockDim.x < T) {          // (kernel-uniform) not the last batch: its answers are needed now
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
-                    if (c[u]) { s_base[i] = old[u]; s_hist[i] = 0u; }      // (the count word becomes the cursor of the pass below)
+                    for (int u = 0; u < 4; u++) {
+                        const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                        if (c[u]) { s_base[i] = old[u]; s_hist[i] = 0u; }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { pend_c[u] = c[u]; pend_old[u] = old[u]; }
+                    pend_b0 = b0;
                 }
-            }
-            __syncthreads();
-            // the keys: (depth bits << 32 | Gaussian id), into the run this block reserved (slot order inside a bucket is arbitrary: the
-            // sort orders by the whole key)
-            const uint64_t key = out_tiles ? (((uint64_t)__float_as_uint(out_depth) << 32) | (uint32_t)idx) : 0ull;
-            wave_for_each_tile(out_rect, gx, key, [&](int t, uint64_t k) {
-                const uint32_t pos = s_base[t] + atomicAdd(&s_hist[t], 1u);
-                if (pos < key_stride) keys[(size_t)t * key_stride + pos] = k;      // (a bucket that overflows drops the frame: scan block)
-            });
-            if (it + 1 < iters) {                            // the next iteration counts from zero again
-                __syncthreads();
-                for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
             }
         }
         // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos (the reference: a device-wide inclusive
@@ -495,6 +492,26 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             if (radii_out) radii_out[idx] = out_radius;
         }
         __syncthreads();
+        if (scatter) {
+            // ---- scatter mode, second half: the reserved runs' starts, then the keys -- (depth bits << 32 | Gaussian id) -- into them (slot
+            // order inside a bucket is arbitrary: the sort orders by the whole key)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = pend_b0 + u * (int)blockDim.x + (int)threadIdx.x;
+                if (pend_c[u]) { s_base[i] = pend_old[u]; s_hist[i] = 0u; }      // (the count word becomes the cursor of the pass below)
+            }
+            __syncthreads();
+            const uint64_t key = out_tiles ? (((uint64_t)__float_as_uint(out_depth) << 32) | (uint32_t)idx) : 0ull;
+            wave_for_each_tile(out_rect, gx, key, [&](int t, uint64_t k) {
+                const uint32_t pos = s_base[t] + atomicAdd(&s_hist[t], 1u);
+                if (pos < key_stride) keys[(size_t)t * key_stride + pos] = k;      // (a bucket that overflows drops the frame: scan block)
+            });
+            if (it + 1 < iters) {                            // the next iteration counts from zero again
+                __syncthreads();
+                for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
+                __syncthreads();
+            }
+        }
         FSTAMP(4);
     }
     if (lds_hist && !scatter) {                              // (scatter mode added its counts with the reserving atomics)

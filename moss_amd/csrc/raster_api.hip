@@ -194,7 +194,7 @@ static int forward_impl(
     // kernel -- the sort workgroups derive their chunk tables from the tile counts, and the scan rides along with the sort kernel as one
     // extra block: preprocess, sort, merge, blend = FOUR launches (rounds 2-4: five, with a scatter kernel of its own; the reference: 7+).
     // (a capacity so small that a bucket would hold no key at all keeps the scan -> scatter chain, whose only bound is the total)
-    uint32_t key_stride = (capacity > 0 && scatter_folds_scan(fp)) ? bucket_key_stride(BinView::at(nullptr, (int)capacity), T) : 0u;
+    uint32_t key_stride = (capacity > 0 && forward_buckets_keys(fp)) ? bucket_key_stride(BinView::at(nullptr, (int)capacity), T) : 0u;
     if (key_stride < 2u) key_stride = 0u;
     const bool bucketed = key_stride != 0u;
     int R = 0, total_chunks = 0;
@@ -238,7 +238,7 @@ static int forward_impl(
 
     if (R > 0) {
         if (!bucketed) {
-            { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, "moss:scatter"); launch_scatter(fp, g, im, b, false, capacity, s); }
+            { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, "moss:scatter"); launch_scatter(fp, g, im, b, s); }
             STAGE_CHECK("scatter");
         }
 #ifdef MOSS_DIAG
