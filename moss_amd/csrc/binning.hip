@@ -66,17 +66,31 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
                                              uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
                                              uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
                                              uint32_t* s_wave, uint32_t* s_max, uint32_t* s_bucket /* 34 */,
-                                             int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
+                                             int n_groups,
                                              uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table,
+                                             const uint32_t* __restrict__ group_rtot, uint32_t* __restrict__ group_rbase,
+                                             uint32_t pool_cap /* cells the record pool of this binning buffer holds (0xffffffff: sized afterwards) */,
                                              uint32_t key_stride = 0u /* != 0: the keys sit in per-tile buckets of this many slots (preprocess.hip, scatter mode) */)
 {
     const int tid = threadIdx.x;
     // every header word is WRITTEN here and the queue words are zeroed (the blend kernels pop from them): nothing in the image
     // buffer needs a clear in front of the forward when the counters kernels add to live in the caller's frame state
     if (tid < Q_LINES) queues[(size_t)tid * QLINE_WORDS] = 0u;
-    if (tid >= 8 && tid < HEADER_WORDS) header[tid] = 0u;
+    if (tid >= 8 && tid < HEADER_WORDS && tid != 9) header[tid] = 0u;     // ([9]: the pool's cells in use, written below)
     if (tid == 0) *s_max = 0;
     if (tid < 34) s_bucket[tid] = 0;
+    // FIRST (while nothing else is live: this block shares the sort kernel's register budget -- 64 VGPRs for two workgroups per CU):
+    // where the cell runs of every group of 256 Gaussians start in the record pool (the preprocess kernel left group-relative run starts
+    // and the groups' totals), and how many cells the frame needs: header[9].
+    uint32_t pool_total;
+    {
+        const int gchunk = (n_groups + NT - 1) / NT;
+        const int gb = tid * gchunk, ge = min(n_groups, gb + gchunk);
+        uint32_t gs = 0;
+        for (int i = gb; i < ge; i++) gs += group_rtot[i];
+        uint32_t goff = block_scan<NT>(gs, s_wave, pool_total);
+        for (int i = gb; i < ge; i++) { group_rbase[i] = goff; goff += group_rtot[i]; }
+    }
     const int chunk = (T + NT - 1) / NT;
     const int b = tid * chunk, e = min(T, b + chunk);
     uint32_t sum = 0, mx = 0, nch = 0;
@@ -91,15 +105,22 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
     // caller derives from it holds the longest list: the bucket size is proportional to the capacity)
     bool overflow = total > capacity;
     uint32_t needed = total;
+    // A frame that needs more cells than the record pool holds is dropped like one that needs more instances than the capacity (`needed`
+    // so that the pool of the caller's next capacity holds it: POOL_CELLS_PER_INSTANCE R + 4096 cells, BinView::default_pool_cells).
+    if (pool_total > pool_cap || pool_total > POOL_MAX_CELLS) {
+        overflow = true;
+        needed = max(needed, pool_total / (uint32_t)POOL_CELLS_PER_INSTANCE + 1u);
+    }
     if (key_stride != 0u) {
         if (mx) atomicMax(s_max, mx);
         __syncthreads();
         const uint32_t longest = *s_max;
         if (longest > key_stride) {
             overflow = true;
-            const unsigned long long want = ((unsigned long long)longest * capacity + key_stride - 1u) / key_stride + 1ull;
-            needed = (uint32_t)(want > 0xfffffff0ull ? 0xfffffff0ull : want);
-            needed = max(needed, total);
+            // (in float, rounded up by a margin: a hint for the caller's capacity policy; a 64-bit division here cost this kernel --
+            // the scan block shares the sort kernel's register budget -- its second workgroup per CU: 70 VGPRs, 12.9 -> 16.7 us)
+            const float want = (float)longest * (float)capacity / (float)key_stride * 1.001f + 2.0f;
+            needed = max(needed, want >= 4.29e9f ? 0xfffffff0u : (uint32_t)want);
         }
         // (s_max keeps the longest list: the atomicMax below repeats it for the lists that are kept, header[1] reports it either way)
     }
@@ -121,6 +142,7 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         header[0] = overflow ? 0u : total; header[1] = *s_max; header[4] = overflow ? 0u : total_chunks;
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
         header[6] = needed;                            // instances this frame needs (for the host's capacity policy)
+        header[9] = overflow ? 0u : pool_total;        // cells of the record pool in use: what merge_gather clears of the validity bits
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
         header[3] = 0u;
         header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u);       // (the preprocess kernel's flags: it finished before this one)
@@ -140,17 +162,6 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
             o += v;
         }
     }
-    // where the inst_pos slot runs of every group of 256 Gaussians start (the preprocess kernel left group-relative run starts
-    // and the groups' totals): the reference's device-wide scan of tiles_touched, rasterizer_impl.cu:279, at 1/256 of its length
-    {
-        const int gchunk = (n_groups + NT - 1) / NT;
-        const int gb = tid * gchunk, ge = min(n_groups, gb + gchunk);
-        uint32_t gs = 0;
-        for (int i = gb; i < ge; i++) gs += group_tot[i];
-        uint32_t gtotal;
-        uint32_t goff = block_scan<NT>(gs, s_wave, gtotal);
-        for (int i = gb; i < ge; i++) { group_base[i] = goff; goff += group_tot[i]; }
-    }
 }
 
 // One 1024-thread block: ranges[t] = [start,end) from the exclusive scan of the per-tile histogram, chunk_base[t] = number
@@ -159,14 +170,15 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
 __global__ void __launch_bounds__(1024)
 scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges, uint32_t* __restrict__ chunk_base,
             uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
-            int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
-            uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table)
+            int n_groups,
+            uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table,
+            const uint32_t* __restrict__ group_rtot, uint32_t* __restrict__ group_rbase, uint32_t pool_cap)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_bucket[34];
     scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                       n_groups, group_tot, group_base, flags_acc, queues, work_table);
+                       n_groups, flags_acc, queues, work_table, group_rtot, group_rbase, pool_cap);
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111) of the SYNCHRONOUS path (and of frames with more tiles than the LDS
@@ -391,8 +403,9 @@ chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chun
                   uint32_t* __restrict__ header, unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup, else NULL */,
                   uint4* __restrict__ frame_state, uint32_t frame_state_n16,
                   uint32_t key_stride, const uint32_t* __restrict__ tile_count, uint32_t capacity, int light_log2,
-                  uint32_t* __restrict__ tile_order, int n_groups, const uint32_t* __restrict__ group_tot, uint32_t* __restrict__ group_base,
-                  uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table)
+                  uint32_t* __restrict__ tile_order, int n_groups,
+                  uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table,
+                  const uint32_t* __restrict__ group_rtot, uint32_t* __restrict__ group_rbase, uint32_t pool_cap)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[2][CHUNK];
     __shared__ ChunkOwner s_own;
@@ -407,8 +420,10 @@ chunk_sort_kernel(int T, uint2* __restrict__ ranges, uint32_t* __restrict__ chun
         // workgroup to leave and then ran alone: 12.1 -> 15.4 us)
         grid--; wg--;
         if (blockIdx.x == 0) {                               // the scan block
+            if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memrealtime();
             scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                               n_groups, group_tot, group_base, flags_acc, queues, work_table, key_stride);
+                               n_groups, flags_acc, queues, work_table, group_rtot, group_rbase, pool_cap, key_stride);
+            if (stamps && tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
             return;
         }
     } else {
@@ -509,7 +524,7 @@ __global__ void __launch_bounds__(MERGE_THREADS) __attribute__((amdgpu_num_sgpr(
 merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView g, const uint2* __restrict__ ranges,
                     const uint32_t* __restrict__ chunk_base, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ point_list,
-                    float4* __restrict__ inst_rec, uint32_t* __restrict__ inst_mask, uint16_t* __restrict__ inst_bmask,
+                    float4* __restrict__ inst_rec, uint32_t* __restrict__ cell_valid, uint16_t* __restrict__ inst_bmask,
                     unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup (after the sort's), else NULL */,
                     uint32_t key_stride /* != 0: tile t's keys start at t * key_stride (buckets), else at its range */,
                     uint4* __restrict__ frame_state, uint32_t frame_state_n16)
@@ -520,6 +535,12 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     // bucketed keys (asynchronous path): the sort kernel read the tile counts of the caller's frame state itself, so the state is
     // re-zeroed for the next forward HERE (every workgroup of the grid takes a slice, before anything can make it leave)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frame_state_n16; i += gridDim.x * blockDim.x) frame_state[i] = make_uint4(0u, 0u, 0u, 0u);
+    // no gradient record yet: one bit per cell of the record pool the frame uses (header[9], written by the scan block; set by the
+    // backward blend).  (Rounds 2-4: a 4-byte mask word per instance, zeroed by the instance's own thread below.)
+    {
+        const uint32_t n_words = (header[9] + 31u) / 32u + 1u;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) cell_valid[i] = 0u;
+    }
     KSTAMP(0); RSTAMP(5);
     for (uint32_t it = blockIdx.x;; it += gridDim.x) {
     // XCD-aware chunk order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), chunks are in tile order, and neighbouring
@@ -578,7 +599,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
         asm volatile("" : "+v"(id));                          // (opaque: otherwise the address arithmetic -- and with it the wait for
                                                               // the key -- is hoisted in front of the siblings' loads)
         const float4* const gsrc = g.geo + 4 * (size_t)id;    // the Gaussian's one 64-byte record
-        ga = gsrc[0]; gb = gsrc[1]; gc = gsrc[2]; gd = gsrc[3]; slot_base = g.group_base[id >> 8];
+        ga = gsrc[0]; gb = gsrc[1]; gc = gsrc[2]; gd = gsrc[3]; slot_base = g.group_rbase[id >> 8];      // (where the group's CELL runs start)
     };
     // the group's chunks into LDS, searched side by side
     auto search_group = [&](uint32_t s0) {
@@ -630,19 +651,18 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     float4* rec = inst_rec + 3 * (size_t)pos;
     if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 8 + 3] = ga.x == 12345.678f ? 1ull : __builtin_amdgcn_s_memtime();
     const uint2 r = make_uint2(__float_as_uint(gd.x), __float_as_uint(gd.y));
-    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff;
     const int tx = (int)tile % gx, ty = (int)tile / gx;
-    // the instance's SLOT: its place in its Gaussian's run (group base + run start + index of this tile in the rectangle).  The
-    // backward blend files its gradient records and mask bits under it, so that the per-Gaussian gather walks [run, run + n) directly;
-    // it travels in the record's third word (the cull half-width, which only this kernel reads -- from the geometry record).
-    asm volatile("" :: "v"(gd.w));                            // (keeps the record's last register out of reuse while its load is in flight:
-                                                              // the allocator put the slot base there and waited for the load to do so)
-    const uint32_t slot = slot_base + __float_as_uint(gd.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-    inst_mask[slot] = 0u;                                     // no gradient record yet (set by the backward blend)
+    // Where the instance's gradient-record cells are (common.h: box_cells): the Gaussian's run in the pool (group base + its start in
+    // the group, the geometry record's last word) + the cells in front of this tile, in closed form from the box.  It travels in the
+    // record's third word, packed with the box's width in the tile, so that the backward blend finds the cell of a block with three
+    // integer operations (pack_cell_word) and the per-Gaussian gather needs no table at all: it sums its run.
+    const BoxCells bc = box_cells(ga.x, ga.y, ga.z, ga.w, r);
+    const TileCells tc = tile_cells(bc, tx, ty);
+    const uint32_t cell_word = pack_cell_word(slot_base + __float_as_uint(gd.z) + (uint32_t)tc.first, tc, tx, ty);
     // (fourth word: the entry's 1-based position in its tile's list, as a float -- what the blend kernels record as the last contributor
     // and compare against it; exact below 2^24.  With it in the record a blender reads nothing but the record ring per entry.)
     // (second word: {B, C, A, opacity} -- the order in which the blend trips multiply the conic by (dx, dy) as register pairs: blend.hip, pair_power)
-    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(slot), (float)(rank + 1u)); rec[1] = make_float4(gb.y, gb.z, gb.x, gb.w); rec[2] = gc;
+    rec[0] = make_float4(ga.x, ga.y, __uint_as_float(cell_word), (float)(rank + 1u)); rec[1] = make_float4(gb.y, gb.z, gb.x, gb.w); rec[2] = gc;
     // (non-temporal or write-through stores here: +3 / +7 us -- the write-back at the kernel's end is cheaper)
     {
         // which 4x4 pixel blocks of this tile the entry's alpha >= 1/255 bounding box {x, y, hx, hy} touches (pixel centres are
@@ -775,9 +795,13 @@ static int light_log2_knob()
 
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s)
 {
+    // (the scan kernel of its own: the synchronous path, whose pool is sized AFTER the host has read the frame's cell count -- no bound
+    // here -- and asynchronous frames of more tiles than the LDS histogram holds, whose pool is the default one of the capacity)
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
+    const uint32_t pool_cap = capacity < 0 ? 0xffffffffu : (uint32_t)std::min<size_t>(BinView::default_pool_cells((int)capacity), 0xfffffff0u);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
-                       im.header, cap, light_log2_knob(), (P + 255) / 256, g.group_tot, g.group_base, im.flags_acc, im.queues, im.work_table);
+                       im.header, cap, light_log2_knob(), (P + 255) / 256, im.flags_acc, im.queues, im.work_table,
+                       g.group_rtot, g.group_rbase, pool_cap);
 }
 
 // Whether the asynchronous forward can do without a scan (and a scatter) kernel of its own: the tile histogram must fit the LDS of the
@@ -788,11 +812,12 @@ bool forward_buckets_keys(const FrameParams& fp)
     return on && fp.gx * fp.gy <= MAX_LDS_TILES;
 }
 
-// Bucketed keys (asynchronous path): the key area of the binning buffer -- the gradient-record slabs, dead until the backward -- cut
-// into one bucket per tile.  Proportional to the capacity the buffer was sized for, ~40x the average list at the usual 2x margin.
+// Bucketed keys (asynchronous path): the key area of the binning buffer -- the gradient-record pool, dead until the backward -- cut
+// into one bucket per tile.  Proportional to the capacity the buffer was sized for: 36 keys per instance of capacity / tiles, i.e. ~70x
+// the average list at the usual 2x margin (the bench frame's longest list: 20x its average).
 uint32_t bucket_key_stride(const BinView& b, int num_tiles)
 {
-    const unsigned long long area = (unsigned long long)b.slabs * b.slab_stride_floats * 4ull / sizeof(uint64_t);    // keys the area holds
+    const unsigned long long area = (unsigned long long)b.pool_cells * GRAD_REC_FLOATS * 4ull / sizeof(uint64_t);    // keys the area holds
     unsigned long long stride = num_tiles > 0 ? area / (unsigned long long)num_tiles : 0ull;
     stride = std::min<unsigned long long>(stride, 0x7fffffffull / (unsigned long long)std::max(num_tiles, 1));    // 32-bit key indices
     return (uint32_t)(stride & ~1ull);                       // (buckets start 16-byte aligned)
@@ -833,7 +858,8 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     const uint32_t fs_n16 = (uint32_t)(frame_state ? (frame_state_bytes - FS_COUNTERS_OFFSET) / 16 : 0);
     const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
 #define SORT_ARGS T, im.ranges, im.chunk_base, b.keys, im.header, sort_stamps, key_stride ? nullptr : fs, key_stride ? 0u : fs_n16, key_stride,     \
-                  im.tile_count, cap, light_log2_knob(), im.tile_order, (fp.P + 255) / 256, g.group_tot, g.group_base, im.flags_acc, im.queues, im.work_table
+                  im.tile_count, cap, light_log2_knob(), im.tile_order, (fp.P + 255) / 256, im.flags_acc, im.queues, im.work_table, \
+                  g.group_rtot, g.group_rbase, (uint32_t)std::min<size_t>(b.pool_cells, 0xfffffff0u)
     if (part == 0) {
         // (self-scan: one block more, the scan block -- inside the bound on resident workgroups, so that it never waits for a slot)
         const int sort_grid = key_stride ? std::max(1, std::min(grid, max_grid - 1)) + 1 : grid;
@@ -841,7 +867,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
         else MOSS_LAUNCH_TIMED((chunk_sort_kernel<MAX_LDS_TILES / SORT_THREADS>), dim3(sort_grid), dim3(SORT_THREADS), 0, s, SORT_ARGS);
     } else
     MOSS_LAUNCH_TIMED(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
-                       b.point_list, b.inst_rec, b.inst_mask, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr,
+                       b.point_list, b.inst_rec, b.cell_valid, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr,
                        key_stride, key_stride ? fs : nullptr, key_stride ? fs_n16 : 0u);
 #undef SORT_ARGS
 }

@@ -192,7 +192,7 @@ __device__ __forceinline__ float row_slot_sum(float v)
 // bitwise reproducible).
 // ---------------------------------------------------------------------------------------------------------
 
-constexpr int WAVE_BLOCKS = 16;           // 4x4-pixel blocks per tile = items per tile = gradient slabs
+constexpr int WAVE_BLOCKS = 16;           // 4x4-pixel blocks per tile = items per tile
 
 struct Rec { float4 a, b, c; };
 
@@ -297,7 +297,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                                                     float4 (*ring)[3], const float* __restrict__ bg_color, const float* __restrict__ final_Ts,
                                                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                                                     const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
-                                                    float* __restrict__ inst_grad, size_t slab_stride, uint32_t* __restrict__ inst_mask,
+                                                    float* __restrict__ inst_grad /* the record pool */, uint32_t* __restrict__ cell_valid,
                                                     int flags)
 {
     const int ox = (tile % gx) * TILE + (q & 1) * 8, oy = (tile / gx) * TILE + (q >> 1) * 8;
@@ -319,11 +319,11 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
     const float nTb = -T_final * bg_dot;
-    // records and mask words are addressed by the instance's SLOT (its place in its Gaussian's run, carried in the record's third
-    // word): the per-Gaussian gather then needs no position table
-    float* const my_grad = inst_grad + (size_t)q * slab_stride;                             // light tiles use slabs / mask bits 0..3
-    uint32_t* const my_mask = inst_mask;
-    const uint32_t q_bit = 1u << q;
+    // A record goes to a CELL of the Gaussian's run in the record pool (common.h: box_cells; the record's third word says where the
+    // instance's cells start): here, one record per (entry, QUADRANT), to the cell of the first of the quadrant's four blocks that the
+    // entry's block mask flags (that block is inside the box: the mask is the box test, refined).  The per-Gaussian gather sums the
+    // cells whose validity bit is set, whatever tile or path left them.
+    float* const my_grad = inst_grad;
     const int row = lane >> 4;
     float T = T_final, Q = 0.0f;
 
@@ -338,6 +338,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
         bool hit = base + lane < n_eff;
         if (hit && (flags & 1)) hit = (bmk & qmask) != 0u;
         unsigned long long m = __ballot(hit);
+        const uint32_t bmk_cur = bmk;                        // (lane e: the block mask of this batch's entry e)
         bmk = bmk_nxt;
         ring[lane][0] = cur.a; ring[lane][1] = cur.b; ring[lane][2] = cur.c;
         __builtin_amdgcn_wave_barrier();
@@ -375,7 +376,12 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 v[k][4] = __fmaf_rn(wy, b.y, wx * b.x);
                 v[k][5] = wx * dx; v[k][6] = wx * dy; v[k][7] = wy * dy;
                 v[k][8] = v8;
-                pos4[k] = pos; slot4[k] = __float_as_uint(a.z);
+                pos4[k] = pos;
+                {   // the entry's cell for this quadrant: first flagged block b of the quadrant -> (w >> 2) - 16 + (b >> 2) (nbx) + (b & 3)
+                    const uint32_t w = __float_as_uint(a.z), be = (uint32_t)__builtin_amdgcn_readlane((int)bmk_cur, e) & qmask;
+                    const int b = be ? __ffs((int)be) - 1 : 0;
+                    slot4[k] = (w >> 2) - 16u + (uint32_t)((b >> 2) * (int)((w & 3u) + 1u) + (b & 3));
+                }
                 any4[k] = __ballot(al > 0.0f) != 0ull;
             }
             if (any4[0] || any4[1] || any4[2] || any4[3]) {
@@ -390,7 +396,7 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                     dst[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
                     dst[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
                     dst[2] = make_float4(tot[8], 0.f, 0.f, 0.f);
-                    atomicOr(&my_mask[my_pos], q_bit);
+                    atomicOr(&cell_valid[my_pos >> 5], 1u << (my_pos & 31u));
                 }
             }
         }
@@ -818,7 +824,7 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
                                                     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                                                     const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths,
                                                     const float* __restrict__ dL_dalphas, float* __restrict__ inst_grad,
-                                                    size_t slab_stride, uint32_t* __restrict__ inst_mask, int flags,
+                                                    uint32_t* __restrict__ cell_valid, int flags,
                                                     int lo, int hi_limit, const float* __restrict__ seg_state)
 {
     // Walks the list positions [lo, end) of the block back to front.  seg_state == NULL: the block's own item -- its range ends where
@@ -856,9 +862,8 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
         if (dL_dalphas) gpa = dL_dalphas[pix_id];
     }
     const float bg_dot = bg_color[0] * gpr + bg_color[1] * gpg + bg_color[2] * gpb;
-    float* const my_grad = inst_grad + (size_t)blk * slab_stride;   // this block's slab, addressed by the instance's slot (see the light path)
-    uint32_t* const my_mask = inst_mask;
-    const uint32_t blk_bit = 1u << blk;
+    float* const my_grad = inst_grad;                        // the record pool: an (entry, block) pair's cell from the record's third word (see the light path)
+    const uint32_t cell_row = (uint32_t)(blk >> 2), cell_off = (uint32_t)(blk & 3) - 16u;     // (wave-uniform)
     const uint16_t* const bm = inst_bmask + rg.x;
     const float4* const recs = inst_rec + 3 * (size_t)rg.x;
     const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;
@@ -955,13 +960,15 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
             any |= any >> 32; any |= any >> 16; any |= any >> 8; any |= any >> 4;
             const uint32_t any_rows = ((uint32_t)any & 15u) * 0x00010001u;
             if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)any_rows << 32) | any_rows)) {
-                const uint32_t gslot = __float_as_uint(f.a.z);
-                const uint32_t o = __umul24(gslot, (uint32_t)(NPART * 4)) + m0_bytes;
+                // the cell of (this entry, this block): (w >> 2) - 16 + block row x box width in the tile + block column (common.h: pack_cell_word)
+                const uint32_t w = __float_as_uint(f.a.z);
+                const uint32_t cell = (w >> 2) + __umul24(cell_row, (w & 3u) + 1u) + cell_off;
+                const uint32_t o = (cell << 5) + (cell << 4) + m0_bytes;                 // x 48 bytes
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s0), rs_grad, o, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s1), rs_grad, o + 16u, 0, 0);
                 if (row == 0) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s2), rs_grad, o + 32u, 0, 0);
-                    atomicOr(&my_mask[gslot], blk_bit);
+                    atomicOr(&cell_valid[cell >> 5], 1u << (cell & 31u));
                 }
             }
         }
@@ -1239,7 +1246,7 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
                            const uint16_t* __restrict__ inst_bmask,
                            const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                            const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths, const float* __restrict__ dL_dalphas,
-                           float* __restrict__ inst_grad /* [16][R][12] */, size_t slab_stride, uint32_t* __restrict__ inst_mask,
+                           float* __restrict__ inst_grad /* the record pool: [cells][12] */, uint32_t* __restrict__ cell_valid,
                            int flags, unsigned long long* __restrict__ wstamps /* diagnostics: 16 words per wave, else NULL */,
                            const uint4* __restrict__ seg_desc, const float* __restrict__ seg_state, uint32_t seg_cap,
                            const uint32_t* __restrict__ tail_start, const uint32_t* __restrict__ seg_counts, int fwd_grid, int fwd_pairs)
@@ -1306,8 +1313,8 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
             n_seg++;
             // {tile | block << 28, first instance of the tile, first position, end position}: everything the item needs in ONE load
             heavy_backward_item<EXACT>(W, H, gx, (int)(d.x & 0x0fffffffu), (int)(d.x >> 28), lane, make_uint2(d.y, d.y + d.w), inst_rec, inst_bmask,
-                                &s_heavy[wv], bg_color, final_Ts, n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride,
-                                inst_mask, flags, (int)d.z, (int)d.w, (flags & 64) ? nullptr : seg_state + slot_idx * SEG_STATE_FLOATS);
+                                &s_heavy[wv], bg_color, final_Ts, n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad,
+                                cell_valid, flags, (int)d.z, (int)d.w, (flags & 64) ? nullptr : seg_state + slot_idx * SEG_STATE_FLOATS);
             c_seg += WSTAMP() - tp1;
             uint32_t nxt = 0u;
             if (lane == 0) nxt = atomicAdd(head, 1u) + (uint32_t)q_waves;
@@ -1329,12 +1336,12 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
         n_tail++;
         if (it.heavy)
             heavy_backward_item<EXACT>(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, &s_heavy[wv], bg_color, final_Ts,
-                                n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags,
+                                n_contrib, dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, cell_valid, flags,
                                 (flags & 32) ? 0 : __builtin_amdgcn_readfirstlane((int)tail_start[(size_t)it.tile * WAVE_BLOCKS + it.sub]),
                                 0x7fffffff, nullptr);
         else
             light_backward_item<EXACT>(W, H, gx, it.tile, it.sub, lane, it.rg, inst_rec, inst_bmask, ring, bg_color, final_Ts, n_contrib,
-                                dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, slab_stride, inst_mask, flags);
+                                dL_dpixels, dL_ddepths, dL_dalphas, inst_grad, cell_valid, flags);
         c_tail += WSTAMP() - tq1;
     }
     if (wstamps && lane == 0) {
@@ -1408,8 +1415,6 @@ unsigned long long* g_stamps = nullptr;      // diagnostics buffer registered by
 unsigned long long* g_bwd_stamps = nullptr;  // ... by moss_raster_debug_set_bwd_stamps: 16 words per wave of the backward blend kernel
 #endif
 
-// gradient-record slabs per instance: one per 4x4 block (sparse: only blended pairs are written and flagged in inst_mask)
-int blend_subgroups() { return WAVE_BLOCKS; }
 
 void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinView b,
                           float* out_color, float* out_depth, float* out_alpha, hipStream_t s)
@@ -1463,13 +1468,13 @@ void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinV
     if (exact)
         MOSS_LAUNCH_TIMED(blend_backward_wave_kernel<true>, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.work_table, im.header,
                            im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
-                           dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
+                           dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.cell_valid,
                            flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
                            forward_grid(T, true) /* the forward kernel's grid */, forward_pairs());
     else
         MOSS_LAUNCH_TIMED(blend_backward_wave_kernel<false>, dim3(wgs), dim3(256), 0, s, fp.W, fp.H, fp.gx, im.work_table, im.header,
                            im.queues + (size_t)Q_BWD * QLINE_WORDS, b.inst_rec, b.inst_bmask, fp.bg_dev, im.final_T, im.n_contrib, dL_dpix,
-                           dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.slab_stride_floats, b.inst_mask,
+                           dL_ddepth, dL_dalpha, reinterpret_cast<float*>(b.inst_grad), b.cell_valid,
                            flags, g_bwd_stamps, b.seg_desc, b.seg_state, b.seg_cap, im.tail_start, im.seg_counts,
                            forward_grid(T, false) /* the forward kernel's grid */, forward_pairs());
 }

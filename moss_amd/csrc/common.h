@@ -9,8 +9,10 @@
 //       [1] {conic.A, conic.B, conic.C, opacity}  } [0..2] are copied, in sorted order, into the per-instance stream the
 //       [2] {r, g, b, depth}                      } blend kernels read (inst_rec; there [0] = {pix.x, pix.y, slot, list position + 1}
 //                                                   and [1] = {B, C, A, opacity}: blend.hip, pair_power)
-//       [3] bits {rect.min (x | y<<16), rect.max, point_offsets, tiles_touched}   tile rectangle (getRect result) + slot run
-//     tiles_touched u32, point_offsets u32 (also kept as plain arrays: the backward reads them coalesced), radius i32,
+//       [3] bits {rect.min (x | y<<16), rect.max, rec_offsets, rec_count}   tile rectangle (getRect result) + the Gaussian's run of
+//                                                   gradient-record cells (box_cells below): start relative to its group of 256, length
+//     tiles_touched u32, rec_offsets u32, rec_count u32 (plain arrays: the backward reads them coalesced), per group of 256 Gaussians
+//     group_rtot / group_rbase u32 (the group's cells; where its runs start in the record pool), radius i32,
 //     clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
@@ -18,15 +20,16 @@
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
 //     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id)
-//     inst_pos   u32[R]   for Gaussian g, its k-th tile (row-major inside its rect): position in point_list
 //     inst_rec   48 B * R  the three records of every instance in sorted order (written by the tile sort)
-//     scratch    48 B * R * slabs  forward: 64-bit sort keys (depth<<32|id) in the first 8R bytes;
-//                          backward: per-instance partial gradients, 3 float4 per instance and slab
+//     cell_valid 1 bit per record-pool cell: the backward blend left a record there
+//     pool       48 B * cells (~6 R; exact in the synchronous forward)   forward: 64-bit sort keys (depth<<32|id);
+//                          backward: partial gradients, 3 float4 per (Gaussian, 4x4 pixel block under its bounding box) -- see box_cells
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <algorithm>
 #include "moss_raster.h"
 
 namespace moss {
@@ -52,8 +55,9 @@ inline T* carve(char*& p, size_t count)
 
 struct GeomView {
     float4* geo;             // 4 float4 per Gaussian, see the layout comment at the top of this file
-    uint32_t* tiles_touched; uint32_t* point_offsets;    // point_offsets: start of the Gaussian's slot run RELATIVE to its group of 256
-    uint32_t* group_tot; uint32_t* group_base;           // per group of 256 consecutive Gaussians: instances, and where its runs start
+    uint32_t* tiles_touched;
+    uint32_t* rec_offsets; uint32_t* rec_count;          // the Gaussian's run of gradient-record CELLS (box_cells below): start relative to its group, length
+    uint32_t* group_rtot; uint32_t* group_rbase;         // per group: cells, and where its cell runs start in the record pool
     int* radius;
     uint8_t* clamped;
     float* cov3D;
@@ -61,8 +65,9 @@ struct GeomView {
     {
         GeomView g; char* p = base; size_t n = (size_t)P;
         g.geo = carve<float4>(p, 4 * n);
-        g.tiles_touched = carve<uint32_t>(p, n); g.point_offsets = carve<uint32_t>(p, n);
-        g.group_tot = carve<uint32_t>(p, (n + 255) / 256); g.group_base = carve<uint32_t>(p, (n + 255) / 256);
+        g.tiles_touched = carve<uint32_t>(p, n);
+        g.rec_offsets = carve<uint32_t>(p, n); g.rec_count = carve<uint32_t>(p, n);
+        g.group_rtot = carve<uint32_t>(p, (n + 255) / 256); g.group_rbase = carve<uint32_t>(p, (n + 255) / 256);
         g.radius = carve<int>(p, n);
         g.clamped = carve<uint8_t>(p, n);
         g.cov3D = carve<float>(p, 6 * n);
@@ -182,6 +187,56 @@ __device__ __forceinline__ void wave_for_each_tile(uint2 rect, int gx, uint64_t 
 }
 #endif
 
+#if defined(__HIPCC__)
+// THE GRADIENT-RECORD POOL (round 5; rounds 1-4: sixteen slabs of one 48-byte record per instance, 768 B per instance of address space).
+// A record is the nine partial gradient sums one 4x4 pixel block of the image contributes to one Gaussian (blend.hip, backward).  A
+// Gaussian can only leave records for the blocks its alpha >= 1/255 bounding box {x, y, hx, hy} (geo[0]) reaches inside its tile
+// rectangle: its CELLS, a run of consecutive pool records per Gaussian (group-relative start: GeomView::rec_offsets; bases: the scan).
+// Inside the run the cells are ordered by tile (the rectangle's tiles row-major: the Gaussian's instances), inside a tile row-major over
+// the box's blocks in that tile -- every instance's cells are consecutive, and where they start follows in closed form from the box:
+//   cells in front of tile (tx, ty) = rows_before * NBX + nby(ty) * cols_before,   nby(ty) = box rows inside tile row ty.
+// box_cells() is THE definition, evaluated with the same bits by the preprocess kernel (counts), merge_gather (where an instance's
+// cells start: it rides in the instance's record) and the per-Gaussian backward (how many cells to sum).
+// The box must contain every block merge_gather's block mask can flag: there block column cb (pixels 4cb .. 4cb + 3) passes iff
+// fl(x + hx) >= 4cb and fl(x - hx) <= 4cb + 3; here cb <= floor(fl(x + hx) / 4) (the same condition: the division by 4 is exact) and
+// cb >= floor(fl(x - hx) / 4) (<= the exact bound ceil((fl(x - hx) - 3) / 4): at most one column more).  Infinite extents (NaN opacity)
+// clip to the rectangle; negative ones (opacity <= 0) give an empty box.
+struct BoxCells { int gx0, gy0, nbx, nby; };               // global block coordinates of the first cell; columns, rows (<= 0: empty)
+__device__ __forceinline__ BoxCells box_cells(float x, float y, float hx, float hy, uint2 rect)
+{
+#pragma clang fp contract(off)
+    const int x0 = (int)(rect.x & 0xffffu), y0 = (int)(rect.x >> 16), x1 = (int)(rect.y & 0xffffu), y1 = (int)(rect.y >> 16);
+    BoxCells c;
+    const float lx = fmaxf(floorf((x - hx) * 0.25f), (float)(4 * x0)), ux = fminf(floorf((x + hx) * 0.25f), (float)(4 * x1 - 1));
+    const float ly = fmaxf(floorf((y - hy) * 0.25f), (float)(4 * y0)), uy = fminf(floorf((y + hy) * 0.25f), (float)(4 * y1 - 1));
+    // (NaN-free: x, y finite for a Gaussian with a rectangle; hx, hy finite, +inf or -1)
+    c.gx0 = (int)lx; c.gy0 = (int)ly;
+    c.nbx = (x1 > x0 && y1 > y0 && ux >= lx && uy >= ly) ? (int)ux - c.gx0 + 1 : 0;
+    c.nby = c.nbx > 0 ? (int)uy - c.gy0 + 1 : 0;
+    return c;
+}
+// where the cells of the instance in tile (tx, ty) start inside the Gaussian's run, and that tile's share of the box
+struct TileCells { int first; int gx0, gy0, nbx, nby; };   // (global block coordinates again; nbx / nby <= 0: the box misses the tile)
+__device__ __forceinline__ TileCells tile_cells(const BoxCells& c, int tx, int ty)
+{
+    TileCells t;
+    t.gx0 = max(c.gx0, 4 * tx); t.gy0 = max(c.gy0, 4 * ty);
+    t.nbx = min(c.gx0 + c.nbx, 4 * tx + 4) - t.gx0; t.nby = min(c.gy0 + c.nby, 4 * ty + 4) - t.gy0;
+    const int rows_before = max(0, min(c.gy0 + c.nby, 4 * ty) - c.gy0), cols_before = max(0, min(c.gx0 + c.nbx, 4 * tx) - c.gx0);
+    t.first = rows_before * c.nbx + max(t.nby, 0) * cols_before;
+    return t;
+}
+// The word an instance's record carries in place of the slot of rounds 2-4 (inst_rec[0].z): from it the backward blend finds the cell of
+// block (bx, by) of the instance's tile -- cell = (w >> 2) - 16 + by * ((w & 3) + 1) + bx -- i.e. w = ((base - by0 * nbx - bx0 + 16) << 2) |
+// (nbx - 1) with base = the pool index of the instance's first cell and (bx0, by0) that cell's block inside the tile.
+__device__ __forceinline__ uint32_t pack_cell_word(uint32_t base, const TileCells& t, int tx, int ty)
+{
+    const int nbx = max(t.nbx, 1);
+    return (uint32_t)(((int)base - (t.gy0 - 4 * ty) * nbx - (t.gx0 - 4 * tx) + 16) << 2) | (uint32_t)(nbx - 1);
+}
+constexpr uint32_t POOL_MAX_CELLS = 80u * 1000u * 1000u;    // the kernels address the pool with 32-bit byte offsets: 48 B x 80M < 4 GB (and < the word's 30 bits)
+#endif
+
 // Per-kernel timing (moss_raster_profile_*): while a single-kernel stage is being timed, its launcher dispatches through
 // hipExtLaunchKernelGGL with the stage's two events attached to the KERNEL (begin / end of execution, what rocprofv3 reports),
 // instead of hipEventRecord calls around the launch (which also see the launch latency in front of the kernel: +5-10 us eager).
@@ -210,39 +265,47 @@ constexpr int knob(const char*, int dflt) { return dflt; }
 constexpr unsigned long long* g_stamps = nullptr;
 constexpr unsigned long long* g_bwd_stamps = nullptr;
 #endif
-int blend_subgroups();       // gradient-record slabs per instance (16: one per 4x4 block of a tile), blend.hip
 
+// Record pool capacity of a binning buffer sized for R instances when nothing better is known (the asynchronous forward, whose R is the
+// caller's capacity -- about twice the frame's -- and moss_raster_binning_bytes): POOL_CELLS_PER_INSTANCE cells per instance.  Measured
+// need, cells per instance of the FRAME: 3.7 (bench frame, configs[2]), 4.5 (configs[4]), 5.0 (configs[1]: Gaussians that span 4-12
+// tiles), 5.5 (configs[0]); the most cells of one Gaussian there: 88 / 240 / 81 / 70.
+// The synchronous forward reads the frame's exact cell count back with R and sizes the pool for it.
+constexpr int POOL_CELLS_PER_INSTANCE = 6;
 struct BinView {
     uint32_t* point_list;
-    uint32_t* inst_mask;     // per instance, by SLOT (Gaussian-major: the run of Gaussian g's instances): bit b set <=> slab b holds a record for it
     uint16_t* inst_bmask;    // per instance (sorted order): bit b set <=> its alpha >= 1/255 bounding box touches 4x4 block b of its tile
-    uint64_t* keys;          // aliases inst_grad (dead after the sort)
+    uint64_t* keys;          // aliases the record pool (dead after the sort)
     float4* inst_rec;        // 3 float4 per instance, sorted order: what the blend kernels stage (contiguous per tile)
-    float4* inst_grad;       // `slabs` slabs of 3 float4 per instance (one slab per 4x4 block of a tile)
     uint4* seg_desc;         // NUM_XCD_QUEUES regions of seg_cap descriptors {tile, block, first position, end position}
     float* seg_state;        // SEG_STATE_FLOATS per descriptor
     uint32_t seg_cap;        // slots per region
-    int slabs; size_t slab_stride_floats;
-    static BinView at(char* base, int R)
+    uint32_t* cell_valid;    // one bit per pool cell: the backward blend left a record there (zeroed by merge_gather); sized for 16 cells
+                             // per instance -- the most a frame can need -- so that its place does not depend on the pool's size
+    float4* inst_grad;       // THE POOL: 3 float4 per cell (see box_cells); the LAST array of the buffer: only its size varies
+    size_t pool_cells;       // its capacity
+    static BinView at(char* base, int R, long long pool_cells = -1)
     {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
-        b.slabs = blend_subgroups();
-        b.slab_stride_floats = align_up(GRAD_REC_FLOATS * n * 4) / 4;
         b.point_list = carve<uint32_t>(p, n);
-        b.inst_mask = carve<uint32_t>(p, n);
         b.inst_bmask = carve<uint16_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);
         b.seg_cap = (uint32_t)seg_region_cap(R);
         b.seg_desc = carve<uint4>(p, (size_t)NUM_XCD_QUEUES * b.seg_cap);
         b.seg_state = carve<float>(p, (size_t)NUM_XCD_QUEUES * b.seg_cap * SEG_STATE_FLOATS);
+        b.cell_valid = carve<uint32_t>(p, (16 * n + 31) / 32 + 2);
         b.inst_grad = reinterpret_cast<float4*>(p);
         b.keys = reinterpret_cast<uint64_t*>(b.inst_grad);
+        b.pool_cells = pool_cells >= 0 ? (size_t)pool_cells : default_pool_cells(R);
         return b;
     }
-    static size_t bytes(int R)
+    static size_t default_pool_cells(int R) { return (size_t)POOL_CELLS_PER_INSTANCE * (size_t)(R > 0 ? R : 1) + 4096; }
+    // bytes of a buffer for R instances whose pool holds `pool_cells` cells (never less than the sort keys need: they alias it)
+    static size_t bytes(int R, long long pool_cells = -1)
     {
-        char* z = nullptr; BinView b = at(z, R);
-        return (size_t)((char*)b.inst_grad - z) + (size_t)b.slabs * b.slab_stride_floats * 4;
+        char* z = nullptr; BinView b = at(z, R, pool_cells);
+        const size_t n = (size_t)(R > 0 ? R : 1);
+        return (size_t)((char*)b.inst_grad - z) + align_up(std::max(b.pool_cells * GRAD_REC_FLOATS * 4, n * sizeof(uint64_t)));
     }
 };
 
@@ -285,7 +348,7 @@ void launch_clear(void* ptr, size_t bytes, hipStream_t s);
 void clear_frame_state(char* frame_state, size_t bytes, hipStream_t s);   // its per-frame words (not the sticky dropped-frame count)
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header, group bases
-bool forward_buckets_keys(const FrameParams& fp);                                              // asynchronous forward without scan / scatter kernels, see binning.hip
+bool forward_buckets_keys(const FrameParams& fp);                                                // asynchronous forward without scan / scatter kernels, see binning.hip
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);   // duplicateWithKeys of the synchronous path (ranges known)
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
                       char* frame_state, size_t frame_state_bytes, int part,   // part 0: chunk sort, part 1: merge + emit

@@ -296,6 +296,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
         FSTAMP(1);
         int out_radius = 0; uint32_t out_tiles = 0; uint2 out_rect = make_uint2(0u, 0u);
         float out_depth = 0.0f;
+        uint32_t out_cells = 0u;                             // gradient-record cells of this Gaussian (common.h: box_cells)
         if (idx < P) do {
             // RAW_POSE: the canonical position is posed here, p = T x + t (the reference's caller does it with torch ops,
             // gaussian_renderer/__init__.py:74-77); rows of T times x summed left to right, then the translation
@@ -425,6 +426,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
             out_depth = p_view.z;
             out_tiles = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
             out_rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+            { const BoxCells bc = box_cells(pix.x, pix.y, hx, hy, out_rect); out_cells = (uint32_t)(max(bc.nbx, 0) * max(bc.nby, 0)); }
 
         } while (0);
         FSTAMP(2);
@@ -468,27 +470,31 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
                 }
             }
         }
-        // point_offsets: each Gaussian needs a private run of `tiles_touched` slots in inst_pos (the reference: a device-wide inclusive
-        // scan, rasterizer_impl.cu:279).  Here: the run's start RELATIVE to the block's group of 256 Gaussians (a block prefix sum) and
-        // the group's total; the scan block that rides along with the scatter kernel turns the totals into group bases.  (Round 1-2
-        // reserved the group's slots with ONE returning atomic per block on a header word: 391 atomics on one address, 11 ns each --
-        // the last block got its answer 4.5 us after the first: the tail of this kernel, scripts/sort_stamps.py.)
-        uint32_t incl = out_tiles;
+        // rec_offsets: each Gaussian needs a private run of `out_cells` records in the record pool (the reference's counterpart: the
+        // device-wide inclusive scan of tiles_touched, rasterizer_impl.cu:279).  Here: the run's start RELATIVE to the block's group of 256
+        // Gaussians (a block prefix sum) and the group's total; the scan block that rides along with the sort kernel turns the totals
+        // into group bases.  (Round 1-2 reserved the group's run with ONE returning atomic per block on a header word: 391 atomics on
+        // one address, 11 ns each -- the last block got its answer 4.5 us after the first: the tail of this kernel, scripts/sort_stamps.py.)
+        uint32_t rincl = out_cells;
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-        if (lane == 63) s_wsum[wv] = incl;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ry = __shfl_up(rincl, d);
+            if (lane >= d) rincl += ry;
+        }
+        if (lane == 63) s_wsum[wv] = rincl;
         __syncthreads();
         if (threadIdx.x == 0 && (it * gridDim.x + blockIdx.x) * blockDim.x < (unsigned)P)
-            g.group_tot[it * gridDim.x + blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-        uint32_t wbase = 0u;
-        for (int w = 0; w < wv; w++) wbase += s_wsum[w];
+            g.group_rtot[it * gridDim.x + blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t rwbase = 0u;
+        for (int w = 0; w < wv; w++) rwbase += s_wsum[w];
         if (idx < P) {
             g.radius[idx] = out_radius;
             g.tiles_touched[idx] = out_tiles;
-            g.point_offsets[idx] = wbase + incl - out_tiles;
+            g.rec_offsets[idx] = rwbase + rincl - out_cells; g.rec_count[idx] = out_cells;
+            // (third word: where the Gaussian's cell run starts, relative to its group: merge_gather reads it with the rectangle)
             g.geo[4 * (size_t)idx + 3] = make_float4(__uint_as_float(out_rect.x), __uint_as_float(out_rect.y),
-                                                     __uint_as_float(wbase + incl - out_tiles), __uint_as_float(out_tiles));
+                                                     __uint_as_float(rwbase + rincl - out_cells), __uint_as_float(out_cells));
             if (radii_out) radii_out[idx] = out_radius;
         }
         __syncthreads();
@@ -706,89 +712,58 @@ __device__ __forceinline__ void scale_rot_backward(int idx, const float* dcov, c
     }
 }
 
-// A Gaussian that covers much of the image owns up to gx*gy instances x 16 records -- a serial sum of thousands of 48-byte gathers
-// for one lane -- so those (`is_big`) are summed by the 64 lanes of the wave together, one Gaussian at a time (lane-strided partial
-// sums, then a fixed butterfly): still a fixed order, hence bitwise reproducible.  The owner's lane receives sums[0..8] =
-// {colour r, g, b, mean2D x, y, conic A, B, C, opacity}.  Must be called with the whole wave converged.
-__device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t n_inst,
-                                            const uint32_t* __restrict__ inst_mask, const float4* __restrict__ inst_grad,
-                                            size_t slab_stride_f4, float* sums)
+// A Gaussian's gradient records are the CELLS of its run in the record pool whose validity bit is set (common.h: box_cells; the bits
+// are set by the backward blend).  One that covers much of the image owns thousands of cells -- a serial sum of thousands of 48-byte
+// gathers for one lane -- so those (`is_big`: more than COOP_WORDS words of validity bits) are summed by the 64 lanes of the wave
+// together, one Gaussian at a time: lane l takes cells c0 + l, c0 + l + 64, ... (consecutive lanes read consecutive records: a wide
+// Gaussian's cells are mostly flagged, and its run is contiguous -- rounds 1-4 walked instance slots x slabs with dependent loads),
+// eight cells per lane in flight; then a fixed butterfly.  A fixed order, hence bitwise reproducible.  The owner's lane receives
+// sums[0..8] = {colour r, g, b, mean2D x, y, conic A, B, C, opacity}.  Must be called with the whole wave converged.
+__device__ __forceinline__ uint32_t run_word_mask(uint32_t word, uint32_t c0, uint32_t c1)   // bits of validity word `word` that belong to cells [c0, c1)
+{
+    const uint32_t base = word << 5;
+    const uint32_t lo = c0 > base ? c0 - base : 0u, hi = c1 > base ? min(c1 - base, 32u) : 0u;
+    if (hi <= lo) return 0u;
+    return (hi >= 32u ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+}
+__device__ __forceinline__ void coop_gather(bool is_big, uint32_t c0, uint32_t c1,
+                                            const uint32_t* __restrict__ cell_valid, const float4* __restrict__ inst_grad, float* sums)
     {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr uint32_t OOB = 0xffffffffu, RSRC3 = 0x00020000u;
+        // (buffer loads: an out-of-range offset returns 0 without a memory request -- an absent or unflagged cell costs nothing and adds 0)
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)cell_valid, 0, 0xffffff00u, RSRC3);
+        const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)inst_grad, 0, 0xffffff00u, RSRC3);
         unsigned long long big = __ballot(is_big);
-        const int lane = (int)(threadIdx.x & 63u);
+        const uint32_t lane = threadIdx.x & 63u;
         while (big) {
             const int src = __ffsll(big) - 1;
             big &= big - 1;
-            const uint32_t boff = __shfl(off, src), bn = __shfl(n_inst, src);
+            const uint32_t bc0 = __shfl(c0, src), bc1 = __shfl(c1, src);
             float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            {
-                // Sparse records.  A Gaussian that covers the image owns ~1000 instances with up to 4 (light tiles) or 16 (heavy
-                // tiles) flagged records each, found through the mask words (inst_mask -> record): walked
-                // naively that is thousands of DEPENDENT loads for one wave (measured: +90 us per frame with ~50 such Gaussians).
-                // So: 16 instances per lane at a time, their positions and masks fetched together, then the first four flagged
-                // records of every instance with unconditional loads in straight-line code (the next instance's loads are
-                // issued before this one's are summed); further records (only heavy tiles have them) in a clean-up loop.
-                constexpr int IPL = 16;                                          // instances per lane per round
-                for (uint32_t c0 = 0; c0 < bn; c0 += 64u * IPL) {
-                    uint32_t p[IPL], mk[IPL];
+            constexpr int CPL = 8;                                               // cells per lane per round
+            for (uint32_t r0 = bc0; r0 < bc1; r0 += 64u * CPL) {
+                uint32_t vw[CPL];
 #pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
-                        p[i] = boff + min(k, bn - 1u);                              // the instance's slot: records and masks are filed under it
-                    }
+                for (int i = 0; i < CPL; i++) {
+                    const uint32_t cell = r0 + 64u * (uint32_t)i + lane;
+                    vw[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, cell < bc1 ? (cell >> 5) * 4u : OOB, 0, 0);
+                }
+                v4f ra[CPL], rb[CPL]; float rc[CPL];
 #pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        const uint32_t k = c0 + 64u * i + (uint32_t)lane;
-                        const uint32_t m = inst_mask[p[i]];
-                        mk[i] = k < bn ? m : 0u;
-                    }
-                    struct Quad { float4 r[4][3]; float w[4]; };
-                    auto fetch = [&](int i) {
-                        Quad qd;
-                        uint32_t m = mk[i];
-                        int sl = m ? __ffs((int)m) - 1 : 0;                      // no flagged record: slab 0 is read and ignored
+                for (int i = 0; i < CPL; i++) {
+                    const uint32_t cell = r0 + 64u * (uint32_t)i + lane;
+                    const bool on = ((vw[i] >> (cell & 31u)) & 1u) != 0u;       // (vw = 0 beyond the run)
+                    const uint32_t o = on ? cell * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
+                    ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
+                    rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, on ? o + 16u : OOB, 0, 0);
+                    rc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rec, on ? o + 32u : OOB, 0, 0));
+                }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            qd.w[j] = m ? 1.0f : 0.0f;
-                            if (m) { sl = __ffs((int)m) - 1; m &= m - 1u; }
-                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
-                            qd.r[j][0] = rec[0]; qd.r[j][1] = rec[1]; qd.r[j][2] = rec[2];
-                        }
-                        mk[i] = m;                                               // what is left for the clean-up loop
-                        return qd;
-                    };
-                    auto add = [&](const Quad& qd) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            // unflagged slots may hold anything (never written): select, do not multiply
-                            const bool on = qd.w[j] != 0.0f;
-                            acc[0] += on ? qd.r[j][0].x : 0.f; acc[1] += on ? qd.r[j][0].y : 0.f; acc[2] += on ? qd.r[j][0].z : 0.f;
-                            acc[3] += on ? qd.r[j][0].w : 0.f; acc[4] += on ? qd.r[j][1].x : 0.f; acc[5] += on ? qd.r[j][1].y : 0.f;
-                            acc[6] += on ? qd.r[j][1].z : 0.f; acc[7] += on ? qd.r[j][1].w : 0.f; acc[8] += on ? qd.r[j][2].x : 0.f;
-                        }
-                    };
-                    const int rounds = (int)min((uint32_t)IPL, (bn - c0 + 63u) / 64u);     // wave-uniform: rounds with any instance
-                    Quad cur = fetch(0);
-#pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        if (i < rounds) {
-                            Quad nxt = cur;
-                            if (i + 1 < rounds) nxt = fetch(i + 1);
-                            add(cur);
-                            cur = nxt;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < IPL; i++) {
-                        for (uint32_t mbits = mk[i]; mbits != 0u; mbits &= mbits - 1u) {
-                            const int sl = __ffs((int)mbits) - 1;
-                            const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)p[i];
-                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                            acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
-                            acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
-                            acc[8] += r2.x;
-                        }
-                    }
+                for (int i = 0; i < CPL; i++) {
+                    acc[0] += ra[i].x; acc[1] += ra[i].y; acc[2] += ra[i].z; acc[3] += ra[i].w;
+                    acc[4] += rb[i].x; acc[5] += rb[i].y; acc[6] += rb[i].z; acc[7] += rb[i].w;
+                    acc[8] += rc[i];
                 }
             }
 #pragma unroll
@@ -796,7 +771,7 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d);
             }
-            if (lane == src) {
+            if ((int)lane == src) {
 #pragma unroll
                 for (int q = 0; q < 9; q++) sums[q] = acc[q];
             }
@@ -807,7 +782,7 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t off, uint32_t 
 // the dL_dsh records leave the same way.  Per thread a record is 48 floats at a 192-byte stride, i.e. every one of the 48 loads
 // and 48 stores of a wave would touch 64 different cache lines; through LDS (row stride 49 words: conflict-free) the global side
 // is 12 fully coalesced 16-byte accesses per lane.
-// Gradient records are sparse: slab b of an instance holds a record only if bit b of its inst_mask is set (blend.hip).
+// Gradient records are sparse: cell c of the Gaussian's run holds a record only if bit c of cell_valid is set (blend.hip).
 constexpr int SH_ROW = 49;
 constexpr int GATHER_CAP = 320;                          // records of a wave gathered per pass (8 rows of 64)
 constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
@@ -823,8 +798,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                            const float* __restrict__ scales, const float* __restrict__ rotations,
                            const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                            const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
-                           GeomView g, const float4* __restrict__ inst_grad,
-                           int slabs, size_t slab_stride_f4, const uint32_t* __restrict__ inst_mask, const uint32_t* __restrict__ header,
+                           GeomView g, const float4* __restrict__ inst_grad /* the record pool */,
+                           const uint32_t* __restrict__ cell_valid /* one bit per cell: a record was left there */, const uint32_t* __restrict__ header,
                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
@@ -881,7 +856,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     const bool in_range = idx < P;                           // no early return: the wave gathers large Gaussians together
     // All first-level loads are issued together and unconditionally (clamped indices): the 12 SH float4 of this thread's share of
     // the block's records, tiles_touched, point_offsets, the header flags.  Stamps showed this phase -- 12 SH loads each waited
-    // for in turn, then a five-deep chain tiles_touched -> point_offsets -> inst_pos -> inst_mask -> record -- taking 48k of a
+    // for in turn, then (round 2) a five-deep chain tiles_touched -> point_offsets -> inst_pos -> inst_mask -> record -- taking 48k of a
     // block's 62k cycles.
     const int idc = min(idx, P - 1);
     float4 shv[12];
@@ -895,7 +870,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             else shv[j] = src[f / 12 < rows_used ? min((size_t)min(gaussian_of_row((f / 12) << lpg_l2), P - 1) * 12 + (size_t)(f % 12), total4 - 1) : total4 - 1];
         }
     }
-    const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.point_offsets[idc] + g.group_base[idc >> 8], hdr_flags = header[2];
+    // (the Gaussian's run of cells in the record pool: where it starts -- group base + start in the group -- and how long it is)
+    const uint32_t tt_raw = g.tiles_touched[idc], off_raw = g.rec_offsets[idc] + g.group_rbase[idc >> 8], cells_raw = g.rec_count[idc], hdr_flags = header[2];
     // Every per-Gaussian input of the arithmetic at the end is requested HERE too, unconditionally (clamped index): the position, the
     // transform, the covariance, scales / rotation, the raw opacity, the clamp flags -- none depends on the gather.  Loads complete
     // in order: read where they are used -- behind the fused update's moment loads, which are requested before the arithmetic so that
@@ -960,68 +936,63 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // stay bit for bit), like moss_adamw_flat_guarded on the frame's status word
     const bool fa_on = FUSED && !(hdr_flags & ERRFLAG_OVERFLOW);
 
-    // Sum the per-instance partial records.  A Gaussian with few instances (the norm: 2-3) is summed by its own lane.  One that
-    // covers much of the image owns up to gx*gy instances x `slabs` records -- a serial sum of thousands of 48-byte gathers -- so
-    // those are summed by the 64 lanes of the wave together (lane-strided partial sums, then a fixed butterfly): still a fixed
-    // order, hence bitwise reproducible.
-    constexpr uint32_t COOP_INST = 16;
-    const uint32_t off = visible ? off_raw : 0u;
-    uint32_t k_first = 0;                                    // first instance the serial loop below still has to visit
-    // (buffer loads address with 32-bit byte offsets: beyond 4 GB of record slabs -- R > 5.5M instances -- the serial loop does it all)
-    if ((unsigned long long)slabs * slab_stride_f4 * 16ull < 0xffffff00ull) {
-        // Sparse records, the common case (a Gaussian owns 2-3 instances, at most 16 here, with 1-2 flagged records each): walked one
-        // after the other, every record costs three DEPENDENT loads (inst_pos -> inst_mask -> record) and the wave waits for its
-        // lane with the most instances: stamps showed this phase taking 48k of a block's 62k cycles.  Here all positions, then all
-        // masks, then -- four instances at a time -- the first two flagged records of each instance are fetched as batches of
-        // independent loads.  The summation order is fixed (batch of 4 instances, round of 2 records, instance, slab), so gradients
-        // stay bitwise reproducible.
-        const bool mine = visible && n_inst <= COOP_INST;
+    // Sum the Gaussian's gradient records: the cells of its run [c0, c1) in the record pool whose validity bit is set (common.h:
+    // box_cells; the backward blend sets the bits).  A run of <= COOP_WORDS words of validity bits (the norm: 10-20 cells, one or two
+    // words) is summed by the Gaussian's own lane -- or its group of lanes; one that covers much of the image owns thousands of cells
+    // and is summed by the 64 lanes of the wave together (coop_gather: lane-strided partial sums, then a fixed butterfly): still a
+    // fixed order, hence bitwise reproducible.
+    constexpr uint32_t COOP_WORDS = 16;
+    const uint32_t c0 = visible ? off_raw : 0u, c1 = c0 + (visible ? cells_raw : 0u);
+    const uint32_t word0 = c0 >> 5, n_words = c1 > c0 ? ((c1 + 31u) >> 5) - word0 : 0u;
+    {
+        // Sparse records (a Gaussian owns 2-3 instances of 4-5 cells each, about half of them flagged): walked one after the other, every
+        // record costs two DEPENDENT loads (validity word -> record) and the wave waits for its lane with the most: stamps showed this
+        // phase taking 48k of a block's 62k cycles in round 2.  Here all validity words, then -- four words at a time -- the first
+        // two flagged records of each word are fetched as batches of independent loads.  The summation order is fixed (batch of 4 words,
+        // round of 2 records, word, bit), so gradients stay bitwise reproducible.
+        const bool mine = n_words != 0u && n_words <= COOP_WORDS;
         PSTAMP(8);
-        // LPG = 16 (LPG_L2 == 4): the 16 lanes of a Gaussian's group take ONE instance each -- lane (g, j) the j-th of Gaussian g's
-        // <= 16 instances: one mask load per lane instead of sixteen per owner, and the filing loop below (serial over a lane's
-        // instances and their flagged slabs, the whole wave in step) runs <= 16 rounds for any wave: with four owners doing the
-        // filing of four Gaussians x 16 instances alone it was 16k of a block's 34k cycles (scripts/prebwd_fused_stamps.py, configs[1]).
+        // LPG = 16 (LPG_L2 == 4): the 16 lanes of a Gaussian's group take ONE validity word each -- lane (g, j) the j-th of Gaussian g's
+        // <= 16 words: one word load per lane instead of sixteen per owner, and the filing loop below (serial over a lane's words and
+        // their flagged cells, the whole wave in step) runs over one word per lane: with four owners doing the filing of four Gaussians
+        // alone it was 16k of a block's 34k cycles (scripts/prebwd_fused_stamps.py, configs[1]).
         const int lane_g = (int)(threadIdx.x & 63u);
-        uint32_t g_off = off, g_n = mine ? n_inst : 0u;
+        uint32_t g_c0 = c0, g_c1 = c1, g_n = mine ? n_words : 0u;
         if constexpr (LPG_L2 == 4) {
-            g_off = (uint32_t)__shfl((int)g_off, lane_g & ~15); g_n = (uint32_t)__shfl((int)g_n, lane_g & ~15);
+            g_c0 = (uint32_t)__shfl((int)g_c0, lane_g & ~15); g_c1 = (uint32_t)__shfl((int)g_c1, lane_g & ~15); g_n = (uint32_t)__shfl((int)g_n, lane_g & ~15);
         }
-        const bool has_inst = (uint32_t)(lane_g & 15) < g_n;         // (LPG = 16 only)
-        uint32_t wmax = LPG_L2 == 4 ? (has_inst ? 1u : 0u) : (mine ? n_inst : 0u);
+        const bool has_word = (uint32_t)(lane_g & 15) < g_n;         // (LPG = 16 only)
+        uint32_t wmax = LPG_L2 == 4 ? (has_word ? 1u : 0u) : (mine ? n_words : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
-        // Loads are PREDICATED per lane (a lane without a k-th instance issues no request): the random 4- and 48-byte reads are
-        // bound by request count (stamps: 16 + 16 + 72 unconditional loads per lane cost 51k cycles per wave).  Each batch is waited
-        // for as a whole, so the compiler's vmcnt(0) after predicated loads costs nothing here.
-        // BUFFER loads: a lane without a k-th instance / j-th record passes an out-of-range offset, which returns 0 WITHOUT a memory
+        // BUFFER loads: a lane without a k-th word / j-th record passes an out-of-range offset, which returns 0 WITHOUT a memory
         // request.  That keeps every load unconditional (no branch, so the compiler counts its waits exactly and a batch is in
         // flight together) and free for absent lanes -- these random 4- and 48-byte reads are bound by request count (stamps:
         // 104 unconditional global loads per lane cost 51k cycles per wave; predicated ones were each waited for at their join).
+        // (32-bit byte offsets: the scan refuses a frame of more than POOL_MAX_CELLS cells -- 48 B x 80M < 4 GB)
         typedef float v4f __attribute__((ext_vector_type(4)));
         constexpr uint32_t OOB = 0xffffffffu, RSRC3 = 0x00020000u;
-        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)inst_mask, 0, 0xffffff00u, RSRC3);
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)cell_valid, 0, 0xffffff00u, RSRC3);
         const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)inst_grad, 0, 0xffffff00u, RSRC3);
-        const uint32_t slab_bytes = (uint32_t)(slab_stride_f4 * 16);
-        // (records and mask words are filed under the instance's SLOT = run start + k: no position table between the Gaussian and
-        // its records -- round 2 went Gaussian -> inst_pos -> inst_mask -> record, one more dependent round trip)
-        uint32_t pp[COOP_INST], mm[COOP_INST];
+        // (no table between the Gaussian and its records: the run's start and length are per-Gaussian values of the forward pass)
+        uint32_t pp[COOP_WORDS], mm[COOP_WORDS];             // validity word index, its bits inside the run
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++) pp[k] = LPG_L2 == 4 ? (k == 0 ? g_off + (uint32_t)(lane_g & 15) : 0u) : off + (uint32_t)k;
+        for (int k = 0; k < (int)COOP_WORDS; k++) pp[k] = LPG_L2 == 4 ? (k == 0 ? (g_c0 >> 5) + (uint32_t)(lane_g & 15) : 0u) : word0 + (uint32_t)k;
         PSTAMP(9);
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++) {
-            if constexpr (LPG_L2 == 4) mm[k] = k == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs_msk, has_inst ? pp[0] * 4u : OOB, 0, 0) : 0u;
-            else mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_inst) ? pp[k] * 4u : OOB, 0, 0);
+        for (int k = 0; k < (int)COOP_WORDS; k++) {
+            if constexpr (LPG_L2 == 4) mm[k] = k == 0 ? (__builtin_amdgcn_raw_buffer_load_b32(rs_msk, has_word ? pp[0] * 4u : OOB, 0, 0) & run_word_mask(pp[0], g_c0, g_c1)) : 0u;
+            else mm[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (mine && (uint32_t)k < n_words) ? pp[k] * 4u : OOB, 0, 0) & run_word_mask(pp[k], c0, c1);
         }
         PSTAMP(10);
         // ---- two ways to fetch the flagged records, chosen per wave.  How many records each lane owns:
         uint32_t cnt = 0u;
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++) cnt += (uint32_t)__popc(mm[k]);
+        for (int k = 0; k < (int)COOP_WORDS; k++) cnt += (uint32_t)__popc(mm[k]);
         uint32_t incl = cnt;
-        uint32_t bmax = 0u;                                   // byte b: the most records one instance of batch b (instances 4b .. 4b+3) has
+        uint32_t bmax = 0u;                                   // byte b: the most records one word of batch b (words 4b .. 4b+3) has
 #pragma unroll
-        for (int k = 0; k < (int)COOP_INST; k++) {
+        for (int k = 0; k < (int)COOP_WORDS; k++) {
             const uint32_t pc = (uint32_t)__popc(mm[k]), sh = 8u * (uint32_t)(k >> 2);
             bmax = max(bmax & (0xffu << sh), pc << sh) | (bmax & ~(0xffu << sh));
         }
@@ -1039,23 +1010,23 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
         }
         const uint32_t W_all = (uint32_t)__shfl((int)incl, 63);
-        // DIRECT (lane by lane: four instances x two records per round trip) makes sum over the batches of ceil(most records of one
-        // instance / 2) round trips of 2-4k cycles (few waves ... a busy memory system); BALANCED (below) a pass of ~20k cycles -- filing,
+        // DIRECT (lane by lane: four words x two records per round trip) makes sum over the batches of ceil(most records of one
+        // word / 2) round trips of 2-4k cycles (few waves ... a busy memory system); BALANCED (below) a pass of ~20k cycles -- filing,
         // one round of requests, the scans --
         // per GATHER_CAP records of the wave, whoever owns them.  Balanced pays when the records are unevenly spread (cfg3: 5 per lane
         // on average, 30 for the busiest: 24 vs 28 us); when every lane owns many (cfg2's wide Gaussians) it would be passes on end
         // (61 vs 24 us).
         const uint32_t passes = (W_all + (uint32_t)GATHER_CAP - 1u) / (uint32_t)GATHER_CAP;
         const uint32_t direct_trips = ((bmax & 0xffu) + 1u) / 2u + (((bmax >> 8) & 0xffu) + 1u) / 2u + (((bmax >> 16) & 0xffu) + 1u) / 2u + ((bmax >> 24) + 1u) / 2u;
-        const bool balanced = LPG_L2 == 4 ? true :           // (the group's lanes hold one instance each: only the list form sums a Gaussian's records)
+        const bool balanced = LPG_L2 == 4 ? true :           // (the group's lanes hold one word each: only the list form sums a Gaussian's records)
                               (raw & 0x200) ? false : (raw & 0x400) ? true : (passes == 1u ? direct_trips >= 5u : passes * 8u < direct_trips);     // (0x200 / 0x400: diagnostics, MOSS_GATHER=1 / 2)
         if (!balanced) {
 #pragma unroll
-        for (int kb = 0; kb < (int)COOP_INST; kb += 4) {
+        for (int kb = 0; kb < (int)COOP_WORDS; kb += 4) {
             if ((uint32_t)kb < wmax) {                       // wave-uniform
                 uint32_t bits[4] = { mm[kb], mm[kb + 1], mm[kb + 2], mm[kb + 3] };
-                // rounds of (4 instances x their next 2 flagged records); almost always one round, an instance whose box covers
-                // a whole heavy tile has up to 16 records = 8 rounds.  The order (round, instance, slab) is fixed.
+                // rounds of (4 words x their next 2 flagged records); a word whose cells are all flagged has 32 records = 16 rounds.
+                // The order (round, word, bit) is fixed.
                 do {
                     v4f rr[4][2][3];
 #pragma unroll
@@ -1065,7 +1036,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                             const bool any = bits[k] != 0u;
                             const uint32_t sl = any ? (uint32_t)(__ffs((int)bits[k]) - 1) : 0u;
                             bits[k] &= bits[k] - 1u;                               // (0 stays 0)
-                            const uint32_t o = any ? sl * slab_bytes + pp[kb + k] * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
+                            const uint32_t o = any ? ((pp[kb + k] << 5) + sl) * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
                             rr[k][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
                             rr[k][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 16u : OOB, 0, 0);
                             rr[k][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, any ? o + 32u : OOB, 0, 0);
@@ -1088,7 +1059,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         // ---- wave-balanced gather.  A lane owns 3-5 flagged records on average but some own 30+: fetched lane by lane (round 2: four
         // instances x two records per round trip) the wave made 4-6 dependent round trips for its busiest lane -- 17k of a block's 41k
         // cycles.  Here the wave's records are put in ONE list (lane i's records at list positions base_i .. base_i + c_i - 1, in the
-        // fixed order instance, slab), every lane fetches the records at positions lane, lane + 64, ... whoever owns them -- all
+        // fixed order of their cells), every lane fetches the records at positions lane, lane + 64, ... whoever owns them -- all
         // requested before any is waited for -- and a segmented scan over each row of 64 hands every owner its sum.  The order of the
         // additions is fixed by the list: bitwise reproducible.
         {
@@ -1097,7 +1068,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             const int lane = (int)(threadIdx.x & 63u);
             const uint32_t base = incl - cnt, W = W_all;
             // whose run a lane picks up: its own records -- or, LPG = 16, the owner lane its whole group's (the sixteen lanes' runs are
-            // consecutive in the list, in instance order: the same order of additions as one lane filing all of them)
+            // consecutive in the list, in cell order: the same order of additions as one lane filing all of them)
             uint32_t run_base = base, run_cnt = cnt;
             bool head_ok = true;                                                          // the lane's first record starts a Gaussian's run
             if constexpr (LPG_L2 == 4) {
@@ -1107,19 +1078,19 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             }
             for (uint32_t w0 = 0u; w0 < W; w0 += (uint32_t)GATHER_CAP) {                 // (one pass unless the wave owns > GATHER_CAP records)
                 const uint32_t w1 = min(W, w0 + (uint32_t)GATHER_CAP);
-                // 1. every lane files its records' descriptors {head of the lane's run << 31 | slab << 27 | slot}
+                // 1. every lane files its records' descriptors {head of the lane's run << 31 | cell}
                 __builtin_amdgcn_wave_barrier();
                 {
                     uint32_t j = base;
 #pragma unroll
-                    for (int k = 0; k < (int)COOP_INST; k++) {
+                    for (int k = 0; k < (int)COOP_WORDS; k++) {
                         if ((uint32_t)k < wmax) {                                        // wave-uniform
                             uint32_t bits = mm[k];
                             while (__ballot(bits != 0u) != 0ull) {
                                 if (bits != 0u) {
                                     const uint32_t sl = (uint32_t)(__ffs((int)bits) - 1);
                                     bits &= bits - 1u;
-                                    if (j >= w0 && j < w1) w_desc[j - w0] = ((j == base && head_ok) ? 0x80000000u : 0u) | (sl << 27) | pp[k];
+                                    if (j >= w0 && j < w1) w_desc[j - w0] = ((j == base && head_ok) ? 0x80000000u : 0u) | ((pp[k] << 5) + sl);
                                     j++;
                                 }
                             }
@@ -1136,7 +1107,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                     const uint32_t w = w0 + 64u * (uint32_t)r + (uint32_t)lane;
                     const bool on = w < w1;
                     dsc[r] = on ? w_desc[w - w0] : 0x80000000u;
-                    const uint32_t o = on ? ((dsc[r] >> 27) & 15u) * slab_bytes + (dsc[r] & 0x07ffffffu) * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
+                    const uint32_t o = on ? (dsc[r] & 0x7fffffffu) * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
                     ra[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
                     rb[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, on ? o + 16u : OOB, 0, 0);
                     rc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rec, on ? o + 32u : OOB, 0, 0));
@@ -1174,26 +1145,11 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                 }
             }
         }
-        k_first = COOP_INST;                                 // nothing left for the serial loop
         PSTAMP(11);
-    }
-    if (visible && n_inst <= COOP_INST) {
-        for (uint32_t k = k_first; k < n_inst; k++) {
-            const uint32_t pos = off + k;
-            // only the slabs flagged in the instance's mask, ascending
-            for (uint32_t mbits = inst_mask[pos]; mbits != 0u; mbits &= mbits - 1u) {
-                const int sl = __ffs((int)mbits) - 1;
-                const float4* rec = inst_grad + (size_t)sl * slab_stride_f4 + (GRAD_REC_FLOATS / 4) * (size_t)pos;
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                gcol.x += r0.x; gcol.y += r0.y; gcol.z += r0.z; gmx += r0.w;
-                gmy += r1.x; gca += r1.y; gcb += r1.z; gcc += r1.w;
-                gop += r2.x;
-            }
-        }
     }
     {
         float sums[9] = { gcol.x, gcol.y, gcol.z, gmx, gmy, gca, gcb, gcc, gop };
-        coop_gather(visible && n_inst > COOP_INST, off, n_inst, inst_mask, inst_grad, slab_stride_f4, sums);
+        coop_gather(n_words > COOP_WORDS, c0, c1, cell_valid, inst_grad, sums);
         gcol.x = sums[0]; gcol.y = sums[1]; gcol.z = sums[2]; gmx = sums[3]; gmy = sums[4]; gca = sums[5]; gcb = sums[6]; gcc = sums[7]; gop = sums[8];
     }
     PSTAMP(12);
@@ -1582,7 +1538,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
                        ((STAGE) ? (size_t)threads * SH_ROW * sizeof(float) : 0) + (size_t)((threads + 63) / 64) * GATHER_WORDS * 4, s,                                               \
                        fp.P, fp.D, fp.M, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y, -0.5f * (float)fp.W, -0.5f * (float)fp.H, fp.scale_modifier, \
                        means3D, shs, scales, rotations, cov3D_precomp, fp.view_dev, fp.proj_dev, fp.campos_dev,                 \
-                       g, b.inst_grad, b.slabs, b.slab_stride_floats / 4, b.inst_mask, header, dL_dmean2D, dL_dconic, \
+                       g, b.inst_grad, b.cell_valid, header, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, transforms, dL_dtransforms, opacities, fp.raw | gather_knob | (gl2 << 12), g_stamps, queues, translation, dL_dtranslation, fa)
     // (lanes per Gaussian: instantiated for the staged-SH kernels -- MOSS's case, M = 16 -- only)
     if (stage && lpg_l2 == 4) { if (fa.tensors != 0u) LAUNCH_PB(true, true, 4); else LAUNCH_PB(true, false, 4); }

@@ -198,6 +198,7 @@ static int forward_impl(
     if (key_stride < 2u) key_stride = 0u;
     const bool bucketed = key_stride != 0u;
     int R = 0, total_chunks = 0;
+    long long pool_cells = -1;                               // (-1: the default pool of a buffer for R instances, BinView::default_pool_cells)
     char* bin_ptr = nullptr;
     BinView b;
     if (bucketed) {
@@ -217,13 +218,20 @@ static int forward_impl(
         if (capacity < 0) {
             // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
             if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
-            HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 32, hipMemcpyDeviceToHost, s));
+            // ... and the frame's gradient-record cells (header[9]) size the record pool at the buffer's end exactly
+            HIP_TRY(hipMemcpyAsync(g_pinned.p, im.header, 40, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             R = (int)g_pinned.p[0];
             total_chunks = (int)g_pinned.p[4];
+            pool_cells = (long long)g_pinned.p[9];
             if (g_pinned.p[2] & ERRFLAG_PREFILTERED) {
                 abandon_frame_state();
                 return fail(MOSS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+            }
+            if (g_pinned.p[2] & ERRFLAG_OVERFLOW) {                      // (the only overflow a synchronous forward knows)
+                abandon_frame_state();
+                return fail(MOSS_ERR_UNSUPPORTED, "the frame needs more than 80M gradient-record cells (4x4 pixel blocks under the Gaussians' "
+                                                  "bounding boxes): the record pool is addressed with 32-bit byte offsets");
             }
         } else {
             // Asynchronous: no read-back.  Buffers and grids are sized for the caller's capacity; kernels bound themselves with the
@@ -231,9 +239,9 @@ static int forward_impl(
             R = (int)capacity;
             total_chunks = (int)(capacity / 1024) + T;
         }
-        bin_ptr = binning_alloc(binning_user, BinView::bytes(R));
+        bin_ptr = binning_alloc(binning_user, BinView::bytes(R, pool_cells));
         if (!bin_ptr) { abandon_frame_state(); return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL"); }
-        b = BinView::at(bin_ptr, R);
+        b = BinView::at(bin_ptr, R, pool_cells);
     }
 
     if (R > 0) {

@@ -35,7 +35,7 @@ char* grow(void* user, size_t nbytes)                     // resizeFunctional, r
         return reinterpret_cast<char*>(t->data_ptr());
     } catch (const std::exception& e) {
         g_alloc_error = std::string("allocating ") + std::to_string(nbytes) + " bytes of rasterizer scratch failed (the binning buffer takes "
-                        "~834 B per (Gaussian, tile) instance, see INTEGRATION.md): " + e.what();
+                        "~360 B per (Gaussian, tile) instance: 66 B of tables + 48 B per gradient-record cell, see INTEGRATION.md): " + e.what();
         return nullptr;
     }
 }

@@ -21,6 +21,7 @@ L.moss_raster_debug_set_stamps(None)
 s = buf.cpu().numpy()[131072:]
 for name, off in (("chunk_sort [lookup, key load, network, store]", 0), ("merge_gather [lookup, keys+searches, gather, emit]", 8 * 1024)):
     w = s[off: off + 8 * 1024].reshape(-1, 8).astype(np.float64)
+    scan_row = w[0].copy() if (off == 0 and w[0, 0] == 0 and w[0, 5] > 0) else None     # (--async: workgroup 0 of the sort kernel is the scan block)
     w = w[(w[:, 0] > 0) & (w[:, 4] > 0)]
     # the clocks of the 8 XCDs are not synchronised: spans per XCD (workgroup index % 8)
     ph = np.diff(w[:, :5], axis=1)
@@ -28,6 +29,8 @@ for name, off in (("chunk_sort [lookup, key load, network, store]", 0), ("merge_
     t0 = w[:, 5].min()
     print("   realtime (us): workgroup starts median %.2f last %.2f | ends median %.2f p90 %.2f last %.2f" % (
         np.median(w[:, 5] - t0) / 100, (w[:, 5].max() - t0) / 100, np.median(w[:, 7] - t0) / 100, np.percentile(w[:, 7] - t0, 90) / 100, (w[:, 7].max() - t0) / 100))
+    if scan_row is not None:
+        print("   the scan block (workgroup 0): start %.2f end %.2f" % ((scan_row[5] - t0) / 100, (scan_row[7] - t0) / 100))
     big = w[:, 6] >= (1024 if off == 0 else 3)
     if big.any():
         print("   full chunks / tiles of >= 3 chunks:", int(big.sum()), "mean phases", np.diff(w[big, :5], axis=1).mean(0).astype(int))
@@ -41,7 +44,7 @@ for i, name in ((0, "start"), (1, "loads issued + SH staged"), (2, "geometry don
 
 w = s[16384: 16384 + 8 * 512].reshape(-1, 8).astype(np.float64)
 w = w[w[:, 0] > 0]
-t0 = w[:, 0].min()
+t0 = w[:, 0].min() if len(w) else 0.0
 scan = w[w[:, 5] > 0]; blk = w[w[:, 4] > 0]
 print("scatter blocks", len(blk), "(realtime us, relative to the first block's start)" if len(blk) else "(none: the preprocess kernel wrote the keys)")
 for i, name in [] if not len(blk) else ((0, "start"), (1, "own instances counted"), (2, "tile starts known"), (3, "runs reserved"), (4, "keys written, end")):

@@ -1493,6 +1493,7 @@ def test_scale_beyond_the_largest_baseline_config(gpu, hip_lib):
     sc = scenes.body_scene(1_000_000, 2048, 2048, 540.0 * 4, init_like=False, name="stress")
     d = hp.inputs_of(sc, "scale_rot")
     runs = []
+    torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
     for _ in range(2):
         t = hp.hip_forward(d, gpu)
         dc, dd, da = hp.image_grads(2048, 2048, seed=5)
@@ -1501,6 +1502,16 @@ def test_scale_beyond_the_largest_baseline_config(gpu, hip_lib):
     assert runs[0][0] == runs[1][0] > 3_000_000
     for a, b in zip(runs[0][1:], runs[1][1:]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+    # Scratch: the binning buffer of this frame (the synchronous forward sizes the gradient-record pool for the frame's cells exactly)
+    # and the whole test's peak (inputs, two runs' outputs and gradients, scratch): rounds 1-4 held 16 record slabs per instance --
+    # 834 B per instance, 3.2 GB for this frame; review item 7 of round 4 asked for <= 400 B per instance and <= 4 GiB peak here.
+    R = runs[0][0]
+    per_instance = t.binning.numel() / R
+    assert per_instance <= 400, per_instance
+    assert hip_lib.moss_raster_binning_bytes(R) <= 400 * R
+    assert torch.cuda.max_memory_allocated() <= 4 << 30, torch.cuda.max_memory_allocated() / 2**30
+    print(f"1M Gaussians: R = {R}, binning buffer {t.binning.numel() / 2**20:.0f} MiB = {per_instance:.0f} B per instance, "
+          f"peak allocated {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
 
 
 @pytest.mark.parametrize("with_transforms", [False, True])

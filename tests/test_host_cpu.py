@@ -99,6 +99,8 @@ def test_scratch_size_functions_are_host_only_and_monotonic(hip_lib):
     assert g[0] < g[1] < g[2] and g[2] < 100000 * 120           # ~ 100 B per Gaussian
     b = [hip_lib.moss_raster_binning_bytes(r) for r in (0, 1000, 1000000)]
     assert b[0] <= b[1] < b[2]
+    # the binning buffer: ~66 B of per-instance tables + a record pool of 6 cells x 48 B per instance (rounds 1-4: 16 slabs, 834 B)
+    assert b[2] <= 400 * 1000000 and b[0] < (16 << 20)              # (the constant: the blend kernels' segment queues)
     assert hip_lib.moss_raster_image_bytes(512, 512) >= 512 * 512 * 8
     assert hip_lib.moss_knn_workspace_bytes(6890) >= 6890 * 24
     assert hip_lib.moss_loss_workspace_bytes(3, 512, 512) >= 3 * 3 * 512 * 512 * 4
@@ -728,6 +730,35 @@ def test_per_gaussian_backward_keeps_two_waves_per_simd():
     assert set(found) == {(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 0, 4), (1, 1, 4)}, found
     for key, (vg, ag, occ, scr) in found.items():
         assert occ >= 2 and vg + ag <= 256 and scr <= 128, f"preprocess_backward_kernel<STAGE_SH={key[0]}, FUSED={key[1]}, LPG_L2={key[2]}>: {vg} VGPRs + {ag} AGPRs, {occ} waves per SIMD, {scr} B scratch"
+
+
+def test_sort_kernel_keeps_two_workgroups_per_cu():
+    """chunk_sort_kernel runs 1024-thread workgroups -- four waves per SIMD each -- and its whole grid (the frame's chunks + the scan
+    block that rides along on the asynchronous path) must be resident at once: two workgroups per CU = 8 waves per SIMD = at most 64
+    VGPRs.  Round 5 measured what 70 cost (a 64-bit division in the scan block's overflow hint, values held across its third block
+    scan): 12.9 -> 16.7 us, late workgroups starting 8 us into the kernel (scripts/sort_stamps.py)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from moss_amd import build as hip_build
+    src = os.path.join(ROOT, "moss_amd", "csrc", "binning.hip")
+    with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "moss_amd", "lib")) as tmp:
+        cmd = [hipcc] + [a for a in hip_build.COMMON if a != "-Wall"] + hip_build.SOURCES["binning.hip"] + \
+              ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(tmp, "bn.o")]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    found = {}
+    for b in re.split(r"remark: Function Name: ", p.stderr)[1:]:
+        m = re.search(r"chunk_sort_kernelILi(\d)E", b.split()[0])
+        if m:
+            found[int(m.group(1))] = (int(re.search(r"VGPRs: (\d+)", b).group(1)), int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)))
+    assert set(found) == {1, 8}, found
+    for k, (vg, occ) in found.items():
+        assert vg <= 64 and occ >= 8, f"chunk_sort_kernel<{k}>: {vg} VGPRs, {occ} waves per SIMD"
 
 
 def _active_sh_rank_main(rank, world, port, q):
