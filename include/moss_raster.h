@@ -154,6 +154,9 @@ int moss_raster_forward_async(
 
 /* Enqueue (on `stream`) a copy of the forward's 8 status words from the image buffer to pinned host memory:
  * [0] instances rendered  [1] longest tile list  [2] flags: bit0 prefiltered-point culled, bit1 capacity overflow
+ * [3] the capacity that holds this frame: >= [6] -- the buffer's gradient-record pool (6 cells of 48 B per instance of capacity; a
+ *     frame of wide Gaussians uses up to 16 per instance) and the per-tile key buckets are sized from the capacity too; a caller's
+ *     policy grows the capacity from THIS word (moss_amd/diff_gaussian_rasterization/_C.py: margin x [3])
  * [4] sort chunks  [5] non-empty tiles  [6] instances the frame needed. */
 #define MOSS_STATUS_PREFILTERED 1u
 #define MOSS_STATUS_OVERFLOW    2u

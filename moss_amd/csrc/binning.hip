@@ -104,13 +104,11 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
     // (bucketed keys: a tile that outgrew its bucket lost keys -- the same answer, and `needed` is scaled so that the capacity the
     // caller derives from it holds the longest list: the bucket size is proportional to the capacity)
     bool overflow = total > capacity;
-    uint32_t needed = total;
+    uint32_t needed = total;                             // the CAPACITY that holds this frame: header[3] (its instances: header[6])
     // A frame that needs more cells than the record pool holds is dropped like one that needs more instances than the capacity (`needed`
     // so that the pool of the caller's next capacity holds it: POOL_CELLS_PER_INSTANCE R + 4096 cells, BinView::default_pool_cells).
-    if (pool_total > pool_cap || pool_total > POOL_MAX_CELLS) {
-        overflow = true;
-        needed = max(needed, pool_total / (uint32_t)POOL_CELLS_PER_INSTANCE + 1u);
-    }
+    needed = max(needed, pool_total / (uint32_t)POOL_CELLS_PER_INSTANCE + 1u);
+    if (pool_total > pool_cap || pool_total > POOL_MAX_CELLS) overflow = true;
     if (key_stride != 0u) {
         if (mx) atomicMax(s_max, mx);
         __syncthreads();
@@ -141,10 +139,11 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
         for (int k = 0; k < 33; k++) { const uint32_t c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
         header[0] = overflow ? 0u : total; header[1] = *s_max; header[4] = overflow ? 0u : total_chunks;
         header[5] = s_bucket[32];                      // number of tiles that own at least one instance (they come first)
-        header[6] = needed;                            // instances this frame needs (for the host's capacity policy)
+        header[6] = total;                             // instances this frame needs
+        header[3] = needed;                            // ... and the capacity that holds it (>= [6]: the record pool and the key buckets
+                                                       // are sized from the capacity too) -- for the host's capacity policy
         header[9] = overflow ? 0u : pool_total;        // cells of the record pool in use: what merge_gather clears of the validity bits
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
-        header[3] = 0u;
         header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u);       // (the preprocess kernel's flags: it finished before this one)
         if (flags_acc != header + 2) {                                      // frame state: zero again for the next forward ...
             *flags_acc = 0u;

@@ -16,7 +16,7 @@
 //     clamped u8 (bit c = channel c),
 //     cov3D float[6] (only written when computed from scale/rotation)
 //   image buffer
-//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=inst_pos slot allocator [4]=sort chunks [5]=non-empty tiles [6]=instances needed [16..31]=work-queue heads of the forward/backward blend
+//     header u32[16]: [0]=R (num_rendered) [1]=longest tile list [2]=error flags [3]=capacity that holds the frame (>= [6]: instances, record-pool cells / 6, key buckets) [4]=sort chunks [5]=non-empty tiles [6]=instances of the frame [9]=record-pool cells in use [16..31]=work-queue heads of the forward/backward blend
 //     tile_count u32[T], tile_cursor u32[T], ranges uint2[T], final_T f32[N], n_contrib u32[N]
 //   binning buffer (per (Gaussian,tile) instance, R entries)
 //     point_list u32[R]   Gaussian ids, tile-major, each tile's run sorted by (depth bits, id)
@@ -76,7 +76,7 @@ struct GeomView {
     static size_t bytes(int P) { char* z = nullptr; GeomView g = at(z, P); return (size_t)((char*)g.cov3D - z) + align_up(6 * (size_t)P * 4); }
 };
 
-// header words: [0] R, [1] longest tile list, [2] error flags, [3] inst_pos slot allocator, [4] sort chunks, [5] tiles that own
+// header words: [0] R, [1] longest tile list, [2] error flags, [3] the capacity that holds the frame (>= [6]), [4] sort chunks, [5] tiles that own
 // instances, [6] instances needed, [7] heavy tiles (list length >= 2^LIGHT_TILE_LOG2; they come first in tile_order), [8]/[9] unused, [10] backward leaver count,
 // [16..23] / [24..31] per-XCD queue heads of the wave blend kernels (forward / backward)
 constexpr int HEADER_WORDS = 32;

@@ -30,8 +30,9 @@ FRAME_STATE_DROPPED_WORD = 4                         # include/moss_raster.h MOS
 
 
 class CapacityOverflow(RuntimeError):
-    """An asynchronous forward needed more (Gaussian, tile) instances than its binning capacity: that frame rendered nothing
-    (outputs = background, gradients = 0).  ``needed`` / ``capacity``: the frame's demand and the capacity the context has now."""
+    """An asynchronous forward needed more (Gaussian, tile) instances than its binning capacity -- or more gradient-record cells / key
+    bucket slots than a buffer of that capacity holds: that frame rendered nothing (outputs = background, gradients = 0).
+    ``needed`` / ``capacity``: the capacity that would have held the frame and the capacity the context has now."""
 
     def __init__(self, needed, capacity):
         super().__init__(f"rasterize_gaussians (async): a frame needed {needed} (Gaussian, tile) instances but the binning "
@@ -87,12 +88,13 @@ class RasterContext:
             return
         self.pending = None
         needed, flags = int(status[6]), int(status[2])
-        self.last_needed = needed
-        if needed * 1.25 > self.capacity:                       # drifting towards the limit: grow ahead of time
-            self.capacity = int(needed * self.margin) + 1024
+        want = max(needed, int(status[3]))                      # the capacity that holds the frame: its instances, and the record pool / key
+        self.last_needed = needed                               # buckets that are sized from the capacity (include/moss_raster.h, status words)
+        if want * 1.25 > self.capacity:                         # drifting towards the limit: grow ahead of time
+            self.capacity = int(want * self.margin) + 1024
         if flags & 2:
             self._raised_overflows += 1                         # the caller hears about this frame here: it is not a silently dropped one
-            raise CapacityOverflow(needed, self.capacity)
+            raise CapacityOverflow(want, self.capacity)
         if flags & 1:
             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
 
@@ -221,6 +223,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     elif cx.enabled and P > 0:                               # first (synchronous) call of an async session: learn the size
         cx.capacity = max(cx.capacity, int(rendered * cx.margin) + 1024)
         cx.last_needed = rendered
+        if means3D.is_cuda and rendered > 0:                 # ... including what the frame asks of the record pool (status word [3])
+            cx._request_status(img, means3D.device)
+            cx._consume_status(block=True)
     global last_num_rendered
     cx.last_num_rendered = last_num_rendered = cx.last_needed if use_async else rendered
     return res

@@ -76,8 +76,12 @@ for seed in range(first, first + n_cases):
             # no scatter kernel) must render the same frame bit for bit, down to the sorted lists -- and so must the exact-math mode's
             # integers (its blend decisions are checked against the oracle by tests/test_gpu_exact.py)
             from moss_amd.diff_gaussian_rasterization import _C
-            cx = _C.RasterContext(); cx.set_async(True, capacity=2 * t.R + 1024)
+            cx = _C.RasterContext(); cx.set_async(True)      # (capacity 0: the first call is synchronous and learns it -- instances AND record-pool cells)
             a_ = t.args; c_ = d.cam
+            _C.rasterize_gaussians(a_["bg"], a_["means3D"], a_["colors"], a_["opacity"], a_["scales"], a_["rotations"], d.scale_modifier,
+                                   a_["cov3D"], a_["view"], a_["proj"], c_.tanfovx, c_.tanfovy, c_.H, c_.W, a_["sh"], d.degree, a_["campos"],
+                                   False, 0, a_["transforms"], 0, cx)
+            assert cx.capacity >= 2 * t.R
             ra = _C.rasterize_gaussians(a_["bg"], a_["means3D"], a_["colors"], a_["opacity"], a_["scales"], a_["rotations"], d.scale_modifier,
                                         a_["cov3D"], a_["view"], a_["proj"], c_.tanfovx, c_.tanfovy, c_.H, c_.W, a_["sh"], d.degree, a_["campos"],
                                         False, 0, a_["transforms"], 0, cx)

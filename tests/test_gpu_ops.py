@@ -500,6 +500,65 @@ def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode
         assert torch.equal(a, c)
 
 
+def test_async_record_pool_overflow_and_the_learned_capacity(gpu, hip_lib):
+    """The binning buffer of an asynchronous forward holds a gradient-record pool of 6 cells per instance of CAPACITY (body scenes use
+    3.7-5.5 per instance of the frame); a frame of wide Gaussians -- every instance covers its whole tile: 16 cells -- asks for more
+    than `2 R` gives.  Such a frame is dropped like one with too many instances (status word [3] = the capacity that holds it), the
+    capacity grows from that word, and a context that learns its capacity from a first synchronous call gets it right at once: the
+    asynchronous frame then equals the synchronous one bit for bit, gradients included."""
+    from moss_amd.diff_gaussian_rasterization import _C
+    g = torch.Generator().manual_seed(11)
+    P, H, W = 300, 256, 256
+    s = scenes.config1()
+    cam = s.camera
+    # wide, fairly opaque Gaussians in front of config1's camera: boxes of many tiles each
+    d0 = hp.inputs_of(s, "scale_rot")
+    means = d0.means3D[:1].repeat(P, 1) + 0.15 * torch.randn(P, 3, generator=g)
+    scales_ = torch.full((P, 3), 1.5) * (0.5 + torch.rand(P, 3, generator=g))          # (the camera is ~3 away: every one covers the image)
+    rot = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=1)
+    opa = torch.full((P, 1), 0.9)
+    sh = 0.3 * torch.randn(P, d0.shs.shape[1], 3, generator=g)
+    a = dict(bg=d0.bg.to(gpu), means3D=means.to(gpu), opacity=opa.to(gpu), scales=scales_.to(gpu), rotations=rot.to(gpu),
+             view=cam.viewmatrix.to(gpu), proj=cam.projmatrix.to(gpu), sh=sh.to(gpu), campos=cam.campos.to(gpu))
+    E = torch.empty(0, device=gpu)                             # (no precomputed colours / covariances)
+
+    def forward(cx, debug=0):
+        return _C.rasterize_gaussians(a["bg"], a["means3D"], E, a["opacity"], a["scales"], a["rotations"], 1.0, E, a["view"], a["proj"],
+                                      cam.tanfovx, cam.tanfovy, cam.H, cam.W, a["sh"], d0.degree, a["campos"], False, debug, None, 0, cx)
+
+    def backward(cx, r, dc):
+        z = torch.zeros(1, cam.H, cam.W, device=gpu)
+        return _C.rasterize_gaussians_backward(a["bg"], a["means3D"], r[4], E, a["scales"], a["rotations"], 1.0, E, a["view"], a["proj"],
+                                               cam.tanfovx, cam.tanfovy, dc, z, z, a["sh"], d0.degree, a["campos"], r[5], r[0], r[6], r[7], r[3], 0,
+                                               None, 0, None, cx)
+    ref = forward(_C.RasterContext())                          # synchronous
+    R = int(ref[0])
+    assert R > 1000
+    dc = torch.rand(3, cam.H, cam.W, device=gpu)
+    gref = backward(_C.RasterContext(), ref, dc)
+    # (1) capacity 2 R + 1024 as in rounds 2-4: enough instances, too few record cells -> dropped, reported, grown
+    cx = _C.RasterContext(); cx.set_async(True, capacity=2 * R + 1024)
+    r1 = forward(cx)
+    with pytest.raises(_C.CapacityOverflow) as exc:
+        cx.check_status()
+    assert exc.value.needed > 2 * R + 1024 and cx.last_needed == R, (exc.value.needed, R)
+    assert float(r1[3].abs().max()) == 0.0                     # rendered nothing
+    assert cx.capacity >= 2 * exc.value.needed
+    r2 = forward(cx); cx.check_status()                        # the grown capacity fits
+    for u, v in zip(r2[1:5], ref[1:5]):
+        assert torch.equal(u, v)
+    # (2) a context that learns from its first, synchronous call
+    cx = _C.RasterContext(); cx.set_async(True)
+    forward(cx)
+    assert cx.capacity > 2 * R + 1024
+    r3 = forward(cx); cx.check_status()
+    assert cx.last_needed == R
+    for u, v in zip(r3[1:5], ref[1:5]):
+        assert torch.equal(u, v)
+    for u, v in zip(backward(cx, r3, dc), gref):
+        assert torch.equal(u, v)
+
+
 def test_dropped_frame_is_not_an_optimizer_step(gpu, hip_lib, async_mode):
     """A frame that overflows its capacity renders nothing; a step captured in a hipGraph cannot skip its optimizer on the host.  With
     the frame's status word as the guard (FlatAdamW.step(skip_word=...), C ABI moss_adamw_flat_guarded) the update kernel turns itself
