@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=${1:-r03_final}
 OUT=$PWD/gpurun_out/$TAG
 if [ -z "$PMC_ONLY" ]; then rm -rf $OUT; fi
-mkdir -p $OUT/pmc; cd /tmp
+mkdir -p $OUT/pmc $OUT/markers; cd /tmp
 if [ -z "$PMC_ONLY" ]; then
 # the bench line as the driver sees it (no profiler attached), then the same command under rocprofv3 (whose tool perturbs the
 # bench's own kernel-attached events by ~10 %: its line is kept beside the kernel statistics for reference only)
@@ -27,6 +27,11 @@ pmc p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 # the scalar unit beside the vector unit (round 4's review, item 5: the forward blend executes as many SALU as VALU instructions)
 pmc p5 SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pmc p6 SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SMEM SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS
+# the stage ranges (MOSS_DEBUG_TRACE: roctx ranges around every launch of the op, include/moss_raster.h) beside the kernels they hold:
+# eager launches (ranges are host-side: a graph replay has none), no counters in this pass
+rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $OUT/markers -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --graph 0 --debug-bits 8 --steps 30 --warmup 10 --no-cpu-baseline --no-callers > $OUT/markers/trace.log 2>&1
+rm -f $OUT/markers/trace_kernel_trace.csv
+echo "marker pass done"
 cd $GRAFT_REPO_ROOT
 python3 scripts/summarize_pmc.py $OUT/pmc $OUT/pmc_summary.json $OUT/pmc_stage_summary.json > $OUT/pmc_hbm_bytes.txt 2>&1
 python3 - <<PY
