@@ -634,11 +634,20 @@ def main(argv=None):
     rf_b, rb_b = algorithmic_bytes(P, Pv, R, N, tiles, 16, args.mode in ("scale_rot", "lbs"), transforms=args.mode == "lbs", fused_adamw=False)
     raster_b = dict(rf_b); raster_b.update(rb_b)
     if stage_ms.get("scan", 0.0) == 0.0:
-        # asynchronous forward: the scan rides along with the scatter kernel (no launch of its own) -- its bytes count there
-        all_b["scatter"] += all_b.pop("scan")
-        raster_b["scatter"] += raster_b.pop("scan")
-        stage_ms.pop("scan", None)
-        raster_stage_ms = {k: v for k, v in raster_stage_ms.items() if k != "scan"}
+        # asynchronous forward: the scan rides along with another kernel (no launch of its own) -- its bytes count there: with the
+        # scatter kernel (rounds 2-4), or, when no scatter kernel runs either (round 5: the preprocess kernel writes the keys into
+        # per-tile buckets, the scan is one block of the sort kernel), scan -> chunk_sort and scatter -> preprocess_fwd
+        no_scatter = stage_ms.get("scatter", 0.0) == 0.0
+        for b in (all_b, raster_b):
+            if no_scatter:
+                b["chunk_sort"] += b.pop("scan")
+                b["preprocess_fwd"] += b.pop("scatter")
+            else:
+                b["scatter"] += b.pop("scan")
+        drop = ("scan", "scatter") if no_scatter else ("scan",)
+        for k in drop:
+            stage_ms.pop(k, None)
+        raster_stage_ms = {k: v for k, v in raster_stage_ms.items() if k not in drop}
     dom_bytes = all_b[dominant]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     total_bytes = sum(all_b.values())
