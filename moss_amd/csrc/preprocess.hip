@@ -859,12 +859,16 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // for in turn, then (round 2) a five-deep chain tiles_touched -> point_offsets -> inst_pos -> inst_mask -> record -- taking 48k of a
     // block's 62k cycles.
     const int idc = min(idx, P - 1);
+    // float4 of the block's SH rows per lane: 12 with a Gaussian per lane (64 rows x 12 float4 over 64 lanes); with sixteen lanes per
+    // Gaussian the block's rows_used x 12 float4 are fewer than its lanes: ONE (round 5's first version ran all twelve iterations of
+    // the staging, hoisting and update loops there, eleven of them on clamped dummy rows: 48 AdamW elements per lane for one used)
+    constexpr int SH_J = LPG_L2 == 0 ? 12 : 1;
     float4 shv[12];
     if (STAGE_SH) {
         const size_t total4 = (size_t)P * 12;               // in float4 units (48 floats = 12)
         const float4* src = reinterpret_cast<const float4*>(shs);
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < SH_J; j++) {
             const int f = (int)threadIdx.x + j * (int)blockDim.x;         // float4 f of the block's rows: staged row f / 12, part f % 12
             if constexpr (LPG_L2 == 0) shv[j] = src[min((size_t)gaussian_of_row(f / 12) * 12 + (size_t)(f % 12), total4 - 1)];
             else shv[j] = src[f / 12 < rows_used ? min((size_t)min(gaussian_of_row((f / 12) << lpg_l2), P - 1) * 12 + (size_t)(f % 12), total4 - 1) : total4 - 1];
@@ -905,7 +909,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         // into LDS right away (row stride 49: conflict-free rows): the SH loads are the oldest outstanding ones, so this waits for
         // them only, and their 48 registers are free during the gather (holding them across it spilled to scratch)
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < SH_J; j++) {
             const int f = threadIdx.x + j * blockDim.x;
             if (LPG_L2 == 0 || f / 12 < rows_used) {
                 float* d = &s_sh[((f / 12) << lpg_l2) * SH_ROW + (f % 12) * 4];
@@ -1199,7 +1203,7 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     }
     // ... and so are the moments of the block's SH rows (24 float4 per lane): in flight during the arithmetic below
     // (FA_HOIST of the 12 slots: all 12 pairs are 96 registers held across the arithmetic -- 260 in all, one wave per SIMD)
-    constexpr int FA_HOIST = 10;
+    constexpr int FA_HOIST = SH_J < 10 ? SH_J : 10;
     float4 fa_m4[12], fa_v4[12];
     const bool fa_sh = STAGE_SH && fa_on && (fa.tensors & OPT_SH);
     if (fa_sh) {
@@ -1379,14 +1383,14 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             float4 p4[12];
             float4 (&m4)[12] = fa_m4, (&v4)[12] = fa_v4;
 #pragma unroll
-            for (int j = 0; j < 12; j++) {
+            for (int j = 0; j < SH_J; j++) {
                 const int f = (int)threadIdx.x + j * (int)blockDim.x;
                 const size_t a = (size_t)min(gaussian_of_row(LPG_L2 == 0 ? f / 12 : (min(f / 12, rows_used - 1) << lpg_l2)), P - 1) * 12 + (size_t)(f % 12);
                 p4[j] = pw[a];
                 if (j >= FA_HOIST) { m4[j] = mw[a]; v4[j] = vw[a]; }
             }
 #pragma unroll
-            for (int j = 0; j < 12; j++) {
+            for (int j = 0; j < SH_J; j++) {
                 const int f = (int)threadIdx.x + j * (int)blockDim.x, part = f % 12;
                 const int q = LPG_L2 == 0 ? f / 12 : min(f / 12, rows_used - 1);
                 const int gi = (LPG_L2 == 0 || f / 12 < rows_used) ? gaussian_of_row(q << lpg_l2) : 0x7fffffff;
