@@ -62,8 +62,11 @@ __global__ void __launch_bounds__(256)
 ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Win win,
                   float* __restrict__ dmap /* [3][C][H][W] */, float* __restrict__ partials /* [blocks][2] */,
                   const float* __restrict__ alpha, const float* __restrict__ mask, float lambda_mask,
-                  float* __restrict__ dL_dalpha, float* __restrict__ mask_partials /* [tiles] */)
+                  float* __restrict__ dL_dalpha, float* __restrict__ mask_partials /* [tiles] */,
+                  unsigned long long* __restrict__ stamps /* diagnostics (MOSS_LOSS_STAMPS, -DMOSS_DIAG builds): 8 words per workgroup, else NULL */)
 {
+#define LSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+    LSTAMP(0);
     __shared__ float s_x[LP][LP + 1];
     __shared__ float s_y[LP][LP + 1];
     __shared__ float s_h[5][LP][LT + 1];
@@ -94,7 +97,9 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             if (i < LP * LP) { s_x[r][q] = in ? vx[k] : 0.0f; s_y[r][q] = in ? vy[k] : 0.0f; }
         }
     }
+    LSTAMP(1);
     __syncthreads();
+    LSTAMP(2);
     if (tid < (LT / SEG) * LP) {                         // horizontal 11-tap for the 5 moments: rows run along the lanes (odd row
         const int r = tid % LP, q0 = (tid / LP) * SEG;   // stride: conflict-free LDS reads), a thread owns columns q0 .. q0 + SEG - 1
         // (moments in pairs: v_pk_fma_f32 does two of the five accumulations per instruction)
@@ -123,6 +128,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         }
     }
     __syncthreads();
+    LSTAMP(3);
     const int lx = tid % LT, ly0 = (tid / LT) * VR;      // vertical: column lx, rows ly0 .. ly0 + VR - 1
     v2f m01[VR], m23[VR]; float m4[VR];
 #pragma unroll
@@ -176,10 +182,12 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             }
         }
     }
+    LSTAMP(4);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { ssim_v += __shfl_xor(ssim_v, d); l1_v += __shfl_xor(l1_v, d); mask_v += __shfl_xor(mask_v, d); }
     if ((tid & 63) == 0) { s_red[0][tid >> 6] = ssim_v; s_red[1][tid >> 6] = l1_v; s_red[2][tid >> 6] = mask_v; }
     __syncthreads();
+    LSTAMP(5);
     if (tid == 0) {
         const size_t b = ((size_t)tile.c * gridDim.y + tile.by) * gridDim.x + tile.bx;
         partials[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
@@ -193,8 +201,10 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
                   const float* __restrict__ alpha, const float* __restrict__ mask, Win win,
                   const float* __restrict__ dmap, const float* __restrict__ partials, int nblocks,
                   float lambda_dssim, float lambda_mask, float* __restrict__ dL_dimg, float* __restrict__ dL_dalpha,
-                  const float* __restrict__ mask_partials, float* __restrict__ loss_out, float lambda_l1)
+                  const float* __restrict__ mask_partials, float* __restrict__ loss_out, float lambda_l1,
+                  unsigned long long* __restrict__ stamps)
 {
+    LSTAMP(0);
     __shared__ float s_d[3][LP][LP + 1];
     __shared__ float s_h[3][LP][LT + 1];
     __shared__ float s_red[3][4];
@@ -223,7 +233,9 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             if (i < LP * LP) { s_d[0][r][q] = in ? v[0][k] : 0.0f; s_d[1][r][q] = in ? v[1][k] : 0.0f; s_d[2][r][q] = in ? v[2][k] : 0.0f; }
         }
     }
+    LSTAMP(1);
     __syncthreads();
+    LSTAMP(2);
     if (tid < (LT / SEG) * LP) {                         // horizontal pass of the three derivative maps (see pass 1)
         const int r = tid % LP, q0 = (tid / LP) * SEG;
         v2f a01[SEG]; float a2[SEG];
@@ -245,6 +257,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         for (int j = 0; j < SEG; j++) { s_h[0][r][q0 + j] = a01[j].x; s_h[1][r][q0 + j] = a01[j].y; s_h[2][r][q0 + j] = a2[j]; }
     }
     __syncthreads();
+    LSTAMP(3);
     const int lx = tid % LT, ly0 = (tid / LT) * VR;
     v2f f01[VR]; float f2[VR];
 #pragma unroll
@@ -274,6 +287,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             dL_dimg[o] = (lambda_l1 * sgn) / N - lambda_dssim * dssim / N;     // (lambda_l1 = 1: the same bits as sgn / N)
         }
     }
+    LSTAMP(4);
     // Block (0,0,0) folds pass 1's partials into the four loss terms (no separate "finish" launch: a minimal launch costs 4-5 us).
     // Everything it reads was written by pass 1, an earlier kernel -- which is why the mask term is computed there.
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
@@ -296,6 +310,8 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         }
     }
 }
+
+#undef LSTAMP
 
 Win make_window()
 {
@@ -346,9 +362,10 @@ extern "C" int moss_photometric_loss_weighted(int C, int H, int W, const float* 
     float* partials = carve<float>(p, (size_t)gx * gy * C * 2);
     float* mask_partials = carve<float>(p, (size_t)gx * gy);
     static const Win win = make_window();
+    unsigned long long* const loss_stamps = (g_stamps && knob("MOSS_LOSS_STAMPS", 0)) ? g_stamps : nullptr;      // (product build: constant NULL)
     const dim3 grid(gx, gy, C);
-    hipLaunchKernelGGL(ssim_pass1_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials);
+    hipLaunchKernelGGL(ssim_pass1_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
     hipLaunchKernelGGL(ssim_pass2_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1);
+                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 1024 : nullptr);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
