@@ -462,6 +462,35 @@ def test_async_forward_equals_sync_forward(gpu, hip_lib, async_mode, raw):
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("size", [1024, 2048])
+def test_async_forward_equals_sync_forward_beyond_one_tile_per_sort_thread(gpu, hip_lib, async_mode, size):
+    """The asynchronous forward has three shapes by the number of tiles T: T <= 1024 (the bench frame: keys bucketed by the preprocess
+    kernel, one tile per thread of the sort workgroups' self-scan), T <= 8192 (the same with up to 8 tiles per thread: 1024 x 1024), and
+    beyond that -- the tile histogram no longer fits the LDS -- the scan -> scatter chain of rounds 2-4 with global histogram atomics
+    (2048 x 2048: 16 384 tiles).  Each must give the synchronous forward's frame bit for bit, gradients included."""
+    from types import SimpleNamespace
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import camera_view
+    s = scenes.body_scene(40_000, size, size, 540.0 * size / 512, init_like=False, name=f"body{size}")
+    pc = GaussianSet(s, device=gpu)
+    cam = camera_view(s.camera, gpu)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, raw_parameters_in_op=True)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu)
+    w = torch.rand(3, size, size, device=gpu)
+    ref = _train_like_step(pc, cam, pipe, bg, w)
+    async_mode.set_async(True)
+    _train_like_step(pc, cam, pipe, bg, w)                    # synchronous: learns the capacity
+    for _ in range(2):
+        got = _train_like_step(pc, cam, pipe, bg, w)          # asynchronous
+    async_mode.check_async_status()
+    assert int(async_mode._C.ASYNC.frame_state.count_nonzero()) == 0
+    assert float(ref[1].sum()) > 1000.0                       # something was rendered
+    for a, c in zip(ref[:3], got[:3]):
+        assert torch.equal(a, c)
+    for a, c in zip(ref[3], got[3]):
+        assert torch.equal(a, c)
+
+
 def test_async_overflow_renders_nothing_and_is_reported(gpu, hip_lib, async_mode):
     """A frame that needs more (Gaussian, tile) instances than the capacity: background image, zero alpha, zero gradients (never
     an out-of-bounds write), the overflow flag raised at the next status check, and the capacity grown from the needed size."""
