@@ -58,6 +58,7 @@ __device__ __forceinline__ TileId xcd_tile()
 // into the outputs whose window holds it.  Vertical: a thread owns VR consecutive rows of one column.  32 x 32 tiles: the halo costs
 // 1.7x instead of 2.6x.
 
+template <bool SKIP_EMPTY>   // (see EMPTY TILES below: the instantiation for grids of more than one residency round)
 __global__ void __launch_bounds__(256)
 ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Win win,
                   float* __restrict__ dmap /* [3][C][H][W] */, float* __restrict__ partials /* [blocks][2] */,
@@ -78,6 +79,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     const int tid = threadIdx.x;
     const float* xc = img + (size_t)c * H * W;
     const float* yc = gt + (size_t)c * H * W;
+    bool nonzero = false;
 
     {
         // the tile + halo: all loads first (clamped addresses, no branch: they are in flight together), then the LDS stores
@@ -94,13 +96,25 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const int i = tid + 256 * k, r = i / LP, q = i % LP;
             const int gx_ = x0 + q - HALO, gy_ = y0 + r - HALO;
             const bool in = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
-            if (i < LP * LP) { s_x[r][q] = in ? vx[k] : 0.0f; s_y[r][q] = in ? vy[k] : 0.0f; }
+            if (i < LP * LP) {
+                const float a = in ? vx[k] : 0.0f, b = in ? vy[k] : 0.0f;
+                s_x[r][q] = a; s_y[r][q] = b;
+                if constexpr (SKIP_EMPTY) nonzero |= (a != 0.0f) || (b != 0.0f);       // (NaN counts as content)
+            }
         }
     }
     LSTAMP(1);
-    __syncthreads();
+    // EMPTY TILES.  MOSS's frames are masked people on black: three quarters of a frame's tiles are exactly zero in BOTH images, halo
+    // included.  Every windowed moment of such a tile is exactly +0 (sums of w * 0 from +0), so the two filter passes are skipped and the
+    // epilogue runs on zero moments: the same bits, the same stores.  At 512 x 512 all 768 workgroups are resident at once and the
+    // kernel lasts as long as one non-empty workgroup either way (measured in rounds 4 and 5: 18.8 -> 19.1 us for the two kernels, a dense
+    // frame 19.1 -> 19.9): there the plain instantiation runs.  At 1024 x 1024 -- MOSS's ZJU-MoCap resolution, BASELINE configs[4] -- the
+    // grid takes four rounds and the empty tiles leave at once: 56.9 -> 50.5 us on a masked frame (a dense one: 60.1 -> 61.2).
+    bool tile_nonzero = true;
+    if constexpr (SKIP_EMPTY) tile_nonzero = __syncthreads_or(nonzero ? 1 : 0) != 0;
+    else __syncthreads();
     LSTAMP(2);
-    if (tid < (LT / SEG) * LP) {                         // horizontal 11-tap for the 5 moments: rows run along the lanes (odd row
+    if (tile_nonzero && tid < (LT / SEG) * LP) {                         // horizontal 11-tap for the 5 moments: rows run along the lanes (odd row
         const int r = tid % LP, q0 = (tid / LP) * SEG;   // stride: conflict-free LDS reads), a thread owns columns q0 .. q0 + SEG - 1
         // (moments in pairs: v_pk_fma_f32 does two of the five accumulations per instruction)
         v2f a01[SEG], a23[SEG]; float a4[SEG];
@@ -133,6 +147,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     v2f m01[VR], m23[VR]; float m4[VR];
 #pragma unroll
     for (int j = 0; j < VR; j++) { m01[j] = v2f{0.f, 0.f}; m23[j] = v2f{0.f, 0.f}; m4[j] = 0.f; }
+    if (tile_nonzero) {
 #pragma unroll
     for (int i = 0; i < VR + 10; i++) {
         const v2f v01 = v2f{s_h[0][ly0 + i][lx], s_h[1][ly0 + i][lx]}, v23 = v2f{s_h[2][ly0 + i][lx], s_h[3][ly0 + i][lx]};
@@ -146,6 +161,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
                 m4[j] = __fmaf_rn(w, v4, m4[j]);
             }
         }
+    }
     }
     float ssim_v = 0.f, l1_v = 0.f, mask_v = 0.f;
     const float inv_hw = 1.0f / ((float)H * (float)W);
@@ -196,6 +212,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     }
 }
 
+template <bool SKIP_EMPTY>
 __global__ void __launch_bounds__(256)
 ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                   const float* __restrict__ alpha, const float* __restrict__ mask, Win win,
@@ -216,6 +233,11 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     const size_t plane3 = (size_t)C * H * W;
     const float N = (float)C * (float)H * (float)W;
 
+    // this thread's output pixels (column lx, rows ly0 .. ly0 + VR - 1): their x and y are requested with the maps (one round trip)
+    const int lx = tid % LT, ly0 = (tid / LT) * VR;
+    const int px = x0 + lx;
+    float xs[VR] = {}, ys[VR] = {};
+    bool content = false;
     {
         constexpr int NLD = (LP * LP + 255) / 256;
         float v[3][NLD];
@@ -225,18 +247,39 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const size_t o = (size_t)c * H * W + (size_t)min(max(y0 + r - HALO, 0), H - 1) * W + min(max(x0 + q - HALO, 0), W - 1);
             v[0][k] = dmap[o]; v[1][k] = dmap[plane3 + o]; v[2][k] = dmap[2 * plane3 + o];
         }
+        if constexpr (SKIP_EMPTY) {
+#pragma unroll
+            for (int j = 0; j < VR; j++) {
+                const size_t o = ((size_t)c * H + min(y0 + ly0 + j, H - 1)) * W + min(px, W - 1);
+                xs[j] = img[o]; ys[j] = gt[o];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
             const int i = tid + 256 * k, r = i / LP, q = i % LP;
             const int gx_ = x0 + q - HALO, gy_ = y0 + r - HALO;
             const bool in = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
-            if (i < LP * LP) { s_d[0][r][q] = in ? v[0][k] : 0.0f; s_d[1][r][q] = in ? v[1][k] : 0.0f; s_d[2][r][q] = in ? v[2][k] : 0.0f; }
+            if (i < LP * LP) {
+                const float d0 = in ? v[0][k] : 0.0f;
+                s_d[0][r][q] = d0; s_d[1][r][q] = in ? v[1][k] : 0.0f; s_d[2][r][q] = in ? v[2][k] : 0.0f;
+                if constexpr (SKIP_EMPTY) content |= d0 != 0.0f;       // (NaN counts as content)
+            }
+        }
+        if constexpr (SKIP_EMPTY) {
+#pragma unroll
+            for (int j = 0; j < VR; j++) content |= (xs[j] != 0.0f) || (ys[j] != 0.0f);
         }
     }
     LSTAMP(1);
-    __syncthreads();
+    // EMPTY TILES (see pass 1).  Where the first derivative map is zero on the whole window (the moments mu1, mu2 vanish there: nothing
+    // but black within 10 pixels) and x = y = 0 on the tile, the gradient is  (w * 0) + 2 * 0 * (w * D_xx) + 0 * (w * D_xy)  =  +0  for any
+    // finite second and third map -- and the filters below, run on such a window, give exactly that (a sum of w * (+-0) from +0 is +0;
+    // +0 + (+-0) = +0): skipped, same bits.
+    bool tile_content = true;
+    if constexpr (SKIP_EMPTY) tile_content = __syncthreads_or(content ? 1 : 0) != 0;
+    else __syncthreads();
     LSTAMP(2);
-    if (tid < (LT / SEG) * LP) {                         // horizontal pass of the three derivative maps (see pass 1)
+    if (tile_content && tid < (LT / SEG) * LP) {         // horizontal pass of the three derivative maps (see pass 1)
         const int r = tid % LP, q0 = (tid / LP) * SEG;
         v2f a01[SEG]; float a2[SEG];
 #pragma unroll
@@ -258,10 +301,10 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     }
     __syncthreads();
     LSTAMP(3);
-    const int lx = tid % LT, ly0 = (tid / LT) * VR;
     v2f f01[VR]; float f2[VR];
 #pragma unroll
     for (int j = 0; j < VR; j++) { f01[j] = v2f{0.f, 0.f}; f2[j] = 0.f; }
+    if (tile_content) {
 #pragma unroll
     for (int i = 0; i < VR + 10; i++) {
         const v2f v01 = v2f{s_h[0][ly0 + i][lx], s_h[1][ly0 + i][lx]};
@@ -274,13 +317,13 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             }
         }
     }
-    const int px = x0 + lx;
+    }
 #pragma unroll
     for (int j = 0; j < VR; j++) {
         const int py = y0 + ly0 + j;
         if (px < W && py < H) {
             const size_t o = ((size_t)c * H + py) * W + px;
-            const float x = img[o], y = gt[o];
+            const float x = SKIP_EMPTY ? xs[j] : img[o], y = SKIP_EMPTY ? ys[j] : gt[o];
             const float dssim = f01[j].x + 2.f * x * f01[j].y + y * f2[j];     // d(sum SSIM)/dx
             const float d = x - y;
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
@@ -312,6 +355,16 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
 }
 
 #undef LSTAMP
+
+int loss_device_cus()
+{
+    static const int n = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }();
+    return n;
+}
 
 Win make_window()
 {
@@ -364,8 +417,15 @@ extern "C" int moss_photometric_loss_weighted(int C, int H, int W, const float* 
     static const Win win = make_window();
     unsigned long long* const loss_stamps = (g_stamps && knob("MOSS_LOSS_STAMPS", 0)) ? g_stamps : nullptr;      // (product build: constant NULL)
     const dim3 grid(gx, gy, C);
-    hipLaunchKernelGGL(ssim_pass1_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
-    hipLaunchKernelGGL(ssim_pass2_kernel, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 1024 : nullptr);
+    // more workgroups than are resident at once (three per CU: 42 KB of LDS each): the instantiations that let empty tiles leave early
+    if ((size_t)gx * gy * C > (size_t)3 * loss_device_cus()) {
+        hipLaunchKernelGGL(ssim_pass1_kernel<true>, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
+        hipLaunchKernelGGL(ssim_pass2_kernel<true>, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 1024 : nullptr);
+    } else {
+        hipLaunchKernelGGL(ssim_pass1_kernel<false>, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
+        hipLaunchKernelGGL(ssim_pass2_kernel<false>, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 1024 : nullptr);
+    }
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }

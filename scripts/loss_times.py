@@ -7,7 +7,7 @@ import torch
 from moss_amd import _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()
-C, H, W = 3, 512, 512
+C, H, W = 3, (1024 if "1024" in sys.argv else 512), (1024 if "1024" in sys.argv else 512)
 g = torch.Generator().manual_seed(3)
 yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
 def body(cx, cy, rx, ry):
@@ -16,11 +16,12 @@ def body(cx, cy, rx, ry):
 if "full" in sys.argv:
     img = torch.rand(C, H, W, generator=g); gt = torch.rand(C, H, W, generator=g); alpha = torch.rand(1, H, W, generator=g); mask = (torch.rand(1, H, W, generator=g) > 0.5).float()
 else:
-    m1, m2 = body(250, 260, 70, 200), body(262, 256, 74, 196)
+    k_ = H / 512.0
+    m1, m2 = body(250 * k_, 260 * k_, 70 * k_, 200 * k_), body(262 * k_, 256 * k_, 74 * k_, 196 * k_)
     img = torch.rand(C, H, W, generator=g) * m1; gt = torch.rand(C, H, W, generator=g) * m2
     alpha = m1[None] * 0.97; mask = m2[None]
 img, gt, alpha, mask = (t.to(dev).contiguous() for t in (img, gt, alpha, mask))
-tiles = sum(1 for by in range(16) for bx in range(16)
+tiles = sum(1 for by in range(H // 32) for bx in range(W // 32)
             if float(img[:, max(0, 32 * by - 5):32 * by + 37, max(0, 32 * bx - 5):32 * bx + 37].abs().sum() + gt[:, max(0, 32 * by - 5):32 * by + 37, max(0, 32 * bx - 5):32 * bx + 37].abs().sum()) > 0)
 ws = torch.empty(int(L.moss_loss_workspace_bytes(C, H, W)), dtype=torch.uint8, device=dev)
 out = torch.zeros(4, device=dev); dimg = torch.empty_like(img); dalpha = torch.empty_like(alpha)
@@ -40,5 +41,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(10): gr.replay()
 e1.record(); torch.cuda.synchronize()
-print(f"non-empty tiles (halo included): {tiles} of 256; loss {out.tolist()}; both kernels: {e0.elapsed_time(e1) / 200 * 1e3:.2f} us per call (graph of 20 calls)")
-print("checksums", float(dimg.double().abs().sum()), float(dalpha.double().abs().sum()))
+print(f"{H}x{W}: non-empty tiles (halo included): {tiles} of {(H // 32) * (W // 32)}; loss {out.tolist()}; both kernels: {e0.elapsed_time(e1) / 200 * 1e3:.2f} us per call (graph of 20 calls)")
+import hashlib
+print("checksums", float(dimg.double().abs().sum()), float(dalpha.double().abs().sum()),
+      "sha256 of (loss terms, dL_dimage, dL_dalpha):", hashlib.sha256(out.cpu().numpy().tobytes() + dimg.cpu().numpy().tobytes() + dalpha.cpu().numpy().tobytes()).hexdigest()[:16])

@@ -30,7 +30,10 @@ def test_fused_loss_matches_torch_reference(gpu, hip_lib, shape):
     assert hp.rel_err(al.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("shape,blobs", [((3, 160, 200), 2), ((3, 512, 512), 1), ((3, 96, 96), 0)])
+# (the last three: more than 768 workgroups -- three per CU -- so the launcher picks the instantiations that skip the filters of empty
+#  tiles, loss.hip "EMPTY TILES"; the others run the plain ones)
+@pytest.mark.parametrize("shape,blobs", [((3, 160, 200), 2), ((3, 512, 512), 1), ((3, 96, 96), 0),
+                                         ((3, 1024, 1024), 2), ((3, 700, 900), 2), ((3, 544, 544), 0)])
 def test_fused_loss_on_masked_frames_with_empty_tiles(gpu, hip_lib, shape, blobs):
     """MOSS's frames are masked people on black: most 32x32 tiles of a frame are exactly zero in BOTH images.  The loss kernels skip
     the filters there (loss.hip, "EMPTY TILES") -- the values they leave must be the general path's: checked against the float64 torch
