@@ -235,7 +235,6 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
     // tables (binning.hip, chunk_sort_kernel).  A tile that outgrows its bucket drops the frame like a capacity overflow (flagged by
     // the scan block, `needed` scaled so that the caller's next capacity fits it).
     const bool scatter = keys != nullptr;
-    uint32_t* const s_base = s_hist + ((T + 3) & ~3);        // scatter mode: where this block's run starts in each tile's bucket
     if (lds_hist) {
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_hist[i] = 0;
         __syncthreads();
@@ -250,7 +249,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
     // SH staging (M == 16 only): per thread a record is 48 floats at a 192-byte stride, i.e. each of the 48 scalar loads of a wave
     // touches 64 cache lines.  The block's 256 records of this iteration are instead read with coalesced 16-byte loads into LDS
     // (row stride 49 words: conflict-free) and evaluated from there -- same values, same arithmetic, so still bit-exact.
-    float* const s_shf = reinterpret_cast<float*>(s_hist + (lds_hist ? ((T + 3) & ~3) * (scatter ? 2 : 1) : 0));
+    float* const s_shf = reinterpret_cast<float*>(s_hist + (lds_hist ? ((T + 3) & ~3) : 0));
     for (int it = 0; it < iters; it++) {
         const int idx = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         if (stage_sh) {
@@ -461,7 +460,7 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
-                        if (c[u]) { s_base[i] = old[u]; s_hist[i] = 0u; }
+                        if (c[u]) s_hist[i] = old[u];        // (the count word becomes the CURSOR of the pass below: it starts at the run's start)
                     }
                 } else {
 #pragma unroll
@@ -504,12 +503,12 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = pend_b0 + u * (int)blockDim.x + (int)threadIdx.x;
-                if (pend_c[u]) { s_base[i] = pend_old[u]; s_hist[i] = 0u; }      // (the count word becomes the cursor of the pass below)
+                if (pend_c[u]) s_hist[i] = pend_old[u];       // (the count word becomes the cursor of the pass below)
             }
             __syncthreads();
             const uint64_t key = out_tiles ? (((uint64_t)__float_as_uint(out_depth) << 32) | (uint32_t)idx) : 0ull;
             wave_for_each_tile(out_rect, gx, key, [&](int t, uint64_t k) {
-                const uint32_t pos = s_base[t] + atomicAdd(&s_hist[t], 1u);
+                const uint32_t pos = atomicAdd(&s_hist[t], 1u);
                 if (pos < key_stride) keys[(size_t)t * key_stride + pos] = k;      // (a bucket that overflows drops the frame: scan block)
             });
             if (it + 1 < iters) {                            // the next iteration counts from zero again
@@ -1477,9 +1476,13 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     static const int per_thread = knob("MOSS_PREPROCESS_ITEMS", 1);
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
-    const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) * (scatter_keys ? 2 : 1) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
+    const size_t lds_h = lds_hist ? (size_t)((T + 3) & ~3) * sizeof(uint32_t) : 0, lds_s = (size_t)256 * SH_ROW_F * sizeof(float);
+    // (dynamic LDS beyond the default 64 KB of a launch -- 1024 x 1024: 16 KB of histogram + 49 KB of SH rows -- is asked for once; two
+    // such blocks still fit a CU's 160 KB.  Round 5's first scatter mode kept a second array of run starts beside the histogram: 82 KB
+    // there, no SH staging and ONE block per CU)
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     const int stage_sh = (fp.M == 16 && shs != nullptr && colors_precomp == nullptr && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 &&
-                          lds_h + lds_s <= 65536 /* default dynamic-LDS limit of a launch */ && knob("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
+                          lds_h + lds_s <= (big_lds ? 80u * 1024u : 65536u) && knob("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
     const size_t lds = lds_h + (stage_sh ? lds_s : 0);
     MOSS_LAUNCH_TIMED(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
                        fp.P, fp.D, fp.M, fp.W, fp.H, fp.gx, fp.gy, fp.tan_fovx, fp.tan_fovy, fp.focal_x, fp.focal_y,
