@@ -421,11 +421,11 @@ extern "C" int moss_photometric_loss_weighted(int C, int H, int W, const float* 
     if ((size_t)gx * gy * C > (size_t)3 * loss_device_cus()) {
         hipLaunchKernelGGL(ssim_pass1_kernel<true>, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
         hipLaunchKernelGGL(ssim_pass2_kernel<true>, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 1024 : nullptr);
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 4096 : nullptr);
     } else {
         hipLaunchKernelGGL(ssim_pass1_kernel<false>, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
         hipLaunchKernelGGL(ssim_pass2_kernel<false>, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 1024 : nullptr);
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 4096 : nullptr);
     }
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }

@@ -783,7 +783,7 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t c0, uint32_t c
 // is 12 fully coalesced 16-byte accesses per lane.
 // Gradient records are sparse: cell c of the Gaussian's run holds a record only if bit c of cell_valid is set (blend.hip).
 constexpr int SH_ROW = 49;
-constexpr int GATHER_CAP = 320;                          // records of a wave gathered per pass (8 rows of 64)
+constexpr int GATHER_CAP = 320;                          // records of a wave gathered per pass (5 rows of 64; 384: no gain, round 5)
 constexpr int GATHER_WORDS = GATHER_CAP + 64 * 9;        // per wave: the descriptor list + one row of scanned values
 // FUSED: the kernel also takes the AdamW step of the parameters named in fa.tensors (moss_raster_backward_raw_adamw) -- an
 // instantiation of its own, so that the plain backward keeps its code and registers and a kernel trace tells the two apart.
