@@ -15,7 +15,8 @@ L = _lib.lib()
 assert L.moss_build_has_diagnostics(), "run with MOSS_AMD_LIB_DIR=lib_diag (python -m moss_amd.build --diag)"
 L.moss_raster_debug_set_stamps.argtypes = [ctypes.c_void_p]
 cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "cfg3"
-s = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[cfg]()
+s = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5,
+     "moss45k": lambda: scenes.body_scene(45_695, 1024, 1024, 1080.0, init_like=False, name="moss45k")}[cfg]()
 cam = camera_view(s.camera, dev)
 bg = torch.zeros(3, device=dev)
 w = torch.rand(3, s.camera.H, s.camera.W, device=dev)
@@ -49,6 +50,9 @@ for fused in (False, True):
     sub = np.diff(st[:, 8:13], axis=1)
     print("inside phase 0 [.., masks requested, masks in + counted, records gathered, coop gather] mean:", sub.mean(0).astype(int), "p90:", np.percentile(sub, 90, axis=0).astype(int))
     print("p90:", np.percentile(ph, 90, axis=0).astype(int), " block total mean", int((st[:, 6] - st[:, 0]).mean()), "max", int((st[:, 6] - st[:, 0]).max()))
+    tot = st[:, 6] - st[:, 0]
+    worst = np.argsort(-tot)[:8]
+    print("slowest blocks: total cycles", tot[worst].astype(int).tolist(), "| [masks requested, masks in, records gathered, coop gather]:", sub[worst].astype(int).tolist())
     r0 = st[:, 13].min()
     print("realtime (us): block starts median %.2f p90 %.2f last %.2f | block ends median %.2f p90 %.2f last %.2f" % (
         np.median(st[:, 13] - r0) / 100, np.percentile(st[:, 13] - r0, 90) / 100, (st[:, 13].max() - r0) / 100,

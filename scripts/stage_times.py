@@ -12,7 +12,10 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--order", default="as_is", help="as_is | morton (Gaussians re-indexed along a 3-D Morton curve) | random")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-scene = {"cfg1": scenes.config1, "cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[args.config]()
+# (moss45k: MOSS's own ceiling -- 45 695 Gaussians, scene/gaussian_model.py:496 -- at its ZJU-MoCap resolution, 1024 x 1024)
+scene = {"cfg1": scenes.config1, "cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5,
+         "moss45k": lambda: scenes.body_scene(45_695, 1024, 1024, 1080.0, init_like=False, name="moss45k"),
+         "moss7k": lambda: scenes.body_scene(6_890, 1024, 1024, 1080.0, init_like=True, name="moss7k")}[args.config]()
 if args.order != "as_is":
     from moss_amd.densify import spatial_order
     perm = spatial_order(scene.means3D) if args.order == "morton" else torch.randperm(scene.P, generator=torch.Generator().manual_seed(1))
