@@ -725,33 +725,54 @@ __device__ __forceinline__ uint32_t run_word_mask(uint32_t word, uint32_t c0, ui
     if (hi <= lo) return 0u;
     return (hi >= 32u ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
 }
+// NG Gaussians per round, 64 / NG lanes each: 1 -- the whole wave on one Gaussian -- for runs of more than COOP_WORDS validity words;
+// 4 -- sixteen lanes each, 128 cells per Gaussian and round -- for the MID-SIZE runs (more than MID_CELLS cells): at MOSS's own sizes
+// (45 695 Gaussians at 1024 x 1024: ~50 cells and ~25 records per Gaussian, a tail of several hundred) the per-lane forms below file a
+// lane's hundreds of records one by one while 63 lanes wait, and eight of 714 blocks took 190k cycles against a median of 55k
+// (profiles/r05_notes.md section 13).
+template <int NG>
 __device__ __forceinline__ void coop_gather(bool is_big, uint32_t c0, uint32_t c1,
                                             const uint32_t* __restrict__ cell_valid, const float4* __restrict__ inst_grad, float* sums)
     {
         typedef float v4f __attribute__((ext_vector_type(4)));
         constexpr uint32_t OOB = 0xffffffffu, RSRC3 = 0x00020000u;
+        constexpr uint32_t LPR = 64u / (uint32_t)NG;                             // lanes per Gaussian of a round
         // (buffer loads: an out-of-range offset returns 0 without a memory request -- an absent or unflagged cell costs nothing and adds 0)
         const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)cell_valid, 0, 0xffffff00u, RSRC3);
         const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)inst_grad, 0, 0xffffff00u, RSRC3);
         unsigned long long big = __ballot(is_big);
-        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t lane = threadIdx.x & 63u, grp = lane / LPR, j = lane % LPR;
         while (big) {
-            const int src = __ffsll(big) - 1;
-            big &= big - 1;
-            const uint32_t bc0 = __shfl(c0, src), bc1 = __shfl(c1, src);
+            // this round's Gaussians: the next NG flagged lanes (wave-uniform), group g of lanes takes src[g]
+            int src[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) { src[g] = big ? __ffsll(big) - 1 : -1; big &= big - 1ull; }
+            int my_src = src[0];
+#pragma unroll
+            for (int g = 1; g < NG; g++) my_src = grp == (uint32_t)g ? src[g] : my_src;
+            // (both shuffles by EVERY lane: a lane that sat out a conditional shuffle would hand its value to nobody -- ds_bpermute returns 0
+            // for an inactive source lane -- and the owner of a run is usually not among the lanes that sum it)
+            const uint32_t bc0 = __shfl(c0, max(my_src, 0)), bc1_any = __shfl(c1, max(my_src, 0));
+            const uint32_t bc1 = my_src >= 0 ? bc1_any : bc0;
+            uint32_t nmax = 0u;                                                  // the longest run of the round: the loop below is wave-uniform
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const uint32_t n = src[g] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)(c1 - c0), max(src[g], 0)) : 0u;
+                nmax = max(nmax, n);
+            }
             float acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
             constexpr int CPL = 8;                                               // cells per lane per round
-            for (uint32_t r0 = bc0; r0 < bc1; r0 += 64u * CPL) {
+            for (uint32_t r0 = 0u; r0 < nmax; r0 += LPR * CPL) {
                 uint32_t vw[CPL];
 #pragma unroll
                 for (int i = 0; i < CPL; i++) {
-                    const uint32_t cell = r0 + 64u * (uint32_t)i + lane;
+                    const uint32_t cell = bc0 + r0 + LPR * (uint32_t)i + j;
                     vw[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, cell < bc1 ? (cell >> 5) * 4u : OOB, 0, 0);
                 }
                 v4f ra[CPL], rb[CPL]; float rc[CPL];
 #pragma unroll
                 for (int i = 0; i < CPL; i++) {
-                    const uint32_t cell = r0 + 64u * (uint32_t)i + lane;
+                    const uint32_t cell = bc0 + r0 + LPR * (uint32_t)i + j;
                     const bool on = ((vw[i] >> (cell & 31u)) & 1u) != 0u;       // (vw = 0 beyond the run)
                     const uint32_t o = on ? cell * (uint32_t)(GRAD_REC_FLOATS * 4) : OOB;
                     ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, o, 0, 0);
@@ -765,14 +786,21 @@ __device__ __forceinline__ void coop_gather(bool is_big, uint32_t c0, uint32_t c
                     acc[8] += rc[i];
                 }
             }
+            // a fixed butterfly over the Gaussian's lanes, then every owner picks up its group's sums
 #pragma unroll
             for (int q = 0; q < 9; q++) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d);
+                for (int d = (int)LPR / 2; d >= 1; d >>= 1) acc[q] += __shfl_xor(acc[q], d);
             }
-            if ((int)lane == src) {
 #pragma unroll
-                for (int q = 0; q < 9; q++) sums[q] = acc[q];
+            for (int g = 0; g < NG; g++) {
+                if (src[g] >= 0) {                                               // (wave-uniform)
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[q]), g * (int)LPR));
+                        if ((int)lane == src[g]) sums[q] = v;
+                    }
+                }
             }
         }
     }
@@ -944,16 +972,19 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // words) is summed by the Gaussian's own lane -- or its group of lanes; one that covers much of the image owns thousands of cells
     // and is summed by the 64 lanes of the wave together (coop_gather: lane-strided partial sums, then a fixed butterfly): still a
     // fixed order, hence bitwise reproducible.
-    constexpr uint32_t COOP_WORDS = 16;
+    constexpr uint32_t COOP_WORDS = 16, MID_CELLS = 96;
     const uint32_t c0 = visible ? off_raw : 0u, c1 = c0 + (visible ? cells_raw : 0u);
     const uint32_t word0 = c0 >> 5, n_words = c1 > c0 ? ((c1 + 31u) >> 5) - word0 : 0u;
+    // (mid-size runs -- MID_CELLS < cells, <= COOP_WORDS words -- go four at a time through the lane-per-cell form, coop_gather<4>; with
+    // sixteen lanes per Gaussian, the small-P instantiation, the group's lanes take a word each already)
+    const bool mid_size = LPG_L2 == 0 && (c1 - c0) > MID_CELLS && n_words <= COOP_WORDS;
     {
         // Sparse records (a Gaussian owns 2-3 instances of 4-5 cells each, about half of them flagged): walked one after the other, every
         // record costs two DEPENDENT loads (validity word -> record) and the wave waits for its lane with the most: stamps showed this
         // phase taking 48k of a block's 62k cycles in round 2.  Here all validity words, then -- four words at a time -- the first
         // two flagged records of each word are fetched as batches of independent loads.  The summation order is fixed (batch of 4 words,
         // round of 2 records, word, bit), so gradients stay bitwise reproducible.
-        const bool mine = n_words != 0u && n_words <= COOP_WORDS;
+        const bool mine = n_words != 0u && n_words <= COOP_WORDS && !mid_size;
         PSTAMP(8);
         // LPG = 16 (LPG_L2 == 4): the 16 lanes of a Gaussian's group take ONE validity word each -- lane (g, j) the j-th of Gaussian g's
         // <= 16 words: one word load per lane instead of sixteen per owner, and the filing loop below (serial over a lane's words and
@@ -1152,7 +1183,8 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     }
     {
         float sums[9] = { gcol.x, gcol.y, gcol.z, gmx, gmy, gca, gcb, gcc, gop };
-        coop_gather(n_words > COOP_WORDS, c0, c1, cell_valid, inst_grad, sums);
+        if constexpr (LPG_L2 == 0) coop_gather<4>(mid_size, c0, c1, cell_valid, inst_grad, sums);
+        coop_gather<1>(n_words > COOP_WORDS, c0, c1, cell_valid, inst_grad, sums);
         gcol.x = sums[0]; gcol.y = sums[1]; gcol.z = sums[2]; gmx = sums[3]; gmy = sums[4]; gca = sums[5]; gcb = sums[6]; gcc = sums[7]; gop = sums[8];
     }
     PSTAMP(12);

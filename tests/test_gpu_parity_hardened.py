@@ -129,6 +129,23 @@ def test_cfg5_precomp_full_size(gpu, hip_lib):
     _end_to_end(d, gpu, "cfg5_precomp")
 
 
+def test_mid_size_runs_of_gradient_records(gpu, hip_lib):
+    """MOSS's own regime -- tens of thousands of Gaussians on a 1024 x 1024 frame -- scaled down: 12 000 Gaussians at 768 x 768, where a
+    Gaussian covers ~5 tiles and ~50 gradient-record cells and hundreds of them have 100-500.  Runs of more than 96 cells (and at most
+    sixteen validity words) are summed four Gaussians at a time by sixteen lanes each (preprocess.hip, coop_gather<4>): the owner of a
+    run is usually NOT among the lanes that sum it.  (P > 8192: the one-Gaussian-per-lane kernel, not the small-P one.)"""
+    sc = scenes.body_scene(12_000, 768, 768, 810.0, init_like=False, name="mid_size_runs")
+    d = hp.inputs_of(sc, "scale_rot")
+    fw, t, e = tp._check_forward(d, gpu)
+    # the scene must be what the docstring says
+    al = lambda x: (x + 255) // 256 * 256
+    off = al(64 * d.P) + al(4 * d.P) + al(4 * d.P)
+    cells = t.geom.cpu().numpy()[off: off + 4 * d.P].view(np.uint32)
+    assert int(((cells > 96) & (cells <= 480)).sum()) > 200, int((cells > 96).sum())
+    tp._check_backward(d, gpu, fw, t, e)
+    _end_to_end(d, gpu, "mid_size_runs")
+
+
 # ---- raw-parameter mode (what bench.py runs): the op receives logits / log-scales / unnormalised quaternions -------------------
 
 def _raw_parameters(scene, seed=9):
