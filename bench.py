@@ -66,7 +66,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "moss7k", "moss45k"],
+                    help="cfg2 / cfg3 / cfg5 = BASELINE configs[1] / [2] / [4]; moss7k / moss45k (not BASELINE configurations: analysis "
+                         "aids) = MOSS's own floor and ceiling -- 6 890 (scene/dataset_readers.py:720) and 45 695 Gaussians "
+                         "(scene/gaussian_model.py:496) -- at its ZJU-MoCap resolution, 1024 x 1024")
     ap.add_argument("--mode", default="lbs", choices=["precomp", "scale_rot", "lbs", "lbs_python"],
                     help="lbs (default: MOSS's data flow, gaussian_renderer/__init__.py:88-93 -- scales, rotations and a per-Gaussian "
                          "3x3 LBS transform that changes every frame -- with the covariance product inside the op); "
@@ -429,7 +432,9 @@ def main(argv=None):
 
     # ---- workload (identical Gaussians on every rank, one camera per rank) ---------------------------------
     poses = scenes.look_at_ring(max(world, 8))
-    maker = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5}[args.config]
+    maker = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5,
+             "moss7k": lambda seed=scenes.SEED: scenes.body_scene(6_890, 1024, 1024, 1080.0, init_like=True, seed=seed, name="moss7k"),
+             "moss45k": lambda seed=scenes.SEED: scenes.body_scene(45_695, 1024, 1024, 1080.0, init_like=False, seed=seed, name="moss45k")}[args.config]
     scene = maker()
     if args.order == "morton":
         from moss_amd.densify import spatial_order

@@ -70,7 +70,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     LSTAMP(0);
     __shared__ float s_x[LP][LP + 1];
     __shared__ float s_y[LP][LP + 1];
-    __shared__ float s_h[5][LP][LT + 1];
+    __shared__ float s_h[4][LP][LT + 1];                 // (four moments, below: 36.7 KB of LDS in all -- FOUR workgroups per CU; five: 42.2 KB, three)
     __shared__ float s_red[3][4];
 
     const TileId tile = xcd_tile();
@@ -116,49 +116,48 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     LSTAMP(2);
     if (tile_nonzero && tid < (LT / SEG) * LP) {                         // horizontal 11-tap for the 5 moments: rows run along the lanes (odd row
         const int r = tid % LP, q0 = (tid / LP) * SEG;   // stride: conflict-free LDS reads), a thread owns columns q0 .. q0 + SEG - 1
-        // (moments in pairs: v_pk_fma_f32 does two of the five accumulations per instruction)
-        v2f a01[SEG], a23[SEG]; float a4[SEG];
+        // FOUR windowed moments, in two pairs (v_pk_fma_f32 does a pair per instruction): E[x], E[y], E[x^2 + y^2], E[xy].  SSIM needs
+        // the two variances only as their SUM (b2 = sigma1^2 + sigma2^2 + C2), and so do its derivatives (dS/dsigma1^2 = dS/db2): rounds
+        // 1-4 filtered x^2 and y^2 separately -- a fifth moment, a third instruction per tap, and the 5.5 KB of LDS that kept this kernel
+        // at three workgroups per CU.
+        v2f a01[SEG], a23[SEG];
 #pragma unroll
-        for (int j = 0; j < SEG; j++) { a01[j] = v2f{0.f, 0.f}; a23[j] = v2f{0.f, 0.f}; a4[j] = 0.f; }
+        for (int j = 0; j < SEG; j++) { a01[j] = v2f{0.f, 0.f}; a23[j] = v2f{0.f, 0.f}; }
 #pragma unroll
         for (int i = 0; i < SEG + 10; i++) {
             const float a = s_x[r][q0 + i], b = s_y[r][q0 + i];
             const v2f ab = v2f{a, b}, sq = ab * ab;
-            const float xy = a * b;
+            const v2f sx = v2f{sq.x + sq.y, a * b};                                // (x^2 + y^2, x y)
 #pragma unroll
             for (int j = 0; j < SEG; j++) {
                 if (i - j >= 0 && i - j <= 10) {
                     const float w = win.g[i - j];
                     const v2f w2 = v2f{w, w};
-                    a01[j] = __builtin_elementwise_fma(w2, ab, a01[j]); a23[j] = __builtin_elementwise_fma(w2, sq, a23[j]);
-                    a4[j] = __fmaf_rn(w, xy, a4[j]);
+                    a01[j] = __builtin_elementwise_fma(w2, ab, a01[j]); a23[j] = __builtin_elementwise_fma(w2, sx, a23[j]);
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < SEG; j++) {
             s_h[0][r][q0 + j] = a01[j].x; s_h[1][r][q0 + j] = a01[j].y; s_h[2][r][q0 + j] = a23[j].x; s_h[3][r][q0 + j] = a23[j].y;
-            s_h[4][r][q0 + j] = a4[j];
         }
     }
     __syncthreads();
     LSTAMP(3);
     const int lx = tid % LT, ly0 = (tid / LT) * VR;      // vertical: column lx, rows ly0 .. ly0 + VR - 1
-    v2f m01[VR], m23[VR]; float m4[VR];
+    v2f m01[VR], m23[VR];
 #pragma unroll
-    for (int j = 0; j < VR; j++) { m01[j] = v2f{0.f, 0.f}; m23[j] = v2f{0.f, 0.f}; m4[j] = 0.f; }
+    for (int j = 0; j < VR; j++) { m01[j] = v2f{0.f, 0.f}; m23[j] = v2f{0.f, 0.f}; }
     if (tile_nonzero) {
 #pragma unroll
     for (int i = 0; i < VR + 10; i++) {
         const v2f v01 = v2f{s_h[0][ly0 + i][lx], s_h[1][ly0 + i][lx]}, v23 = v2f{s_h[2][ly0 + i][lx], s_h[3][ly0 + i][lx]};
-        const float v4 = s_h[4][ly0 + i][lx];
 #pragma unroll
         for (int j = 0; j < VR; j++) {
             if (i - j >= 0 && i - j <= 10) {
                 const float w = win.g[i - j];
                 const v2f w2 = v2f{w, w};
                 m01[j] = __builtin_elementwise_fma(w2, v01, m01[j]); m23[j] = __builtin_elementwise_fma(w2, v23, m23[j]);
-                m4[j] = __fmaf_rn(w, v4, m4[j]);
             }
         }
     }
@@ -170,11 +169,12 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     for (int j = 0; j < VR; j++) {
         const int ly = ly0 + j, py = y0 + ly;
         if (px < W && py < H) {
-            const float mu1 = m01[j].x, mu2 = m01[j].y, exx = m23[j].x, eyy = m23[j].y, exy = m4[j];
+            const float mu1 = m01[j].x, mu2 = m01[j].y, ess = m23[j].x /* E[x^2 + y^2] */, exy = m23[j].y;
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-            const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
+            const float s12 = exy - mu12;
+            // sigma1^2 + sigma2^2 = E[x^2 + y^2] - mu1^2 - mu2^2 (utils/loss_utils.py:73-75 forms the two variances and adds them)
+            const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = (ess - mu1_sq - mu2_sq) + C2;
             // (hardware reciprocals, ~1 ulp: this file is compiled with correctly rounded division, ten instructions apiece, and the
             // four quotients per pixel-channel were an eighth of this kernel's vector instructions; b1 >= C1, b2 ~ C2 + variances)
             const float rb1 = __builtin_amdgcn_rcpf(b1), rb2 = __builtin_amdgcn_rcpf(b2), inv = rb1 * rb2;
