@@ -66,10 +66,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "moss7k", "moss45k"],
-                    help="cfg2 / cfg3 / cfg5 = BASELINE configs[1] / [2] / [4]; moss7k / moss45k (not BASELINE configurations: analysis "
-                         "aids) = MOSS's own floor and ceiling -- 6 890 (scene/dataset_readers.py:720) and 45 695 Gaussians "
-                         "(scene/gaussian_model.py:496) -- at its ZJU-MoCap resolution, 1024 x 1024")
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "moss7k", "moss45k", "moss45k_512"],
+                    help="cfg2 / cfg3 / cfg5 = BASELINE configs[1] / [2] / [4]; the others are not BASELINE configurations (analysis aids): "
+                         "MOSS's own floor and ceiling -- 6 890 (scene/dataset_readers.py:720) and 45 695 Gaussians "
+                         "(scene/gaussian_model.py:496).  moss45k_512 = the ceiling at MOSS's ZJU-MoCap resolution, 512 x 512 (ZJU frames are "
+                         "loaded at image_scaling 0.5, scene/dataset_readers.py:540; cfg2 is the floor at that resolution); moss7k / moss45k = "
+                         "floor / ceiling at 1024 x 1024, the MonoCap resolution (image_scaling 1.0, :299)")
     ap.add_argument("--mode", default="lbs", choices=["precomp", "scale_rot", "lbs", "lbs_python"],
                     help="lbs (default: MOSS's data flow, gaussian_renderer/__init__.py:88-93 -- scales, rotations and a per-Gaussian "
                          "3x3 LBS transform that changes every frame -- with the covariance product inside the op); "
@@ -184,6 +186,7 @@ class Harness:
         from moss_amd import loss as mloss
         self.torch, self.dev, self.world, self.args = torch, dev, world, args
         self.mode, self.forward = mode, forward
+        self._cam, self._bg = cam, bg
         self.ctx = dgr.RasterContext()                       # this harness's own asynchronous-forward state and gradient sinks
         unified = not torch_adamw and not torch_activations
         self.pc = pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
@@ -259,7 +262,7 @@ class Harness:
                 bucket.detach_grads()       # gradients are WRITTEN into the bucket by the backward kernels
             else:
                 bucket.attach()             # zero the bucket; autograd accumulates into it
-            out = render(cam, pc, pipe, bg, transforms=lbs_T)
+            out = render(cam, pc, pipe, bg, transforms=self.lbs_T)      # (self.lbs_T: re-indexed by a densification event)
             if fused_loss is True:
                 # the loss kernels write [loss, L1, SSIM, mask] into the bucket's tail: it travels with the gradients, no copy
                 loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
@@ -379,6 +382,27 @@ class Harness:
                                                              " + eager RCCL all-reduce and AdamW" if self.sharded is None else
                                                              " + eager RCCL reduce-scatter, AdamW on the rank's shard, all-gather") if self.world > 1 else "")
 
+    def densify_event(self, step, reset_opacity=False):
+        """One scripted densification event on this harness (moss_amd.scenes.scripted_densification -> moss_amd.surgery.densification_event):
+        clone + split + prune of the CURRENT set, optimizer moments / bucket / statistics / LBS table re-laid-out, capacity re-learned by a
+        forward-only probe, the captured step re-captured.  MOSS does this every 100 iterations from 400 to 2000 (train_ZJU.py:171-186)."""
+        torch = self.torch
+        from moss_amd import scenes
+        from moss_amd.gaussian_renderer import render
+        from moss_amd.surgery import densification_event
+        pc = self.pc
+        t = {"xyz": pc._xyz.data, "f_dc": pc._features_dc.data, "f_rest": pc._features_rest.data, "opacity": pc._opacity.data,
+             "scaling": pc._scaling.data, "rotation": pc._rotation.data}
+        ev = scenes.scripted_densification(t, step, self.dev, reset_opacity=reset_opacity)
+
+        def probe():                                         # forward only (no gradient, no optimizer step): sizes the capacity of the new set
+            with torch.no_grad():
+                render(self._cam, pc, self.pipe, self._bg, transforms=self.lbs_T)
+        pg = {} if self.lbs_T is None else {"T": self.lbs_T}
+        return densification_event(pc, self.opt, append=ev["append"], prune=ev["prune"], reset_opacity=ev["reset_opacity"],
+                                   stats=self.stats if hasattr(self.stats, "prune") else None, context=self.ctx, graphed=self.graphed, probe=probe,
+                                   per_gaussian=pg, after_surgery=lambda d: setattr(self, "lbs_T", d.get("T", self.lbs_T)))
+
     def time_steps(self, n, barrier=None):
         torch = self.torch
         if barrier:
@@ -434,7 +458,8 @@ def main(argv=None):
     poses = scenes.look_at_ring(max(world, 8))
     maker = {"cfg2": scenes.config2, "cfg3": scenes.config3, "cfg5": scenes.config5,
              "moss7k": lambda seed=scenes.SEED: scenes.body_scene(6_890, 1024, 1024, 1080.0, init_like=True, seed=seed, name="moss7k"),
-             "moss45k": lambda seed=scenes.SEED: scenes.body_scene(45_695, 1024, 1024, 1080.0, init_like=False, seed=seed, name="moss45k")}[args.config]
+             "moss45k": lambda seed=scenes.SEED: scenes.body_scene(45_695, 1024, 1024, 1080.0, init_like=False, seed=seed, name="moss45k"),
+             "moss45k_512": lambda seed=scenes.SEED: scenes.body_scene(45_695, 512, 512, 540.0, init_like=False, seed=seed, name="moss45k_512")}[args.config]
     scene = maker()
     if args.order == "morton":
         from moss_amd.densify import spatial_order
@@ -692,8 +717,9 @@ def main(argv=None):
                                        else "reduce-scatter + AdamW on the rank's shard + all-gather") + " (SURVEY 8e)")
                                    + "; value_allreduce / value_sharded / value_loss_only in this line: the same step under each of the three exchanges"),
                    "forward": args.forward, "launch": h.graph_note if use_graph else "eager launches",
+                   # (was_fused: what the TIMED region ran -- the rasterizer-only pass above takes the step out of the backward afterwards)
                    "optimizer": ("AdamW step taken by the per-Gaussian backward kernel (moss_raster_backward_raw_adamw); bit-identical to the flat "
-                                 "kernel, reported beside as callers.unfused_optimizer") if h.fused_opt else "flat AdamW kernel over the gradient bucket",
+                                 "kernel, reported beside as callers.unfused_optimizer") if was_fused else "flat AdamW kernel over the gradient bucket",
                    "glue": "compiled PyTorch-ROCm extension moss_amd/lib/_moss_C.so over the C ABI of libmoss_raster.so",
                    **({"debug_bits": int(args.debug_bits)} if args.debug_bits else {})},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -762,6 +788,8 @@ def main(argv=None):
         result["value_precomp"] = result["callers"].get("precomp_graph", {}).get("value")
         if "small_P_cfg2" in result["callers"]:
             result["value_small_P_cfg2"] = result["callers"]["small_P_cfg2"].get("value")
+        if "densify_schedule" in result["callers"]:
+            result["value_densify_schedule"] = result["callers"]["densify_schedule"].get("value")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
         result["cpu_baseline_autograd"] = cpu_baseline_autograd()
@@ -821,6 +849,15 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         # scene/gaussian_model.py:496): BASELINE configs[1] through the headline's harness
         specs["small_P_cfg2"] = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations,
                                      torch_adamw=False, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer))
+    if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw and args.fused_optimizer:
+        # the headline's step THROUGH MOSS's densification schedule (train_ZJU.py:171-186: an event every 100 iterations): 400 steps with a
+        # scripted clone / split / prune event after every 100th (an opacity reset with the second), the optimizer's rows, the bucket, the
+        # capacity and the captured graph rebuilt at each (moss_amd.surgery.densification_event) -- on the headline workload and on
+        # configs[1], MOSS's own starting point
+        same = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations, torch_adamw=False,
+                    forward="async", graph=1, fused_optimizer=True)
+        specs["densify_schedule"] = dict(same)
+        specs["densify_schedule_cfg2"] = dict(same)
     only = [x for x in getattr(args, "callers_only", "").split(",") if x]
     for name, kw in specs.items():
         if only and name not in only:
@@ -828,7 +865,7 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         try:
             sc, T_ = scene, lbs_T
             cam_, gt_, mask_ = cam, gt, gt_mask
-            if name == "small_P_cfg2":
+            if name in ("small_P_cfg2", "densify_schedule_cfg2"):
                 from moss_amd import scenes as _scenes
                 from moss_amd.gaussian_model import GaussianSet as _GS
                 from moss_amd.gaussian_renderer import render as _render, camera_view as _camera_view
@@ -861,6 +898,11 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
             if h.use_graph:
                 h.capture()
                 h.time_steps(warmup)                         # (replays: clocks and caches as in the timed region)
+            if name.startswith("densify_schedule"):
+                res[name] = _densify_schedule(h, dev, sc)
+                del h
+                torch.cuda.empty_cache()
+                continue
             if name in ("as_generated_order", "spatial_order", "small_P_cfg2"):
                 # three segments, the median one reported (with the segments beside it): late in a process that has built and dropped
                 # four harnesses a segment now and then takes a one-off host stall of tens of milliseconds, which is not what the
@@ -891,6 +933,33 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
             res[name] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
         torch.cuda.empty_cache()
     return res
+
+
+def _densify_schedule(h, dev, sc, steps=400, every=100):
+    """`steps` replays of the captured headline step with a scripted densification event after every `every`-th: wall time of the whole
+    schedule (events included) and of the steps alone, the cost of each event, the row counts."""
+    import torch
+    torch.cuda.synchronize(dev)
+    t_steps, events, rows = 0.0, [], [int(h.pc._xyz.shape[0])]
+    t_all0 = time.perf_counter()
+    done = 0
+    while done < steps:
+        dt, _ = h.time_steps(every)
+        t_steps += dt
+        done += every
+        rep = h.densify_event(done, reset_opacity=(done == 2 * every))
+        events.append(rep["event_ms"]); rows.append(rep["rows_after"])
+    torch.cuda.synchronize(dev)
+    t_all = time.perf_counter() - t_all0
+    h.ctx.check_status()
+    return {"value": round(steps / t_all, 2), "unit": "iters/s", "ms_per_step": round(1e3 * t_all / steps, 4), "steps": steps,
+            "events": len(events), "event_ms": events, "event_ms_mean": round(sum(events) / len(events), 3),
+            "value_between_events": round(steps / t_steps, 2), "ms_per_step_between_events": round(1e3 * t_steps / steps, 4),
+            "rows": rows, "graph_recaptures": h.graphed.recaptures, "dropped_frames": h.graphed.dropped_frames,
+            "workload": f"{sc.name}: the headline's step (lbs, fused optimizer, one hipGraph) with a scripted clone / split / prune event every "
+                        f"{every} steps (MOSS: train_ZJU.py:171-186); an event = optimizer rows + moments, bucket, statistics, LBS table "
+                        f"re-laid-out, capacity re-learned by a forward-only probe, the step re-captured",
+            "launch": h.graph_note}
 
 
 def densify_side(pc, out):

@@ -65,8 +65,23 @@ class DensifyStats:
         g[g.isnan()] = 0.0
         return g
 
-    def reset(self) -> None:
-        self.xyz_gradient_accum.zero_(); self.denom.zero_(); self.max_radii2D.zero_()
+    def reset(self, P: int = None) -> None:
+        """All three back to zero -- for ``P`` Gaussians if given: ``densification_postfix`` re-creates them at the new size
+        (scene/gaussian_model.py:451-454)."""
+        if P is not None and int(P) != self.denom.shape[0]:
+            dev = self.denom.device
+            self.xyz_gradient_accum = torch.zeros((int(P), 1), device=dev)
+            self.denom = torch.zeros((int(P), 1), device=dev)
+            self.max_radii2D = torch.zeros((int(P),), device=dev)
+        else:
+            self.xyz_gradient_accum.zero_(); self.denom.zero_(); self.max_radii2D.zero_()
+
+    def prune(self, keep_mask: torch.Tensor) -> None:
+        """``prune_points`` keeps the surviving rows of the three statistics (scene/gaussian_model.py:406-410)."""
+        keep = keep_mask.to(self.denom.device).bool()
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep].contiguous()
+        self.denom = self.denom[keep].contiguous()
+        self.max_radii2D = self.max_radii2D[keep].contiguous()
 
 
 def densify_stats_update(max_radii2D: torch.Tensor, xyz_gradient_accum: torch.Tensor, denom: torch.Tensor,

@@ -72,6 +72,21 @@ class RasterContext:
     def set_async(self, enabled: bool, capacity: int = 0, margin: float = 2.0):
         self.enabled, self.capacity, self.margin, self.pending = bool(enabled), int(capacity), float(margin), None
 
+    def relearn_capacity(self):
+        """Forget the learned binning capacity: the NEXT forward of this context runs synchronously (like the first one of an
+        asynchronous session) and sizes the capacity from what it finds -- for the moments the set of Gaussians changes from outside
+        (densify / prune).  Call it outside graph capture; a hipGraph captured with the old capacity must be captured again."""
+        self._consume_quiet()
+        self.capacity = 0
+        self.pending = None
+
+    def _consume_quiet(self):
+        """Pick up a pending status report (it belongs to a frame of the OLD set) without losing an overflow it carries."""
+        try:
+            self._consume_status(block=True)
+        except CapacityOverflow:
+            pass                                             # (counted in _raised_overflows: the frame rendered nothing, the caller re-learns anyway)
+
     def _status_buffer(self):
         if self.status_buf is None:
             self.status_buf = torch.zeros(8, dtype=torch.int32).pin_memory()
@@ -221,9 +236,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         if not capturing and cx.pending is None:
             cx._request_status(img, means3D.device)
     elif cx.enabled and P > 0:                               # first (synchronous) call of an async session: learn the size
+        learning = cx.capacity == 0                          # (debug bit 0 / CPU tensors also come here, with a capacity already learned)
         cx.capacity = max(cx.capacity, int(rendered * cx.margin) + 1024)
         cx.last_needed = rendered
-        if means3D.is_cuda and rendered > 0:                 # ... including what the frame asks of the record pool (status word [3])
+        if learning and means3D.is_cuda and rendered > 0:    # ... including what the frame asks of the record pool (status word [3])
+            cx._consume_status(block=True)                   # (a report still pending from an earlier asynchronous frame is not lost)
             cx._request_status(img, means3D.device)
             cx._consume_status(block=True)
     global last_num_rendered

@@ -79,7 +79,20 @@ class GradBucket:
     optimizer path (``ShardedStep``); the 4-float loss block is 4-aligned, so it never straddles two shards."""
 
     def __init__(self, params, world: int = 1):
+        """COLLECTIVE when a process group of more than one rank is initialised: the constructor issues the ``ReduceOp.AVG`` probe
+        all-reduce (``avg_supported``), so EVERY rank must construct its bucket(s), in the same order relative to other collectives
+        (a rank-0-only evaluation bucket would hang the job; build such buckets before ``init_process_group`` or on every rank)."""
         self.params = [p for p in params if p.requires_grad]
+        self.world = max(int(world), 1)
+        self._layout()
+        # whether the collective library averages inside the collective is decided HERE, once, on every rank alike -- not at the first
+        # exchange, which may sit inside a hipGraph capture or behind a rank-dependent branch (ADVICE r4; needs the process group)
+        dev = self.params[0].device
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            avg_supported(dev if dev.type == "cuda" else None)
+
+    def _layout(self):
+        """Offsets, the flat buffer and its views from the CURRENT shapes of ``self.params`` (constructor and ``relayout``)."""
         self.sizes = [p.numel() for p in self.params]
         self.offsets, off = [], 0
         for n in self.sizes:
@@ -89,7 +102,6 @@ class GradBucket:
         self.n_params = off                                # length of the parameter region (inner padding included)
         self.tail = (self.n_params + 3) // 4 * 4           # offset of the loss block
         self.n_exchange = self.tail + 4                    # what has to travel: gradients + loss block
-        self.world = max(int(world), 1)
         self.shard_len, padded = shard_layout(self.n_exchange, self.world)
         dev = self.params[0].device
         self.flat = torch.zeros(padded if self.world > 1 else self.n_exchange, dtype=torch.float32, device=dev)
@@ -99,10 +111,17 @@ class GradBucket:
         self.loss_terms = self.flat[off:off + 4]          # [loss, L1, SSIM, mask L2]: moss_photometric_loss can write here directly
         self._offset = {id(p): off for p, off in zip(self.params, self.offsets)}
         self._handed_out = set()
-        # whether the collective library averages inside the collective is decided HERE, once, on every rank alike -- not at the first
-        # exchange, which may sit inside a hipGraph capture or behind a rank-dependent branch (needs the process group)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            avg_supported(dev if dev.type == "cuda" else None)
+
+    def relayout(self):
+        """The parameters changed SHAPE (rows pruned or appended: MOSS's densification, scene/gaussian_model.py:377-454; the Parameter
+        objects are the same): a new flat buffer with the new offsets -- all-zero, like a fresh bucket -- and new views; the loss block
+        moves with the tail.  Views handed out before (``views``, ``loss_terms``, sinks, ``.grad``) belong to the OLD buffer: every
+        parameter's ``.grad`` is dropped here, and a hipGraph that captured a step over the old buffer must be captured again
+        (``FlatAdamW.prune_rows`` / ``append_rows`` call this; ``moss_amd.surgery.densification_event`` does the whole sequence).
+        No collective: every replica calls it with the same shapes."""
+        for p in self.params:
+            p.grad = None
+        self._layout()
 
     def pack(self, tensors):
         """The flat image (``n_params`` floats, zeros in the alignment gaps) of one tensor per parameter, in parameter order."""

@@ -73,6 +73,43 @@ class GaussianSet(nn.Module):
         self.spatially_ordered = True
         return perm
 
+    # ---- the three moments MOSS rebuilds its tensors AND its optimizer state (scene/gaussian_model.py:314-317, :396-411, :436-454), on a
+    # FlatAdamW: the Parameter objects stay, their storage and the moments are re-laid-out by the optimizer.  Decision logic (which
+    # Gaussians to clone / split / prune: densify_and_clone / _split / _prune, :456-620) is MOSS's and stays there.
+    def _flat(self, optimizer):
+        if not (hasattr(optimizer, "prune_rows") and hasattr(optimizer, "append_rows") and hasattr(optimizer, "reset_rows")):
+            raise TypeError("GaussianSet surgery drives a moss_amd.optim.FlatAdamW; with a torch-state optimizer (torch.optim.AdamW, "
+                            "moss_amd.optim.AdamW) MOSS's own cat_tensors_to_optimizer / _prune_optimizer / replace_tensor_to_optimizer apply")
+        return optimizer
+
+    def prune_points(self, mask, optimizer, stats=None):
+        """``prune_points(mask)`` (scene/gaussian_model.py:396-411): rows where ``mask`` is True are REMOVED from every parameter, from
+        both moments of each and from the densification statistics."""
+        keep = ~mask.bool()
+        self._flat(optimizer).prune_rows(keep)
+        if stats is not None:
+            stats.prune(keep)
+
+    def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation, optimizer, stats=None):
+        """``densification_postfix`` (scene/gaussian_model.py:436-454): the new Gaussians are appended to every parameter with zero
+        moments, and the three statistics start again from zero at the new size."""
+        opt = self._flat(optimizer)
+        if self.unified_features:
+            rows = {id(self._features): torch.cat((new_features_dc, new_features_rest), dim=1)}
+        else:
+            rows = {id(self._features_dc): new_features_dc, id(self._features_rest): new_features_rest}
+        rows.update({id(self._xyz): new_xyz, id(self._opacity): new_opacities, id(self._scaling): new_scaling, id(self._rotation): new_rotation})
+        index = {id(p): i for i, p in enumerate(opt.bucket.params)}
+        opt.append_rows({index[k]: v for k, v in rows.items()})
+        if stats is not None:
+            stats.reset(self._xyz.shape[0])
+
+    def reset_opacity(self, optimizer):
+        """``reset_opacity`` (scene/gaussian_model.py:314-317): opacity = min(opacity, 0.01) in logits, both moments of it zeroed."""
+        with torch.no_grad():
+            new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self._opacity) * 0.01))
+        self._flat(optimizer).reset_rows(self._opacity, new)
+
     # activations as in scene/gaussian_model.py:46-56,134-166
     @property
     def get_xyz(self):

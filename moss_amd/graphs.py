@@ -62,6 +62,19 @@ class GraphedStep:
         self.graph.replay()
         return self.outputs
 
+    def recapture(self, probe=None) -> None:
+        """Capture ``fn`` again after something it bakes in has changed from OUTSIDE: the parameter / moment / bucket buffers
+        (``FlatAdamW.prune_rows`` / ``append_rows``: MOSS densifies every 100 iterations, train_ZJU.py:171-186), the SH degree, a
+        learning rate passed as a launch argument.  No eager warm-up run of ``fn`` (it is a training step and would be an uncounted
+        one).  ``probe`` (optional): a side-effect-free callable run eagerly first -- e.g. a forward-only ``render()`` of the new set
+        under ``torch.no_grad()`` after ``RasterContext.relearn_capacity()`` -- so that the capture sees the capacity the new set needs."""
+        if probe is not None:
+            probe()
+            torch.cuda.synchronize(self.device)
+        self.graph = None                                    # (the old graph's private pool goes back before the new capture allocates)
+        self._capture(warmup=0)
+        self.recaptures += 1
+
     def check(self) -> bool:
         """Call every few hundred steps (it synchronises): verifies that the last replayed frame fitted its binning capacity
         (raises like ``check_async_status`` if it did not) and, when the instance count has drifted to within 25 % of the captured

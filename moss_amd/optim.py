@@ -39,32 +39,50 @@ class FlatAdamW:
         / world); the caller reduce-scatters the gradient bucket into ``grad_shard`` before ``step()`` and all-gathers ``flat_params``
         after it -- ``moss_amd.dist.ShardedStep`` does both."""
         self.bucket = bucket
-        params = bucket.params
-        lr_of, pat_of = {}, {}
+        self._lr_of, self._pat_of = {}, {}
         for gidx, grp in enumerate(param_groups):
             for p in grp["params"]:
-                lr_of[id(p)] = float(grp["lr"])
+                self._lr_of[id(p)] = float(grp["lr"])
                 # optional periodic pattern (period, split, lr_rest): first `split` of every `period` elements use lr, the rest lr_rest
-                pat_of[id(p)] = grp.get("lr_pattern")
-        total = bucket.n_params                              # (every tensor starts 16-byte aligned: GradBucket.offsets)
-        dev = params[0].device
+                self._pat_of[id(p)] = grp.get("lr_pattern")
+        if len(bucket.params) > 8:
+            raise ValueError("FlatAdamW supports at most 8 learning-rate segments")
         self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
         if self.shard is not None and self.shard[1] != bucket.world:
             raise ValueError(f"shard=(rank, {self.shard[1]}) but the bucket was laid out for {bucket.world} shards")
+        self._adopt_layout([p.data for p in bucket.params], None, None)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.t = 0
+        self.fused = None                                    # set by fuse_into_backward
+        # device-side step counter + completion counters, each on a cache line of its own: the LIBRARY says how large (csrc/optim.hip)
+        dev = bucket.params[0].device
+        self.step_state = torch.zeros(int(lib().moss_adamw_state_bytes()) // 4, dtype=torch.int32, device=dev) if capturable else None
+
+    def _adopt_layout(self, values, exp_avg, exp_avg_sq):
+        """(Re)build the flat buffers for the bucket's CURRENT layout: ``values[i]`` becomes parameter i (re-homed as a view of
+        ``flat_params``), ``exp_avg[i]`` / ``exp_avg_sq[i]`` its moments (None: zeros -- a fresh optimizer).  The constructor and the
+        row surgery (``prune_rows`` / ``append_rows``) end here; learning rates that ``set_learning_rates`` changed are kept."""
+        bucket = self.bucket
+        params = bucket.params
+        total = bucket.n_params                              # (every tensor starts 16-byte aligned: GradBucket.offsets)
+        dev = params[0].device
         # (sharded: the parameter buffer mirrors the bucket's padded layout -- parameters, loss block, padding -- so that the
         # all-gather of the updated shards is in place)
         self.flat_params = torch.zeros(bucket.flat.numel() if self.shard is not None else total, dtype=torch.float32, device=dev)
+        old_lr = {i: (float(self.seg_lr[i]), float(self.seg_lr2[i])) for i in range(getattr(self, "nseg", 0))}
         ends, lrs, periods, splits, lr2s = [], [], [], [], []
         for i, (p, n, off) in enumerate(zip(params, bucket.sizes, bucket.offsets)):
-            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat_params[off:off + n].view_as(p)              # the parameter now lives in the flat buffer
+            self.flat_params[off:off + n].copy_(values[i].reshape(-1))
+            p.data = self.flat_params[off:off + n].view(values[i].shape)      # the parameter now lives in the flat buffer
             # a segment runs to the (aligned) start of the next tensor: the <= 3 floats of padding behind a tensor are zeros with zero
             # gradients, which the update leaves zero
-            ends.append(bucket.offsets[i + 1] if i + 1 < len(params) else total); lrs.append(lr_of[id(p)])
-            pat = pat_of[id(p)]
+            ends.append(bucket.offsets[i + 1] if i + 1 < len(params) else total); lrs.append(self._lr_of[id(p)])
+            pat = self._pat_of[id(p)]
             periods.append(int(pat[0]) if pat else 0); splits.append(int(pat[1]) if pat else 0); lr2s.append(float(pat[2]) if pat else 0.0)
-        if len(ends) > 8:
-            raise ValueError("FlatAdamW supports at most 8 learning-rate segments")
+        for i, (lr, lr2) in old_lr.items():                  # (a schedule's current rates survive a re-layout)
+            lrs[i] = lr
+            if periods[i]:
+                lr2s[i] = lr2
         self.n = total
         self.seg_end = (C.c_longlong * len(ends))(*ends)
         self.seg_lr = (C.c_float * len(lrs))(*lrs)
@@ -82,11 +100,9 @@ class FlatAdamW:
             self.grad_shard = torch.zeros(per, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(max(self.count, 1), dtype=torch.float32, device=dev)
-        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
-        self.t = 0
-        self.fused = None                                    # set by fuse_into_backward
-        # device-side step counter + completion counters, each on a cache line of its own: the LIBRARY says how large (csrc/optim.hip)
-        self.step_state = torch.zeros(int(lib().moss_adamw_state_bytes()) // 4, dtype=torch.int32, device=dev) if capturable else None
+        if exp_avg is not None:                              # (row surgery: unsharded by construction)
+            for m, v, n, off in zip(exp_avg, exp_avg_sq, bucket.sizes, bucket.offsets):
+                self.exp_avg[off:off + n].copy_(m.reshape(-1)); self.exp_avg_sq[off:off + n].copy_(v.reshape(-1))
 
     # ---- the update applied by the rasterizer's backward kernel itself -----------------------------------------------------------
     def fuse_into_backward(self, context, means3D=None, sh=None, opacity=None, scales=None, rotations=None, local_only=False):
@@ -153,6 +169,7 @@ class FlatAdamW:
         self.fused = _FusedAdamW(st, ptrs, self)
         self._fused_context = context or _C.DEFAULT
         self._fused_context.fused_adamw = self.fused
+        self._fused_args = (dict(given), bool(local_only))   # (row surgery re-fuses with the same names: the moments move)
         return self.fused
 
     def unfuse(self, context=None):
@@ -165,6 +182,7 @@ class FlatAdamW:
             cx.fused_adamw = None
         self.fused = None
         self._fused_context = None
+        self._fused_args = None
 
     def set_learning_rates(self, rates):
         """A learning-rate schedule.  ``rates``: {parameter (or its index in the bucket): lr, or (lr, lr_rest) for a tensor with a
@@ -239,6 +257,80 @@ class FlatAdamW:
                     for flat in (self.flat_params, self.exp_avg, self.exp_avg_sq):
                         v = flat[off:off + n].view_as(p)
                         v.copy_(v[perm].clone())
+
+    # ---- row surgery: MOSS's densification rebuilds its tensors AND its optimizer state (scene/gaussian_model.py:362-454) ----------
+    def _row_params(self, n_rows):
+        return [p.dim() >= 1 and p.shape[0] == n_rows for p in self.bucket.params]
+
+    def _relayout(self, values, exp_avg, exp_avg_sq):
+        """New parameter values / moments (one tensor per bucket parameter, the Parameter OBJECTS stay) -> new bucket layout, new flat
+        buffers, the fused step re-armed on the new moment addresses.  Everything that holds device addresses of the old buffers -- a
+        captured hipGraph above all -- is stale afterwards: ``GraphedStep.recapture()``."""
+        if self.shard is not None:
+            raise RuntimeError("row surgery on a SHARDED FlatAdamW: a parameter row's moments live on several ranks; use the all-reduce "
+                               "exchange while the set densifies (or gather, rebuild and re-shard)")
+        fused = getattr(self, "_fused_args", None) if self.fused is not None else None
+        cx = getattr(self, "_fused_context", None)
+        for p, v in zip(self.bucket.params, values):
+            p.data = v                                       # (the new shapes: what the bucket lays itself out from)
+        self.bucket.relayout()
+        self._adopt_layout(values, exp_avg, exp_avg_sq)
+        if fused is not None:
+            self.fuse_into_backward(cx, local_only=fused[1], **fused[0])
+
+    def _moments_of(self, i):
+        off, n = self.bucket.offsets[i], self.bucket.sizes[i]
+        shape = self.bucket.params[i].shape
+        return self.exp_avg[off:off + n].view(shape), self.exp_avg_sq[off:off + n].view(shape)
+
+    @torch.no_grad()
+    def prune_rows(self, keep_mask: torch.Tensor):
+        """``_prune_optimizer(mask)`` (scene/gaussian_model.py:377-394): every parameter whose leading dimension is len(keep_mask)
+        keeps the rows where the mask is True, and so do its two moments; the shared step count stays (torch keeps ``state['step']``
+        too).  The Parameter objects are the same afterwards (``.data`` re-homed in the new flat buffer, ``.grad`` dropped)."""
+        keep = keep_mask.to(self.flat_params.device).bool()
+        rows = self._row_params(int(keep.numel()))
+        vals, ms, vs = [], [], []
+        for i, (p, is_row) in enumerate(zip(self.bucket.params, rows)):
+            m, v = self._moments_of(i)
+            vals.append((p.data[keep] if is_row else p.data).clone()); ms.append((m[keep] if is_row else m).clone()); vs.append((v[keep] if is_row else v).clone())
+        self._relayout(vals, ms, vs)
+
+    @torch.no_grad()
+    def append_rows(self, new_rows):
+        """``cat_tensors_to_optimizer(tensors_dict)`` (scene/gaussian_model.py:413-434): ``new_rows`` maps a parameter (the object, or
+        its index in the bucket) to the rows appended to it; their moments start at ZERO (``torch.zeros_like(extension_tensor)``,
+        :422-423), the existing rows keep theirs, the shared step count stays.  Parameters not named keep their shape."""
+        index = {id(p): i for i, p in enumerate(self.bucket.params)}
+        ext = {}
+        for key, t in new_rows.items():
+            ext[key if isinstance(key, int) else index[id(key)]] = t
+        vals, ms, vs = [], [], []
+        for i, p in enumerate(self.bucket.params):
+            m, v = self._moments_of(i)
+            if i in ext:
+                e = ext[i].detach().to(device=p.device, dtype=torch.float32)
+                if tuple(e.shape[1:]) != tuple(p.shape[1:]):
+                    raise ValueError(f"append_rows: rows of shape {tuple(e.shape)} do not extend a parameter of shape {tuple(p.shape)}")
+                vals.append(torch.cat((p.data, e), dim=0)); ms.append(torch.cat((m, torch.zeros_like(e)), dim=0)); vs.append(torch.cat((v, torch.zeros_like(e)), dim=0))
+            else:
+                vals.append(p.data.clone()); ms.append(m.clone()); vs.append(v.clone())
+        self._relayout(vals, ms, vs)
+
+    @torch.no_grad()
+    def reset_rows(self, param, values: torch.Tensor):
+        """``replace_tensor_to_optimizer(tensor, name)`` (scene/gaussian_model.py:362-375; ``reset_opacity`` :314-317): the parameter
+        takes ``values`` and BOTH its moments are zeroed.  Same shape, same addresses: in place, nothing is re-laid-out and a captured
+        hipGraph stays valid (the copies run on the current stream, in order with the replays)."""
+        i = param if isinstance(param, int) else {id(p): k for k, p in enumerate(self.bucket.params)}[id(param)]
+        p = self.bucket.params[i]
+        if tuple(values.shape) != tuple(p.shape):
+            raise ValueError(f"reset_rows: values of shape {tuple(values.shape)} for a parameter of shape {tuple(p.shape)}")
+        if self.shard is not None:
+            raise RuntimeError("reset_rows on a sharded FlatAdamW: the parameter's moments live on several ranks")
+        p.data.copy_(values.detach())
+        m, v = self._moments_of(i)
+        m.zero_(); v.zero_()
 
     def step(self, skip_word=None, skip_mask=2):
         """One update.  ``skip_word`` (capturable optimizers only): a one-element int32 / float32 DEVICE tensor; if

