@@ -790,6 +790,20 @@ def main(argv=None):
             result["value_small_P_cfg2"] = result["callers"]["small_P_cfg2"].get("value")
         if "densify_schedule" in result["callers"]:
             result["value_densify_schedule"] = result["callers"]["densify_schedule"].get("value")
+    if world == 1 and not args.no_callers and headline and (not args.callers_only or "eval" in args.callers_only.split(",")):
+        # the evaluation path (render_ZJU.py:56-72): forward-only renders of the same Gaussians, on configs[2] and configs[4]
+        torch.cuda.empty_cache()
+        result["eval"] = {"configs[2]": eval_block(dev, scene, cam, bg, lbs_transforms())}
+        try:
+            sc5 = scenes.config5()
+            gT5 = torch.Generator().manual_seed(1234)
+            T5 = (torch.eye(3) + 0.05 * torch.randn(sc5.means3D.shape[0], 3, 3, generator=gT5)).to(dev)
+            result["eval"]["configs[4]"] = eval_block(dev, sc5, camera_view(sc5.camera, dev), bg, T5)
+            del sc5, T5
+        except Exception as e:                               # a side measurement must not take the headline down with it
+            result["eval"]["configs[4]"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        result["value_eval_fps"] = result["eval"]["configs[2]"].get("fps_async_graph")
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, args, gt, gt_mask)
         result["cpu_baseline_autograd"] = cpu_baseline_autograd()
@@ -940,26 +954,116 @@ def _densify_schedule(h, dev, sc, steps=400, every=100):
     schedule (events included) and of the steps alone, the cost of each event, the row counts."""
     import torch
     torch.cuda.synchronize(dev)
-    t_steps, events, rows = 0.0, [], [int(h.pc._xyz.shape[0])]
+    t_steps, events, rows, phases, first = 0.0, [], [int(h.pc._xyz.shape[0])], [], []
     t_all0 = time.perf_counter()
     done = 0
     while done < steps:
-        dt, _ = h.time_steps(every)
-        t_steps += dt
+        # (the first replay of a freshly captured graph pays its upload: timed on its own and reported as part of what an event costs)
+        dt1, _ = h.time_steps(1)
+        dt, _ = h.time_steps(every - 1)
+        t_steps += dt + dt1
+        if done:
+            first.append(round(1e3 * dt1, 3))
         done += every
         rep = h.densify_event(done, reset_opacity=(done == 2 * every))
         events.append(rep["event_ms"]); rows.append(rep["rows_after"])
+        phases.append({k: rep[k] for k in ("surgery_ms", "probe_ms", "capture_ms")})
     torch.cuda.synchronize(dev)
     t_all = time.perf_counter() - t_all0
     h.ctx.check_status()
     return {"value": round(steps / t_all, 2), "unit": "iters/s", "ms_per_step": round(1e3 * t_all / steps, 4), "steps": steps,
-            "events": len(events), "event_ms": events, "event_ms_mean": round(sum(events) / len(events), 3),
+            "events": len(events), "event_ms": events, "event_ms_mean": round(sum(events) / len(events), 3), "event_phases_ms": phases,
+            "first_replay_after_event_ms": first,
             "value_between_events": round(steps / t_steps, 2), "ms_per_step_between_events": round(1e3 * t_steps / steps, 4),
             "rows": rows, "graph_recaptures": h.graphed.recaptures, "dropped_frames": h.graphed.dropped_frames,
             "workload": f"{sc.name}: the headline's step (lbs, fused optimizer, one hipGraph) with a scripted clone / split / prune event every "
                         f"{every} steps (MOSS: train_ZJU.py:171-186); an event = optimizer rows + moments, bucket, statistics, LBS table "
                         f"re-laid-out, capacity re-learned by a forward-only probe, the step re-captured",
             "launch": h.graph_note}
+
+
+def eval_block(dev, scene, cam, bg, lbs_T, n=200):
+    """Novel-view rendering as MOSS's render_ZJU.py:56-72 does it -- `render(view, gaussians, pipeline, background)` under
+    torch.no_grad(), here with the per-Gaussian LBS transforms and translation handed to the op (`transforms=`, `translation=`) -- at SH
+    degree 3.  The glue tells the C ABI MOSS_FORWARD_ONLY: same images bit for bit, no backward state, 62 B of binning buffer per instance.
+      fps_sync         the reference's behaviour: every render sizes its binning buffer from a host read-back (one synchronisation)
+      fps_async_graph  capacity-bounded forward (no read-back), the render captured once in a hipGraph and replayed
+      fps_training_forward_async_graph   the TRAINING forward (grad mode on, no backward run) the same way: what the flag saves"""
+    import torch
+    from types import SimpleNamespace
+    from moss_amd import _lib
+    from moss_amd import diff_gaussian_rasterization as dgr
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render
+    from moss_amd.graphs import GraphedStep
+    pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=True)
+    tl = torch.zeros(scene.means3D.shape[0], 3, device=dev)
+    res = {"workload": f"{scene.name}: {scene.means3D.shape[0]} Gaussians, {scene.camera.W}x{scene.camera.H}, SH degree 3, "
+                       "render(view, pc, pipe, bg, transforms=, translation=) under torch.no_grad()"}
+
+    def make(async_):
+        cx = dgr.RasterContext()
+        cx.set_async(async_)
+        pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, fused_activations=False,
+                               transforms_in_op=True, pose_in_op=True, raw_parameters_in_op=True, raster_context=cx)
+        return cx, pipe
+
+    def timed(fn, k):
+        fn(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k
+
+    # --- synchronous, eager (the reference's flow)
+    cx, pipe = make(False)
+
+    def eval_render():
+        with torch.no_grad():
+            return render(cam, pc, pipe, bg, transforms=lbs_T, translation=tl)["render"]
+    for _ in range(5):
+        eval_render()
+    dt = timed(eval_render, n)
+    R = int(cx.last_num_rendered)
+    res.update(fps_sync=round(1.0 / dt, 1), ms_sync=round(1e3 * dt, 4), num_rendered=R,
+               binning_bytes_per_instance=round(_lib.lib().moss_raster_binning_bytes_forward_only(R) / max(R, 1), 1),
+               binning_bytes_per_instance_training=round(_lib.lib().moss_raster_binning_bytes(R) / max(R, 1), 1))
+    # --- asynchronous + one hipGraph per render
+    cx, pipe = make(True)
+    for _ in range(3):
+        eval_render()
+    torch.cuda.synchronize(dev)
+    g = GraphedStep(lambda: eval_render(), warmup=2, device=dev, context=cx)
+    dt = timed(g, n)
+    cx.check_status()
+    res.update(fps_async_graph=round(1.0 / dt, 1), ms_async_graph=round(1e3 * dt, 4))
+    # its kernels, one by one (eager, kernel-attached events)
+    _lib.profile_enable(None)
+    for _ in range(20):
+        eval_render()
+    torch.cuda.synchronize(dev)
+    res["stages_us"] = {k: round(1e3 * v[0] / v[1], 1) for k, v in _lib.profile_read().items() if v[1]}
+    _lib.profile_enable([])
+    del g
+    # --- the training forward the same way (grad mode on; the autograd node is built and dropped, no backward)
+    cx, pipe = make(True)
+
+    def train_forward():
+        return render(cam, pc, pipe, bg, transforms=lbs_T, translation=tl)["render"].detach()
+    for _ in range(3):
+        train_forward()
+    torch.cuda.synchronize(dev)
+    g = GraphedStep(train_forward, warmup=2, device=dev, context=cx)
+    dt = timed(g, n)
+    res.update(fps_training_forward_async_graph=round(1.0 / dt, 1), ms_training_forward_async_graph=round(1e3 * dt, 4))
+    _lib.profile_enable(None)
+    for _ in range(20):
+        train_forward()
+    torch.cuda.synchronize(dev)
+    res["stages_us_training_forward"] = {k: round(1e3 * v[0] / v[1], 1) for k, v in _lib.profile_read().items() if v[1]}
+    _lib.profile_enable([])
+    return res
 
 
 def densify_side(pc, out):

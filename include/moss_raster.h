@@ -34,7 +34,10 @@ extern "C" {
  * load: compare ITS compile-time MOSS_ABI_VERSION with moss_abi_version(). */
 /* ABI 5 (round 5): two more bits of `debug` -- MOSS_DEBUG_EXACT_MATH, MOSS_DEBUG_TRACE (below) -- and moss_raster_binning_bytes
  * follows the slimmer gradient-record layout.  No signature changed. */
-#define MOSS_ABI_VERSION 5
+/* ABI 6 (round 6): MOSS_FORWARD_ONLY (a bit of the forward entry points' `debug` argument) + moss_raster_binning_bytes_forward_only;
+ * moss_fused_adamw gained sh_active_degree / sh_inactive_zero and moss_adamw_flat_ex takes the same two per segment (degree-aware SH
+ * traffic: coefficients above the highest degree ever active are never read or written when they are known to be zero). */
+#define MOSS_ABI_VERSION 6
 /* Version 3 (round 4): EVERY forward / backward entry point takes the `debug` bit set (version 2: only moss_raster_forward /
  * moss_raster_backward did, so MOSS_DEBUG_NO_BLOCK_CULL was silently dropped on the _async / _tf / _raw paths: last argument before
  * `stream`); moss_adamw_flat_guarded (an optimizer step that a dropped frame turns into a no-op); MOSS_RAW_POSE and the
@@ -90,6 +93,17 @@ const char* moss_last_error(void);
 #define MOSS_DEBUG_NO_BLOCK_CULL 2
 #define MOSS_DEBUG_EXACT_MATH    4
 #define MOSS_DEBUG_TRACE         8
+/* MOSS_FORWARD_ONLY (16; ABI 6; a bit of the same argument of every FORWARD entry point -- not a diagnostic: the one call option the
+ * reference's signature has no room for): the caller promises that NO backward call follows this forward -- an evaluation render
+ * (render_ZJU.py:56-72: `render(view, gaussians, pipeline, background)` under torch.no_grad()).  The outputs are the
+ * training forward's BIT FOR BIT (the blend folds its sums at the same list positions); what is not produced is the state only the
+ * backward reads: depth-segment cuts, per-block tails, gradient-record cells and their validity bits.  The binning buffer then holds
+ * ids, block masks, the 48-byte records and the 8-byte sort keys only: moss_raster_binning_bytes_forward_only(R), 62 B per instance
+ * (training: ~370 B).  With a capacity (asynchronous variants) the keys go through the scan -> scatter chain into exact ranges -- six
+ * launches -- because the per-tile key buckets of the four-launch training forward live in the record pool's address space.
+ * A backward call over such buffers is a no-op that returns ZERO gradients and takes no optimizer step (status flag
+ * MOSS_STATUS_FORWARD_ONLY; the kernels check it on the device, like a capacity overflow): never out-of-bounds. */
+#define MOSS_FORWARD_ONLY        16
 int moss_raster_forward(
     moss_alloc_fn geometry_alloc, void* geometry_user,
     moss_alloc_fn binning_alloc, void* binning_user,
@@ -160,6 +174,7 @@ int moss_raster_forward_async(
  * [4] sort chunks  [5] non-empty tiles  [6] instances the frame needed. */
 #define MOSS_STATUS_PREFILTERED 1u
 #define MOSS_STATUS_OVERFLOW    2u
+#define MOSS_STATUS_FORWARD_ONLY 4u  /* the forward ran with MOSS_FORWARD_ONLY: its buffers carry no backward state */
 int moss_raster_read_status(const char* image_buffer, uint32_t* host_pinned_out, void* stream);
 
 /*
@@ -492,6 +507,7 @@ int moss_gaussian_activate_backward(int P, int K, const float* rotation, const f
 size_t moss_raster_geometry_bytes(int P);
 size_t moss_raster_image_bytes(int width, int height);
 size_t moss_raster_binning_bytes(int R);
+size_t moss_raster_binning_bytes_forward_only(int R);   /* the binning buffer of a MOSS_FORWARD_ONLY forward (ABI 6) */
 
 /*
  * Re-express the opaque geometry buffer in the reference's GeometryState terms

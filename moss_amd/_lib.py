@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(_HERE, os.environ.get("MOSS_AMD_LIB_DIR", "lib"))
 LIB_PATH = os.path.join(_LIB_DIR, "libmoss_raster.so")
 EXT_PATH = os.path.join(_LIB_DIR, "_moss_C.so")          # the compiled PyTorch extension (csrc/torch_binding.cpp) over the same C ABI
-ABI_VERSION = 5                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
+ABI_VERSION = 6                                          # include/moss_raster.h MOSS_ABI_VERSION this binding was written against
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -39,6 +39,8 @@ def _declare(lib):
     lib.moss_raster_image_bytes.argtypes = [_i, _i]
     lib.moss_raster_binning_bytes.restype = C.c_size_t
     lib.moss_raster_binning_bytes.argtypes = [_i]
+    lib.moss_raster_binning_bytes_forward_only.restype = C.c_size_t
+    lib.moss_raster_binning_bytes_forward_only.argtypes = [_i]
     lib.moss_raster_frame_state_bytes.restype = C.c_size_t
     lib.moss_raster_frame_state_bytes.argtypes = [_i, _i]
     lib.moss_build_has_diagnostics.restype = _i

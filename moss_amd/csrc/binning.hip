@@ -70,7 +70,8 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
                                              uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table,
                                              const uint32_t* __restrict__ group_rtot, uint32_t* __restrict__ group_rbase,
                                              uint32_t pool_cap /* cells the record pool of this binning buffer holds (0xffffffff: sized afterwards) */,
-                                             uint32_t key_stride = 0u /* != 0: the keys sit in per-tile buckets of this many slots (preprocess.hip, scatter mode) */)
+                                             uint32_t key_stride = 0u /* != 0: the keys sit in per-tile buckets of this many slots (preprocess.hip, scatter mode) */,
+                                             bool forward_only = false /* MOSS_FORWARD_ONLY: there is no record pool -- nothing to overflow */)
 {
     const int tid = threadIdx.x;
     // every header word is WRITTEN here and the queue words are zeroed (the blend kernels pop from them): nothing in the image
@@ -82,6 +83,8 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
     // FIRST (while nothing else is live: this block shares the sort kernel's register budget -- 64 VGPRs for two workgroups per CU):
     // where the cell runs of every group of 256 Gaussians start in the record pool (the preprocess kernel left group-relative run starts
     // and the groups' totals), and how many cells the frame needs: header[9].
+    // (forward only: the count is still taken -- header[3] stays the capacity a TRAINING forward of this frame would need, so a
+    // forward-only probe can size a training step's capacity -- but there is no pool to overflow)
     uint32_t pool_total;
     {
         const int gchunk = (n_groups + NT - 1) / NT;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
     // A frame that needs more cells than the record pool holds is dropped like one that needs more instances than the capacity (`needed`
     // so that the pool of the caller's next capacity holds it: POOL_CELLS_PER_INSTANCE R + 4096 cells, BinView::default_pool_cells).
     needed = max(needed, pool_total / (uint32_t)POOL_CELLS_PER_INSTANCE + 1u);
-    if (pool_total > pool_cap || pool_total > POOL_MAX_CELLS) overflow = true;
+    if (!forward_only && (pool_total > pool_cap || pool_total > POOL_MAX_CELLS)) overflow = true;
     if (key_stride != 0u) {
         if (mx) atomicMax(s_max, mx);
         __syncthreads();
@@ -144,7 +147,7 @@ __device__ __forceinline__ void scan_outputs(int T, const uint32_t* __restrict__
                                                        // are sized from the capacity too) -- for the host's capacity policy
         header[9] = overflow ? 0u : pool_total;        // cells of the record pool in use: what merge_gather clears of the validity bits
         header[7] = s_bucket[32 - light_log2];         // heavy tiles: list length >= 2^light_log2 (classes clz <= 31 - log2)
-        header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u);       // (the preprocess kernel's flags: it finished before this one)
+        header[2] = *flags_acc | (overflow ? ERRFLAG_OVERFLOW : 0u) | (forward_only ? ERRFLAG_FORWARD_ONLY : 0u);   // (the preprocess kernel's flags: it finished before this one)
         if (flags_acc != header + 2) {                                      // frame state: zero again for the next forward ...
             *flags_acc = 0u;
             if (overflow) flags_acc[FS_DROPPED_WORD] += 1u;                 // ... except its STICKY count of frames that rendered nothing
@@ -171,13 +174,13 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
             uint32_t* __restrict__ tile_order, uint32_t* __restrict__ header, uint32_t capacity, int light_log2,
             int n_groups,
             uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues, uint4* __restrict__ work_table,
-            const uint32_t* __restrict__ group_rtot, uint32_t* __restrict__ group_rbase, uint32_t pool_cap)
+            const uint32_t* __restrict__ group_rtot, uint32_t* __restrict__ group_rbase, uint32_t pool_cap, int forward_only)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_max;
     __shared__ uint32_t s_bucket[34];
     scan_outputs<1024>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
-                       n_groups, flags_acc, queues, work_table, group_rtot, group_rbase, pool_cap);
+                       n_groups, flags_acc, queues, work_table, group_rtot, group_rbase, pool_cap, 0u, forward_only != 0);
 }
 
 // duplicateWithKeys equivalent (rasterizer_impl.cu:70-111) of the SYNCHRONOUS path (and of frames with more tiles than the LDS
@@ -526,7 +529,8 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
                     float4* __restrict__ inst_rec, uint32_t* __restrict__ cell_valid, uint16_t* __restrict__ inst_bmask,
                     unsigned long long* __restrict__ stamps /* diagnostics: 8 words per workgroup (after the sort's), else NULL */,
                     uint32_t key_stride /* != 0: tile t's keys start at t * key_stride (buckets), else at its range */,
-                    uint4* __restrict__ frame_state, uint32_t frame_state_n16)
+                    uint4* __restrict__ frame_state, uint32_t frame_state_n16,
+                    int forward_only /* MOSS_FORWARD_ONLY: no record pool -- no validity bits to clear, no cell word in the record */)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[MERGE_OC][CHUNK];
     __shared__ ChunkOwner s_own;
@@ -536,7 +540,7 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < frame_state_n16; i += gridDim.x * blockDim.x) frame_state[i] = make_uint4(0u, 0u, 0u, 0u);
     // no gradient record yet: one bit per cell of the record pool the frame uses (header[9], written by the scan block; set by the
     // backward blend).  (Rounds 2-4: a 4-byte mask word per instance, zeroed by the instance's own thread below.)
-    {
+    if (!forward_only) {
         const uint32_t n_words = (header[9] + 31u) / 32u + 1u;
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) cell_valid[i] = 0u;
     }
@@ -655,9 +659,12 @@ merge_gather_kernel(const uint32_t* __restrict__ header, int gx, int T, GeomView
     // the group, the geometry record's last word) + the cells in front of this tile, in closed form from the box.  It travels in the
     // record's third word, packed with the box's width in the tile, so that the backward blend finds the cell of a block with three
     // integer operations (pack_cell_word) and the per-Gaussian gather needs no table at all: it sums its run.
-    const BoxCells bc = box_cells(ga.x, ga.y, ga.z, ga.w, r);
-    const TileCells tc = tile_cells(bc, tx, ty);
-    const uint32_t cell_word = pack_cell_word(slot_base + __float_as_uint(gd.z) + (uint32_t)tc.first, tc, tx, ty);
+    uint32_t cell_word = 0u;                                  // (forward only: nobody will look for the instance's cells)
+    if (!forward_only) {
+        const BoxCells bc = box_cells(ga.x, ga.y, ga.z, ga.w, r);
+        const TileCells tc = tile_cells(bc, tx, ty);
+        cell_word = pack_cell_word(slot_base + __float_as_uint(gd.z) + (uint32_t)tc.first, tc, tx, ty);
+    }
     // (fourth word: the entry's 1-based position in its tile's list, as a float -- what the blend kernels record as the last contributor
     // and compare against it; exact below 2^24.  With it in the record a blender reads nothing but the record ring per entry.)
     // (second word: {B, C, A, opacity} -- the order in which the blend trips multiply the conic by (dx, dy) as register pairs: blend.hip, pair_power)
@@ -792,7 +799,7 @@ static int light_log2_knob()
     return v;
 }
 
-void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s)
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s, bool forward_only)
 {
     // (the scan kernel of its own: the synchronous path, whose pool is sized AFTER the host has read the frame's cell count -- no bound
     // here -- and asynchronous frames of more tiles than the LDS histogram holds, whose pool is the default one of the capacity)
@@ -800,7 +807,7 @@ void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capac
     const uint32_t pool_cap = capacity < 0 ? 0xffffffffu : (uint32_t)std::min<size_t>(BinView::default_pool_cells((int)capacity), 0xfffffff0u);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, im.tile_count, im.ranges, im.chunk_base, im.tile_order,
                        im.header, cap, light_log2_knob(), (P + 255) / 256, im.flags_acc, im.queues, im.work_table,
-                       g.group_rtot, g.group_rbase, pool_cap);
+                       g.group_rtot, g.group_rbase, pool_cap, forward_only ? 1 : 0);
 }
 
 // Whether the asynchronous forward can do without a scan (and a scatter) kernel of its own: the tile histogram must fit the LDS of the
@@ -867,7 +874,7 @@ void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b
     } else
     MOSS_LAUNCH_TIMED(merge_gather_kernel, dim3((grid + 7) / 8 * 8 * MERGE_PARTS), dim3(MERGE_THREADS), 0, s, im.header, fp.gx, T, g, im.ranges, im.chunk_base, b.keys,
                        b.point_list, b.inst_rec, b.cell_valid, b.inst_bmask, sort_stamps ? sort_stamps + 8 * 1024 : nullptr,
-                       key_stride, key_stride ? fs : nullptr, key_stride ? fs_n16 : 0u);
+                       key_stride, key_stride ? fs : nullptr, key_stride ? fs_n16 : 0u, fp.forward_only);
 #undef SORT_ARGS
 }
 

@@ -470,6 +470,8 @@ struct SegEmit {
     uint32_t cap;                // slots in the range
     uint32_t count;              // slots filled so far
     int seg_hits;                // hits per segment (a power of two, multiple of 4)
+    bool store;                  // false (MOSS_FORWARD_ONLY): the cuts are made -- the sums are folded piece by piece, so that the image has
+                                 // the bits of the training forward -- but nothing of them is kept: no LDS rows, no descriptors, no state
     float* cut_sums;             // LDS, per wave: [MAX_CUTS][16 pixels][6] -- T at the cut + the five sums the piece in front of it collected
     uint2* cut_pos;              // LDS, per wave: [MAX_CUTS] -- {first position, end position} of that piece
 };
@@ -689,11 +691,13 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         if (n_cuts == MAX_CUTS || se.count + (uint32_t)n_cuts >= se.cap) return;
         GROUP_ALLREDUCE(4, Cr, OP_ADD) GROUP_ALLREDUCE(4, Cg, OP_ADD) GROUP_ALLREDUCE(4, Cb, OP_ADD)
         GROUP_ALLREDUCE(4, Dacc, OP_ADD) GROUP_ALLREDUCE(4, weight, OP_ADD)
-        if (slot == 0) {
-            float* cs = se.cut_sums + (n_cuts * 16 + pl) * 6;
-            cs[0] = T; cs[1] = Cr; cs[2] = Cg; cs[3] = Cb; cs[4] = Dacc; cs[5] = weight;
+        if (se.store) {                                      // (wave-uniform)
+            if (slot == 0) {
+                float* cs = se.cut_sums + (n_cuts * 16 + pl) * 6;
+                cs[0] = T; cs[1] = Cr; cs[2] = Cg; cs[3] = Cb; cs[4] = Dacc; cs[5] = weight;
+            }
+            if (lane == 0) se.cut_pos[n_cuts] = make_uint2((uint32_t)p_prev, (uint32_t)p_cur);
         }
-        if (lane == 0) se.cut_pos[n_cuts] = make_uint2((uint32_t)p_prev, (uint32_t)p_cur);
         tCr += Cr; tCg += Cg; tCb += Cb; tD += Dacc; tW += weight;
         Cr = 0.f; Cg = 0.f; Cb = 0.f; Dacc = 0.f; weight = 0.f;
         p_prev = p_cur;
@@ -775,7 +779,9 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
     GROUP_ALLREDUCE(4, Cr, OP_ADD) GROUP_ALLREDUCE(4, Cg, OP_ADD) GROUP_ALLREDUCE(4, Cb, OP_ADD)
     GROUP_ALLREDUCE(4, weight, OP_ADD) GROUP_ALLREDUCE(4, Dacc, OP_ADD)
     GROUP_ALLREDUCE(4, T_stop, OP_MAX) GROUP_ALLREDUCE(4, last_contributor, OP_MAX)
-    if (n_cuts > 0) {
+    if (n_cuts > 0 && !se.store) {                            // forward only: the totals, nothing else
+        Cr += tCr; Cg += tCg; Cb += tCb; Dacc += tD; weight += tW;
+    } else if (n_cuts > 0) {
         // Write the block's pieces out: descriptor, T at the piece's far end, and the suffix blends there -- the sums of everything
         // behind it, added up from the back: behind the last cut lies what was collected since (Cr ...).
         __builtin_amdgcn_wave_barrier();
@@ -799,7 +805,7 @@ __device__ __forceinline__ void heavy_forward_blend(int W, int H, int gx, int ti
         Cr += tCr; Cg += tCg; Cb += tCb; Dacc += tD; weight += tW;     // the pixel's totals
     }
     const float Tf = T_stop >= 0.0f ? T_stop : T;
-    if (lane == 0) tail_start[(size_t)tile * WAVE_BLOCKS + blk] = (uint32_t)p_prev;   // the block's own backward item starts here
+    if (lane == 0 && se.store) tail_start[(size_t)tile * WAVE_BLOCKS + blk] = (uint32_t)p_prev;   // the block's own backward item starts here
     if (inside && slot == 0) {
         const size_t pix_id = (size_t)W * py + px, plane = (size_t)W * H;
         final_T[pix_id] = Tf;
@@ -1088,7 +1094,8 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
                           float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int flags,
                           unsigned long long* __restrict__ stamps /* optional diagnostics: 8 words per item, else NULL */,
                           uint4* __restrict__ seg_desc, float* __restrict__ seg_state, uint32_t seg_cap, int seg_hits,
-                          uint32_t* __restrict__ tail_start, uint32_t* __restrict__ seg_counts, int role_swap, int prio_mode)
+                          uint32_t* __restrict__ tail_start, uint32_t* __restrict__ seg_counts, int role_swap, int prio_mode,
+                          int seg_store /* 0: MOSS_FORWARD_ONLY -- cut (same image bits as the training forward) but keep nothing */)
 {
     // Two wave PAIRS per workgroup (see PairCtl): per pair a record ring + hit list, the cuts of the block being blended, and the
     // control words.  A light item uses 3 KB of the pair's ring per wave as its record ring.
@@ -1186,6 +1193,8 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
             const size_t first = (size_t)qx * seg_cap + (size_t)my_rank * share;
             se.desc = seg_desc + first; se.state = seg_state + first * SEG_STATE_FLOATS;
             se.cap = (seg_hits > 0 && q_pairs <= MAX_FWD_QUEUE_WAVES && seg_cap <= 65535u) ? share : 0u;
+            se.store = seg_store != 0;
+            if (!se.store && se.cap != 0u) se.cap = 0x7fffffffu;            // (cuts where the training forward would cut; no slot is filled, the range never runs full)
             se.count = 0u; se.seg_hits = seg_hits > 0 ? seg_hits : (1 << 30);
             se.cut_sums = s_cut_sums[pair]; se.cut_pos = s_cut_pos[pair];
         }
@@ -1210,7 +1219,7 @@ blend_forward_wave_kernel(int W, int H, int gx, int T_tiles, const uint32_t* __r
             if (lane == 0) lds_poke(&ctl->fin_seq, seq);
         }
         // how many of its slots this pair filled (EVERY pair writes its count: the backward kernel sums them per region)
-        if (lane == 0 && my_rank < MAX_FWD_QUEUE_WAVES) seg_counts[(size_t)qx * MAX_FWD_QUEUE_WAVES + my_rank] = se.count;
+        if (lane == 0 && my_rank < MAX_FWD_QUEUE_WAVES && se.store) seg_counts[(size_t)qx * MAX_FWD_QUEUE_WAVES + my_rank] = se.count;
     }
     if (prio_mode != 0) set_wave_prio(0);
     // ---- light phase: every wave on its own (queue indices only grow: once a pair has drawn a light item, heavy ones are gone)
@@ -1257,6 +1266,9 @@ blend_backward_wave_kernel(int W, int H, int gx, const uint4* __restrict__ work_
     static_assert(sizeof(HeavyLdsBwd) >= 64 * 3 * sizeof(float4), "the light path's ring lives inside the heavy path's LDS");
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: say so)
     float4 (*const ring)[3] = reinterpret_cast<float4 (*)[3]>(&s_heavy[wv]);
+    // a forward that was told MOSS_FORWARD_ONLY left no backward state (and a binning buffer without a record pool): nothing to do --
+    // the per-Gaussian backward then writes zero gradients, as after a capacity overflow
+    if (header[2] & ERRFLAG_FORWARD_ONLY) return;
     const int n_work = (int)header[5];
     const int nq = min(NUM_XCD_QUEUES, (int)gridDim.x), qx = (int)blockIdx.x % nq;
     const int n_heavy = (int)header[7];
@@ -1434,19 +1446,19 @@ void launch_blend_forward(const FrameParams& fp, GeomView g, ImageView im, BinVi
         MOSS_LAUNCH_TIMED((blend_forward_wave_kernel<8, false>), dim3(wgs), dim3(1024), FwdLds<8>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
-                          role_swap, prio_mode);
+                          role_swap, prio_mode, fp.forward_only ? 0 : 1);
     else
 #endif
     if (exact)
         MOSS_LAUNCH_TIMED((blend_forward_wave_kernel<2, true>), dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
-                          role_swap, prio_mode);
+                          role_swap, prio_mode, fp.forward_only ? 0 : 1);
     else
         MOSS_LAUNCH_TIMED((blend_forward_wave_kernel<2, false>), dim3(wgs), dim3(256), FwdLds<2>::bytes, s, fp.W, fp.H, fp.gx, T, im.tile_order, im.header,
                           im.queues + (size_t)Q_FWD * QLINE_WORDS, im.work_table, b.inst_rec, b.inst_bmask, fp.bg_dev, out_color, out_depth, out_alpha,
                           im.final_T, im.n_contrib, flags, g_stamps, b.seg_desc, b.seg_state, b.seg_cap, seg_hits, im.tail_start, im.seg_counts,
-                          role_swap, prio_mode);
+                          role_swap, prio_mode, fp.forward_only ? 0 : 1);
 }
 
 void launch_blend_backward(const FrameParams& fp, GeomView g, ImageView im, BinView b,

@@ -40,6 +40,7 @@ constexpr size_t BUF_ALIGN = 256;
 constexpr int MAX_LDS_TILES = 8192;      // tile histograms are privatised in LDS up to this many tiles
 constexpr uint32_t ERRFLAG_PREFILTERED = 1u;
 constexpr uint32_t ERRFLAG_OVERFLOW = 2u;      // asynchronous forward: the frame needs more instances than the caller's capacity
+constexpr uint32_t ERRFLAG_FORWARD_ONLY = 4u;  // MOSS_FORWARD_ONLY: the scratch holds no backward state (the backward kernels leave at once, zero gradients)
 constexpr int FS_DROPPED_WORD = 4;             // frame state: sticky count of overflowed frames (include/moss_raster.h MOSS_FRAME_STATE_DROPPED_WORD)
 constexpr size_t FS_COUNTERS_OFFSET = 256;     // frame state: where the per-frame tile counters start
 
@@ -284,12 +285,24 @@ struct BinView {
                              // per instance -- the most a frame can need -- so that its place does not depend on the pool's size
     float4* inst_grad;       // THE POOL: 3 float4 per cell (see box_cells); the LAST array of the buffer: only its size varies
     size_t pool_cells;       // its capacity
-    static BinView at(char* base, int R, long long pool_cells = -1)
+    // forward_only (MOSS_FORWARD_ONLY: an evaluation render, render_ZJU.py:56-72 -- no backward will follow): what the forward itself
+    // reads -- ids, block masks, the 48-byte records -- and the 8-byte sort keys; no depth-segment slots, no validity bits, no record
+    // pool: 62 B per instance where the training layout takes ~370.
+    static BinView at(char* base, int R, long long pool_cells = -1, bool forward_only = false)
     {
         BinView b; char* p = base; size_t n = (size_t)(R > 0 ? R : 1);
         b.point_list = carve<uint32_t>(p, n);
         b.inst_bmask = carve<uint16_t>(p, n);
         b.inst_rec = carve<float4>(p, 3 * n);
+        if (forward_only) {
+            b.seg_cap = (uint32_t)seg_region_cap(R);         // (the NUMBER the training layout would have: the forward blend cuts its sums where
+                                                             // the training forward does -- same image bits -- without keeping the pieces)
+            b.seg_desc = nullptr; b.seg_state = nullptr; b.cell_valid = nullptr;
+            b.inst_grad = reinterpret_cast<float4*>(p);
+            b.keys = reinterpret_cast<uint64_t*>(p);
+            b.pool_cells = 0;
+            return b;
+        }
         b.seg_cap = (uint32_t)seg_region_cap(R);
         b.seg_desc = carve<uint4>(p, (size_t)NUM_XCD_QUEUES * b.seg_cap);
         b.seg_state = carve<float>(p, (size_t)NUM_XCD_QUEUES * b.seg_cap * SEG_STATE_FLOATS);
@@ -301,9 +314,9 @@ struct BinView {
     }
     static size_t default_pool_cells(int R) { return (size_t)POOL_CELLS_PER_INSTANCE * (size_t)(R > 0 ? R : 1) + 4096; }
     // bytes of a buffer for R instances whose pool holds `pool_cells` cells (never less than the sort keys need: they alias it)
-    static size_t bytes(int R, long long pool_cells = -1)
+    static size_t bytes(int R, long long pool_cells = -1, bool forward_only = false)
     {
-        char* z = nullptr; BinView b = at(z, R, pool_cells);
+        char* z = nullptr; BinView b = at(z, R, pool_cells, forward_only);
         const size_t n = (size_t)(R > 0 ? R : 1);
         return (size_t)((char*)b.inst_grad - z) + align_up(std::max(b.pool_cells * GRAD_REC_FLOATS * 4, n * sizeof(uint64_t)));
     }
@@ -322,6 +335,7 @@ struct FrameParams {
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int prefiltered;
     int raw;                 // RAW_* bits: which of opacity / scales / rotations arrive as MOSS's raw parameters (activated inside the op)
+    int forward_only;        // MOSS_FORWARD_ONLY: no backward state is produced (no depth-segment cuts, no gradient-record cells)
     int no_block_cull;       // MOSS_DEBUG_NO_BLOCK_CULL of the call's `debug` argument: the blend kernels ignore the per-instance block masks
     int exact_math;          // MOSS_DEBUG_EXACT_MATH: the blend kernels decide every pixel's list with the reference's source arithmetic (blend.hip)
     const float* view_dev; const float* proj_dev; const float* campos_dev; const float* bg_dev;
@@ -347,13 +361,13 @@ void launch_mark_visible(int P, const float* means3D, const float* view16_dev, u
 void launch_clear(void* ptr, size_t bytes, hipStream_t s);
 void clear_frame_state(char* frame_state, size_t bytes, hipStream_t s);   // its per-frame words (not the sticky dropped-frame count)
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
-void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s);                 // offsets, ranges, header, group bases
+void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s, bool forward_only = false);   // offsets, ranges, header, group bases
 bool forward_buckets_keys(const FrameParams& fp);                                                // asynchronous forward without scan / scatter kernels, see binning.hip
 void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);   // duplicateWithKeys of the synchronous path (ranges known)
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
                       char* frame_state, size_t frame_state_bytes, int part,   // part 0: chunk sort, part 1: merge + emit
                       uint32_t key_stride = 0 /* != 0: bucketed keys written by the preprocess kernel; the sort scans the tile counts itself */,
-                      long long capacity = -1);
+                      long long capacity = -1);   // (fp.forward_only: merge_gather emits no cell words and clears no validity bits)
 uint32_t bucket_key_stride(const BinView& b, int num_tiles);  // slots per tile bucket the key area of this binning buffer holds (binning.hip)
 void launch_export_binning(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R,
                            uint64_t* keys, uint32_t* point_list, uint32_t* ranges, float* final_T, uint32_t* n_contrib, hipStream_t s);

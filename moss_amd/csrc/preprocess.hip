@@ -962,10 +962,11 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     float A_cov[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } }, d2_cov[3] = { 0, 0, 0 };   // the 2x3 projection A = J Rv and dL/dS2 of step (1): kept for step (6)
     // visible <=> radii > 0 (backward.cu:156,367).  After a capacity overflow of the asynchronous forward nothing was
     // rendered and the instance tables are unwritten: every Gaussian then gets zero gradients.
-    const bool visible = n_inst > 0 && !(hdr_flags & ERRFLAG_OVERFLOW);
+    // (likewise after a forward that was told MOSS_FORWARD_ONLY: no backward state exists, the binning buffer has no record pool)
+    const bool visible = n_inst > 0 && !(hdr_flags & (ERRFLAG_OVERFLOW | ERRFLAG_FORWARD_ONLY));
     // a frame that overflowed its capacity rendered nothing: its optimizer step is a no-op (parameters, moments and the step count
     // stay bit for bit), like moss_adamw_flat_guarded on the frame's status word
-    const bool fa_on = FUSED && !(hdr_flags & ERRFLAG_OVERFLOW);
+    const bool fa_on = FUSED && !(hdr_flags & (ERRFLAG_OVERFLOW | ERRFLAG_FORWARD_ONLY));
 
     // Sum the Gaussian's gradient records: the cells of its run [c0, c1) in the record pool whose validity bit is set (common.h:
     // box_cells; the backward blend sets the bits).  A run of <= COOP_WORDS words of validity bits (the norm: 10-20 cells, one or two

@@ -124,7 +124,7 @@ FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
     fp.focal_y = H / (2.0f * tan_fovy);         // rasterizer_impl.cu:224-225
     fp.focal_x = W / (2.0f * tan_fovx);
-    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0; fp.no_block_cull = 0; fp.exact_math = 0;
+    fp.scale_modifier = scale_modifier; fp.prefiltered = prefiltered; fp.raw = 0; fp.no_block_cull = 0; fp.exact_math = 0; fp.forward_only = 0;
     fp.view_dev = view; fp.proj_dev = proj; fp.campos_dev = campos; fp.bg_dev = bg;
     return fp;
 }
@@ -179,6 +179,12 @@ static int forward_impl(
     fp.raw = cov3D_precomp ? (raw_flags & RAW_OPACITY) : raw_flags;     // scales / rotations are not read with a precomputed covariance
     fp.no_block_cull = (debug_flags & MOSS_DEBUG_NO_BLOCK_CULL) ? 1 : 0;
     fp.exact_math = (debug_flags & MOSS_DEBUG_EXACT_MATH) ? 1 : 0;
+    // MOSS_FORWARD_ONLY: an evaluation render (render_ZJU.py:56-72) -- the caller promises that no backward follows.  Same images, bit for
+    // bit; no depth-segment state, no gradient-record cells, no validity bits, and a binning buffer of 62 B per instance (ids, block
+    // masks, records, sort keys) instead of ~370.  The keys then take the scan -> scatter chain into exact ranges (the per-tile buckets
+    // of the training forward live in the record pool's address space, which this buffer does not have).
+    const bool fwd_only = (debug_flags & MOSS_FORWARD_ONLY) != 0;
+    fp.forward_only = fwd_only ? 1 : 0;
     const bool trace = (debug_flags & MOSS_DEBUG_TRACE) != 0;
     const int T = fp.gx * fp.gy;
 
@@ -194,7 +200,7 @@ static int forward_impl(
     // kernel -- the sort workgroups derive their chunk tables from the tile counts, and the scan rides along with the sort kernel as one
     // extra block: preprocess, sort, merge, blend = FOUR launches (rounds 2-4: five, with a scatter kernel of its own; the reference: 7+).
     // (a capacity so small that a bucket would hold no key at all keeps the scan -> scatter chain, whose only bound is the total)
-    uint32_t key_stride = (capacity > 0 && forward_buckets_keys(fp)) ? bucket_key_stride(BinView::at(nullptr, (int)capacity), T) : 0u;
+    uint32_t key_stride = (capacity > 0 && !fwd_only && forward_buckets_keys(fp)) ? bucket_key_stride(BinView::at(nullptr, (int)capacity), T) : 0u;
     if (key_stride < 2u) key_stride = 0u;
     const bool bucketed = key_stride != 0u;
     int R = 0, total_chunks = 0;
@@ -213,7 +219,7 @@ static int forward_impl(
                                 bucketed ? b.keys : nullptr, key_stride); }
     STAGE_CHECK("preprocess");
     if (!bucketed) {
-        { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s); }
+        { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s, fwd_only); }
         STAGE_CHECK("scan");
         if (capacity < 0) {
             // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
@@ -239,9 +245,9 @@ static int forward_impl(
             R = (int)capacity;
             total_chunks = (int)(capacity / 1024) + T;
         }
-        bin_ptr = binning_alloc(binning_user, BinView::bytes(R, pool_cells));
+        bin_ptr = binning_alloc(binning_user, BinView::bytes(R, pool_cells, fwd_only));
         if (!bin_ptr) { abandon_frame_state(); return fail(MOSS_ERR_ALLOC, "binning allocator returned NULL"); }
-        b = BinView::at(bin_ptr, R, pool_cells);
+        b = BinView::at(bin_ptr, R, pool_cells, fwd_only);
     }
 
     if (R > 0) {
@@ -332,6 +338,7 @@ const char* moss_last_error(void) { return g_err; }
 size_t moss_raster_geometry_bytes(int P) { return GeomView::bytes(P > 0 ? P : 1); }
 size_t moss_raster_image_bytes(int width, int height) { return ImageView::bytes(width, height); }
 size_t moss_raster_binning_bytes(int R) { return BinView::bytes(R); }
+size_t moss_raster_binning_bytes_forward_only(int R) { return BinView::bytes(R, -1, true); }
 
 static int backward_impl(
     int P, int D, int M, int R,

@@ -22,6 +22,7 @@ HINT_SPATIAL_ORDER = 8                               # MOSS_HINT_SPATIAL_ORDER: 
 RAW_POSE = 16                                        # MOSS_RAW_POSE: means3D are canonical positions, posed inside the op (T x + translation)
 # bits of the `debug` argument (GaussianRasterizationSettings.debug may be the reference's bool or an OR of these; include/moss_raster.h)
 DEBUG_SYNC, DEBUG_NO_BLOCK_CULL, DEBUG_EXACT_MATH, DEBUG_TRACE = 1, 2, 4, 8
+FORWARD_ONLY = 16                                    # MOSS_FORWARD_ONLY: a bit of the same argument -- no backward will follow (evaluation render)
 
 last_num_rendered = 0   # num_rendered of the most recent forward call of ANY context (kept for callers that predate contexts)
 

@@ -120,6 +120,18 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         transforms=None, raw_flags=0, context=None, translation=None):
+    # An EVALUATION render -- grad mode off (render_ZJU.py:56-72 renders under torch.no_grad()) or no input that could receive a
+    # gradient -- is told so at the C ABI (MOSS_FORWARD_ONLY): same images bit for bit, none of the state only a backward reads, a
+    # binning buffer of 62 B per instance instead of ~370.  No autograd node: the outputs are plain tensors, as torch itself returns
+    # them from a Function applied without grad.
+    if not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in
+                                            (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, transforms, translation))):
+        rs = raster_settings
+        res = _call_native(_C.rasterize_gaussians, (
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
+            int(rs.debug) | _C.FORWARD_ONLY, transforms, int(raw_flags), context, translation), rs.debug, "snapshot_fw.dump", "forward")
+        return res[1], res[4], res[2], res[3]                # color, radii, depth, alpha
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, transforms, raw_flags, context, translation)
 

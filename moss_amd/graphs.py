@@ -36,6 +36,9 @@ class GraphedStep:
         self.context = context                               # the RasterContext whose capacity is baked into the graph (None: the default one)
         self.recaptures = 0
         self.dropped_frames = 0                              # frames that overflowed the baked-in capacity (they rendered nothing)
+        # ONE memory pool for every capture of this step: a re-capture (densification every 100 iterations, a grown capacity) then finds
+        # the scratch blocks of the graph it replaces in the pool instead of going to hipMalloc / hipFree for ~100 MB each time
+        self._pool = torch.cuda.graph_pool_handle()
         self._capture(max(int(warmup), 1))
 
     def _capture(self, warmup):
@@ -51,7 +54,7 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # thread_local: other threads (e.g. a data loader pinning memory) may make HIP calls during the capture
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, pool=self._pool, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn()
         torch.cuda.synchronize(dev)
         # overflows of EAGER forwards on this context before (or during the warm-up of) this capture were raised to, or seen by, the

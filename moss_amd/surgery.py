@@ -68,17 +68,24 @@ def densification_event(pc, optimizer, *, append=None, prune=None, reset_opacity
     recaptured = False
     if after_surgery is not None:
         after_surgery(per_gaussian)
+
+    def lap():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
+    t1 = t2 = t3 = lap()
     if shape_changed:
         if getattr(pc, "spatially_ordered", False):
             pc.spatially_ordered = False                     # (appended rows sit at the end: index neighbours are no longer spatial neighbours)
         if context is not None:
             context.relearn_capacity()
-        if graphed is not None:
-            graphed.recapture(probe)
-            recaptured = True
-        elif probe is not None:
+        if probe is not None:
             probe()
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
+        t2 = t3 = lap()
+        if graphed is not None:
+            graphed.recapture()
+            recaptured = True
+            t3 = lap()
     return {"rows_before": rows_before, "rows_after": int(pc._xyz.shape[0]), "recaptured": recaptured,
-            "event_ms": round(1e3 * (time.perf_counter() - t0), 3), "per_gaussian": per_gaussian}
+            "event_ms": round(1e3 * (t3 - t0), 3), "surgery_ms": round(1e3 * (t1 - t0), 3), "probe_ms": round(1e3 * (t2 - t1), 3),
+            "capture_ms": round(1e3 * (t3 - t2), 3), "per_gaussian": per_gaussian}

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for n in sorted(diag_names):
         assert not hasattr(hip_lib, n), f"{n} is a diagnostic entry point and must not be in the product build"
     assert hip_lib.moss_build_has_diagnostics() == 0
-    assert re.search(r"#define\s+MOSS_ABI_VERSION\s+5\b", text) and hip_lib.moss_abi_version() == 5
+    assert re.search(r"#define\s+MOSS_ABI_VERSION\s+6\b", text) and hip_lib.moss_abi_version() == 6
     assert hip_lib.moss_last_error() == b""
     assert hip_lib.moss_adamw_state_bytes() == int(re.search(r"#define\s+MOSS_ADAMW_STATE_BYTES\s+(\d+)", text).group(1))
 
