@@ -176,7 +176,7 @@ class Harness:
 
     def __init__(self, args, dev, rank, world, scene, cam, gt, gt_mask, bg, *, mode, activations, torch_activations, torch_adamw,
                  forward, graph, fused_loss=True, caller_side=None, lbs_T=None, exchange="allreduce", fused_optimizer=True,
-                 raw_in_op=False):
+                 raw_in_op=False, sh_degree=3):
         import torch
         from types import SimpleNamespace
         from moss_amd import dist as mdist
@@ -189,7 +189,9 @@ class Harness:
         self._cam, self._bg = cam, bg
         self.ctx = dgr.RasterContext()                       # this harness's own asynchronous-forward state and gradient sinks
         unified = not torch_adamw and not torch_activations
-        self.pc = pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=unified)
+        # (below degree 3: MOSS's own state -- the coefficients above the active degree are still the zeros they were created as,
+        # scene/gaussian_model.py:179-181, and have never received a gradient)
+        self.pc = pc = GaussianSet(scene, sh_degree=sh_degree, device=dev, unified_features=unified, zero_inactive_sh=sh_degree < 3)
         self.pipe = pipe = SimpleNamespace(
             convert_SHs_python=False, compute_cov3D_python=(mode in ("precomp", "lbs_python")), debug=int(getattr(args, "debug_bits", 0)),
             fused_activations=not torch_activations, transforms_in_op=(mode == "lbs"),
@@ -220,6 +222,11 @@ class Harness:
                                  shard=(rank, world) if self.exchange_kind == "sharded" else None)
             if self.exchange_kind == "sharded":
                 self.sharded = mdist.ShardedStep(bucket, self.opt, rank, world)
+            if unified:
+                # the degree-aware SH update (MOSS trains below degree 3 for 2999 of 3000 iterations): moments of never-active coefficients
+                # are not touched, their known-zero parameters neither; dL_dsh is written for the active coefficients only
+                self.opt.set_active_sh_degree(sh_degree)
+                self.ctx.sh_grad_active_only = True
         self.use_graph = bool(graph) and forward == "async" and not torch_adamw and caller_side is None
         self.ctx.set_async(forward == "async")
         if unified:
@@ -790,6 +797,9 @@ def main(argv=None):
             result["value_small_P_cfg2"] = result["callers"]["small_P_cfg2"].get("value")
         if "densify_schedule" in result["callers"]:
             result["value_densify_schedule"] = result["callers"]["densify_schedule"].get("value")
+        for d_ in (0, 1, 2):
+            if f"sh_degree_{d_}" in result["callers"]:
+                result[f"value_sh_degree_{d_}"] = result["callers"][f"sh_degree_{d_}"].get("value")
     if world == 1 and not args.no_callers and headline and (not args.callers_only or "eval" in args.callers_only.split(",")):
         # the evaluation path (render_ZJU.py:56-72): forward-only renders of the same Gaussians, on configs[2] and configs[4]
         torch.cuda.empty_cache()
@@ -863,6 +873,12 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         # scene/gaussian_model.py:496): BASELINE configs[1] through the headline's harness
         specs["small_P_cfg2"] = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations,
                                      torch_adamw=False, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer))
+    if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw:
+        # the headline at the SH degrees MOSS actually trains at: 0 / 1 / 2 for iterations 1-2999, 3 for the last one (train_ZJU.py:85-86,
+        # scene/gaussian_model.py:171-173).  Coefficients above the active degree start as zeros (:179-181) and are never touched
+        for d_ in (0, 1, 2):
+            specs[f"sh_degree_{d_}"] = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations,
+                                            torch_adamw=False, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer), sh_degree=d_)
     if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw and args.fused_optimizer:
         # the headline's step THROUGH MOSS's densification schedule (train_ZJU.py:171-186: an event every 100 iterations): 400 steps with a
         # scripted clone / split / prune event after every 100th (an opacity reset with the second), the optimizer's rows, the bucket, the
@@ -905,7 +921,8 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
             h = Harness(args, dev, 0, 1, sc, cam_, gt_, mask_, bg, lbs_T=T_ if kw["mode"] in ("lbs", "lbs_python") else None, **kw)
             if name == "spatial_order":
                 h.pc.spatially_ordered = True                # what GaussianSet.reorder_spatially() leaves behind: render() hints the op
-            n_steps = 3 * steps if name in ("as_generated_order", "spatial_order", "small_P_cfg2") else steps
+            seg3 = name in ("as_generated_order", "spatial_order", "small_P_cfg2") or name.startswith("sh_degree_")
+            n_steps = 3 * steps if seg3 else steps
             for _ in range(warmup):
                 h.step()
             torch.cuda.synchronize(dev)
@@ -917,7 +934,7 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                 del h
                 torch.cuda.empty_cache()
                 continue
-            if name in ("as_generated_order", "spatial_order", "small_P_cfg2"):
+            if seg3:
                 # three segments, the median one reported (with the segments beside it): late in a process that has built and dropped
                 # four harnesses a segment now and then takes a one-off host stall of tens of milliseconds, which is not what the
                 # pair is there to compare
@@ -930,8 +947,10 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                 h.ctx.check_status()
             res[name] = {"value": round(n_steps / dt, 2), "unit": "iters/s", "ms_per_step": round(1e3 * dt / n_steps, 4), "steps": n_steps,
                          "launch": h.graph_note if h.use_graph else "eager launches", "forward": kw["forward"]}
-            if name == "small_P_cfg2":
-                res[name]["workload"] = f"BASELINE configs[1]: {sc.means3D.shape[0]} Gaussians, 512x512, the headline's step (lbs, fused optimizer, one hipGraph)"
+            if name == "small_P_cfg2" or name.startswith("sh_degree_"):
+                res[name]["workload"] = (f"BASELINE configs[1]: {sc.means3D.shape[0]} Gaussians, 512x512, the headline's step (lbs, fused optimizer, one hipGraph)"
+                                         if name == "small_P_cfg2" else
+                                         f"the headline's workload and step at ACTIVE SH degree {kw['sh_degree']} (coefficients above it zero, as MOSS creates them)")
                 # its kernels, one by one (eager replay with the library's kernel-attached events)
                 _lib_ = sys.modules["moss_amd._lib"]
                 _lib_.profile_enable(None)

@@ -320,6 +320,28 @@ int moss_adamw_flat_guarded(long long first, long long count, float* params, con
                             double beta1, double beta2, float eps, float weight_decay, void* step_state,
                             const uint32_t* skip_word, uint32_t skip_mask, void* stream);
 
+/* Every form of the flat update behind one argument block (ABI 6), plus the DEGREE-AWARE update of an SH tensor: MOSS trains at SH
+ * degree 0 / 1 / 2 for iterations 1-2999 and at degree 3 for the last one (train_ZJU.py:85-86, scene/gaussian_model.py:171-173); the
+ * coefficients above the highest degree that has ever been active have received no gradient, so their moments are exactly zero and their
+ * AdamW step is the decoupled weight decay alone.
+ *   segment_active (NULL = none; else one int per segment, meaningful where segment_period[s] > 0 and a multiple of 4): of every
+ *     `period` elements of segment s only the first segment_active[s] are ACTIVE (0 = all).  Inactive elements: gradient and moments are
+ *     neither read nor written; the parameter takes p <- p (1 - lr wd), which is bit for bit what the full update gives for g = m = v = 0.
+ *   inactive_zero != 0: the caller also knows the inactive PARAMETERS to be exactly zero (MOSS initialises features_rest with zeros,
+ *     scene/gaussian_model.py:179-181, and 0 x decay = 0): they are not read or written at all.
+ *   first / count as moss_adamw_flat_range; step_state NULL: `step` counts from 1, else the device-side counter; skip_word (with
+ *   step_state) as moss_adamw_flat_guarded.  The results equal those of the corresponding older entry point bit for bit. */
+typedef struct moss_adamw_flat_args {
+    long long first, count;
+    float* params; const float* grads; float* exp_avg; float* exp_avg_sq;
+    int num_segments; const long long* segment_end; const float* segment_lr;
+    const int* segment_period; const int* segment_split; const float* segment_lr2;
+    const int* segment_active; int inactive_zero;
+    double beta1, beta2; float eps, weight_decay;
+    int step; void* step_state; const uint32_t* skip_word; uint32_t skip_mask;
+} moss_adamw_flat_args;
+int moss_adamw_flat_ex(const moss_adamw_flat_args* args, void* stream);
+
 /*
  * k nearest reference points of every query point, 3-D, exact, k = 1..4: replaces the third-party
  * `knn_cuda.KNN(k, transpose_mode=True)(ref, query)` MOSS calls at scene/gaussian_model.py:85-86,586,657,759,827 (a CUDA-only
@@ -408,12 +430,17 @@ int moss_raster_backward_tf(
  *   (gaussian_renderer/__init__.py:74-77: torch.matmul(transforms, means3D[..., None]).squeeze(-1) + translation).  dL_dmean3D is
  *   then the gradient w.r.t. x (= T^T dL/dp: it can be written straight into the position parameter's gradient), dL_dtransforms
  *   gains dL/dp x^T, and dL_dtranslation (P,3; may be NULL) = dL/dp.
+ *   MOSS_SH_GRAD_ACTIVE_ONLY (ABI 6; backward entry points): dL_dsh is written for the coefficients of the ACTIVE degree only, (D+1)^2 of
+ *   M per Gaussian; the rest of the destination is left untouched.  For a caller whose destination already holds zeros there and whose
+ *   consumers never read them -- a gradient sink into a zero-initialised bucket consumed by the degree-aware flat AdamW
+ *   (moss_adamw_flat_ex) and the active-degree exchange.  Without the bit every element is written (zeros above the degree), as ever.
  */
 #define MOSS_RAW_OPACITY 1
 #define MOSS_RAW_SCALE 2
 #define MOSS_RAW_ROTATION 4
 #define MOSS_HINT_SPATIAL_ORDER 8
 #define MOSS_RAW_POSE 16
+#define MOSS_SH_GRAD_ACTIVE_ONLY 32
 int moss_raster_forward_raw(
     moss_alloc_fn geometry_alloc, void* geometry_user, moss_alloc_fn binning_alloc, void* binning_user,
     moss_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
@@ -468,6 +495,13 @@ typedef struct moss_fused_adamw {
     int32_t lr_segment[5];       /* per tensor: its entry s (0..7) in the step-state block's learning-rate table, or -1; when word
                                   * MOSS_ADAMW_LR_VALID_WORD of step_state is non-zero the kernel reads lr from float word
                                   * MOSS_ADAMW_LR_WORD0 + s (sh: lr_sh_rest from MOSS_ADAMW_LR2_WORD0 + s) instead of from this struct */
+    int32_t sh_active_degree;    /* ABI 6.  The HIGHEST SH degree that has ever been active for these parameters (0..3; the call's own
+                                  * D is the floor; 3 = everything is active, the behaviour before ABI 6).  Coefficients above it have
+                                  * never received a gradient: their moments are exactly zero and are neither read nor written, and
+                                  * their parameters take the weight decay alone -- bit for bit the full update's result.  MOSS: degree
+                                  * 0 / 1 / 2 for iterations 1-2999 (train_ZJU.py:85-86). */
+    int32_t sh_inactive_zero;    /* != 0: the caller also knows those parameters to be exactly ZERO (features_rest starts as zeros,
+                                  * scene/gaussian_model.py:179-181; 0 x decay = 0): they are not read or written at all */
 } moss_fused_adamw;
 int moss_raster_backward_raw_adamw(
     int P, int D, int M, int R,

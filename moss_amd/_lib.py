@@ -130,6 +130,8 @@ def _declare(lib):
     lib.moss_adamw_flat_range.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _i, _p, _p]
     lib.moss_adamw_flat_guarded.restype = _i
     lib.moss_adamw_flat_guarded.argtypes = [C.c_longlong, C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _p, _p, C.c_uint32, _p]
+    lib.moss_adamw_flat_ex.restype = _i
+    lib.moss_adamw_flat_ex.argtypes = [_p, _p]
     lib.moss_gaussian_activate_forward.restype = _i
     lib.moss_gaussian_activate_forward.argtypes = [_i, _i] + [_p] * 12
     lib.moss_gaussian_activate_backward.restype = _i
@@ -148,7 +150,16 @@ class FusedAdamWStruct(C.Structure):
     """``moss_fused_adamw`` of include/moss_raster.h (host struct handed to ``moss_raster_backward_raw_adamw``)."""
     _fields_ = [("tensors", C.c_uint32), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_float * 5),
                 ("lr_sh_rest", C.c_float), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float),
-                ("step_state", C.c_void_p), ("lr_segment", C.c_int32 * 5)]
+                ("step_state", C.c_void_p), ("lr_segment", C.c_int32 * 5), ("sh_active_degree", C.c_int32), ("sh_inactive_zero", C.c_int32)]
+
+
+class AdamWFlatArgs(C.Structure):
+    """``moss_adamw_flat_args`` of include/moss_raster.h (``moss_adamw_flat_ex``: every form of the flat update + the degree-aware SH update)."""
+    _fields_ = [("first", C.c_longlong), ("count", C.c_longlong), ("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p),
+                ("exp_avg_sq", C.c_void_p), ("num_segments", C.c_int), ("segment_end", C.c_void_p), ("segment_lr", C.c_void_p),
+                ("segment_period", C.c_void_p), ("segment_split", C.c_void_p), ("segment_lr2", C.c_void_p), ("segment_active", C.c_void_p),
+                ("inactive_zero", C.c_int), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("step", C.c_int), ("step_state", C.c_void_p), ("skip_word", C.c_void_p), ("skip_mask", C.c_uint32)]
 
 
 OPT_BITS = {"means3D": 1, "sh": 2, "opacity": 4, "scales": 8, "rotations": 16}      # MOSS_OPT_*; position = index in the struct's arrays

@@ -96,6 +96,11 @@ struct FusedAdam {
     float* v[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     float lr[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     float lr_sh_rest = 0.f;                                  // sh: lr[1] for a Gaussian's first 3 floats (features_dc), this for the other 45
+    // DEGREE-AWARE SH update (include/moss_raster.h: moss_fused_adamw.sh_active_degree): of a record's 12 float4 only the first
+    // sh_active_parts hold a coefficient that has ever received a gradient (degree 0 / 1 / 2 / 3: 1 / 3 / 7 / 12); the float4 behind
+    // them have zero moments -- not read, not written -- and take the weight decay alone, or nothing at all when the caller knows their
+    // parameters to be exactly zero (sh_inactive_zero).  The same bits as the full update.
+    int sh_active_parts = 12, sh_inactive_zero = 0;
     int lr_segment[5] = { -1, -1, -1, -1, -1 };              // each tensor's entry in the step-state block's learning-rate table (-1: none)
     AdamBetas betas;
     float eps = 1e-15f, weight_decay = 0.f;

@@ -330,6 +330,7 @@ constexpr int RAW_SCALE = 2;        // scales are logarithms:           get_scal
 constexpr int HINT_SPATIAL_ORDER = 8; // (not a raw-parameter bit) index neighbours are spatial neighbours: include/moss_raster.h
 constexpr int RAW_POSE = 16;        // means3D are CANONICAL positions: posed inside the op, p = T x (+ translation)   (gaussian_renderer/__init__.py:74-77)
 constexpr int RAW_ROTATION = 4;     // rotations are not normalised:    get_rotation = normalize(_rotation)       (:146-147)
+constexpr int SH_GRAD_ACTIVE_ONLY = 32; // (not a raw-parameter bit) dL_dsh: only the coefficients of the active degree are written: include/moss_raster.h
 struct FrameParams {
     int P, D, M, W, H, gx, gy;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;

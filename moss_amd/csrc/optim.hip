@@ -10,7 +10,12 @@
 namespace moss {
 namespace {
 
-struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; float lr2[8]; };
+// active[s] (with period[s] > 0): of every `period` elements of segment s only the first `active` have ever received a gradient -- the SH
+// record (P,16,3) while MOSS trains below its maximum degree (train_ZJU.py:85-86: degree 0 / 1 / 2 for iterations 1-2999): the rest has
+// zero gradients and zero moments, so its AdamW step is the weight decay alone and its moments stay zero: they are not touched.
+// inactive_zero: those parameters are also known to be exactly zero (MOSS initialises features_rest with zeros,
+// scene/gaussian_model.py:179-181; 0 x decay = 0): nothing of them is read or written at all.  Same bits as the full update either way.
+struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; float lr2[8]; int active[8]; int inactive_zero; };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))   // (eight waves per SIMD: the scalar file admits six at 106 SGPRs)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -32,32 +37,34 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
     // rounded sqrt / divisions the update was ~40 vector instructions per element, ten million per step: as much issue time as the
     // kernel's 165 MB are HBM time)
     const float inv_bc1 = 1.0f / bc1, inv_bc2_sqrt = 1.0f / bc2_sqrt;
+    // (buffer loads: an out-of-range offset returns 0 WITHOUT a memory request -- what an element that is not to be read costs; the
+    // arrays of a launch are < 4 GB: launch_adamw falls back to treating everything as active otherwise)
+    constexpr uint32_t OOB = 0xffffffffu, RSRC3 = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xffffff00u, RSRC3);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0xffffff00u, RSRC3);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)m, 0, 0xffffff00u, RSRC3);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)v, 0, 0xffffff00u, RSRC3);
+    typedef float v4f __attribute__((ext_vector_type(4)));
     for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += (long long)gridDim.x * blockDim.x) {
         const long long i = i4 * 4, gi = first + i;          // index in the arrays / in the flat buffer (segment table)
-        float pv[4], gv[4], mv[4], vv[4];
-        const bool full = i + 4 <= n;
-        if (full) {
-            const float4 a = reinterpret_cast<const float4*>(p)[i4], b = reinterpret_cast<const float4*>(g)[i4];
-            const float4 c = reinterpret_cast<const float4*>(m)[i4], d = reinterpret_cast<const float4*>(v)[i4];
-            pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
-            mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
-        } else {
-            for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
-        }
         // Learning rate of each of the 4 elements: the segment of the first element (static indices only: a run-time index into the
         // kernel-argument tables would spill them to scratch), then its optional periodic pattern with ONE 32-bit modulo per
         // thread, stepped for the other elements.  A thread whose 4 elements straddle a segment end takes the general lookup.
         float lr4[4];
+        bool dead4 = false;                                  // all four elements are INACTIVE ones (see Segs): decay only, or nothing
         {
-            long long seg_start = 0, seg_end = first + n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0, seg_i = 0;
+            long long seg_start = 0, seg_end = first + n; float lr_a = 0.f, lr_b = 0.f; int period = 0, split = 0, seg_i = 0, active = 0;
 #pragma unroll
             for (int s = 7; s >= 0; s--) if (s < segs.n && gi < segs.end[s]) {
                 seg_end = segs.end[s]; seg_start = s > 0 ? segs.end[s - 1] : 0;
-                lr_a = segs.lr[s]; lr_b = segs.lr2[s]; period = segs.period[s]; split = segs.split[s]; seg_i = s;
+                lr_a = segs.lr[s]; lr_b = segs.lr2[s]; period = segs.period[s]; split = segs.split[s]; seg_i = s; active = segs.active[s];
             }
             if (lr_table) { lr_a = step_state[ADAMW_LR_WORD0 + seg_i]; lr_b = step_state[ADAMW_LR2_WORD0 + seg_i]; }   // (device-resident rates)
             if (gi + 3 < seg_end) {
                 unsigned ph = period > 0 ? (unsigned)(gi - seg_start) % (unsigned)period : 0u;
+                // (a tensor starts 16-byte aligned and the period is a multiple of 4 where `active` is used: the four elements lie in ONE
+                // record; they are all inactive iff the first one is at or behind the active part rounded up to a float4)
+                dead4 = period > 0 && active > 0 && (period & 3) == 0 && ph >= (unsigned)((active + 3) & ~3);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     lr4[k] = (period > 0 && (int)ph >= split) ? lr_b : lr_a;
@@ -80,6 +87,31 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
                 }
             }
         }
+        float pv[4], gv[4], mv[4], vv[4];
+        const bool full = i + 4 <= n;
+        if (full) {
+            const uint32_t o = (uint32_t)i * 4u;
+            const bool skip_all = dead4 && segs.inactive_zero != 0;
+            const v4f a = __builtin_amdgcn_raw_buffer_load_b128(rs_p, skip_all ? OOB : o, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs_g, dead4 ? OOB : o, 0, 0);
+            const v4f c = __builtin_amdgcn_raw_buffer_load_b128(rs_m, dead4 ? OOB : o, 0, 0), d = __builtin_amdgcn_raw_buffer_load_b128(rs_v, dead4 ? OOB : o, 0, 0);
+            pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+        } else {
+            for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
+            dead4 = false;
+        }
+        if (dead4) {
+            // zero gradient, zero moments: adamw_element's p <- fma(-(lr / bc1), m' * rcp(eps), p') with m' = 0 is p' = p (1 - lr wd)
+            // exactly (and the moments stay zero): the same bits, one multiply.  Known-zero parameters were not even read.
+            if (segs.inactive_zero == 0) {
+                float pn[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) pn[k] = __fmul_rn(pv[k], __fsub_rn(1.0f, __fmul_rn(lr4[k], weight_decay)));
+                if (pn[0] != pv[0] || pn[1] != pv[1] || pn[2] != pv[2] || pn[3] != pv[3])      // (a zero stays a zero: nothing to write)
+                    reinterpret_cast<float4*>(p)[i4] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++)
             adamw_element(pv[k], gv[k], mv[k], vv[k], lr4[k], betas, eps, weight_decay, inv_bc1, inv_bc2_sqrt);
@@ -98,10 +130,16 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
                  const long long* segment_end, const float* segment_lr, const int* segment_period, const int* segment_split,
                  const float* segment_lr2, double beta1, double beta2, float eps, float weight_decay,
                  float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream, long long first = 0,
-                 const uint32_t* skip_word = nullptr, uint32_t skip_mask = 0u)
+                 const uint32_t* skip_word = nullptr, uint32_t skip_mask = 0u, const int* segment_active = nullptr, int inactive_zero = 0)
 {
     Segs segs; segs.n = num_segments;
+    // (the degree-aware form addresses the arrays with 32-bit byte offsets: beyond 4 GB per array everything is treated as active)
+    // (and eps = 0 would make the full update of an all-zero element 0 x rcp(0) = NaN: no shortcut then)
+    const bool aware = segment_active != nullptr && n < (long long)(0xffffff00u / 4u) && eps > 0.0f;
+    segs.inactive_zero = aware ? inactive_zero : 0;
     for (int i = 0; i < 8; i++) {
+        segs.active[i] = (aware && i < num_segments && segment_period && segment_period[i] > 0 && segment_active[i] > 0 &&
+                          segment_active[i] < segment_period[i]) ? segment_active[i] : 0;
         segs.end[i] = i < num_segments ? segment_end[i] : first + n; segs.lr[i] = i < num_segments ? segment_lr[i] : 0.f;
         const bool pat = i < num_segments && segment_period && segment_split && segment_lr2 && segment_period[i] > 0;
         segs.period[i] = pat ? segment_period[i] : 0; segs.split[i] = pat ? segment_split[i] : 0; segs.lr2[i] = pat ? segment_lr2[i] : 0.f;
@@ -178,4 +216,20 @@ extern "C" int moss_adamw_flat_guarded(long long first, long long count, float* 
     return moss::launch_adamw(count, params, grads, exp_avg, exp_avg_sq, num_segments, segment_end, segment_lr, segment_period,
                               segment_split, segment_lr2, beta1, beta2, eps, weight_decay, 1.f, 1.f, (const float*)step_state,
                               (hipStream_t)stream, first, skip_word, skip_mask);
+}
+
+
+// Every form of the flat update behind ONE struct (ABI 6): moss_adamw_flat (step, no step_state), _devstep (step_state), _range
+// (first / count), _guarded (skip_word) -- plus the degree-aware SH update (segment_active, inactive_zero: see Segs above).
+extern "C" int moss_adamw_flat_ex(const moss_adamw_flat_args* a, void* stream)
+{
+    if (!a || a->first < 0 || (a->first & 3) || a->count < 0 || a->num_segments < 1 || a->num_segments > 8 || !a->params || !a->grads ||
+        !a->exp_avg || !a->exp_avg_sq || !a->segment_end || !a->segment_lr || (!a->step_state && a->step < 1) || (a->skip_word && !a->step_state))
+        return MOSS_ERR_INVALID_ARG;
+    if (a->count == 0) return a->step_state ? MOSS_ERR_INVALID_ARG : 0;
+    const double bc1 = a->step_state ? 1.0 : 1.0 - pow(a->beta1, a->step), bc2 = a->step_state ? 1.0 : 1.0 - pow(a->beta2, a->step);
+    return moss::launch_adamw(a->count, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_segments, a->segment_end, a->segment_lr,
+                              a->segment_period, a->segment_split, a->segment_lr2, a->beta1, a->beta2, a->eps, a->weight_decay,
+                              (float)bc1, (float)sqrt(bc2), (const float*)a->step_state, (hipStream_t)stream, a->first, a->skip_word,
+                              a->skip_mask, a->segment_active, a->inactive_zero);
 }

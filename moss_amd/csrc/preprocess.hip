@@ -254,10 +254,20 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
         const int idx = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         if (stage_sh) {
             const size_t base4 = (size_t)(it * gridDim.x + blockIdx.x) * blockDim.x * 12, total4 = (size_t)P * 12;
-            const float4* src = reinterpret_cast<const float4*>(shs);
-            float4 v[12];
+            // DEGREE-AWARE: only the float4 parts of a record that hold a coefficient of the ACTIVE degree are fetched -- 1 / 3 / 7 / 12 of
+            // 12 at degree 0 / 1 / 2 / 3 (MOSS trains below degree 3 for iterations 1-2999, train_ZJU.py:85-86); the others are never read
+            // by the evaluation below.  Buffer loads: an out-of-range offset returns 0 WITHOUT a memory request, and no branch surrounds
+            // the loads (the twelve stay in flight together).  (the launcher stages only while the tensor is < 4 GB: 32-bit offsets)
+            const int na = (3 * (D + 1) * (D + 1) + 3) >> 2;
+            const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc((void*)shs, 0, 0xffffff00u, 0x00020000u);
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f v[12];
 #pragma unroll
-            for (int j = 0; j < 12; j++) v[j] = src[min(base4 + threadIdx.x + (size_t)j * blockDim.x, total4 - 1)];
+            for (int j = 0; j < 12; j++) {
+                const int f = threadIdx.x + j * blockDim.x;  // (base4 is a multiple of 12: f % 12 is the float4's part of its record)
+                const size_t a = min(base4 + (size_t)f, total4 - 1);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_sh, (f % 12) < na ? (uint32_t)a * 16u : 0xffffffffu, 0, 0);
+            }
             __syncthreads();                                 // the previous iteration's readers are done
 #pragma unroll
             for (int j = 0; j < 12; j++) {
@@ -890,15 +900,24 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     // Gaussian the block's rows_used x 12 float4 are fewer than its lanes: ONE (round 5's first version ran all twelve iterations of
     // the staging, hoisting and update loops there, eleven of them on clamped dummy rows: 48 AdamW elements per lane for one used)
     constexpr int SH_J = LPG_L2 == 0 ? 12 : 1;
-    float4 shv[12];
+    // DEGREE-AWARE SH traffic (MOSS trains at degree 0 / 1 / 2 for iterations 1-2999, train_ZJU.py:85-86): of a record's 12 float4 only
+    // the first na_D hold a coefficient of the active degree -- the rest is neither read here nor (sinks that ask for it, the fused
+    // update) written.  Buffer loads throughout: an out-of-range offset returns 0 without a memory request and needs no branch.
+    // (staged only while the tensors are < 4 GB: 32-bit byte offsets, launch_preprocess_backward)
+    typedef float v4f_sh __attribute__((ext_vector_type(4)));
+    constexpr uint32_t SH_OOB = 0xffffffffu;
+    const int na_D = (3 * (D + 1) * (D + 1) + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t rs_shs = __builtin_amdgcn_make_buffer_rsrc((void*)shs, 0, 0xffffff00u, 0x00020000u);
+    v4f_sh shv[12];
     if (STAGE_SH) {
         const size_t total4 = (size_t)P * 12;               // in float4 units (48 floats = 12)
-        const float4* src = reinterpret_cast<const float4*>(shs);
 #pragma unroll
         for (int j = 0; j < SH_J; j++) {
             const int f = (int)threadIdx.x + j * (int)blockDim.x;         // float4 f of the block's rows: staged row f / 12, part f % 12
-            if constexpr (LPG_L2 == 0) shv[j] = src[min((size_t)gaussian_of_row(f / 12) * 12 + (size_t)(f % 12), total4 - 1)];
-            else shv[j] = src[f / 12 < rows_used ? min((size_t)min(gaussian_of_row((f / 12) << lpg_l2), P - 1) * 12 + (size_t)(f % 12), total4 - 1) : total4 - 1];
+            size_t a;
+            if constexpr (LPG_L2 == 0) a = min((size_t)gaussian_of_row(f / 12) * 12 + (size_t)(f % 12), total4 - 1);
+            else a = f / 12 < rows_used ? min((size_t)min(gaussian_of_row((f / 12) << lpg_l2), P - 1) * 12 + (size_t)(f % 12), total4 - 1) : total4 - 1;
+            shv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_shs, (f % 12) < na_D ? (uint32_t)a * 16u : SH_OOB, 0, 0);
         }
     }
     // (the Gaussian's run of cells in the record pool: where it starts -- group base + start in the group -- and how long it is)
@@ -1238,14 +1257,17 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
     constexpr int FA_HOIST = SH_J < 10 ? SH_J : 10;
     float4 fa_m4[12], fa_v4[12];
     const bool fa_sh = STAGE_SH && fa_on && (fa.tensors & OPT_SH);
+    const __amdgpu_buffer_rsrc_t rs_fm = __builtin_amdgcn_make_buffer_rsrc((void*)fa.m[1], 0, 0xffffff00u, 0x00020000u);
+    const __amdgpu_buffer_rsrc_t rs_fv = __builtin_amdgcn_make_buffer_rsrc((void*)fa.v[1], 0, 0xffffff00u, 0x00020000u);
     if (fa_sh) {
-        const float4* const mw = reinterpret_cast<const float4*>(fa.m[1]);
-        const float4* const vw = reinterpret_cast<const float4*>(fa.v[1]);
 #pragma unroll
         for (int j = 0; j < FA_HOIST; j++) {
             const int f = (int)threadIdx.x + j * (int)blockDim.x;
             const size_t a = (size_t)min(gaussian_of_row(LPG_L2 == 0 ? f / 12 : (min(f / 12, rows_used - 1) << lpg_l2)), P - 1) * 12 + (size_t)(f % 12);
-            fa_m4[j] = mw[a]; fa_v4[j] = vw[a];
+            // (moments of the float4 behind the ever-active part are exactly zero: not read -- the load returns the zeros for free)
+            const uint32_t o = (f % 12) < fa.sh_active_parts ? (uint32_t)a * 16u : SH_OOB;
+            const v4f_sh mq = __builtin_amdgcn_raw_buffer_load_b128(rs_fm, o, 0, 0), vq = __builtin_amdgcn_raw_buffer_load_b128(rs_fv, o, 0, 0);
+            fa_m4[j] = make_float4(mq.x, mq.y, mq.z, mq.w); fa_v4[j] = make_float4(vq.x, vq.y, vq.z, vq.w);
         }
     }
     if (in_range) {
@@ -1395,9 +1417,13 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
         __syncthreads();                                     // every row now holds dL_dsh
         if (dL_dsh != nullptr) {
             float4* dst = reinterpret_cast<float4*>(dL_dsh);
+            // (SH_GRAD_ACTIVE_ONLY, raw bit 0x20: the caller's destination holds zeros above the active degree already -- a gradient
+            // sink into a zero-initialised bucket whose consumers never look there -- so those float4 are not written: at degree 0
+            // eleven twelfths of this kernel's largest output)
+            const int n_write = (raw & SH_GRAD_ACTIVE_ONLY) ? na_D : 12;
             for (int f = threadIdx.x; f < (LPG_L2 == 0 ? (int)blockDim.x : rows_used) * 12; f += blockDim.x) {
                 const int gi = gaussian_of_row((f / 12) << lpg_l2);
-                if (gi < P) {
+                if (gi < P && (f % 12) < n_write) {
                     const float* r = &s_dsh[((f / 12) << lpg_l2) * SH_ROW + (f % 12) * 4];
                     dst[(size_t)gi * 12 + (size_t)(f % 12)] = make_float4(r[0], r[1], r[2], r[3]);
                 }
@@ -1414,12 +1440,21 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
             float4* const vw = reinterpret_cast<float4*>(fa.v[1]);
             float4 p4[12];
             float4 (&m4)[12] = fa_m4, (&v4)[12] = fa_v4;
+            const __amdgpu_buffer_rsrc_t rs_fp = __builtin_amdgcn_make_buffer_rsrc((void*)fa.p[1], 0, 0xffffff00u, 0x00020000u);
+            const int n_act = fa.sh_active_parts;            // float4 parts with an ever-active coefficient: the full update
+            const bool skip_rest = fa.sh_inactive_zero != 0; // the others: weight decay alone -- or, known to be zero, nothing at all
 #pragma unroll
             for (int j = 0; j < SH_J; j++) {
-                const int f = (int)threadIdx.x + j * (int)blockDim.x;
-                const size_t a = (size_t)min(gaussian_of_row(LPG_L2 == 0 ? f / 12 : (min(f / 12, rows_used - 1) << lpg_l2)), P - 1) * 12 + (size_t)(f % 12);
-                p4[j] = pw[a];
-                if (j >= FA_HOIST) { m4[j] = mw[a]; v4[j] = vw[a]; }
+                const int f = (int)threadIdx.x + j * (int)blockDim.x, part = f % 12;
+                const size_t a = (size_t)min(gaussian_of_row(LPG_L2 == 0 ? f / 12 : (min(f / 12, rows_used - 1) << lpg_l2)), P - 1) * 12 + (size_t)part;
+                const uint32_t o = (uint32_t)a * 16u;
+                const v4f_sh pq = __builtin_amdgcn_raw_buffer_load_b128(rs_fp, (part < n_act || !skip_rest) ? o : SH_OOB, 0, 0);
+                p4[j] = make_float4(pq.x, pq.y, pq.z, pq.w);
+                if (j >= FA_HOIST) {
+                    const v4f_sh mq = __builtin_amdgcn_raw_buffer_load_b128(rs_fm, part < n_act ? o : SH_OOB, 0, 0);
+                    const v4f_sh vq = __builtin_amdgcn_raw_buffer_load_b128(rs_fv, part < n_act ? o : SH_OOB, 0, 0);
+                    m4[j] = make_float4(mq.x, mq.y, mq.z, mq.w); v4[j] = make_float4(vq.x, vq.y, vq.z, vq.w);
+                }
             }
 #pragma unroll
             for (int j = 0; j < SH_J; j++) {
@@ -1429,15 +1464,25 @@ preprocess_backward_kernel(int P, int D, int M, float tan_fovx, float tan_fovy, 
                 const float* r = &s_dsh[(q << lpg_l2) * SH_ROW + part * 4];
                 float pe[4] = { p4[j].x, p4[j].y, p4[j].z, p4[j].w }, me[4] = { m4[j].x, m4[j].y, m4[j].z, m4[j].w };
                 float ve[4] = { v4[j].x, v4[j].y, v4[j].z, v4[j].w };
+                if (part < n_act) {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    adamw_element(pe[k], r[k], me[k], ve[k], (part == 0 && k < 3) ? fa.lr[1] : fa.lr_sh_rest, fa.betas, fa.eps,
-                                  fa.weight_decay, ib1, ib2);
-                if (gi < P) {
-                    const size_t a = (size_t)gi * 12 + (size_t)part;
-                    pw[a] = make_float4(pe[0], pe[1], pe[2], pe[3]);
-                    mw[a] = make_float4(me[0], me[1], me[2], me[3]);
-                    vw[a] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                    for (int k = 0; k < 4; k++)
+                        adamw_element(pe[k], r[k], me[k], ve[k], (part == 0 && k < 3) ? fa.lr[1] : fa.lr_sh_rest, fa.betas, fa.eps,
+                                      fa.weight_decay, ib1, ib2);
+                    if (gi < P) {
+                        const size_t a = (size_t)gi * 12 + (size_t)part;
+                        pw[a] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+                        mw[a] = make_float4(me[0], me[1], me[2], me[3]);
+                        vw[a] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                    }
+                } else if (!skip_rest) {
+                    // never a gradient, zero moments: adamw_element's result for g = m = v = 0 is p (1 - lr wd) exactly (its last FMA adds
+                    // -(lr / bc1) x 0 x rcp(eps)), and the moments stay zero -- the same bits without touching them
+                    float pn[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pn[k] = __fmul_rn(pe[k], __fsub_rn(1.0f, __fmul_rn(fa.lr_sh_rest, fa.weight_decay)));
+                    if (gi < P && (pn[0] != pe[0] || pn[1] != pe[1] || pn[2] != pe[2] || pn[3] != pe[3]))     // (a zero stays a zero: no write)
+                        pw[(size_t)gi * 12 + (size_t)part] = make_float4(pn[0], pn[1], pn[2], pn[3]);
                 }
             }
         }
@@ -1515,6 +1560,7 @@ void launch_preprocess_forward(const FrameParams& fp, const float* means3D, cons
     // there, no SH staging and ONE block per CU)
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     const int stage_sh = (fp.M == 16 && shs != nullptr && colors_precomp == nullptr && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 &&
+                          (size_t)fp.P * 192u < 0xffffff00u /* the staging loads address the tensor with 32-bit byte offsets */ &&
                           lds_h + lds_s <= (big_lds ? 80u * 1024u : 65536u) && knob("MOSS_PREFWD_STAGE", 1)) ? 1 : 0;
     const size_t lds = lds_h + (stage_sh ? lds_s : 0);
     MOSS_LAUNCH_TIMED(preprocess_forward_kernel, dim3(blocks), dim3(256), lds, s,
@@ -1557,7 +1603,7 @@ void launch_preprocess_backward(const FrameParams& fp, const float* means3D, con
     static const int gl2_env = knob("MOSS_PREBWD_GROUP_LOG2", 0);
     static const int gather_knob = knob("MOSS_GATHER", 0) == 1 ? 0x200 : knob("MOSS_GATHER", 0) == 2 ? 0x400 : 0;
     // (the fused update of the SH records works on the staged rows: raster_api.hip refuses it unless M == 16 and the arrays are aligned)
-    const bool stage = fp.M == 16 && shs != nullptr && (dL_dsh != nullptr || (fa.tensors & OPT_SH)) &&
+    const bool stage = fp.M == 16 && shs != nullptr && (dL_dsh != nullptr || (fa.tensors & OPT_SH)) && (size_t)fp.P * 192u < 0xffffff00u &&
                        (knob("MOSS_PREBWD_STAGE", 1) || (fa.tensors & OPT_SH)) &&
                        (reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0;
     // lanes per Gaussian (see the kernel): 16 while the whole grid is then still resident at once -- P <= 8192 with two waves per SIMD

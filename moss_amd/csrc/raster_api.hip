@@ -3,6 +3,7 @@
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:198-341, :345-447); the stages themselves are this library's own.
 #include "common.h"
 #include "adamw.h"
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -393,6 +394,12 @@ static int backward_impl(
         }
         if ((fused & OPT_ROTATIONS) && ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(opt->exp_avg[4]) | reinterpret_cast<uintptr_t>(opt->exp_avg_sq[4])) & 15u))
             return fail(MOSS_ERR_INVALID_ARG, "MOSS_OPT_ROTATIONS needs 16-byte aligned rotation and moment arrays");
+        {   // degree-aware SH update: float4 parts of a record that hold an ever-active coefficient (the call's own degree is the floor)
+            const int da = std::max(std::min((int)opt->sh_active_degree, 3), std::max(std::min(D, 3), 0));
+            // (eps = 0 would make the full update of an all-zero element 0 x rcp(0) = NaN: no shortcut then)
+            fa.sh_active_parts = opt->eps > 0.0f ? (3 * (da + 1) * (da + 1) + 3) / 4 : 12;
+            fa.sh_inactive_zero = (opt->sh_inactive_zero != 0 && fa.sh_active_parts < 12) ? 1 : 0;
+        }
         fa.tensors = fused; fa.lr_sh_rest = opt->lr_sh_rest;
         fa.betas = AdamBetas(opt->beta1, opt->beta2); fa.eps = opt->eps; fa.weight_decay = opt->weight_decay;
         fa.step_state = reinterpret_cast<const float*>(opt->step_state);
@@ -495,7 +502,7 @@ int moss_raster_backward_raw(
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
     int raw_flags, int debug, void* stream)
 {
-    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE | SH_GRAD_ACTIVE_ONLY)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (raw_flags & RAW_POSE) && !transforms) return fail(MOSS_ERR_INVALID_ARG, "MOSS_RAW_POSE needs the transforms");
     if ((translation || dL_dtranslation) && !(raw_flags & RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "a translation comes with MOSS_RAW_POSE");
     if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))
@@ -521,7 +528,7 @@ int moss_raster_backward_raw_adamw(
     float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtransforms, float* dL_dtranslation,
     const moss_fused_adamw* opt, int raw_flags, int debug, void* stream)
 {
-    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
+    if (raw_flags & ~(RAW_OPACITY | RAW_SCALE | RAW_ROTATION | HINT_SPATIAL_ORDER | RAW_POSE | SH_GRAD_ACTIVE_ONLY)) return fail(MOSS_ERR_INVALID_ARG, "unknown raw_flags bits");
     if (P > 0 && (raw_flags & RAW_POSE) && !transforms) return fail(MOSS_ERR_INVALID_ARG, "MOSS_RAW_POSE needs the transforms");
     if ((translation || dL_dtranslation) && !(raw_flags & RAW_POSE)) return fail(MOSS_ERR_INVALID_ARG, "a translation comes with MOSS_RAW_POSE");
     if (P > 0 && (!scales || !rotations || (transforms && !dL_dtransforms)))

@@ -20,6 +20,7 @@ NUM_CHANNELS = 3   # submodules/diff-gaussian-rasterization/cuda_rasterizer/conf
 RAW_OPACITY, RAW_SCALE, RAW_ROTATION = 1, 2, 4       # include/moss_raster.h MOSS_RAW_*
 HINT_SPATIAL_ORDER = 8                               # MOSS_HINT_SPATIAL_ORDER: OR-ed into raw_flags, changes no result
 RAW_POSE = 16                                        # MOSS_RAW_POSE: means3D are canonical positions, posed inside the op (T x + translation)
+SH_GRAD_ACTIVE_ONLY = 32                             # MOSS_SH_GRAD_ACTIVE_ONLY (backward): dL_dsh is written for the active degree's coefficients only
 # bits of the `debug` argument (GaussianRasterizationSettings.debug may be the reference's bool or an OR of these; include/moss_raster.h)
 DEBUG_SYNC, DEBUG_NO_BLOCK_CULL, DEBUG_EXACT_MATH, DEBUG_TRACE = 1, 2, 4, 8
 FORWARD_ONLY = 16                                    # MOSS_FORWARD_ONLY: a bit of the same argument -- no backward will follow (evaluation render)
@@ -65,6 +66,10 @@ class RasterContext:
         self.last_num_rendered = 0
         self.sinks = dict.fromkeys(_SINK_NAMES)
         self.fused_adamw = None                              # FlatAdamW.fuse_into_backward: the backward kernel takes the optimizer step
+        # opt-in (MOSS_SH_GRAD_ACTIVE_ONLY): the `sh` gradient sink's destination holds zeros above the active SH degree and nobody
+        # reads them (a zero-initialised GradBucket consumed by the degree-aware FlatAdamW and the active-degree exchange): the raw
+        # backward then writes only the active coefficients of dL_dsh -- at degree 0 a twelfth of the kernel's largest output
+        self.sh_grad_active_only = False
         self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
         self._retired_frame_states = []   # outgrown blocks: a captured hipGraph may still hold their address (see _frame_state)
         self._raised_overflows = 0        # overflows of this context already raised as CapacityOverflow (not "dropped by a replay")
@@ -272,12 +277,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                "given the raw parameters (raw_flags)")
         cx.fused_adamw.check_inputs(means3D=means3D, sh=sh, opacity=opacities, scales=scales, rotations=rotations)
         fused = cx.fused_adamw.address
+    sinks = [None if (fused and n in cx.fused_adamw.param_ptrs) else cx._sink(n) for n in ("means3D", "opacity", "sh", "scales", "rotations")]
+    if cx.sh_grad_active_only and int(raw_flags) and sinks[2] is not None:
+        raw_flags = int(raw_flags) | SH_GRAD_ACTIVE_ONLY
     return tuple(ext().rasterize_gaussians_backward(
         background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
         float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_alpha, sh, int(degree), campos, geomBuffer, int(R),
         binningBuffer, imageBuffer, alphas, int(debug), transforms, int(raw_flags), opacities,
-        *(None if (fused and n in cx.fused_adamw.param_ptrs) else cx._sink(n) for n in ("means3D", "opacity", "sh", "scales", "rotations")),
-        translation, fused, bool(all_outputs)))
+        *sinks, translation, fused, bool(all_outputs)))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

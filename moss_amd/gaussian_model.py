@@ -18,7 +18,7 @@ def inverse_sigmoid(x):
 
 
 class GaussianSet(nn.Module):
-    def __init__(self, scene, sh_degree=3, device="cpu", unified_features=False):
+    def __init__(self, scene, sh_degree=3, device="cpu", unified_features=False, zero_inactive_sh=False):
         """unified_features: keep the SH coefficients as ONE (P,16,3) parameter ``_features`` -- ``_features_dc`` / ``_features_rest``
         are then views of it and ``get_features`` needs no torch.cat (47 MB of copies per step and direction at 100k Gaussians).
         The reference's two learning rates (f_dc, f_rest = f_dc / 20) become a periodic pattern of one optimizer segment
@@ -27,6 +27,13 @@ class GaussianSet(nn.Module):
         self.unified_features = bool(unified_features)
         self.max_sh_degree = 3
         self.active_sh_degree = sh_degree
+        if zero_inactive_sh:
+            # MOSS's own state below the maximum degree: features_rest starts as zeros (create_from_pcd, scene/gaussian_model.py:179-181)
+            # and a coefficient receives its first gradient when its degree becomes active (oneupSHdegree, :171-173)
+            import copy
+            scene = copy.copy(scene)
+            scene.shs = scene.shs.clone()
+            scene.shs[:, (int(sh_degree) + 1) ** 2:, :] = 0.0
         self.motion_offset_flag = True
         dev = torch.device(device)
         self._xyz = nn.Parameter(scene.means3D.clone().to(dev))
@@ -40,6 +47,15 @@ class GaussianSet(nn.Module):
         self._opacity = nn.Parameter(inverse_sigmoid(scene.opacities.clamp(1e-4, 1 - 1e-4)).to(dev))
 
     spatially_ordered = False
+
+    def oneupSHdegree(self, optimizer=None):
+        """scene/gaussian_model.py:171-173 (called every 1000 iterations, train_ZJU.py:85-86); a ``FlatAdamW`` is told the new active
+        degree (its degree-aware SH update, ``set_active_sh_degree``).  A captured step must be captured again: the degree is a launch
+        argument of the rasterizer and of the update."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+        if optimizer is not None and hasattr(optimizer, "set_active_sh_degree"):
+            optimizer.set_active_sh_degree(self.active_sh_degree)
 
     def reorder_spatially(self, optimizer=None):
         """Re-index the Gaussians along a Morton curve of their positions (moss_amd.densify.spatial_order) -- parameters in place and,

@@ -54,6 +54,11 @@ class FlatAdamW:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.t = 0
         self.fused = None                                    # set by fuse_into_backward
+        # DEGREE-AWARE SH update (set_active_sh_degree): the SH tensor is the one whose learning rates follow MOSS's (48, 3) pattern --
+        # features_dc / features_rest in one (P,16,3) parameter; 3 = every coefficient is active (nothing is skipped)
+        self.sh_index = next((i for i, p in enumerate(bucket.params) if self._pat_of[id(p)] and tuple(self._pat_of[id(p)][:2]) == (48, 3)
+                              and p.dim() == 3 and tuple(p.shape[1:]) == (16, 3)), None)
+        self.sh_active_degree, self.sh_inactive_zero = 3, False
         # device-side step counter + completion counters, each on a cache line of its own: the LIBRARY says how large (csrc/optim.hip)
         dev = bucket.params[0].device
         self.step_state = torch.zeros(int(lib().moss_adamw_state_bytes()) // 4, dtype=torch.int32, device=dev) if capturable else None
@@ -166,6 +171,7 @@ class FlatAdamW:
             ptrs[name] = p.data_ptr()
         st.beta1, st.beta2, st.eps, st.weight_decay = float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay)
         st.step_state = self.step_state.data_ptr()
+        st.sh_active_degree, st.sh_inactive_zero = int(self.sh_active_degree), int(self.sh_inactive_zero)
         self.fused = _FusedAdamW(st, ptrs, self)
         self._fused_context = context or _C.DEFAULT
         self._fused_context.fused_adamw = self.fused
@@ -183,6 +189,57 @@ class FlatAdamW:
         self.fused = None
         self._fused_context = None
         self._fused_args = None
+
+    # ---- degree-aware SH update --------------------------------------------------------------------------------------------------
+    def set_active_sh_degree(self, degree: int):
+        """Tell the optimizer the ACTIVE SH degree of its (P,16,3) SH parameter (MOSS: ``active_sh_degree`` starts at 0 and goes up every
+        1000 iterations, train_ZJU.py:85-86, scene/gaussian_model.py:171-173 -- 2999 of 3000 iterations run below degree 3).  The
+        optimizer keeps the HIGHEST degree it has been told since the coefficients above it were last seen to have zero moments: those
+        coefficients have never received a gradient, so their AdamW step is the weight decay alone and their moments stay exactly zero --
+        the update kernels (the flat one and the rasterizer backward that takes the step itself) then neither read nor write those
+        moments, and when the parameters there are exactly zero as well (MOSS initialises ``features_rest`` with zeros,
+        scene/gaussian_model.py:179-181: checked HERE, one device reduction and a host read per call) they are not touched at all.
+        Results are bit-identical to the full update.  The degree is a launch argument: a captured step must be captured again
+        (the rasterizer's own ``sh_degree`` is one too).  Returns the degree in force."""
+        if self.sh_index is None:
+            return 3
+        degree = max(0, min(3, int(degree)))
+        k_prev = (self.sh_active_degree + 1) ** 2
+        m, v = self._moments_of(self.sh_index) if self.shard is None else (None, None)
+        if self.shard is not None:
+            degree = 3                                       # (a shard sees a slice of the tensor: everything stays active)
+        elif degree < self.sh_active_degree:
+            # lower than what is in force: only if the moments above it are (still) exactly zero -- a fresh optimizer, or one that
+            # never trained above that degree
+            k = (degree + 1) ** 2
+            if bool(m[:, k:k_prev, :].any().item()) or bool(v[:, k:k_prev, :].any().item()):
+                degree = self.sh_active_degree
+        self.sh_active_degree = degree
+        self._verify_sh_inactive()
+        return self.sh_active_degree
+
+    def _verify_sh_inactive(self):
+        """Re-establish ``sh_inactive_zero`` (and that the moments above the active degree are zero: otherwise everything is active)."""
+        if self.sh_index is None or self.sh_active_degree >= 3 or self.shard is not None:
+            self.sh_active_degree = 3 if self.sh_index is None or self.shard is not None else self.sh_active_degree
+            self.sh_inactive_zero = False
+        else:
+            k = (self.sh_active_degree + 1) ** 2
+            p = self.bucket.params[self.sh_index]
+            m, v = self._moments_of(self.sh_index)
+            if bool(m[:, k:, :].any().item()) or bool(v[:, k:, :].any().item()):
+                self.sh_active_degree, self.sh_inactive_zero = 3, False
+            else:
+                self.sh_inactive_zero = not bool(p.data[:, k:, :].any().item())
+        if self.fused is not None:
+            self.fused.struct.sh_active_degree = int(self.sh_active_degree)
+            self.fused.struct.sh_inactive_zero = int(self.sh_inactive_zero)
+
+    def _seg_active(self):
+        act = (C.c_int * self.nseg)(*([0] * self.nseg))
+        if self.sh_index is not None and self.sh_active_degree < 3:
+            act[self.sh_index] = 3 * (self.sh_active_degree + 1) ** 2
+        return act
 
     def set_learning_rates(self, rates):
         """A learning-rate schedule.  ``rates``: {parameter (or its index in the bucket): lr, or (lr, lr_rest) for a tensor with a
@@ -275,6 +332,8 @@ class FlatAdamW:
             p.data = v                                       # (the new shapes: what the bucket lays itself out from)
         self.bucket.relayout()
         self._adopt_layout(values, exp_avg, exp_avg_sq)
+        if self.sh_active_degree < 3:
+            self._verify_sh_inactive()                       # (appended rows may carry non-zero coefficients above the active degree)
         if fused is not None:
             self.fuse_into_backward(cx, local_only=fused[1], **fused[0])
 
@@ -347,6 +406,7 @@ class FlatAdamW:
             # freeze the parameters
             raise RuntimeError("FlatAdamW.step(): this optimizer was fused into a rasterizer backward, but that context no longer "
                                "carries it (context.fused_adamw was cleared by hand?) -- call optimizer.unfuse() to go back to step()")
+        from ._lib import AdamWFlatArgs
         if skip_word is not None:
             if self.step_state is None:
                 raise RuntimeError("a guarded step needs capturable=True: a host-side step count cannot know about the skipped step")
@@ -355,47 +415,31 @@ class FlatAdamW:
                 # and the all-gather would then spread a half-stepped parameter vector
                 raise RuntimeError("a guarded step (skip_word) on a SHARDED optimizer: the skip is a per-rank decision and would leave the "
                                    "shards at different steps; guard the frame before the gradient exchange instead")
-            first, count = (0, self.n) if self.shard is None else (self.first, self.count)
-            if count == 0:
-                return
-            grads = self.bucket.flat if self.shard is None else self.grad_shard
-            with torch.cuda.device(dev):
-                rc = lib().moss_adamw_flat_guarded(first, count, self.flat_params[first:].data_ptr(), grads.data_ptr(),
-                                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
-                                                   self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]),
-                                                   float(self.eps), float(self.weight_decay), self.step_state.data_ptr(),
-                                                   skip_word.data_ptr(), int(skip_mask) & 0xffffffff,
-                                                   torch.cuda.current_stream(dev).cuda_stream)
-            check(rc, "adamw_flat_guarded")
+        else:
+            self.t += 1
+        first, count = (0, self.n) if self.shard is None else (self.first, self.count)
+        if count == 0:
             return
-        self.t += 1
-        if self.shard is not None:
-            if self.count == 0:
-                return
-            with torch.cuda.device(dev):
-                rc = lib().moss_adamw_flat_range(self.first, self.count, self.flat_params[self.first:].data_ptr(), self.grad_shard.data_ptr(),
-                                                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
-                                                 self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]),
-                                                 float(self.eps), float(self.weight_decay), self.t,
-                                                 None if self.step_state is None else self.step_state.data_ptr(),
-                                                 torch.cuda.current_stream(dev).cuda_stream)
-            check(rc, "adamw_flat_range")
-            return
-        if self.step_state is not None:
-            with torch.cuda.device(dev):
-                rc = lib().moss_adamw_flat_devstep(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(),
-                                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end,
-                                                   self.seg_lr, self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                                   float(self.weight_decay), self.step_state.data_ptr(),
-                                                   torch.cuda.current_stream(dev).cuda_stream)
-            check(rc, "adamw_flat_devstep")
-            return
+        grads = self.bucket.flat if self.shard is None else self.grad_shard
+        # ONE entry point for every form (C ABI moss_adamw_flat_ex: host / device step count, shard range, frame guard) -- and the
+        # degree-aware SH update (set_active_sh_degree)
+        a = AdamWFlatArgs()
+        a.first, a.count = first, count
+        a.params, a.grads = self.flat_params[first:].data_ptr(), grads.data_ptr()
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.num_segments = self.nseg
+        a.segment_end, a.segment_lr = C.addressof(self.seg_end), C.addressof(self.seg_lr)
+        a.segment_period, a.segment_split, a.segment_lr2 = C.addressof(self.seg_period), C.addressof(self.seg_split), C.addressof(self.seg_lr2)
+        act = self._seg_active()
+        a.segment_active, a.inactive_zero = C.addressof(act), int(self.sh_inactive_zero)
+        a.beta1, a.beta2, a.eps, a.weight_decay = float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay)
+        a.step = max(self.t, 1)
+        a.step_state = None if self.step_state is None else self.step_state.data_ptr()
+        a.skip_word = None if skip_word is None else skip_word.data_ptr()
+        a.skip_mask = int(skip_mask) & 0xffffffff
         with torch.cuda.device(dev):
-            rc = lib().moss_adamw_flat(self.n, self.flat_params.data_ptr(), self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                       self.exp_avg_sq.data_ptr(), self.nseg, self.seg_end, self.seg_lr,
-                                       self.seg_period, self.seg_split, self.seg_lr2, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                                       self.t, torch.cuda.current_stream(dev).cuda_stream)
-        check(rc, "adamw_flat")
+            rc = lib().moss_adamw_flat_ex(C.addressof(a), torch.cuda.current_stream(dev).cuda_stream)
+        check(rc, "adamw_flat_ex")
 
 
 class AdamW(torch.optim.Optimizer):
