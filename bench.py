@@ -701,6 +701,7 @@ def main(argv=None):
         gbs = all_b[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         stages[k] = {"ms": ms, "algorithmic_bytes": int(all_b[k]), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5)}
         stages[k].update(_traffic_fields(pmc.get(k)))
+        stages[k]["bound"] = _bound_of(gbs / HBM_PEAK_GBS, pmc.get(k))
 
     result = {
         "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)" if args.config == "cfg3" else f"train iters/sec ({args.config})",
@@ -731,6 +732,12 @@ def main(argv=None):
                    **({"debug_bits": int(args.debug_bits)} if args.debug_bits else {})},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     # the same kernel by SURVEY 8(d)'s bytes ALONE (no optimizer traffic), timed as the plain instantiation in the
+                     # rasterizer-only pass: what `frac` would be if the AdamW step were not riding in it
+                     **({"frac_8d_bytes_only": round(raster_b[dominant] / (raster_stage_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "avg_launch_ms_8d_only": raster_stage_ms[dominant], "algorithmic_bytes_8d_only": int(raster_b[dominant])}
+                        if (dominant in raster_b and raster_stage_ms.get(dominant, 0) > 0 and was_fused) else {}),
+                     "bound_by_the_counters": _bound_of(achieved / HBM_PEAK_GBS, pmc.get(dominant)),
                      # the best a plain streaming kernel reaches on this part (profiles/r01_hbm_bandwidth.json: triad over 1 GiB buffers)
                      "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),
                      # PMC bytes were collected on the headline workload with exactly these kernel sources (profiles/pmc_latest.json is
@@ -879,6 +886,9 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         for d_ in (0, 1, 2):
             specs[f"sh_degree_{d_}"] = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations,
                                             torch_adamw=False, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer), sh_degree=d_)
+        # (degree 0 with the optimizer as a kernel of its own -- the form every N > 1 gradient exchange runs: what the degree-aware FLAT
+        # update and the active-only dL_dsh are worth there; compare with unfused_optimizer, the same at degree 3)
+        specs["sh_degree_0_unfused_optimizer"] = dict(specs["sh_degree_0"], fused_optimizer=False)
     if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw and args.fused_optimizer:
         # the headline's step THROUGH MOSS's densification schedule (train_ZJU.py:171-186: an event every 100 iterations): 400 steps with a
         # scripted clone / split / prune event after every 100th (an opacity reset with the second), the optimizer's rows, the bucket, the
@@ -1145,7 +1155,27 @@ def _traffic_fields(rec):
     if rec.get("traffic_bound") == "upper" and rec.get("hbm_bytes_interval"):
         out["traffic_interval"] = rec["hbm_bytes_interval"]
         out["traffic_is"] = "upper bound (gather reads: FETCH_SIZE doubling uncalibrated)"
+    for k in ("valu_issue_frac", "wave_cycles_waiting_frac", "insts_valu_per_launch", "insts_salu_per_launch", "kernel_cycles"):
+        if k in rec:
+            out[k] = rec[k]
     return out
+
+
+HBM_BOUND_FRAC, VALU_BOUND_FRAC = 0.35, 0.25
+
+
+def _bound_of(frac_hbm, rec):
+    """What a stage is bound by, from its numbers: `hbm` -- it moves its algorithmic bytes at >= 35 % of the nominal 8 TB/s (>= half of
+    what a streaming kernel reaches on this part, 5.9 TB/s); `valu_issue` -- not that, and >= 25 % of ALL the device's vector issue
+    slots held an instruction (committed counters: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles) -- an AVERAGE over the
+    SIMDs: in the blend kernels the SIMDs that drew the long items are full while others idle); `latency` --
+    neither: dependent round trips and tails at one or two waves per SIMD.  null without counters of this source state."""
+    if frac_hbm >= HBM_BOUND_FRAC:
+        return "hbm"
+    v = (rec or {}).get("valu_issue_frac")
+    if v is None:
+        return None
+    return "valu_issue" if v >= VALU_BOUND_FRAC else "latency"
 
 
 def cpu_baseline(scene, args, gt, gt_mask):

@@ -70,6 +70,10 @@ class RasterContext:
         # reads them (a zero-initialised GradBucket consumed by the degree-aware FlatAdamW and the active-degree exchange): the raw
         # backward then writes only the active coefficients of dL_dsh -- at degree 0 a twelfth of the kernel's largest output
         self.sh_grad_active_only = False
+        # Renders without grad (evaluation, render_ZJU.py:56-72) are told MOSS_FORWARD_ONLY: same images, a 62 B / instance binning buffer
+        # instead of ~400.  The price on the CAPACITY-BOUNDED path: its keys take the scan -> scatter chain (six launches) where the
+        # training forward buckets them (four) -- ~15 us per render at 100k Gaussians.  False: no-grad renders run the training forward.
+        self.forward_only_renders = True
         self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
         self._retired_frame_states = []   # outgrown blocks: a captured hipGraph may still hold their address (see _frame_state)
         self._raised_overflows = 0        # overflows of this context already raised as CapacityOverflow (not "dropped by a replay")

@@ -124,7 +124,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     # gradient -- is told so at the C ABI (MOSS_FORWARD_ONLY): same images bit for bit, none of the state only a backward reads, a
     # binning buffer of 62 B per instance instead of ~370.  No autograd node: the outputs are plain tensors, as torch itself returns
     # them from a Function applied without grad.
-    if not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in
+    if (context or _C.DEFAULT).forward_only_renders and not (
+            torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in
                                             (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, transforms, translation))):
         rs = raster_settings
         res = _call_native(_C.rasterize_gaussians, (

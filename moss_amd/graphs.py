@@ -36,15 +36,18 @@ class GraphedStep:
         self.context = context                               # the RasterContext whose capacity is baked into the graph (None: the default one)
         self.recaptures = 0
         self.dropped_frames = 0                              # frames that overflowed the baked-in capacity (they rendered nothing)
-        # ONE memory pool for every capture of this step: a re-capture (densification every 100 iterations, a grown capacity) then finds
-        # the scratch blocks of the graph it replaces in the pool instead of going to hipMalloc / hipFree for ~100 MB each time
-        self._pool = torch.cuda.graph_pool_handle()
+        self.graph = None
         self._capture(max(int(warmup), 1))
 
     def _capture(self, warmup):
         from .diff_gaussian_rasterization import _C
         fn, dev = self.fn, self.device
         self.captured_capacity = (self.context or _C.DEFAULT).capacity   # the binning capacity is a kernel argument: baked into the graph
+        # A RE-capture shares the memory pool of the graph it replaces (kept alive until the new one exists: a pool lives as long as a
+        # graph uses it): what that graph's capture left cached in the pool -- and, from the next re-capture on, the blocks of the
+        # replaced graphs themselves -- serve the new capture instead of hipMalloc / hipFree of ~100 MB of scratch per densification event
+        old = self.graph
+        pool = old.pool() if old is not None else None
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -54,9 +57,10 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # thread_local: other threads (e.g. a data loader pinning memory) may make HIP calls during the capture
-        with torch.cuda.graph(self.graph, pool=self._pool, stream=side, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, pool=pool, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn()
         torch.cuda.synchronize(dev)
+        del old                                              # (its blocks go back to the shared pool)
         # overflows of EAGER forwards on this context before (or during the warm-up of) this capture were raised to, or seen by, the
         # caller: only what the replays drop from here on is counted in ``dropped_frames``
         (self.context or _C.DEFAULT).read_dropped_frames(reset=True)
@@ -74,7 +78,6 @@ class GraphedStep:
         if probe is not None:
             probe()
             torch.cuda.synchronize(self.device)
-        self.graph = None                                    # (the old graph's private pool goes back before the new capture allocates)
         self._capture(warmup=0)
         self.recaptures += 1
 

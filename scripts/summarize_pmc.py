@@ -63,6 +63,17 @@ if stage_out:
                      "hbm_bytes_interval": [sum(p["hbm_bytes_raw"] if p["traffic_bound"] == "upper" else p["hbm_bytes_per_launch"] for p in present),
                                             sum(p["hbm_bytes_per_launch"] for p in present)],
                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), eager-launch bench.py --graph 0 --steps 30 --warmup 10"}
+            # vector-instruction issue (round 6, what bench.py's per-stage `bound` is read from): a SIMD issues at most one VALU instruction
+            # of a wave64 per 4 cycles, so SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles) is the share of the kernel's issue slots that
+            # held one, AVERAGED over the SIMDs (a kernel whose busiest SIMDs are full reads well below 1: the blend kernels).  Kernel
+            # cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs), of the same counter pass.
+            k0 = res[[k for k in ks if k in res][0]]
+            if "SQ_INSTS_VALU" in k0 and k0.get("GRBM_GUI_ACTIVE", 0) > 0:
+                cyc = k0["GRBM_GUI_ACTIVE"] / 8.0
+                st[s].update(insts_valu_per_launch=int(k0["SQ_INSTS_VALU"]), insts_salu_per_launch=int(k0.get("SQ_INSTS_SALU", 0)),
+                             kernel_cycles=int(cyc), valu_issue_frac=round(k0["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 4))
+                if k0.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_WAIT_ANY" in k0:
+                    st[s]["wave_cycles_waiting_frac"] = round(k0["SQ_WAIT_ANY"] / k0["SQ_WAVE_CYCLES"], 4)
     # stamp: the kernel sources these counters were measured on (bench.py emits `traffic` only while this matches the checkout)
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
