@@ -132,20 +132,29 @@ def check_gradients(got, ref, scales, tol=GRAD_TOL, per_gaussian=PER_GAUSSIAN_TO
 
 
 def gaussians_seen_by_fragile_pixels(d, fw, thr=1e-4):
-    """(P,) bool: the Gaussians that sit in the tile list of a pixel with a decision (power > 0, alpha >= 1/255, T (1 - alpha) < 1e-4)
-    within `thr` (relative) of its threshold in the oracle.  Only there can the product path's v_exp_f32 / FMA / v_rcp_f32 arithmetic
-    take another branch than the reference's (tests/test_gpu_exact.py: fast and exact n_contrib differ on such pixels only); every
-    other Gaussian is seen exclusively by pixels on which both sides took IDENTICAL decisions, list entry by list entry."""
+    """(P,) bool: the Gaussians that can CONTRIBUTE to a pixel with a decision (power > 0, alpha >= 1/255, T (1 - alpha) < 1e-4) within
+    `thr` (relative) of its threshold in the oracle -- the entries of that pixel's tile list whose alpha at the pixel reaches 0.9 / 255
+    (a margin of 10 % around the blend's own 1 / 255 test).  Only on such pixels can the product path's v_exp_f32 / FMA / v_rcp_f32
+    arithmetic take another branch than the reference's (tests/test_gpu_exact.py: fast and exact n_contrib differ on such pixels only);
+    every other Gaussian receives its gradient exclusively from pixels on which both sides took IDENTICAL decisions, entry by entry."""
     from oracle import oracle
     frag = ~(np.asarray(fw.margin).reshape(-1) > thr)
     seen = np.zeros(d.P, bool)
     if frag.any():
         gx, _ = oracle.tile_grid(d.W, d.H)
-        idx = np.nonzero(frag)[0]
-        tiles = np.unique((idx // d.W) // 16 * gx + (idx % d.W) // 16)
         rg = np.asarray(fw.ranges).reshape(-1, 2)
-        for tl in tiles:
-            seen[np.asarray(fw.point_list[int(rg[tl, 0]):int(rg[tl, 1])], np.int64)] = True
+        xy = np.asarray(fw.means2D, np.float64).reshape(-1, 2)
+        co = np.asarray(fw.conic_opacity, np.float64).reshape(-1, 4)
+        for pix in np.nonzero(frag)[0]:
+            py, px = int(pix) // d.W, int(pix) % d.W
+            tl = (py // 16) * gx + px // 16
+            ids = np.asarray(fw.point_list[int(rg[tl, 0]):int(rg[tl, 1])], np.int64)
+            if not ids.size:
+                continue
+            dx, dy = xy[ids, 0] - px, xy[ids, 1] - py
+            power = -0.5 * (co[ids, 0] * dx * dx + co[ids, 2] * dy * dy) - co[ids, 1] * dx * dy
+            alpha = co[ids, 3] * np.exp(np.minimum(power, 0.0))
+            seen[ids[(alpha >= 0.9 / 255.0) & (power <= 1e-3)]] = True
     return seen, int(frag.sum())
 
 
