@@ -702,6 +702,13 @@ def main(argv=None):
         stages[k] = {"ms": ms, "algorithmic_bytes": int(all_b[k]), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5)}
         stages[k].update(_traffic_fields(pmc.get(k)))
         stages[k]["bound"] = _bound_of(gbs / HBM_PEAK_GBS, pmc.get(k))
+        if k == "merge_gather":
+            # SURVEY 8(d) prices the sort at keys + ids; what this kernel must ALSO move is the per-instance record: a 64-byte gather of the
+            # Gaussian's geometry record and the 48-byte record + 2-byte block mask it emits -- counted here so that `traffic` has something
+            # to be compared with (rounds 1-5: "5.7-8x algorithmic", against the keys alone)
+            full = all_b[k] + R * (64 + 48 + 2)
+            stages[k]["algorithmic_bytes_incl_record_gather"] = int(full)
+            stages[k]["frac_incl_record_gather"] = round(full / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0
 
     result = {
         "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)" if args.config == "cfg3" else f"train iters/sec ({args.config})",
@@ -804,6 +811,9 @@ def main(argv=None):
             result["value_small_P_cfg2"] = result["callers"]["small_P_cfg2"].get("value")
         if "densify_schedule" in result["callers"]:
             result["value_densify_schedule"] = result["callers"]["densify_schedule"].get("value")
+        for b_ in (2, 4):
+            if f"multi_view_b{b_}" in result["callers"]:
+                result[f"value_views_per_s_b{b_}"] = result["callers"][f"multi_view_b{b_}"].get("value")
         for d_ in (0, 1, 2):
             if f"sh_degree_{d_}" in result["callers"]:
                 result[f"value_sh_degree_{d_}"] = result["callers"][f"sh_degree_{d_}"].get("value")
@@ -898,9 +908,22 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                     forward="async", graph=1, fused_optimizer=True)
         specs["densify_schedule"] = dict(same)
         specs["densify_schedule_cfg2"] = dict(same)
+    if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw:
+        # B views per optimizer step on THIS GPU (moss_amd/multiview.py): the data-parallel step of SURVEY 8(e) -- B cameras, the B
+        # gradient sets averaged in a fixed order, one AdamW step -- with the B single-view chains on B HIP streams inside one hipGraph.
+        # Reported as VIEWS per second beside `value` (which stays one view per step), never as it.
+        for b_ in (1, 2, 4):
+            specs[f"multi_view_b{b_}"] = dict(views=b_)
     only = [x for x in getattr(args, "callers_only", "").split(",") if x]
     for name, kw in specs.items():
         if only and name not in only:
+            continue
+        if name.startswith("multi_view_b"):
+            try:
+                res[name] = _multi_view(dev, scene, bg, lbs_T, kw["views"], steps)
+            except Exception as e:
+                res[name] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+            torch.cuda.empty_cache()
             continue
         try:
             sc, T_ = scene, lbs_T
@@ -976,6 +999,50 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
             res[name] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
         torch.cuda.empty_cache()
     return res
+
+
+def _multi_view(dev, scene, bg, lbs_T, B, steps):
+    """B views of the headline's workload per optimizer step (cameras on a ring around the body, one target per camera)."""
+    import torch
+    from types import SimpleNamespace
+    from moss_amd import scenes
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import camera_view, render
+    from moss_amd.multiview import MultiViewStep
+    c0 = scene.camera
+    cams = [camera_view(scenes.make_camera(c0.W, c0.H, float(c0.K[0, 0]), float(c0.K[1, 1]), float(c0.K[0, 2]), float(c0.K[1, 2]), R_, t_), dev)
+            for R_, t_ in scenes.look_at_ring(8)[:B]]
+    gt_scene = scenes.config3(seed=scenes.SEED + 7) if scene.name == "cfg3" else scene
+    gts = []
+    with torch.no_grad():
+        gpc = GaussianSet(gt_scene, sh_degree=3, device=dev)
+        for cam_ in cams:
+            o = render(cam_, gpc, SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False), bg)
+            gts.append((o["render"].detach().clamp(0, 1).contiguous(), (o["render_alpha"].detach() > 0.5).float().contiguous()))
+        del gpc
+    pc = GaussianSet(scene, sh_degree=3, device=dev, unified_features=True)
+    mv = MultiViewStep(pc, B, cams, gts, bg, lbs_T)
+    for _ in range(3):
+        mv.eager_step()
+    torch.cuda.synchronize(dev)
+    mv.capture()
+    for _ in range(10):
+        mv.step()
+    torch.cuda.synchronize(dev)
+    segs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mv.step()
+        torch.cuda.synchronize(dev)
+        segs.append((time.perf_counter() - t0) / steps)
+    mv.check()
+    dt = sorted(segs)[1]
+    return {"value": round(B / dt, 2), "unit": "views/s", "views_per_step": B, "optimizer_steps_per_s": round(1.0 / dt, 2), "ms_per_step": round(1e3 * dt, 4),
+            "ms_per_view": round(1e3 * dt / B, 4), "steps": steps, "segments_ms_per_step": [round(1e3 * x, 4) for x in segs],
+            "launch": f"one hipGraph replay per step: {B} single-view chains (render, loss, backward into the view's gradient buffer) on {B} HIP "
+                      f"streams, joined in front of ONE flat AdamW kernel that forms the fixed-order average of the {B} buffers itself",
+            "workload": f"{scene.name}: {B} cameras on a ring per optimizer step; gradients = the mean over the views (the N-GPU data-parallel step of SURVEY 8e on one device)"}
 
 
 def _densify_schedule(h, dev, sc, steps=400, every=100):

@@ -339,6 +339,12 @@ typedef struct moss_adamw_flat_args {
     const int* segment_active; int inactive_zero;
     double beta1, beta2; float eps, weight_decay;
     int step; void* step_state; const uint32_t* skip_word; uint32_t skip_mask;
+    /* B views rendered for ONE optimizer step on one device (moss_amd/multiview.py: the data-parallel step of SURVEY 8e with the "ranks"
+     * on one GPU): up to three more gradient buffers of the same layout as `grads` (for a range: its elements [first, first + count)).
+     * The step's gradient is ((grads + grads_extra[0]) + grads_extra[1] ...) x grad_scale, added in that order, one float32 rounding
+     * per operation -- bit for bit what accumulating the views one after the other into one buffer and scaling it gives.
+     * num_grads_extra = 0: `grads` as it is (grad_scale is then ignored). */
+    int num_grads_extra; const float* grads_extra[3]; float grad_scale;
 } moss_adamw_flat_args;
 int moss_adamw_flat_ex(const moss_adamw_flat_args* args, void* stream);
 

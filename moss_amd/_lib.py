@@ -159,7 +159,8 @@ class AdamWFlatArgs(C.Structure):
                 ("exp_avg_sq", C.c_void_p), ("num_segments", C.c_int), ("segment_end", C.c_void_p), ("segment_lr", C.c_void_p),
                 ("segment_period", C.c_void_p), ("segment_split", C.c_void_p), ("segment_lr2", C.c_void_p), ("segment_active", C.c_void_p),
                 ("inactive_zero", C.c_int), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float),
-                ("step", C.c_int), ("step_state", C.c_void_p), ("skip_word", C.c_void_p), ("skip_mask", C.c_uint32)]
+                ("step", C.c_int), ("step_state", C.c_void_p), ("skip_word", C.c_void_p), ("skip_mask", C.c_uint32),
+                ("num_grads_extra", C.c_int), ("grads_extra", C.c_void_p * 3), ("grad_scale", C.c_float)]
 
 
 OPT_BITS = {"means3D": 1, "sh": 2, "opacity": 4, "scales": 8, "rotations": 16}      # MOSS_OPT_*; position = index in the struct's arrays

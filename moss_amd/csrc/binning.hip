@@ -188,16 +188,35 @@ scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ 
 // with ONE returning global atomic (after counting its own instances in LDS) and hands the slots out with LDS atomics.
 // (Rounds 2-4 also ran it on the asynchronous path, with the scan folded in as one extra block; since round 5 the preprocess kernel
 // writes the keys there itself: preprocess.hip, scatter mode.)
+// FOLD_SCAN (the asynchronous forward whose keys are NOT bucketed by the preprocess kernel: MOSS_FORWARD_ONLY renders, whose lean binning
+// buffer has no room for buckets; rounds 2-4: every asynchronous forward): there is no scan kernel in front of this one.  Every block
+// turns the tile histogram into the tiles' start offsets ITSELF (T <= 8192 counts: one coalesced read and a block scan, overlapped
+// with its instance counting), and one extra block at the end of the grid writes what the later kernels need (scan_outputs) -- the
+// scan costs no launch of its own (a 1024-thread, one-block kernel: 5.5-8.8 us) and no memory round trip between the two kernels.
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ keys, int lds_hist, uint32_t* __restrict__ header,
-               unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */)
+               unsigned long long* __restrict__ stamps /* diagnostics: 8 words per block, else NULL */,
+               int fold_scan, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ tile_order,
+               uint32_t capacity, int light_log2, uint32_t* __restrict__ flags_acc, uint32_t* __restrict__ queues,
+               uint4* __restrict__ work_table, uint32_t pool_cap, int forward_only)
 {
 #define SSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()   /* 100 MHz, device-wide */
     SSTAMP(0);
     extern __shared__ uint32_t s_mem[];
-    const int n_blocks = (int)gridDim.x;               // blocks that scatter
-    if (header[0] == 0u) return;                       // nothing rendered (or capacity overflow: see scan_kernel)
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bucket[34];
+    int n_blocks = (int)gridDim.x;                     // blocks that scatter
+    if (fold_scan) {
+        n_blocks--;
+        if ((int)blockIdx.x == n_blocks) {
+            scan_outputs<256>(T, tile_count, ranges, chunk_base, tile_order, header, capacity, light_log2, s_wave, &s_max, s_bucket,
+                              (P + 255) / 256, flags_acc, queues, work_table, g.group_rtot, g.group_rbase, pool_cap, 0u, forward_only != 0);
+            SSTAMP(5);
+            return;
+        }
+    } else if (header[0] == 0u) return;                // nothing rendered (or capacity overflow: see scan_kernel)
     uint32_t* s_cnt = s_mem;
     uint32_t* s_base = s_mem + T;
     // rectangle (geo[3]) and depth (geo[2].w) of the two Gaussians of a trip, requested together, unconditionally
@@ -208,6 +227,13 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
     float4 pre_gd[2]; float pre_dep[2];
     fetch2((int)(blockIdx.x * blockDim.x), pre_gd[0], pre_gd[1], pre_dep[0], pre_dep[1]);
     if (lds_hist) {
+        // (fold_scan) this thread's share of the histogram: requested now, summed after the counting pass
+        const int per = (T + 255) / 256, tb = (int)threadIdx.x * per, te = min(T, tb + per);
+        uint32_t cnt4[4] = { 0u, 0u, 0u, 0u };
+        if (fold_scan && per <= 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) cnt4[u] = tile_count[min(tb + u, T - 1)];
+        }
         for (int i = threadIdx.x; i < T; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
         // (two Gaussians per thread per trip, both rectangles requested before the first is walked: one memory round trip per trip;
@@ -223,6 +249,16 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
             wave_for_each_tile(r1, gx, 0ull, [&](int t, uint64_t) { atomicAdd(&s_cnt[t], 1u); });
         }
         SSTAMP(1);                                           // counted
+        if (fold_scan) {
+            uint32_t sum = 0u;
+            if (per <= 4) { for (int u = 0; u < 4; u++) sum += tb + u < te ? cnt4[u] : 0u; }
+            else for (int i = tb; i < te; i++) sum += tile_count[i];
+            uint32_t total;
+            uint32_t off = block_scan<256>(sum, s_wave, total);      // (its barriers also end the counting pass)
+            if (total == 0u || total > capacity) return;             // nothing rendered / capacity overflow (flag: the scan block)
+            if (per <= 4) { for (int u = 0; u < 4; u++) if (tb + u < te) { s_base[tb + u] = off; off += cnt4[u]; } }
+            else for (int i = tb; i < te; i++) { s_base[i] = off; off += tile_count[i]; }
+        }
         __syncthreads();
         SSTAMP(2);                                           // tile starts known
         // One returning atomic per (block, non-empty tile) reserves the block's run in the tile's bucket.  Four tiles per thread at a
@@ -237,7 +273,7 @@ scatter_kernel(int P, int gx, int T, GeomView g, uint2* __restrict__ ranges, uin
                 for (int u = 0; u < 4; u++) {
                     const int i = b0 + u * (int)blockDim.x + (int)threadIdx.x;
                     c[u] = i < T ? s_cnt[i] : 0u;
-                    start[u] = ranges[min(i, T - 1)].x;
+                    start[u] = fold_scan ? s_base[min(i, T - 1)] : ranges[min(i, T - 1)].x;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -829,7 +865,15 @@ uint32_t bucket_key_stride(const BinView& b, int num_tiles)
     return (uint32_t)(stride & ~1ull);                       // (buckets start 16-byte aligned)
 }
 
-void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s)
+// Whether the scan can ride along with the scatter (no launch of its own): the tile histogram must fit the scatter's LDS and nobody may
+// have to read R back before the binning buffer exists (an asynchronous forward).
+bool scatter_folds_scan(const FrameParams& fp)
+{
+    static const int on = knob("MOSS_FOLD_SCAN", 1);
+    return on && fp.gx * fp.gy <= MAX_LDS_TILES;
+}
+
+void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s, bool fold_scan, long long capacity)
 {
     const int T = fp.gx * fp.gy;
     // (2: timing experiment of MOSS_DIAG builds, no reservation atomics -- the keys are garbage and the forward stops behind this kernel)
@@ -838,8 +882,13 @@ void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, 
     int blocks = (fp.P + 256 * per_thread - 1) / (256 * per_thread);
     if (blocks < 1) blocks = 1;
     const size_t lds = lds_hist ? 2 * (size_t)T * sizeof(uint32_t) : 0;
-    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
-                       lds_hist, im.header, (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 16384 : nullptr);
+    const int fold = (fold_scan && lds_hist && capacity >= 0) ? 1 : 0;
+    const uint32_t cap = capacity < 0 ? 0xffffffffu : (uint32_t)capacity;
+    const uint32_t pool_cap = capacity < 0 ? 0xffffffffu : (uint32_t)std::min<size_t>(BinView::default_pool_cells((int)capacity), 0xfffffff0u);
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks + fold), dim3(256), lds, s, fp.P, fp.gx, T, g, im.ranges, im.tile_cursor, b.keys,
+                       lds_hist, im.header, (g_stamps && knob("MOSS_SORT_STAMPS", 0)) ? g_stamps + 131072 + 16384 : nullptr,
+                       fold, im.tile_count, im.chunk_base, im.tile_order, cap, light_log2_knob(), im.flags_acc, im.queues, im.work_table,
+                       pool_cap, fp.forward_only);
 }
 
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,

@@ -364,7 +364,10 @@ void clear_frame_state(char* frame_state, size_t bytes, hipStream_t s);   // its
 void launch_zero_floats(float* ptr, size_t n, hipStream_t s);
 void launch_scan(int P, GeomView g, ImageView im, int num_tiles, long long capacity, hipStream_t s, bool forward_only = false);   // offsets, ranges, header, group bases
 bool forward_buckets_keys(const FrameParams& fp);                                                // asynchronous forward without scan / scatter kernels, see binning.hip
-void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s);   // duplicateWithKeys of the synchronous path (ranges known)
+bool scatter_folds_scan(const FrameParams& fp);                                                   // asynchronous, un-bucketed forward: the scan rides with the scatter
+void launch_scatter(const FrameParams& fp, GeomView g, ImageView im, BinView b, hipStream_t s,    // duplicateWithKeys into exact ranges
+                    bool fold_scan = false /* no scan kernel ran: every block scans the tile counts itself, one extra block writes the scan's outputs */,
+                    long long capacity = -1);
 void launch_tile_sort(const FrameParams& fp, GeomView g, ImageView im, BinView b, int R, int total_chunks, hipStream_t s,
                       char* frame_state, size_t frame_state_bytes, int part,   // part 0: chunk sort, part 1: merge + emit
                       uint32_t key_stride = 0 /* != 0: bucketed keys written by the preprocess kernel; the sort scans the tile counts itself */,

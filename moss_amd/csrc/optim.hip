@@ -16,11 +16,15 @@ namespace {
 // inactive_zero: those parameters are also known to be exactly zero (MOSS initialises features_rest with zeros,
 // scene/gaussian_model.py:179-181; 0 x decay = 0): nothing of them is read or written at all.  Same bits as the full update either way.
 struct Segs { int n; long long end[8]; float lr[8]; int period[8], split[8]; float lr2[8]; int active[8]; int inactive_zero; };
+// SEVERAL gradient buffers of the same layout (moss_adamw_flat_args.grads_extra): B views rendered for one optimizer step on one device
+// (moss_amd/multiview.py) -- the step's gradient is ((g0 + g1) + g2 ...) x scale, added in THAT order and rounded after every operation
+// (what accumulating the views one after the other into one buffer gives), formed here instead of by B passes over the buffers
+struct MoreGrads { int n; const float* g[3]; float scale; };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))   // (eight waves per SIMD: the scalar file admits six at 106 SGPRs)
 adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
              Segs segs, AdamBetas betas, float eps, float weight_decay, float bc1, float bc2_sqrt,
-             const float* __restrict__ step_state, long long first, const uint32_t* __restrict__ skip_word, uint32_t skip_mask)
+             const float* __restrict__ step_state, long long first, const uint32_t* __restrict__ skip_word, uint32_t skip_mask, MoreGrads more)
 {
     // guard (moss_adamw_flat_guarded): a dropped frame's step is a no-op -- nothing is read or written, the step counter stays
     if (skip_word != nullptr && (*skip_word & skip_mask) != 0u) return;
@@ -95,9 +99,28 @@ adamw_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, fl
             const v4f a = __builtin_amdgcn_raw_buffer_load_b128(rs_p, skip_all ? OOB : o, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs_g, dead4 ? OOB : o, 0, 0);
             const v4f c = __builtin_amdgcn_raw_buffer_load_b128(rs_m, dead4 ? OOB : o, 0, 0), d = __builtin_amdgcn_raw_buffer_load_b128(rs_v, dead4 ? OOB : o, 0, 0);
             pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            if (more.n > 0) {                                // (kernel-uniform) the other views' gradients, in order, then the scale
+                v4f e[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    e[q] = q < more.n ? __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)more.g[q], 0, 0xffffff00u, RSRC3), dead4 ? OOB : o, 0, 0)
+                                      : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 3; q++) if (q < more.n) {
+                    gv[0] = __fadd_rn(gv[0], e[q].x); gv[1] = __fadd_rn(gv[1], e[q].y); gv[2] = __fadd_rn(gv[2], e[q].z); gv[3] = __fadd_rn(gv[3], e[q].w);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) gv[k] = __fmul_rn(gv[k], more.scale);
+            }
             mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
         } else {
-            for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
+            for (int k = 0; k < 4; k++) {
+                const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f;
+                if (more.n > 0) {
+                    for (int q = 0; q < more.n; q++) gv[k] = __fadd_rn(gv[k], ok ? more.g[q][i + k] : 0.f);
+                    gv[k] = __fmul_rn(gv[k], more.scale);
+                }
+            }
             dead4 = false;
         }
         if (dead4) {
@@ -130,8 +153,14 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
                  const long long* segment_end, const float* segment_lr, const int* segment_period, const int* segment_split,
                  const float* segment_lr2, double beta1, double beta2, float eps, float weight_decay,
                  float bc1, float bc2_sqrt, const float* step_state, hipStream_t stream, long long first = 0,
-                 const uint32_t* skip_word = nullptr, uint32_t skip_mask = 0u, const int* segment_active = nullptr, int inactive_zero = 0)
+                 const uint32_t* skip_word = nullptr, uint32_t skip_mask = 0u, const int* segment_active = nullptr, int inactive_zero = 0,
+                 int num_extra = 0, const float* const* grads_extra = nullptr, float grad_scale = 1.0f)
 {
+    MoreGrads more; more.n = 0; more.scale = 1.0f; more.g[0] = more.g[1] = more.g[2] = nullptr;
+    if (num_extra > 0 && grads_extra != nullptr) {
+        more.n = num_extra > 3 ? 3 : num_extra; more.scale = grad_scale;
+        for (int i = 0; i < more.n; i++) more.g[i] = grads_extra[i];
+    }
     Segs segs; segs.n = num_segments;
     // (the degree-aware form addresses the arrays with 32-bit byte offsets: beyond 4 GB per array everything is treated as active)
     // (and eps = 0 would make the full update of an all-zero element 0 x rcp(0) = NaN: no shortcut then)
@@ -149,7 +178,7 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
     if (blocks > max_blocks) blocks = max_blocks;            // (2048: eight 256-thread blocks per CU, all resident at once)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg, exp_avg_sq,
-                       segs, AdamBetas(beta1, beta2), eps, weight_decay, bc1, bc2_sqrt, step_state, first, skip_word, skip_mask);
+                       segs, AdamBetas(beta1, beta2), eps, weight_decay, bc1, bc2_sqrt, step_state, first, skip_word, skip_mask, more);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
 
@@ -224,12 +253,14 @@ extern "C" int moss_adamw_flat_guarded(long long first, long long count, float* 
 extern "C" int moss_adamw_flat_ex(const moss_adamw_flat_args* a, void* stream)
 {
     if (!a || a->first < 0 || (a->first & 3) || a->count < 0 || a->num_segments < 1 || a->num_segments > 8 || !a->params || !a->grads ||
-        !a->exp_avg || !a->exp_avg_sq || !a->segment_end || !a->segment_lr || (!a->step_state && a->step < 1) || (a->skip_word && !a->step_state))
+        !a->exp_avg || !a->exp_avg_sq || !a->segment_end || !a->segment_lr || (!a->step_state && a->step < 1) || (a->skip_word && !a->step_state) ||
+        a->num_grads_extra < 0 || a->num_grads_extra > 3)
         return MOSS_ERR_INVALID_ARG;
+    for (int i = 0; i < a->num_grads_extra; i++) if (!a->grads_extra[i]) return MOSS_ERR_INVALID_ARG;
     if (a->count == 0) return a->step_state ? MOSS_ERR_INVALID_ARG : 0;
     const double bc1 = a->step_state ? 1.0 : 1.0 - pow(a->beta1, a->step), bc2 = a->step_state ? 1.0 : 1.0 - pow(a->beta2, a->step);
     return moss::launch_adamw(a->count, a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_segments, a->segment_end, a->segment_lr,
                               a->segment_period, a->segment_split, a->segment_lr2, a->beta1, a->beta2, a->eps, a->weight_decay,
                               (float)bc1, (float)sqrt(bc2), (const float*)a->step_state, (hipStream_t)stream, a->first, a->skip_word,
-                              a->skip_mask, a->segment_active, a->inactive_zero);
+                              a->skip_mask, a->segment_active, a->inactive_zero, a->num_grads_extra, a->grads_extra, a->grad_scale);
 }

@@ -219,9 +219,13 @@ static int forward_impl(
       launch_preprocess_forward(fp, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, transforms, translation, g, im, radii, s,
                                 bucketed ? b.keys : nullptr, key_stride); }
     STAGE_CHECK("preprocess");
+    // (asynchronous and un-bucketed -- the MOSS_FORWARD_ONLY renders: the scan rides along with the scatter kernel, no launch of its own)
+    const bool fold_scan = !bucketed && capacity >= 0 && scatter_folds_scan(fp);
     if (!bucketed) {
-        { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s, fwd_only); }
-        STAGE_CHECK("scan");
+        if (!fold_scan) {
+            { StageTimer tm(MOSS_STAGE_SCAN, s); TraceRange tr(trace, "moss:scan"); launch_scan(P, g, im, T, capacity, s, fwd_only); }
+            STAGE_CHECK("scan");
+        }
         if (capacity < 0) {
             // The one host round trip of the forward pass: R sizes the binning buffer (rasterizer_impl.cu:283).
             if (!g_pinned.p) HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 64, hipHostMallocDefault));
@@ -253,7 +257,7 @@ static int forward_impl(
 
     if (R > 0) {
         if (!bucketed) {
-            { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, "moss:scatter"); launch_scatter(fp, g, im, b, s); }
+            { StageTimer tm(MOSS_STAGE_SCATTER, s); TraceRange tr(trace, fold_scan ? "moss:scatter+scan" : "moss:scatter"); launch_scatter(fp, g, im, b, s, fold_scan, capacity); }
             STAGE_CHECK("scatter");
         }
 #ifdef MOSS_DIAG

@@ -49,7 +49,7 @@ class _ViewAlias:
 
 
 class MultiViewStep:
-    def __init__(self, pc, B, cameras, targets, bg, transforms=None, translation=None, parallel_streams=True, eps=1e-15):
+    def __init__(self, pc, B, cameras, targets, bg, transforms=None, translation=None, parallel_streams=True, eps=1e-15, fused_sum=True):
         """``pc``: a ``GaussianSet`` with unified SH; ``cameras`` / ``targets``: B camera views and B (image, mask) pairs; ``transforms``
         (P,3,3) / ``translation`` (P,3): the frame's LBS table (one for all views here, or a list of B)."""
         if not getattr(pc, "unified_features", False):
@@ -58,7 +58,10 @@ class MultiViewStep:
         self.cameras, self.targets = list(cameras), list(targets)
         per_view = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * self.B
         self.transforms, self.translation = per_view(transforms), per_view(translation)
+        if not 1 <= self.B <= 4:
+            raise ValueError("1 to 4 views per step")
         self.parallel_streams = bool(parallel_streams) and self.B > 1
+        self.fused_sum = bool(fused_sum) and self.B > 1        # False: the average by torch ops in front of the update (the reference form)
         params = [getattr(pc, n) for n in _NAMES]
         self.bucket = bucket = mdist.GradBucket(params)
         self.opt = FlatAdamW(pc.param_groups(), bucket, eps=eps, capturable=True)
@@ -109,13 +112,17 @@ class MultiViewStep:
         else:
             for b in range(self.B):
                 self._view(b)
-        n = self.bucket.tail + 4                               # (the loss block is averaged with the gradients, as in the N-GPU all-reduce)
-        acc = self.flats[0][:n]
-        for b in range(1, self.B):                             # fixed order: ((g0 + g1) + g2) + ...
-            acc.add_(self.flats[b][:n])
-        if self.B > 1:
-            acc.mul_(1.0 / self.B)
-        self.opt.step()
+        if self.fused_sum:
+            # ((g0 + g1) + g2 ...) x 1/B inside the update kernel (C ABI moss_adamw_flat_ex: grads_extra): no pass of its own over the buffers
+            self.opt.step(extra_grads=self.flats[1:], grad_scale=1.0 / self.B)
+        else:
+            n = self.bucket.n_params
+            acc = self.flats[0][:n]
+            for b in range(1, self.B):                         # fixed order: ((g0 + g1) + g2) + ...
+                acc.add_(self.flats[b][:n])
+            if self.B > 1:
+                acc.mul_(1.0 / self.B)
+            self.opt.step()
         return {"images": list(self.images)}
 
     eager_step = compute

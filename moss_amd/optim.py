@@ -391,12 +391,14 @@ class FlatAdamW:
         m, v = self._moments_of(i)
         m.zero_(); v.zero_()
 
-    def step(self, skip_word=None, skip_mask=2):
+    def step(self, skip_word=None, skip_mask=2, extra_grads=None, grad_scale=1.0):
         """One update.  ``skip_word`` (capturable optimizers only): a one-element int32 / float32 DEVICE tensor; if
         ``skip_word & skip_mask`` is non-zero when the kernel runs, the step is a no-op on the device -- parameters, moments and the
         step counter stay bit for bit (C ABI ``moss_adamw_flat_guarded``).  Not with ``shard``: the skip is a per-rank decision.  ``frame_status_word(img_buffer)`` of a rasterizer forward
         with the default mask 2 skips the step of a frame that overflowed its capacity and rendered nothing (inside a captured
-        hipGraph nobody else can)."""
+        hipGraph nobody else can).  ``extra_grads`` (up to three flat tensors laid out like the bucket) + ``grad_scale``: the step's
+        gradient is ((bucket + extra[0]) + extra[1] ...) x grad_scale, formed inside the update kernel in that order -- B views per
+        optimizer step on one device (``moss_amd.multiview``)."""
         dev = self.flat_params.device
         if getattr(self, "fused", None) is not None:
             cx = getattr(self, "_fused_context", None)
@@ -437,6 +439,14 @@ class FlatAdamW:
         a.step_state = None if self.step_state is None else self.step_state.data_ptr()
         a.skip_word = None if skip_word is None else skip_word.data_ptr()
         a.skip_mask = int(skip_mask) & 0xffffffff
+        extra = list(extra_grads or [])
+        if len(extra) > 3:
+            raise ValueError("at most three extra gradient buffers (four views per step)")
+        a.num_grads_extra, a.grad_scale = len(extra), float(grad_scale)
+        for i, e in enumerate(extra):
+            if e.numel() < grads.numel() or e.dtype != torch.float32 or e.device != grads.device or not e.is_contiguous():
+                raise ValueError("an extra gradient buffer must be a contiguous float32 tensor laid out like the bucket")
+            a.grads_extra[i] = e[first:].data_ptr() if self.shard is None else e.data_ptr()
         with torch.cuda.device(dev):
             rc = lib().moss_adamw_flat_ex(C.addressof(a), torch.cuda.current_stream(dev).cuda_stream)
         check(rc, "adamw_flat_ex")

@@ -177,7 +177,7 @@ def check_backward_unmasked(d, gpu, fw, t, e, zero_depth=False, tol=UNMASKED_GRA
     scales = hp.oracle_gradient_scales(d, hp.replace_forward_state(fw, e), dc, dd, da)
     seen, n_frag = gaussians_seen_by_fragile_pixels(d, fw)
     clear = ~seen
-    assert clear.mean() > 0.5, f"{int(seen.sum())} of {d.P} Gaussians are seen by one of {n_frag} fragile pixels: nothing left to assert on"
+    assert clear.mean() > 0.2, f"{int(seen.sum())} of {d.P} Gaussians are seen by one of {n_frag} fragile pixels: nothing left to assert on"
     errs, bad = {}, {}
     for n in names:
         a, r = getattr(g, n).cpu().numpy(), getattr(ref, n)
