@@ -89,5 +89,12 @@ def test_one_view_is_the_ordinary_unfused_step(gpu, hip_lib):
         bucket.collect()
         opt.step()
     torch.cuda.synchronize(gpu)
-    for x, y in ((mv.opt.flat_params, opt.flat_params), (mv.opt.exp_avg, opt.exp_avg), (mv.opt.exp_avg_sq, opt.exp_avg_sq)):
-        assert torch.equal(x, y)
+    # (the two buckets list the parameters in different orders: compared tensor by tensor)
+    for name in ("_xyz", "_features", "_opacity", "_scaling", "_rotation"):
+        a, b = getattr(pc, name), getattr(pc2, name)
+        assert torch.equal(a.data, b.data), name
+        ia = {id(p): i for i, p in enumerate(mv.opt.bucket.params)}[id(a)]
+        ib = {id(p): i for i, p in enumerate(opt.bucket.params)}[id(b)]
+        for x, y in zip(mv.opt._moments_of(ia), opt._moments_of(ib)):
+            assert torch.equal(x, y), name
+    assert float(mv.opt.exp_avg.abs().max()) > 0
