@@ -1045,10 +1045,34 @@ def _multi_view(dev, scene, bg, lbs_T, B, steps):
             "workload": f"{scene.name}: {B} cameras on a ring per optimizer step; gradients = the mean over the views (the N-GPU data-parallel step of SURVEY 8e on one device)"}
 
 
+def _warm_surgery(dev):
+    """One throw-away densification event on a 64-Gaussian model: torch loads the code object of every kernel it has not used yet at
+    its first launch (tens of milliseconds each on this stack), and an event is the first user of boolean indexing, cat, repeat ... in
+    this process -- that one-off cost is not what `event_ms` is there to report."""
+    import torch
+    from moss_amd import dist as mdist, scenes
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.optim import FlatAdamW
+    from moss_amd.surgery import densification_event
+    pc = GaussianSet(scenes.config1(P=64), sh_degree=3, device=dev, unified_features=True)
+    opt = FlatAdamW(pc.param_groups(), mdist.GradBucket(list(pc.parameters())), eps=1e-15, capturable=True)
+    t = {"xyz": pc._xyz.data, "f_dc": pc._features_dc.data, "f_rest": pc._features_rest.data, "opacity": pc._opacity.data,
+         "scaling": pc._scaling.data, "rotation": pc._rotation.data}
+    T = torch.eye(3, device=dev).repeat(64, 1, 1)
+    for step in (1, 2):
+        ev = scenes.scripted_densification(t, step, dev, reset_opacity=True)
+        rep = densification_event(pc, opt, append=ev["append"], prune=ev["prune"], reset_opacity=True, per_gaussian={"T": T})
+        T = rep["per_gaussian"]["T"]
+        t = {"xyz": pc._xyz.data, "f_dc": pc._features_dc.data, "f_rest": pc._features_rest.data, "opacity": pc._opacity.data,
+             "scaling": pc._scaling.data, "rotation": pc._rotation.data}
+    torch.cuda.synchronize(dev)
+
+
 def _densify_schedule(h, dev, sc, steps=400, every=100):
     """`steps` replays of the captured headline step with a scripted densification event after every `every`-th: wall time of the whole
     schedule (events included) and of the steps alone, the cost of each event, the row counts."""
     import torch
+    _warm_surgery(dev)
     torch.cuda.synchronize(dev)
     t_steps, events, rows, phases, first = 0.0, [], [int(h.pc._xyz.shape[0])], [], []
     t_all0 = time.perf_counter()
