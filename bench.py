@@ -1166,6 +1166,23 @@ def eval_block(dev, scene, cam, bg, lbs_T, n=200):
     res["stages_us"] = {k: round(1e3 * v[0] / v[1], 1) for k, v in _lib.profile_read().items() if v[1]}
     _lib.profile_enable([])
     del g
+    # --- B renders at a time: B forward-only chains on B HIP streams inside one hipGraph (moss_amd.multiview.MultiViewRender)
+    try:
+        from moss_amd import scenes as _sc
+        from moss_amd.gaussian_renderer import camera_view as _cv
+        from moss_amd.multiview import MultiViewRender
+        c0 = scene.camera
+        for B in (2, 4):
+            cams = [_cv(_sc.make_camera(c0.W, c0.H, float(c0.K[0, 0]), float(c0.K[1, 1]), float(c0.K[0, 2]), float(c0.K[1, 2]), R_, t_), dev)
+                    for R_, t_ in _sc.look_at_ring(8)[:B]]
+            mr = MultiViewRender(pc, cams, bg, transforms=lbs_T, translation=tl)
+            mr.capture()
+            dt = timed(mr, max(n // B, 20))
+            mr.check()
+            res[f"fps_async_graph_{B}_streams"] = round(B / dt, 1)
+            del mr
+    except Exception as e:
+        res["fps_async_graph_streams_error"] = f"{type(e).__name__}: {str(e)[:200]}"
     # --- the training forward the same way (grad mode on; the autograd node is built and dropped, no backward)
     cx, pipe = make(True)
 

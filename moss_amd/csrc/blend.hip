@@ -76,6 +76,7 @@ __device__ const uint64_t EXP2F_TAB[32] = {
 __device__ __forceinline__ float expf_det(float x)
 {
 #pragma clang fp contract(off)
+    if (x != x) return x;                                     // expf(NaN) = NaN (a degenerate conic): the reference's min(0.99f, NaN * opacity) then blends at 0.99
     if (!(x > -104.0f)) return 0.0f;
     if (x > 0.0f) x = 0.0f;                                   // (never used for a decision: power > 0 is skipped; keeps the table index sane)
     const double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
@@ -377,12 +378,16 @@ __device__ __forceinline__ void light_backward_item(int W, int H, int gx, int ti
                 v[k][5] = wx * dx; v[k][6] = wx * dy; v[k][7] = wy * dy;
                 v[k][8] = v8;
                 pos4[k] = pos;
+                uint32_t be;
                 {   // the entry's cell for this quadrant: first flagged block b of the quadrant -> (w >> 2) - 16 + (b >> 2) (nbx) + (b & 3)
-                    const uint32_t w = __float_as_uint(a.z), be = (uint32_t)__builtin_amdgcn_readlane((int)bmk_cur, e) & qmask;
+                    const uint32_t w = __float_as_uint(a.z);
+                    be = (uint32_t)__builtin_amdgcn_readlane((int)bmk_cur, e) & qmask;
                     const int b = be ? __ffs((int)be) - 1 : 0;
                     slot4[k] = (w >> 2) - 16u + (uint32_t)((b >> 2) * (int)((w & 3u) + 1u) + (b & 3));
                 }
-                any4[k] = __ballot(al > 0.0f) != 0ull;
+                // (an entry whose block mask has no bit in this quadrant owns no cell here: with culling on it is never visited; with
+                // MOSS_DEBUG_NO_BLOCK_CULL it is, and a record for it would land in front of the instance's cells -- dropped instead)
+                any4[k] = be != 0u && __ballot(al > 0.0f) != 0ull;
             }
             if (any4[0] || any4[1] || any4[2] || any4[3]) {
                 float tot[9];

@@ -411,7 +411,12 @@ preprocess_forward_kernel(int P, int D, int M, int W, int H, int gx, int gy,
 
             // Conservative extent of the region where this Gaussian can reach alpha >= 1/255 (power >= -tau,
             // tau = ln(255*opacity)): half-widths sqrt(2*tau*cov_xx), sqrt(2*tau*cov_yy) of the ellipse's bounding box,
-            // widened by 1e-4 relative + 0.01 px against rounding.  Used only to SKIP work in the blend kernels.
+            // widened by 1e-4 relative + 0.01 px against rounding.  Since round 5 the box does more than let the blend kernels SKIP
+            // work: it SIZES and ADDRESSES memory -- the Gaussian's run of gradient-record cells is the box's 4x4 blocks inside its
+            // tile rectangle (common.h: box_cells), and the backward blend files a record under the (entry, block) pair's cell.  The block
+            // masks are a refinement of this box, so with culling on no pair outside it is ever blended; MOSS_DEBUG_NO_BLOCK_CULL relies
+            // on the same containment (a pixel outside the box never reaches alpha >= 1/255: the margins above are four orders of
+            // magnitude wider than the arithmetic's error; tests/test_gpu_ops.py::test_block_mask_culling_never_changes_a_result).
             const float opa = (raw & RAW_OPACITY) ? sigmoid_act(opa_ld) : opa_ld;
             float hx = __builtin_huge_valf(), hy = __builtin_huge_valf();
             if (opa == opa) {

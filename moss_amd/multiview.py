@@ -23,7 +23,7 @@ from .gaussian_renderer import render
 from .graphs import GraphedStep
 from .optim import FlatAdamW
 
-__all__ = ["MultiViewStep"]
+__all__ = ["MultiViewStep", "MultiViewRender"]
 
 _NAMES = ("_xyz", "_features", "_opacity", "_scaling", "_rotation")
 
@@ -136,5 +136,69 @@ class MultiViewStep:
 
     def check(self):
         """Every view's last frame fitted its capacity (raises ``CapacityOverflow`` otherwise; re-capture after it)."""
+        for v in self.views:
+            v.ctx.check_status()
+
+
+class MultiViewRender:
+    """B evaluation renders at a time (render_ZJU.py:56-72 renders its test views one after the other): the B forward-only chains --
+    ``render()`` under ``torch.no_grad()``, each on a ``RasterContext`` of its own -- on B HIP streams inside one captured hipGraph.
+    A 512 x 512 render is a chain of latency-bound kernels that leaves most of the device idle; B of them overlap.  ``cameras`` may be
+    replaced between replays only by cameras whose tensors are updated IN PLACE (the graph holds their addresses)."""
+
+    def __init__(self, pc, cameras, bg, transforms=None, translation=None, parallel_streams=True, pipe_flags=None):
+        self.pc, self.bg = pc, bg
+        self.cameras = list(cameras)
+        self.B = len(self.cameras)
+        per_view = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * self.B
+        self.transforms, self.translation = per_view(transforms), per_view(translation)
+        self.parallel_streams = bool(parallel_streams) and self.B > 1
+        dev = pc._xyz.device
+        self.dev = dev
+        self.views = []
+        for b in range(self.B):
+            cx = RasterContext()
+            cx.set_async(True)
+            flags = dict(convert_SHs_python=False, compute_cov3D_python=False, debug=False, fused_activations=False,
+                         transforms_in_op=transforms is not None, pose_in_op=transforms is not None,
+                         raw_parameters_in_op=all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation")), raster_context=cx)
+            flags.update(pipe_flags or {})
+            self.views.append(SimpleNamespace(ctx=cx, pipe=SimpleNamespace(**flags), stream=None if b == 0 else torch.cuda.Stream(dev)))
+        self.graphed = None
+
+    def _view(self, b):
+        v = self.views[b]
+        with torch.no_grad():
+            out = render(self.cameras[b], self.pc, v.pipe, self.bg, transforms=self.transforms[b], translation=self.translation[b])
+        return out["render"], out["render_depth"], out["render_alpha"]
+
+    def compute(self):
+        cur = torch.cuda.current_stream(self.dev)
+        outs = [None] * self.B
+        if self.parallel_streams:
+            for b in range(1, self.B):
+                self.views[b].stream.wait_stream(cur)
+            outs[0] = self._view(0)
+            for b in range(1, self.B):
+                with torch.cuda.stream(self.views[b].stream):
+                    outs[b] = self._view(b)
+            for b in range(1, self.B):
+                cur.wait_stream(self.views[b].stream)
+        else:
+            for b in range(self.B):
+                outs[b] = self._view(b)
+        return outs
+
+    def capture(self, warmup=2):
+        self.compute()                                       # (the first, synchronous renders size the capacities)
+        torch.cuda.synchronize(self.dev)
+        self.graphed = GraphedStep(self.compute, warmup=warmup, device=self.dev, context=self.views[0].ctx)
+        return self.graphed
+
+    def __call__(self):
+        """[(image (3,H,W), depth (1,H,W), alpha (1,H,W))] of the B views (the captured graph's static outputs)."""
+        return (self.graphed or self.compute)()
+
+    def check(self):
         for v in self.views:
             v.ctx.check_status()

@@ -98,3 +98,27 @@ def test_one_view_is_the_ordinary_unfused_step(gpu, hip_lib):
         for x, y in zip(mv.opt._moments_of(ia), opt._moments_of(ib)):
             assert torch.equal(x, y), name
     assert float(mv.opt.exp_avg.abs().max()) > 0
+
+
+def test_parallel_evaluation_renders_equal_single_renders(gpu, hip_lib):
+    """MultiViewRender: four forward-only renders on four streams in one hipGraph == the four renders one after the other, bit for bit."""
+    from moss_amd.diff_gaussian_rasterization import RasterContext
+    from moss_amd.gaussian_model import GaussianSet
+    from moss_amd.gaussian_renderer import render
+    from moss_amd.multiview import MultiViewRender
+    scene, cams, gts, bg, T = _setup(gpu, 4)
+    pc = GaussianSet(scene, sh_degree=3, device=gpu, unified_features=True)
+    tl = (0.01 * torch.randn(scene.P, 3, generator=torch.Generator().manual_seed(3))).to(gpu)
+    mr = MultiViewRender(pc, cams, bg, transforms=T, translation=tl)
+    mr.capture()
+    outs = mr()
+    torch.cuda.synchronize(gpu)
+    mr.check()
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, fused_activations=False, transforms_in_op=True,
+                           pose_in_op=True, raw_parameters_in_op=True, raster_context=RasterContext())
+    for b, cam in enumerate(cams):
+        with torch.no_grad():
+            ref = render(cam, pc, pipe, bg, transforms=T, translation=tl)
+        for got, want, name in zip(outs[b], (ref["render"], ref["render_depth"], ref["render_alpha"]), ("render", "depth", "alpha")):
+            assert torch.equal(got, want), (b, name)
+    assert not torch.equal(outs[0][0], outs[1][0])
