@@ -74,6 +74,7 @@ class RasterContext:
         # instead of ~400.  The price on the CAPACITY-BOUNDED path: its keys take the scan -> scatter chain (six launches) where the
         # training forward buckets them (four) -- ~15 us per render at 100k Gaussians.  False: no-grad renders run the training forward.
         self.forward_only_renders = True
+        self._capacity_floor = 0                             # relearn_capacity(): the capacity that was in force before
         self.frame_state = None      # device block the asynchronous forward keeps its per-frame counters in (all-zero between calls)
         self._retired_frame_states = []   # outgrown blocks: a captured hipGraph may still hold their address (see _frame_state)
         self._raised_overflows = 0        # overflows of this context already raised as CapacityOverflow (not "dropped by a replay")
@@ -87,6 +88,9 @@ class RasterContext:
         asynchronous session) and sizes the capacity from what it finds -- for the moments the set of Gaussians changes from outside
         (densify / prune).  Call it outside graph capture; a hipGraph captured with the old capacity must be captured again."""
         self._consume_quiet()
+        # (the capacity in force is remembered: if it still holds the new set with 25 % to spare it is KEPT -- the scratch buffers of a
+        # re-captured step then have the sizes of the ones they replace and come out of the allocator's cache instead of hipMalloc)
+        self._capacity_floor = self.capacity
         self.capacity = 0
         self.pending = None
 
@@ -247,12 +251,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             cx._request_status(img, means3D.device)
     elif cx.enabled and P > 0:                               # first (synchronous) call of an async session: learn the size
         learning = cx.capacity == 0                          # (debug bit 0 / CPU tensors also come here, with a capacity already learned)
-        cx.capacity = max(cx.capacity, int(rendered * cx.margin) + 1024)
+        new_cap = int(rendered * cx.margin) + 1024
+        if learning and cx._capacity_floor >= 1.25 * rendered:
+            new_cap = cx._capacity_floor                     # re-learning (relearn_capacity): the old capacity still holds the new set
+        if learning:
+            cx._capacity_floor = 0
+        cx.capacity = max(cx.capacity, new_cap)
         cx.last_needed = rendered
         if learning and means3D.is_cuda and rendered > 0:    # ... including what the frame asks of the record pool (status word [3])
             cx._consume_status(block=True)                   # (a report still pending from an earlier asynchronous frame is not lost)
             cx._request_status(img, means3D.device)
-            cx._consume_status(block=True)
+            cx._consume_status(block=True)                   # (grows the capacity if word [3] x 1.25 exceeds it)
     global last_num_rendered
     cx.last_num_rendered = last_num_rendered = cx.last_needed if use_async else rendered
     return res
