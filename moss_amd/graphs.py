@@ -21,9 +21,34 @@ Rules the captured function must follow (``bench.py`` and tests/test_gpu_ops.py:
 """
 from __future__ import annotations
 
+import contextlib
+import gc
+
 import torch
 
-__all__ = ["GraphedStep"]
+__all__ = ["GraphedStep", "capturing"]
+
+
+@contextlib.contextmanager
+def capturing(graph, collect=False, **kw):
+    """``torch.cuda.graph(graph, **kw)`` with Python's cyclic garbage collector held off for the duration of the capture.  A
+    ``GraphedStep`` that was dropped together with the object whose bound method it captured is a reference CYCLE: it is freed by
+    whichever allocation happens to trigger a collection -- and if that allocation is a tensor wrapper created inside a LATER capture,
+    ``~CUDAGraph`` (hipGraphExecDestroy) runs while the stream is capturing: "operation not permitted when stream is capturing", raised
+    from a destructor, i.e. ``terminate``.  (torch >= 2.9 no longer calls ``gc.collect()`` on entering a capture.)  With the collector
+    off the dead cycles simply wait for the first collection after the capture; ``collect=True`` frees them (and the device memory they
+    hold) BEFORE it: one full collection, ~45 ms of host time in a process that has torch loaded -- a first capture can afford it, the
+    re-capture of a densification event (5 ms in all) cannot."""
+    was = gc.isenabled()
+    if collect:
+        gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GraphedStep:
@@ -57,7 +82,7 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # thread_local: other threads (e.g. a data loader pinning memory) may make HIP calls during the capture
-        with torch.cuda.graph(self.graph, pool=pool, stream=side, capture_error_mode="thread_local"):
+        with capturing(self.graph, collect=old is None, pool=pool, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn()
         torch.cuda.synchronize(dev)
         del old                                              # (its blocks go back to the shared pool)

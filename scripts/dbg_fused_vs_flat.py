@@ -9,6 +9,7 @@ from moss_amd.gaussian_model import GaussianSet
 from moss_amd.gaussian_renderer import render, camera_view
 from moss_amd.loss import training_loss_fused, backward_from_loss
 from moss_amd.optim import FlatAdamW
+from moss_amd.graphs import capturing
 from moss_amd import diff_gaussian_rasterization as dgr
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -66,7 +67,7 @@ if use_graph:
         torch.cuda.current_stream(dev).wait_stream(side); torch.cuda.synchronize()
         m.opt.restore(snap)
         m.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(m.graph, stream=side):
+        with capturing(m.graph, stream=side):
             m.img = m.compute()
         m.opt.restore(snap)
         torch.cuda.synchronize()

@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from moss_amd import _lib
+from moss_amd.graphs import capturing
 dev = torch.device("cuda:0")
 L = _lib.lib()
 C, H, W = 3, (1024 if "1024" in sys.argv else 512), (1024 if "1024" in sys.argv else 512)
@@ -33,7 +34,7 @@ def call():
 for _ in range(20): call()
 torch.cuda.synchronize()
 gr = torch.cuda.CUDAGraph()
-with torch.cuda.graph(gr):
+with capturing(gr):
     for _ in range(20): call()
 for _ in range(3): gr.replay()
 torch.cuda.synchronize()

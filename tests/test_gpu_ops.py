@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from moss_amd import scenes
+from moss_amd.graphs import capturing
 from oracle import oracle
 from tests import helpers as hp
 
@@ -633,7 +634,7 @@ def test_dropped_frame_is_not_an_optimizer_step(gpu, hip_lib, async_mode):
         torch.cuda.synchronize(gpu)
         cx.pending = None                                                  # (the eager frame's status: not what this test is about)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        with capturing(graph, stream=side):
             img = compute()
         before = state()
         for _ in range(3):
@@ -961,7 +962,7 @@ def test_learning_rate_schedule_without_recapture(gpu, hip_lib, async_mode):
         torch.cuda.current_stream(gpu).wait_stream(side)
         torch.cuda.synchronize(gpu)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        with capturing(graph, stream=side):
             m.step()
         m.opt.restore(snap)                                    # the capture itself ran nothing, but keep the state explicit
         torch.cuda.synchronize(gpu)
@@ -1006,7 +1007,7 @@ def test_step_captured_in_hipgraph_replays_with_new_parameters(gpu, hip_lib, asy
     torch.cuda.current_stream(gpu).wait_stream(side)
     torch.cuda.synchronize(gpu)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
+    with capturing(graph, stream=side):
         g_img = compute()
     for trial in range(2):
         with torch.no_grad():
