@@ -169,6 +169,24 @@ def launch_ranks(argv):
     return 0
 
 
+def _synthetic_bound_mask(gt_mask, grow=12):
+    """(1,H,W) uint8: the silhouette's bounding box grown by ``grow`` pixels with its corners cut (an octagon) -- the shape MOSS's
+    projected 3-D body box has (a convex region a little larger than the person)."""
+    import torch
+    m = gt_mask.reshape(gt_mask.shape[-2], gt_mask.shape[-1]) > 0
+    H, W = m.shape
+    ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
+    if ys.numel() == 0:
+        return torch.ones(1, H, W, dtype=torch.uint8, device=m.device)
+    x0, x1 = max(int(xs[0]) - grow, 0), min(int(xs[-1]) + grow + 1, W)
+    y0, y1 = max(int(ys[0]) - grow, 0), min(int(ys[-1]) + grow + 1, H)
+    yy, xx = torch.meshgrid(torch.arange(H, device=m.device), torch.arange(W, device=m.device), indexing="ij")
+    cut = (min(x1 - x0, y1 - y0)) // 4
+    dx, dy = torch.minimum(xx - x0, x1 - 1 - xx), torch.minimum(yy - y0, y1 - 1 - yy)
+    box = (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1) & (dx + dy >= cut)
+    return box.to(torch.uint8)[None]
+
+
 class Harness:
     """One configuration of the training step on this rank: model, optimizer, gradient bucket, rasterizer context, step functions."""
 
@@ -250,6 +268,12 @@ class Harness:
         import functools
         training_loss = (mloss.training_loss_fused if fused_loss is True else
                          functools.partial(mloss.training_loss, ssim_fn=mloss.ssim_fused) if fused_loss == "ssim" else mloss.training_loss)
+        if fused_loss == "moss":
+            # MOSS's OWN expression (train_ZJU.py:108-119): L1 / mask L2 over the view's bound_mask, SSIM on its bounding rectangle, from
+            # the same two kernels (C ABI moss_photometric_loss_roi).  The bound_mask of a synthetic view: MOSS projects the 3-D box of
+            # the body (a convex region around the person); here the target silhouette's bounding box grown by 12 px, corners cut.
+            self.region = region = mloss.ViewRegion(_synthetic_bound_mask(gt_mask))
+            training_loss = lambda img, a, g_, m_, terms_out=None: mloss.training_loss_moss_fused(img, a, g_, m_, region, terms_out=terms_out)
         self.caller_side = caller_side
         stats = None
         if caller_side == "torch":
@@ -270,7 +294,7 @@ class Harness:
             else:
                 bucket.attach()             # zero the bucket; autograd accumulates into it
             out = render(cam, pc, pipe, bg, transforms=self.lbs_T)      # (self.lbs_T: re-indexed by a densification event)
-            if fused_loss is True:
+            if fused_loss is True or fused_loss == "moss":
                 # the loss kernels write [loss, L1, SSIM, mask] into the bucket's tail: it travels with the gradients, no copy
                 loss = training_loss(out["render"], out["render_alpha"], gt, gt_mask, terms_out=bucket.loss_terms)
                 mloss.backward_from_loss(loss)
@@ -899,6 +923,11 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         # (degree 0 with the optimizer as a kernel of its own -- the form every N > 1 gradient exchange runs: what the degree-aware FLAT
         # update and the active-only dL_dsh are worth there; compare with unfused_optimizer, the same at degree 3)
         specs["sh_degree_0_unfused_optimizer"] = dict(specs["sh_degree_0"], fused_optimizer=False)
+    if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw:
+        # the headline's step with MOSS's OWN loss expression for the three rasterizer-facing terms (train_ZJU.py:108-119: L1 and mask L2
+        # over the view's bound_mask, SSIM on its bounding rectangle) instead of the full-frame form the headline carries since round 1
+        specs["moss_loss_expression"] = dict(mode="lbs", activations=args.activations, torch_activations=args.torch_activations,
+                                             torch_adamw=False, forward="async", graph=1, fused_optimizer=bool(args.fused_optimizer), fused_loss="moss")
     if args.mode == "lbs" and args.forward == "async" and args.graph and not args.torch_adamw and args.fused_optimizer:
         # the headline's step THROUGH MOSS's densification schedule (train_ZJU.py:171-186: an event every 100 iterations): 400 steps with a
         # scripted clone / split / prune event after every 100th (an opacity reset with the second), the optimizer's rows, the bucket, the
@@ -954,7 +983,7 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
             h = Harness(args, dev, 0, 1, sc, cam_, gt_, mask_, bg, lbs_T=T_ if kw["mode"] in ("lbs", "lbs_python") else None, **kw)
             if name == "spatial_order":
                 h.pc.spatially_ordered = True                # what GaussianSet.reorder_spatially() leaves behind: render() hints the op
-            seg3 = name in ("as_generated_order", "spatial_order", "small_P_cfg2") or name.startswith("sh_degree_")
+            seg3 = name in ("as_generated_order", "spatial_order", "small_P_cfg2", "moss_loss_expression") or name.startswith("sh_degree_")
             n_steps = 3 * steps if seg3 else steps
             for _ in range(warmup):
                 h.step()
@@ -980,8 +1009,14 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
                 h.ctx.check_status()
             res[name] = {"value": round(n_steps / dt, 2), "unit": "iters/s", "ms_per_step": round(1e3 * dt / n_steps, 4), "steps": n_steps,
                          "launch": h.graph_note if h.use_graph else "eager launches", "forward": kw["forward"]}
-            if name == "small_P_cfg2" or name.startswith("sh_degree_"):
-                res[name]["workload"] = (f"BASELINE configs[1]: {sc.means3D.shape[0]} Gaussians, 512x512, the headline's step (lbs, fused optimizer, one hipGraph)"
+            if name == "moss_loss_expression":
+                x_, y_, w_, h_ = h.region.xywh
+                res[name]["workload"] = (f"the headline's workload and step with MOSS's own loss expression: bound_mask of {int(h.region.rect[4])} pixels, "
+                                         f"SSIM on its bounding rectangle {w_}x{h_} at ({x_},{y_}) of the {gt_.shape[-1]}x{gt_.shape[-2]} frame")
+            if name == "small_P_cfg2" or name.startswith("sh_degree_") or name == "moss_loss_expression":
+                res[name].setdefault("workload", "")
+                if name != "moss_loss_expression":
+                    res[name]["workload"] = (f"BASELINE configs[1]: {sc.means3D.shape[0]} Gaussians, 512x512, the headline's step (lbs, fused optimizer, one hipGraph)"
                                          if name == "small_P_cfg2" else
                                          f"the headline's workload and step at ACTIVE SH degree {kw['sh_degree']} (coefficients above it zero, as MOSS creates them)")
                 # its kernels, one by one (eager replay with the library's kernel-attached events)

@@ -263,6 +263,20 @@ int moss_photometric_loss(int C, int H, int W, const float* image, const float* 
 int moss_photometric_loss_weighted(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
                                    float lambda_l1, float lambda_dssim, float lambda_mask, float* loss_out, float* dL_dimage,
                                    float* dL_dalpha, char* workspace, size_t workspace_bytes, void* stream);
+/* MOSS's OWN loss expression for these three terms (ABI 6; train_ZJU.py:108-119,131): the L1 and the mask term are means over the
+ * pixels of the view's `bound_mask` -- Ll1 = l1_loss(image[bound], gt[bound]) (:111), mask_loss = l2_loss(alpha[bound], mask[bound])
+ * (:112) -- and SSIM is taken on the crop x, y, w, h = cv2.boundingRect(bound_mask) of both images (:115-119: zero padding at the
+ * CROP's edges, mean over C*w*h).  total = lambda_l1 Ll1 + lambda_mask mask_loss + lambda_dssim (1 - ssim).
+ *   bound: (H,W) bytes, non-zero = counted; NULL = every pixel of the rectangle.
+ *   rect:  FIVE int32 in DEVICE memory: x, y, w, h, and the number of non-zero bytes of `bound` (ignored when bound is NULL).  Device
+ *          memory so that a step captured in a hipGraph changes view by rewriting them (and `bound`, `gt`, `mask`) in place.  The
+ *          rectangle is clipped to the image.  Pixels of `bound` outside it count for nothing (MOSS's rectangle is the bounding box of
+ *          the mask: there are none).  An empty mask gives NaN means, like torch's mean of an empty selection.
+ *   dL_dimage, dL_dalpha: written for the WHOLE image (zero off the crop / off the mask), so they are the gradients of `total`
+ *          w.r.t. the full-size tensors the rasterizer produced.  Same workspace, same two launches, deterministic. */
+int moss_photometric_loss_roi(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
+                              const unsigned char* bound, const int* rect, float lambda_l1, float lambda_dssim, float lambda_mask,
+                              float* loss_out, float* dL_dimage, float* dL_dalpha, char* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Flat fused AdamW (torch.optim.AdamW semantics, amsgrad off) over `n` contiguous fp32 parameters with their gradients and

@@ -122,6 +122,8 @@ def _declare(lib):
     lib.moss_photometric_loss.argtypes = [_i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
     lib.moss_photometric_loss_weighted.restype = _i
     lib.moss_photometric_loss_weighted.argtypes = [_i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
+    lib.moss_photometric_loss_roi.restype = _i
+    lib.moss_photometric_loss_roi.argtypes = [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
     lib.moss_adamw_flat.restype = _i
     lib.moss_adamw_flat.argtypes = [C.c_longlong, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _d, _d, _f, _f, _i, _p]
     lib.moss_adamw_flat_devstep.restype = _i

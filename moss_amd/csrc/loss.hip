@@ -14,6 +14,12 @@
 //           into dL/dx = -lambda/N * (w*D_mu + 2x (w*D_xx) + y (w*D_xy)) + sign(x-y)/N; dL/dalpha alongside; block 0 folds
 //           the partials into the scalar losses.
 // Both passes are HBM-streaming: ~ (2 + 3) * 4 B read/written per pixel-channel in pass 1, (3 + 2 + 1) * 4 B in pass 2.
+//
+// ROI instantiation (moss_photometric_loss_roi): MOSS's OWN expression, train_ZJU.py:108-119 -- the L1 and the mask term are means over
+// the pixels of the view's `bound_mask` (the projected 3-D box of the body), SSIM is taken on the crop cv2.boundingRect(bound_mask) of
+// both images (zero padding at the CROP's edges).  Same tiles (image-aligned), same two launches: "inside" means inside the crop, the
+// sums are weighted by the mask, tiles off the crop leave at once with zero gradients.  The rectangle and the mask's pixel count are
+// read from DEVICE memory (5 ints), so that a captured step can change view by updating them in place.
 #include "common.h"
 
 namespace moss {
@@ -29,6 +35,20 @@ static_assert(LT % SEG == 0 && (LT / SEG) * LP <= 256 && LT * (LT / VR) == 256, 
 
 struct Win { float g[11]; };
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+// the crop [x0, x1) x [y0, y1) clipped to the image, its pixel count and the number of `bound` pixels (= the crop's when there is no mask)
+struct Crop { int x0, y0, x1, y1; float n_pix, n_bound; };
+__device__ __forceinline__ Crop load_crop(const int* __restrict__ rect, int W, int H, bool has_bound)
+{
+    Crop r;
+    const int x = rect[0], y = rect[1], w = max(rect[2], 0), h = max(rect[3], 0);
+    r.x0 = min(max(x, 0), W); r.y0 = min(max(y, 0), H);
+    r.x1 = min(max(x, 0) + min(w, W), W); r.y1 = min(max(y, 0) + min(h, H), H);
+    r.n_pix = (float)(r.x1 - r.x0) * (float)(r.y1 - r.y0);
+    r.n_bound = has_bound ? (float)rect[4] : r.n_pix;
+    return r;
+}
+__device__ __forceinline__ bool in_crop(const Crop& r, int x, int y) { return x >= r.x0 && x < r.x1 && y >= r.y0 && y < r.y1; }
 
 __device__ __forceinline__ float ld0(const float* __restrict__ p, int x, int y, int W, int H)
 {
@@ -58,13 +78,14 @@ __device__ __forceinline__ TileId xcd_tile()
 // into the outputs whose window holds it.  Vertical: a thread owns VR consecutive rows of one column.  32 x 32 tiles: the halo costs
 // 1.7x instead of 2.6x.
 
-template <bool SKIP_EMPTY>   // (see EMPTY TILES below: the instantiation for grids of more than one residency round)
+template <bool SKIP_EMPTY, bool ROI>   // (SKIP_EMPTY: see EMPTY TILES below, the instantiation for grids of more than one residency round)
 __global__ void __launch_bounds__(256)
 ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Win win,
                   float* __restrict__ dmap /* [3][C][H][W] */, float* __restrict__ partials /* [blocks][2] */,
                   const float* __restrict__ alpha, const float* __restrict__ mask, float lambda_mask,
                   float* __restrict__ dL_dalpha, float* __restrict__ mask_partials /* [tiles] */,
-                  unsigned long long* __restrict__ stamps /* diagnostics (MOSS_LOSS_STAMPS, -DMOSS_DIAG builds): 8 words per workgroup, else NULL */)
+                  unsigned long long* __restrict__ stamps /* diagnostics (MOSS_LOSS_STAMPS, -DMOSS_DIAG builds): 8 words per workgroup, else NULL */,
+                  const unsigned char* __restrict__ bound /* ROI: (H,W) 0/1 or NULL */, const int* __restrict__ rect /* ROI: device, x y w h count */)
 {
 #define LSTAMP(i) if (stamps && threadIdx.x == 0) stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
     LSTAMP(0);
@@ -80,6 +101,26 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     const float* xc = img + (size_t)c * H * W;
     const float* yc = gt + (size_t)c * H * W;
     bool nonzero = false;
+    Crop crop = {};
+    if constexpr (ROI) {
+        crop = load_crop(rect, W, H, bound != nullptr);
+        if (x0 >= crop.x1 || x0 + LT <= crop.x0 || y0 >= crop.y1 || y0 + LT <= crop.y0) {
+            // a tile off the crop: no SSIM term, no pixel of the mask (MOSS's rectangle is the mask's bounding box; a mask pixel outside
+            // the rectangle handed in here counts for nothing): zero sums, zero alpha gradient; pass 2 never reads its derivative maps
+            if (c == 0 && alpha != nullptr) {
+                const int lx_ = tid % LT, ly_ = (tid / LT) * VR;
+#pragma unroll
+                for (int j = 0; j < VR; j++)
+                    if (x0 + lx_ < W && y0 + ly_ + j < H) dL_dalpha[(size_t)(y0 + ly_ + j) * W + x0 + lx_] = 0.0f;
+            }
+            if (tid == 0) {
+                const size_t b = ((size_t)tile.c * gridDim.y + tile.by) * gridDim.x + tile.bx;
+                partials[2 * b] = 0.0f; partials[2 * b + 1] = 0.0f;
+                if (c == 0 && alpha != nullptr) mask_partials[tile.by * gridDim.x + tile.bx] = 0.0f;
+            }
+            return;
+        }
+    }
 
     {
         // the tile + halo: all loads first (clamped addresses, no branch: they are in flight together), then the LDS stores
@@ -95,7 +136,7 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         for (int k = 0; k < NLD; k++) {
             const int i = tid + 256 * k, r = i / LP, q = i % LP;
             const int gx_ = x0 + q - HALO, gy_ = y0 + r - HALO;
-            const bool in = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
+            const bool in = ROI ? in_crop(crop, gx_, gy_) : (gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H);
             if (i < LP * LP) {
                 const float a = in ? vx[k] : 0.0f, b = in ? vy[k] : 0.0f;
                 s_x[r][q] = a; s_y[r][q] = b;
@@ -163,12 +204,12 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     }
     }
     float ssim_v = 0.f, l1_v = 0.f, mask_v = 0.f;
-    const float inv_hw = 1.0f / ((float)H * (float)W);
+    const float inv_hw = ROI ? 1.0f / crop.n_bound : 1.0f / ((float)H * (float)W);
     const int px = x0 + lx;
 #pragma unroll
     for (int j = 0; j < VR; j++) {
         const int ly = ly0 + j, py = y0 + ly;
-        if (px < W && py < H) {
+        if (ROI ? in_crop(crop, px, py) : (px < W && py < H)) {
             const float mu1 = m01[j].x, mu2 = m01[j].y, ess = m23[j].x /* E[x^2 + y^2] */, exy = m23[j].y;
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -187,15 +228,19 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const size_t o = ((size_t)c * H + py) * W + px, plane3 = (size_t)C * H * W;
             dmap[o] = dS_dmu1; dmap[plane3 + o] = dS_ds1; dmap[2 * plane3 + o] = dS_ds12;
             ssim_v += S;
-            l1_v += fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
+            float wb = 1.0f;                                                       // (ROI: the L1 and mask terms count the mask's pixels only)
+            if constexpr (ROI) { if (bound != nullptr) wb = bound[(size_t)py * W + px] ? 1.0f : 0.0f; }
+            l1_v += wb * fabsf(s_x[ly + HALO][lx + HALO] - s_y[ly + HALO][lx + HALO]);
             // the alpha-vs-mask L2 term rides on channel 0's tiles; it is computed HERE (not in pass 2, where its gradient would
             // fit just as well) so that everything pass 2's closing fold reads was written by an earlier kernel
             if (c == 0 && alpha != nullptr) {
                 const size_t oa = (size_t)py * W + px;
-                const float da = alpha[oa] - mask[oa];
+                const float da = wb * (alpha[oa] - mask[oa]);
                 mask_v += da * da;
                 dL_dalpha[oa] = lambda_mask * 2.f * da * inv_hw;
             }
+        } else if (ROI && px < W && py < H && c == 0 && alpha != nullptr) {
+            dL_dalpha[(size_t)py * W + px] = 0.0f;
         }
     }
     LSTAMP(4);
@@ -212,15 +257,16 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     }
 }
 
-template <bool SKIP_EMPTY>
+template <bool SKIP_EMPTY, bool ROI>
 __global__ void __launch_bounds__(256)
 ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                   const float* __restrict__ alpha, const float* __restrict__ mask, Win win,
                   const float* __restrict__ dmap, const float* __restrict__ partials, int nblocks,
                   float lambda_dssim, float lambda_mask, float* __restrict__ dL_dimg, float* __restrict__ dL_dalpha,
                   const float* __restrict__ mask_partials, float* __restrict__ loss_out, float lambda_l1,
-                  unsigned long long* __restrict__ stamps)
+                  unsigned long long* __restrict__ stamps, const unsigned char* __restrict__ bound, const int* __restrict__ rect)
 {
+    static_assert(!ROI || SKIP_EMPTY, "the crop instantiation takes the early-leave path");
     LSTAMP(0);
     __shared__ float s_d[3][LP][LP + 1];
     __shared__ float s_h[3][LP][LT + 1];
@@ -231,14 +277,21 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     const int x0 = tile.bx * LT, y0 = tile.by * LT;
     const int tid = threadIdx.x;
     const size_t plane3 = (size_t)C * H * W;
-    const float N = (float)C * (float)H * (float)W;
+    Crop crop = {};
+    bool off_crop = false;                               // (block-uniform)
+    if constexpr (ROI) {
+        crop = load_crop(rect, W, H, bound != nullptr);
+        off_crop = x0 >= crop.x1 || x0 + LT <= crop.x0 || y0 >= crop.y1 || y0 + LT <= crop.y0;
+    }
+    const float N = ROI ? (float)C * crop.n_pix : (float)C * (float)H * (float)W;           // pixels-channels of the SSIM mean
+    const float N1 = ROI ? (float)C * crop.n_bound : N;                                      // ... of the L1 mean
 
     // this thread's output pixels (column lx, rows ly0 .. ly0 + VR - 1): their x and y are requested with the maps (one round trip)
     const int lx = tid % LT, ly0 = (tid / LT) * VR;
     const int px = x0 + lx;
     float xs[VR] = {}, ys[VR] = {};
     bool content = false;
-    {
+    if (!off_crop) {
         constexpr int NLD = (LP * LP + 255) / 256;
         float v[3][NLD];
 #pragma unroll
@@ -258,7 +311,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         for (int k = 0; k < NLD; k++) {
             const int i = tid + 256 * k, r = i / LP, q = i % LP;
             const int gx_ = x0 + q - HALO, gy_ = y0 + r - HALO;
-            const bool in = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
+            const bool in = ROI ? in_crop(crop, gx_, gy_) : (gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H);   // (ROI: pass 1 wrote the maps inside the crop only)
             if (i < LP * LP) {
                 const float d0 = in ? v[0][k] : 0.0f;
                 s_d[0][r][q] = d0; s_d[1][r][q] = in ? v[1][k] : 0.0f; s_d[2][r][q] = in ? v[2][k] : 0.0f;
@@ -327,7 +380,12 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
             const float dssim = f01[j].x + 2.f * x * f01[j].y + y * f2[j];     // d(sum SSIM)/dx
             const float d = x - y;
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            dL_dimg[o] = (lambda_l1 * sgn) / N - lambda_dssim * dssim / N;     // (lambda_l1 = 1: the same bits as sgn / N)
+            if constexpr (ROI) {
+                const float wb = (bound == nullptr || bound[(size_t)py * W + px]) ? 1.0f : 0.0f;
+                dL_dimg[o] = in_crop(crop, px, py) ? (lambda_l1 * sgn * wb) / N1 - lambda_dssim * dssim / N : 0.0f;
+            } else {
+                dL_dimg[o] = (lambda_l1 * sgn) / N - lambda_dssim * dssim / N; // (lambda_l1 = 1: the same bits as sgn / N)
+            }
         }
     }
     LSTAMP(4);
@@ -345,8 +403,8 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
         __syncthreads();
         if (tid == 0) {
             const float ssim_mean = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) / N;
-            const float l1_mean = ((s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3])) / N;
-            const float mask_mean = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) / ((float)H * (float)W);
+            const float l1_mean = ((s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3])) / N1;
+            const float mask_mean = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) / (ROI ? crop.n_bound : (float)H * (float)W);
             const float lm = alpha != nullptr ? lambda_mask : 0.0f;
             loss_out[1] = l1_mean; loss_out[2] = ssim_mean; loss_out[3] = mask_mean;
             loss_out[0] = lambda_l1 * l1_mean + lm * mask_mean + lambda_dssim * (1.0f - ssim_mean);
@@ -419,13 +477,44 @@ extern "C" int moss_photometric_loss_weighted(int C, int H, int W, const float* 
     const dim3 grid(gx, gy, C);
     // more workgroups than are resident at once (three per CU: 42 KB of LDS each): the instantiations that let empty tiles leave early
     if ((size_t)gx * gy * C > (size_t)3 * loss_device_cus()) {
-        hipLaunchKernelGGL(ssim_pass1_kernel<true>, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
-        hipLaunchKernelGGL(ssim_pass2_kernel<true>, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 4096 : nullptr);
+        hipLaunchKernelGGL((ssim_pass1_kernel<true, false>), grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps,
+                           (const unsigned char*)nullptr, (const int*)nullptr);
+        hipLaunchKernelGGL((ssim_pass2_kernel<true, false>), grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 4096 : nullptr,
+                           (const unsigned char*)nullptr, (const int*)nullptr);
     } else {
-        hipLaunchKernelGGL(ssim_pass1_kernel<false>, grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps);
-        hipLaunchKernelGGL(ssim_pass2_kernel<false>, grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 4096 : nullptr);
+        hipLaunchKernelGGL((ssim_pass1_kernel<false, false>), grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha, mask_partials, loss_stamps,
+                           (const unsigned char*)nullptr, (const int*)nullptr);
+        hipLaunchKernelGGL((ssim_pass2_kernel<false, false>), grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, loss_stamps ? loss_stamps + 8 * 4096 : nullptr,
+                           (const unsigned char*)nullptr, (const int*)nullptr);
     }
+    return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+}
+
+// MOSS's own loss expression (train_ZJU.py:108-119,131): Ll1 = l1_loss(image[bound], gt[bound]), mask_loss = l2_loss(alpha[bound], mask[bound]),
+// ssim on the crop boundingRect(bound) of both images.  `bound`: (H,W) bytes, non-zero = counted, or NULL (every pixel of the
+// rectangle); `rect`: FIVE ints in DEVICE memory -- x, y, w, h of the crop and the number of non-zero bytes of `bound` (ignored when
+// bound is NULL) -- which a captured step may rewrite between replays.  Pixels of `bound` outside the rectangle count for nothing
+// (MOSS's rectangle is the mask's bounding box: there are none).  Gradients are written for the WHOLE image (zero off the crop).
+extern "C" int moss_photometric_loss_roi(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,
+                                         const unsigned char* bound, const int* rect, float lambda_l1, float lambda_dssim, float lambda_mask,
+                                         float* loss_out, float* dL_dimage, float* dL_dalpha, char* workspace, size_t workspace_bytes, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !loss_out || !dL_dimage || !workspace || !rect) return MOSS_ERR_INVALID_ARG;
+    if ((alpha == nullptr) != (mask == nullptr) || (alpha && !dL_dalpha)) return MOSS_ERR_INVALID_ARG;
+    if (workspace_bytes < moss_loss_workspace_bytes(C, H, W)) return MOSS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (W + LT - 1) / LT, gy = (H + LT - 1) / LT;
+    char* p = workspace;
+    float* dmap = carve<float>(p, 3 * (size_t)C * H * W);
+    float* partials = carve<float>(p, (size_t)gx * gy * C * 2);
+    float* mask_partials = carve<float>(p, (size_t)gx * gy);
+    static const Win win = make_window();
+    const dim3 grid(gx, gy, C);
+    hipLaunchKernelGGL((ssim_pass1_kernel<true, true>), grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha,
+                       mask_partials, (unsigned long long*)nullptr, bound, rect);
+    hipLaunchKernelGGL((ssim_pass2_kernel<true, true>), grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, (unsigned long long*)nullptr, bound, rect);
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }

@@ -3,7 +3,9 @@
 Semantics follow the reference's utils/loss_utils.py: ``l1_loss`` (:41-42), ``l2_loss`` (:44-45), ``ssim`` with an
 11x11 Gaussian window, sigma 1.5, zero padding, depthwise (:47-87); the step combines them as
 ``L1 + 0.2 * (1 - SSIM)`` (+ 0.5 * mask L2 on the alpha image), the rasterizer-facing terms of train_ZJU.py:111-131.
-Pinned by tests/golden/loss_*.npz (generated from the reference functions).
+Pinned by tests/golden/loss_*.npz (generated from the reference functions); MOSS's own composition -- bound_mask selection for L1 / mask L2,
+boundingRect crop for SSIM, train_ZJU.py:108-119 -- is ``training_loss_moss`` (torch) / ``training_loss_moss_fused`` (HIP), pinned by
+tests/golden/loss_moss.npz.
 """
 from __future__ import annotations
 
@@ -50,6 +52,28 @@ def ssim(img1, img2, window_size=11, size_average=True):
     if size_average:
         return ssim_map.mean()
     return ssim_map.mean(1).mean(1).mean(1)
+
+
+def bounding_rect(bound_mask):
+    """cv2.boundingRect(bound_mask) (train_ZJU.py:115) of a (1,H,W) / (H,W) 0/1 mask as (x, y, w, h) Python ints (a host read: do it once
+    per view when the view is loaded, like the mask's pixel count)."""
+    m = bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) != 0
+    ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
+    if ys.numel() == 0:
+        return 0, 0, 0, 0
+    return int(xs[0]), int(ys[0]), int(xs[-1] - xs[0] + 1), int(ys[-1] - ys[0] + 1)
+
+
+def training_loss_moss(image, alpha, gt_image, bkgd_mask, bound_mask, rect=None, lambda_dssim=0.2, lambda_mask=0.5, ssim_fn=None):
+    """MOSS's own expression, torch ops, line by line (train_ZJU.py:108-119,131): L1 and mask L2 over the pixels of ``bound_mask``
+    (1,H,W), SSIM on the crop ``rect`` = boundingRect(bound_mask) of both images.  The reference form :func:`training_loss_moss_fused` is
+    tested against."""
+    sel = bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) != 0
+    ll1 = l1_loss(image.permute(1, 2, 0)[sel], gt_image.permute(1, 2, 0)[sel])
+    mask_loss = l2_loss(alpha.reshape(sel.shape)[sel], bkgd_mask.reshape(sel.shape)[sel])
+    x, y, w, h = rect if rect is not None else bounding_rect(bound_mask)
+    s = (ssim_fn or ssim)(image[:, y:y + h, x:x + w].unsqueeze(0), gt_image[:, y:y + h, x:x + w].unsqueeze(0))
+    return ll1 + lambda_mask * mask_loss + lambda_dssim * (1.0 - s)
 
 
 def training_loss(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambda_mask=0.5, ssim_fn=None):
@@ -168,3 +192,74 @@ def training_loss_fused(image, alpha, gt_image, gt_mask, lambda_dssim=0.2, lambd
     where the kernels write [loss, L1, SSIM, mask L2] -- e.g. ``GradBucket.loss_terms``, so that the loss travels with the
     gradients in the one all-reduce without a copy; the returned loss is then ``terms_out[0]``."""
     return _FusedPhotometricLoss.apply(image, alpha, gt_image, gt_mask, lambda_dssim, lambda_mask, terms_out)
+
+
+class ViewRegion:
+    """What MOSS's loss needs of a view besides the two target images, prepared ONCE when the view is loaded: ``bound`` (H,W) uint8 on
+    the device, ``rect`` = 5 int32 on the device (x, y, w, h of cv2.boundingRect(bound_mask), the mask's pixel count).  ``copy_(other)``
+    rewrites both in place -- how a step captured in a hipGraph changes view."""
+
+    def __init__(self, bound_mask, rect=None):
+        m = (bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) != 0)
+        self.bound = m.to(torch.uint8).contiguous()
+        x, y, w, h = rect if rect is not None else bounding_rect(m)
+        self.xywh = (x, y, w, h)
+        inside = m[y:y + h, x:x + w]                          # (pixels of the mask outside a caller's rectangle count for nothing)
+        self.rect = torch.tensor([x, y, w, h, int(inside.sum())], dtype=torch.int32, device=m.device)
+
+    def copy_(self, other):
+        self.bound.copy_(other.bound)
+        self.rect.copy_(other.rect)
+        self.xywh = other.xywh
+        return self
+
+
+class _FusedMossLoss(torch.autograd.Function):
+    """C ABI moss_photometric_loss_roi: value and gradients of :func:`training_loss_moss` from the two loss kernels."""
+
+    @staticmethod
+    def forward(ctx, image, alpha, gt_image, bkgd_mask, region, lambda_dssim, lambda_mask, terms_out=None):
+        from ._lib import check, lib
+        L = lib()
+        if not image.is_cuda or image.dtype != torch.float32:
+            raise RuntimeError("fused loss needs float32 GPU tensors; training_loss_moss() is the torch form")
+        C, H, W = image.shape
+        if tuple(region.bound.shape) != (H, W) or region.bound.device != image.device:
+            raise RuntimeError("fused loss: the view's region does not belong to this image")
+        image_c, gt_c = image.contiguous(), gt_image.contiguous()
+        alpha_c, mask_c = alpha.contiguous(), bkgd_mask.to(torch.float32).contiguous()
+        if terms_out is not None:
+            if terms_out.shape != (4,) or terms_out.dtype != torch.float32 or terms_out.device != image.device or not terms_out.is_contiguous():
+                raise RuntimeError("fused loss: terms_out must be 4 contiguous float32 values on the image's device")
+            out = terms_out
+        else:
+            out = torch.empty(4, dtype=torch.float32, device=image.device)
+        d_both = torch.empty((C + 1, H, W), dtype=torch.float32, device=image.device)
+        d_img, d_alpha = d_both[:C], d_both[C:]
+        nbytes = int(L.moss_loss_workspace_bytes(C, H, W))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+        with torch.cuda.device(image.device):
+            rc = L.moss_photometric_loss_roi(C, H, W, image_c.data_ptr(), gt_c.data_ptr(), alpha_c.data_ptr(), mask_c.data_ptr(),
+                                             region.bound.data_ptr(), region.rect.data_ptr(), 1.0, float(lambda_dssim), float(lambda_mask),
+                                             out.data_ptr(), d_img.data_ptr(), d_alpha.data_ptr(), ws.data_ptr(), nbytes,
+                                             torch.cuda.current_stream(image.device).cuda_stream)
+        check(rc, "photometric_loss_roi")
+        ctx.save_for_backward(d_both)
+        ctx.C, ctx.alpha_shape = C, alpha.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (d_both,) = ctx.saved_tensors
+        unit = _UNIT.get(d_both.device)
+        scaled = d_both if (unit is not None and grad_out.data_ptr() == unit.data_ptr()) else grad_out * d_both
+        return scaled[:ctx.C], scaled[ctx.C:].reshape(ctx.alpha_shape), None, None, None, None, None, None
+
+
+def training_loss_moss_fused(image, alpha, gt_image, bkgd_mask, region, lambda_dssim=0.2, lambda_mask=0.5, terms_out=None):
+    """``Ll1 + lambda_mask * mask_loss + lambda_dssim * (1 - ssim_loss)`` with the three terms EXACTLY as MOSS forms them
+    (train_ZJU.py:108-119,131: bound_mask selection, boundingRect crop) -- :func:`training_loss_moss` -- from two HIP kernels.  ``region``:
+    the view's :class:`ViewRegion` (made once per view: the rectangle and the pixel count are host reads).  In MOSS this replaces lines
+    :111-119 (patches/train_ZJU.diff keeps them and swaps only ``ssim``; this is the one-call form).  The remaining terms of :131 (lpips,
+    s3im, nll) are other subsystems' and are added to the returned loss by the caller."""
+    return _FusedMossLoss.apply(image, alpha, gt_image, bkgd_mask, region, lambda_dssim, lambda_mask, terms_out)

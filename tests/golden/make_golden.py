@@ -109,5 +109,51 @@ def main():
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
 
 
+def bounding_rect(mask2d):
+    """cv2.boundingRect of a 0/1 mask (cv2 is not installed here): x, y = the first non-zero column / row, w, h = the extent."""
+    ys, xs = np.nonzero(mask2d)
+    return int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
+
+
+def loss_moss():
+    """loss_moss.npz: MOSS's OWN loss expression for the rasterizer-facing terms, train_ZJU.py:108-119,131 -- the L1 and mask terms over
+    the pixels of `bound_mask`, SSIM on the crop boundingRect(bound_mask) -- composed from the reference's l1_loss / l2_loss / ssim
+    exactly as the script does (lpips / s3im / nll are other subsystems), values and autograd gradients in float64."""
+    g = torch.Generator().manual_seed(3407 + 1)
+    out = {}
+    for i, (H, W, poly) in enumerate([(72, 60, (9, 14, 47, 61)), (56, 88, (30, 0, 81, 40)), (48, 48, (0, 0, 48, 48))]):
+        # (float32-representable inputs: the kernels take float32; stored as float32, evaluated in float64)
+        image = torch.rand(3, H, W, generator=g, dtype=torch.float32).double().requires_grad_(True)
+        gt_image = torch.rand(3, H, W, generator=g, dtype=torch.float32).double()
+        alpha = torch.rand(1, H, W, generator=g, dtype=torch.float32).double().requires_grad_(True)
+        bkgd_mask = (torch.rand(1, H, W, generator=g) > 0.5).double()
+        # bound_mask: the projected 3-D box of the body -- a convex region; here an ellipse inside the rectangle poly = (x0, y0, x1, y1)
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        x0, y0, x1, y1 = poly
+        cx, cy, rx, ry = (x0 + x1 - 1) / 2, (y0 + y1 - 1) / 2, (x1 - x0) / 2, (y1 - y0) / 2
+        bound_mask = ((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0).to(torch.uint8)[None]
+        if i == 2:
+            bound_mask = torch.ones(1, H, W, dtype=torch.uint8)              # the whole frame: the expression without a crop
+        Ll1 = loss_utils.l1_loss(image.permute(1, 2, 0)[bound_mask[0] == 1], gt_image.permute(1, 2, 0)[bound_mask[0] == 1])      # train_ZJU.py:111
+        mask_loss = loss_utils.l2_loss(alpha[bound_mask == 1], bkgd_mask[bound_mask == 1])                                          # :112
+        x, y, w, h = bounding_rect(bound_mask[0].numpy())                                                                             # :115
+        img_pred = image[:, y:y + h, x:x + w].unsqueeze(0)
+        img_gt = gt_image[:, y:y + h, x:x + w].unsqueeze(0)
+        ssim_loss = loss_utils.ssim(img_pred, img_gt)                                                                                 # :119
+        total = Ll1 + 0.5 * mask_loss + 0.2 * (1.0 - ssim_loss)                                                                        # :131
+        total.backward()
+        f32 = lambda t: t.detach().numpy().astype(np.float32)
+        out.update({f"m{i}_image": f32(image), f"m{i}_gt": f32(gt_image), f"m{i}_alpha": f32(alpha),
+                    f"m{i}_bkgd_mask": bkgd_mask.numpy().astype(np.uint8), f"m{i}_bound_mask": bound_mask.numpy(), f"m{i}_rect": np.array([x, y, w, h]),
+                    f"m{i}_l1": Ll1.item(), f"m{i}_mask": mask_loss.item(), f"m{i}_ssim": ssim_loss.item(), f"m{i}_total": total.item(),
+                    f"m{i}_grad_image": image.grad.numpy(), f"m{i}_grad_alpha": alpha.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "loss_moss.npz"), **out)
+    print("wrote loss_moss.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if "--loss-moss" in sys.argv:                            # (round 6: added without regenerating the other fixtures)
+        loss_moss()
+    else:
+        main()
+        loss_moss()

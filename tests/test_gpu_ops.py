@@ -123,6 +123,111 @@ def test_ssim_fused_is_a_drop_in_for_the_reference_ssim(gpu, hip_lib, i):
         ssim_fused(a0.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_fused_moss_loss_matches_reference_golden(gpu, hip_lib, i):
+    """C ABI moss_photometric_loss_roi against the REFERENCE'S OWN numbers for MOSS's own loss expression (tests/golden/loss_moss.npz:
+    train_ZJU.py:108-119,131 composed from utils/loss_utils.py by make_golden.py -- L1 and mask L2 over bound_mask, SSIM on its
+    bounding rectangle).  Tolerances as for the full-frame kernel: values 2e-6, gradients 2e-5 of their largest element; and the
+    gradients are exactly zero off the rectangle (image) / off the mask (alpha)."""
+    import os
+    from moss_amd.loss import ViewRegion, training_loss_moss_fused
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_moss.npz"))
+    img = torch.from_numpy(g[f"m{i}_image"]).to(gpu).requires_grad_(True); gt = torch.from_numpy(g[f"m{i}_gt"]).to(gpu)
+    alpha = torch.from_numpy(g[f"m{i}_alpha"]).to(gpu).requires_grad_(True); bk = torch.from_numpy(g[f"m{i}_bkgd_mask"]).float().to(gpu)
+    bound = torch.from_numpy(g[f"m{i}_bound_mask"]).to(gpu)
+    region = ViewRegion(bound)
+    assert region.xywh == tuple(int(v) for v in g[f"m{i}_rect"]) and int(region.rect[4]) == int(g[f"m{i}_bound_mask"].sum())
+    terms = torch.zeros(4, device=gpu)
+    out = training_loss_moss_fused(img, alpha, gt, bk, region, terms_out=terms)
+    (out * 1.0).backward()
+    total, l1, ssim_v, mk = [float(x) for x in terms.cpu()]
+    assert abs(l1 - float(g[f"m{i}_l1"])) < 2e-6 and abs(ssim_v - float(g[f"m{i}_ssim"])) < 2e-6 and abs(mk - float(g[f"m{i}_mask"])) < 2e-6
+    assert abs(total - float(g[f"m{i}_total"])) < 2e-6 and float(out) == total
+    gi, ga = img.grad.cpu().numpy(), alpha.grad.cpu().numpy()
+    assert hp.rel_err(gi, g[f"m{i}_grad_image"]) < 2e-5
+    assert hp.rel_err(ga, g[f"m{i}_grad_alpha"]) < 2e-5
+    x, y, w, h = region.xywh
+    off = np.ones(gi.shape[1:], bool); off[y:y + h, x:x + w] = False
+    assert float(np.abs(gi[:, off]).max(initial=0.0)) == 0.0
+    assert float(np.abs(ga[0][g[f"m{i}_bound_mask"][0] == 0]).max(initial=0.0)) == 0.0
+
+
+@pytest.mark.parametrize("shape,rect", [((3, 512, 512), (150, 40, 210, 430)), ((3, 1024, 1024), (301, 97, 417, 803)), ((3, 200, 330), (0, 0, 330, 200)),
+                                        ((3, 96, 96), (37, 41, 11, 9)), ((3, 130, 70), (64, 32, 6, 98))])
+def test_fused_moss_loss_matches_torch_expression(gpu, hip_lib, shape, rect):
+    """The same at MOSS's frame sizes (a person's bounding region in a 512^2 / 1024^2 frame; rectangles at odd offsets against the 32 x 32
+    tiles; a rectangle smaller than the SSIM window; the whole frame), against the float64 torch restatement of the expression
+    (``training_loss_moss``, itself pinned by the golden file).  The mask: an ellipse inside the rectangle minus a few holes."""
+    from moss_amd.loss import ViewRegion, training_loss_moss, training_loss_moss_fused
+    C, H, W = shape
+    x, y, w, h = rect
+    g = torch.Generator().manual_seed(11)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    bound = ((((xx - (x + (w - 1) / 2)) / (w / 2)) ** 2 + ((yy - (y + (h - 1) / 2)) / (h / 2)) ** 2) <= 1.0)
+    bound &= torch.rand(H, W, generator=g) > 0.02
+    bound[y, x:x + w] = True; bound[y + h - 1, x:x + w] = True; bound[y:y + h, x] = True; bound[y:y + h, x + w - 1] = True   # (the box is tight)
+    bound = bound[None].to(torch.uint8)
+    img = torch.rand(C, H, W, generator=g); gt = torch.rand(C, H, W, generator=g) * (torch.rand(1, H, W, generator=g) > 0.3)
+    alpha = torch.rand(1, H, W, generator=g); bk = (torch.rand(1, H, W, generator=g) > 0.5).float()
+    a = img.double().requires_grad_(True); b = alpha.double().requires_grad_(True)
+    ref = training_loss_moss(a, b, gt.double(), bk.double(), bound)
+    ref.backward()
+    region = ViewRegion(bound.to(gpu))
+    assert region.xywh == rect
+    X = img.to(gpu).requires_grad_(True); A = alpha.to(gpu).requires_grad_(True)
+    out = training_loss_moss_fused(X, A, gt.to(gpu), bk.to(gpu), region)
+    (out * 1.0).backward()
+    assert abs(float(out) - float(ref)) < 2e-6
+    assert hp.rel_err(X.grad.cpu().numpy(), a.grad.numpy()) < 2e-5
+    assert hp.rel_err(A.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
+    off = torch.ones(H, W, dtype=torch.bool); off[y:y + h, x:x + w] = False
+    assert float(X.grad.cpu()[:, off].abs().sum()) == 0.0 and float(A.grad.cpu()[0][bound[0] == 0].abs().sum()) == 0.0
+
+
+def test_fused_moss_loss_changes_view_inside_a_captured_graph(gpu, hip_lib):
+    """The rectangle, the mask and its pixel count live in device memory: a captured loss changes view by ``ViewRegion.copy_`` --
+    the replay then equals an eager evaluation on the new view, bit for bit."""
+    from moss_amd.loss import ViewRegion, training_loss_moss_fused
+    H = W = 256
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(3, H, W, generator=g).to(gpu); gt = torch.rand(3, H, W, generator=g).to(gpu)
+    alpha = torch.rand(1, H, W, generator=g).to(gpu); bk = (torch.rand(1, H, W, generator=g) > 0.5).float().to(gpu)
+    def region_of(x, y, w, h):
+        m = torch.zeros(1, H, W, dtype=torch.uint8); m[0, y:y + h, x:x + w] = (torch.rand(h, w, generator=g) > 0.2).to(torch.uint8)
+        m[0, y, x] = 1; m[0, y + h - 1, x + w - 1] = 1
+        return ViewRegion(m.to(gpu), rect=(x, y, w, h))
+    views = [region_of(20, 30, 100, 180), region_of(131, 7, 90, 240)]
+    def run(region):
+        X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
+        out = training_loss_moss_fused(X, A, gt, bk, region)
+        (out * 1.0).backward()
+        return out.detach().clone(), X.grad.clone(), A.grad.clone()
+    eager = [run(v) for v in views]
+    live = region_of(20, 30, 100, 180).copy_(views[0])
+    X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
+    terms = torch.zeros(4, device=gpu); gimg = torch.zeros_like(img); galpha = torch.zeros_like(alpha)
+    def body():
+        X.grad = None; A.grad = None
+        out = training_loss_moss_fused(X, A, gt, bk, live, terms_out=terms)
+        (out * 1.0).backward()
+        gimg.copy_(X.grad); galpha.copy_(A.grad)
+    side = torch.cuda.Stream(gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize(gpu)
+    graph = torch.cuda.CUDAGraph()
+    with capturing(graph, stream=side):
+        body()
+    for k in (1, 0, 1):
+        live.copy_(views[k])
+        graph.replay()
+        torch.cuda.synchronize(gpu)
+        assert torch.equal(terms[0], eager[k][0]) and torch.equal(gimg, eager[k][1]) and torch.equal(galpha, eager[k][2])
+    assert not torch.equal(eager[0][1], eager[1][1])
+
+
 # ---------------------------------------------------------------- distCUDA2
 @pytest.mark.parametrize("P", [1, 3, 4, 5, 1000, 6890, 20000])
 def test_dist2_bit_exact_vs_bruteforce_oracle(gpu, hip_lib, P):

@@ -127,6 +127,28 @@ def test_loss_functions_match_reference(i):
     np.testing.assert_allclose(a.grad.numpy(), g[f"l{i}_grad"], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_moss_loss_expression_matches_reference(i):
+    """MOSS's own composition of the three rasterizer-facing terms (train_ZJU.py:108-119,131: L1 and mask L2 over the pixels of
+    bound_mask, SSIM on the crop boundingRect(bound_mask)) -- ``loss.training_loss_moss`` and ``loss.bounding_rect`` -- against the numbers
+    the reference's own functions gave for it (tests/golden/loss_moss.npz, float64; case 1: the mask touches the image's top edge; case 2:
+    the mask is the whole frame, where the expression is ``training_loss``)."""
+    from moss_amd import loss
+    g = _gold("loss_moss.npz")
+    img = torch.from_numpy(g[f"m{i}_image"]).double().requires_grad_(True); gt = torch.from_numpy(g[f"m{i}_gt"]).double()
+    alpha = torch.from_numpy(g[f"m{i}_alpha"]).double().requires_grad_(True); bk = torch.from_numpy(g[f"m{i}_bkgd_mask"]).double()
+    bound = torch.from_numpy(g[f"m{i}_bound_mask"])
+    assert loss.bounding_rect(bound) == tuple(int(v) for v in g[f"m{i}_rect"])
+    total = loss.training_loss_moss(img, alpha, gt, bk, bound)
+    total.backward()
+    assert abs(total.item() - float(g[f"m{i}_total"])) < 1e-7                  # (the reference builds its window in fp32)
+    np.testing.assert_allclose(img.grad.numpy(), g[f"m{i}_grad_image"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(alpha.grad.numpy(), g[f"m{i}_grad_alpha"], rtol=1e-9, atol=1e-12)
+    if i == 2:
+        a2 = img.detach().clone().requires_grad_(True)
+        assert abs(loss.training_loss(a2, alpha.detach(), gt, bk).item() - total.item()) < 1e-12
+
+
 # ------------------------------------------------------------------------------------------------ known answers
 def _single(opacity=0.8, sigma=0.02, z=0.0, color=(0.9, 0.3, 0.1), W=64, H=64, bg=(0.0, 0.0, 0.0)):
     s = scenes.config1(P=1, W=W, H=H)
