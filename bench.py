@@ -472,6 +472,15 @@ def main(argv=None):
     from moss_amd.gaussian_model import GaussianSet
     from moss_amd.gaussian_renderer import render, camera_view
     from types import SimpleNamespace
+    # Python's cyclic collector: a full (generation 2) pass over a process that has torch loaded walks ~10^6 module-level objects -- 45-55 ms
+    # of HOST time (measured), at whatever allocation happens to trip it: inside a timed region of 20 x 0.19 ms, in the middle of a
+    # densification event, or -- before moss_amd.graphs.capturing held it off -- inside a graph capture, where freeing a dropped
+    # GraphedStep aborts the process.  What exists now (the modules) is moved to the permanent generation: later passes look only at what
+    # this program creates (a few ms at worst).  INTEGRATION.md recommends the same two lines to a training script.
+    import gc
+    import moss_amd.graphs, moss_amd.surgery, moss_amd.multiview, moss_amd.optim, moss_amd.loss, moss_amd.densify   # noqa: F401,E401
+    gc.collect()
+    gc.freeze()
 
     rank, world, local_rank = mdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks (python bench.py --gpus N does it itself)"
