@@ -75,6 +75,9 @@ const char* moss_last_error(void);
  * ignore the per-instance 4x4-block masks and test every list entry against every block.  The masks only SKIP (entry, block)
  * pairs that cannot reach alpha >= 1/255: final_T and n_contrib are bit-identical either way, images and gradients equal up to
  * float32 summation order (tests/test_gpu_ops.py::test_block_mask_culling_never_changes_a_result).  Per call, no global state.
+ * In the BACKWARD the masks' box is also an addressing contract (a pair's gradient record has a cell only inside the box): a pair
+ * outside it leaves no record in this mode either (light tiles: visited, record dropped; heavy tiles: the masks are followed) --
+ * whether such a pair could have reached 1/255 is what the no-cull FORWARD image shows.
  * MOSS_DEBUG_EXACT_MATH (4; ABI 5; forward AND the matching backward call): the blend kernels evaluate what decides a pixel's list
  * -- the exponent, exp(), alpha, the transmittance chain -- exactly as the reference's SOURCE reads (forward.cu:336-356,
  * backward.cu:504-516): `power = -0.5f * (A dx dx + C dy dy) - B dx dy` with one rounding per operation (the fast path spells two

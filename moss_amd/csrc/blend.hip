@@ -877,7 +877,11 @@ __device__ __forceinline__ void heavy_backward_item(int W, int H, int gx, int ti
     const uint32_t cell_row = (uint32_t)(blk >> 2), cell_off = (uint32_t)(blk & 3) - 16u;     // (wave-uniform)
     const uint16_t* const bm = inst_bmask + rg.x;
     const float4* const recs = inst_rec + 3 * (size_t)rg.x;
-    const uint32_t all_hit = (flags & 1) ? 0u : 0xffffu;
+    // MOSS_DEBUG_NO_BLOCK_CULL is NOT followed here: a gradient record's cell exists only for the blocks of the entry's alpha >= 1/255 box
+    // (common.h: pack_cell_word), so a pair outside the box has nowhere to leave a record -- its cell index would be another instance's.
+    // The backward of a heavy tile always walks the masks (the light path above visits everything and drops such records).  Whether a
+    // pair outside its box could have reached 1/255 at all is what the no-cull FORWARD shows (the image differs from the culled one).
+    const uint32_t all_hit = 0u;
 
     // Pixel state, replicated in the pixel's lanes: T and Q = sum_k accum_k * g_k, where accum_k are the reference's
     // accum_rec[3] / accum_depth_rec / accum_alpha_rec at the moment they are used (backward.cu:529,543,548).
