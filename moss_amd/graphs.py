@@ -30,22 +30,38 @@ __all__ = ["GraphedStep", "capturing"]
 
 
 @contextlib.contextmanager
-def capturing(graph, collect=False, **kw):
-    """``torch.cuda.graph(graph, **kw)`` with Python's cyclic garbage collector held off for the duration of the capture.  A
-    ``GraphedStep`` that was dropped together with the object whose bound method it captured is a reference CYCLE: it is freed by
-    whichever allocation happens to trigger a collection -- and if that allocation is a tensor wrapper created inside a LATER capture,
-    ``~CUDAGraph`` (hipGraphExecDestroy) runs while the stream is capturing: "operation not permitted when stream is capturing", raised
-    from a destructor, i.e. ``terminate``.  (torch >= 2.9 no longer calls ``gc.collect()`` on entering a capture.)  With the collector
-    off the dead cycles simply wait for the first collection after the capture; ``collect=True`` frees them (and the device memory they
-    hold) BEFORE it: one full collection, ~45 ms of host time in a process that has torch loaded -- a first capture can afford it, the
-    re-capture of a densification event (5 ms in all) cannot."""
+def capturing(graph, collect=False, empty_cache=True, pool=None, stream=None, capture_error_mode="global"):
+    """``torch.cuda.graph(graph, pool=, stream=, capture_error_mode=)`` with two differences.
+
+    * Python's cyclic garbage collector is held off for the duration of the capture.  A ``GraphedStep`` that was dropped together
+      with the object whose bound method it captured is a reference CYCLE: it is freed by whichever allocation happens to trigger a
+      collection -- and if that allocation is a tensor wrapper created inside a LATER capture, ``~CUDAGraph`` (hipGraphExecDestroy) runs
+      while the stream is capturing: "operation not permitted when stream is capturing", raised from a destructor, i.e. ``terminate``.
+      (torch >= 2.9 no longer calls ``gc.collect()`` on entering a capture.)  With the collector off the dead cycles simply wait for the
+      first collection after the capture; ``collect=True`` frees them (and the device memory they hold) BEFORE it: one full collection,
+      ~45 ms of host time in a process that has torch loaded -- a first capture can afford it, the re-capture of a densification event
+      (5 ms in all) cannot.
+    * ``empty_cache=False`` skips the ``torch.cuda.empty_cache()`` that ``torch.cuda.graph`` performs on entry.  It returns every cached
+      segment to the driver (measured at a densification event of the bench frame: 9-11 hipFree and 14-17 hipMalloc per event, 6 ms when
+      the driver answers at once and 40-60 ms when it does not).  A first capture wants it (the private pool is carved out of what is
+      free); a RE-capture into the pool of the graph it replaces does not."""
     was = gc.isenabled()
     if collect:
         gc.collect()
     gc.disable()
     try:
-        with torch.cuda.graph(graph, **kw):
-            yield
+        if empty_cache:
+            with torch.cuda.graph(graph, pool=pool, stream=stream, capture_error_mode=capture_error_mode):
+                yield
+        else:
+            side = stream if stream is not None else torch.cuda.Stream()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                graph.capture_begin(*(() if pool is None else (pool,)), capture_error_mode=capture_error_mode)
+                try:
+                    yield
+                finally:
+                    graph.capture_end()
     finally:
         if was:
             gc.enable()
@@ -62,19 +78,28 @@ class GraphedStep:
         self.recaptures = 0
         self.dropped_frames = 0                              # frames that overflowed the baked-in capacity (they rendered nothing)
         self.graph = None
+        self.outputs = None
         self._capture(max(int(warmup), 1))
 
     def _capture(self, warmup):
         from .diff_gaussian_rasterization import _C
         fn, dev = self.fn, self.device
         self.captured_capacity = (self.context or _C.DEFAULT).capacity   # the binning capacity is a kernel argument: baked into the graph
-        # A RE-capture shares the memory pool of the graph it replaces (kept alive until the new one exists: a pool lives as long as a
-        # graph uses it): what that graph's capture left cached in the pool -- and, from the next re-capture on, the blocks of the
-        # replaced graphs themselves -- serve the new capture instead of hipMalloc / hipFree of ~100 MB of scratch per densification event
-        old = self.graph
-        pool = old.pool() if old is not None else None
+        # A RE-capture goes into the memory pool of the graph it replaces, and that graph is destroyed FIRST: its blocks -- the
+        # rasterizer's scratch buffers, ~250 MB at the bench frame -- are then free in the pool and serve the new capture instead of
+        # hipMalloc (9-13 driver allocations per densification event while the old graph was kept alive until the new one existed;
+        # each now and then takes 40-60 ms).  A pool lives only as long as a graph uses it (torch asserts `use_count > 0`), so a
+        # one-element ANCHOR graph captured into the same pool keeps it alive across the gap.
+        first = self.graph is None
+        pool = None if first else self._pool
+        self.graph = None                                    # (the replaced graph and its static outputs go before the new capture)
+        self.outputs = None
         self.graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(dev)
+        # ONE capture stream for the life of the step: the allocator's free blocks belong to the stream that allocated them, also inside
+        # a graph's private pool -- a new side stream per capture could not take a single block the replaced graph had left behind
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(int(warmup)):                     # (0 on a re-capture: fn() has side effects -- it is a training step)
@@ -82,13 +107,30 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # thread_local: other threads (e.g. a data loader pinning memory) may make HIP calls during the capture
-        with capturing(self.graph, collect=old is None, pool=pool, stream=side, capture_error_mode="thread_local"):
+        with capturing(self.graph, collect=first, empty_cache=first, pool=pool, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn()
         torch.cuda.synchronize(dev)
-        del old                                              # (its blocks go back to the shared pool)
+        if first:
+            self._pool = self.graph.pool()
+            self._anchor = torch.cuda.CUDAGraph()
+            with capturing(self._anchor, empty_cache=False, pool=self._pool, stream=side, capture_error_mode="thread_local"):
+                self._anchor_out = torch.zeros(1, device=dev)
+            torch.cuda.synchronize(dev)
         # overflows of EAGER forwards on this context before (or during the warm-up of) this capture were raised to, or seen by, the
         # caller: only what the replays drop from here on is counted in ``dropped_frames``
         (self.context or _C.DEFAULT).read_dropped_frames(reset=True)
+
+    def reserve_pool(self, nbytes: int) -> None:
+        """Put ONE free block of ``nbytes`` into this step's graph memory pool (a throw-away capture allocates it; a private pool keeps
+        what it has until it dies).  A re-capture after a densification event needs scratch a little larger than what the replaced
+        graph freed -- the binning buffer follows the capacity, the gradient temporaries the number of Gaussians -- so without this
+        every one of those is a hipMalloc inside the capture (5-13 per event at the bench frame; one in eight takes 40-60 ms).  Twice the
+        scratch of the largest set expected is ample: ``RasterContext`` sizes ~0.4 KB per instance of capacity."""
+        g = torch.cuda.CUDAGraph()
+        with capturing(g, empty_cache=False, pool=self._pool, stream=self._side, capture_error_mode="thread_local"):
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)
+        del t, g
 
     def __call__(self):
         self.graph.replay()

@@ -249,19 +249,25 @@ def scripted_densification(tensors, step, device, reset_opacity=False, clone_fra
     ``moss_amd.surgery.densification_event``: clones of a seeded selection (densify_and_clone: copies), two jittered children with
     scales / 1.6 for another selection whose sources are pruned (densify_and_split, N = 2: :466-475, :526-527), a few more pruned, and
     optionally the opacity reset.  Decisions depend on the parameters' SHAPES and the seed only: every replica takes the same one."""
-    g = torch.Generator().manual_seed(seed + step)
+    # Everything is drawn ON ``device``.  (Round 6 drew on the CPU and copied: per event a dozen pageable host <-> device copies of
+    # 0.4-1 MB buffers that are allocated and freed around them.  At the bench frame's sizes every schedule then had one or two stalls of
+    # 60-100 ms at random places -- a capture, a step segment, this function -- which look like the driver's evict / restore cycle of the
+    # process's queues when host pages it had pinned for such a copy go away; configs[1]'s buffers are below malloc's mmap threshold and
+    # its schedule had none.  profiles/r06_notes.md section 10.)
+    device = torch.device(device)
+    g = torch.Generator(device=device).manual_seed(seed + step)
     P = tensors["xyz"].shape[0]
-    src = torch.randperm(P, generator=g)[:max(int(P * clone_frac), 1)].to(device)
+    src = torch.randperm(P, generator=g, device=device)[:max(int(P * clone_frac), 1)]
     pick = lambda idx: {"new_xyz": tensors["xyz"][idx].clone(), "new_features_dc": tensors["f_dc"][idx].clone(),
                         "new_features_rest": tensors["f_rest"][idx].clone(), "new_opacities": tensors["opacity"][idx].clone(),
                         "new_scaling": tensors["scaling"][idx].clone(), "new_rotation": tensors["rotation"][idx].clone(), "source": idx}
     clone = pick(src)
-    src2 = torch.randperm(P, generator=g)[:max(int(P * split_frac), 1)].to(device)
+    src2 = torch.randperm(P, generator=g, device=device)[:max(int(P * split_frac), 1)]
     split = pick(src2.repeat(2))
-    split["new_xyz"] = split["new_xyz"] + (torch.randn(2 * src2.numel(), 3, generator=g) * 0.004).to(device)
+    split["new_xyz"] = split["new_xyz"] + torch.randn(2 * src2.numel(), 3, generator=g, device=device) * 0.004
     split["new_scaling"] = split["new_scaling"] - math.log(1.6)          # get_scaling / (0.8 N) in log space, :474
     P2 = P + src.numel() + 2 * src2.numel()
-    prune = torch.zeros(P2, dtype=torch.bool)
-    prune[src2.cpu()] = True                                             # the split sources (:526-527)
-    prune[torch.randperm(P2, generator=g)[:max(int(P2 * prune_frac), 1)]] = True
-    return {"append": [clone, split], "prune": prune.to(device), "reset_opacity": bool(reset_opacity)}
+    prune = torch.zeros(P2, dtype=torch.bool, device=device)
+    prune[src2] = True                                                   # the split sources (:526-527)
+    prune[torch.randperm(P2, generator=g, device=device)[:max(int(P2 * prune_frac), 1)]] = True
+    return {"append": [clone, split], "prune": prune, "reset_opacity": bool(reset_opacity)}

@@ -17,11 +17,22 @@ A ``reset_opacity`` alone changes no shape and no address: it is applied in plac
 """
 from __future__ import annotations
 
+import gc
 import time
 
 import torch
 
 __all__ = ["densification_event"]
+
+
+def reserve_workspace(nbytes, device):
+    """Make torch's caching allocator hold ONE free segment of ``nbytes`` (allocate it, release it -- call after the first graph capture,
+    which empties the cache).  A densification event builds new flat parameter / gradient / moment buffers and their gathered sources
+    (seven tensors of 236 B per Gaussian) a little larger than the ones it frees, so none of them fits a cached block and every one
+    is a hipMalloc -- a few hundred microseconds each, and now and then 40-60 ms.  Blocks split off a large cached segment cost nothing
+    and merge back when they are freed.  3 KB per Gaussian of the LARGEST set expected is ample; an MI355X has 288 GB."""
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    del t
 
 
 def densification_event(pc, optimizer, *, append=None, prune=None, reset_opacity=False, stats=None, context=None, graphed=None,
@@ -40,6 +51,13 @@ def densification_event(pc, optimizer, *, append=None, prune=None, reset_opacity
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+
+    def counters():
+        # what can make ONE event cost ten times the others: a segment allocated from / returned to the driver (hipMalloc / hipFree by
+        # torch's caching allocator), a full pass of Python's cyclic collector (45-55 ms in a process that has torch loaded)
+        st = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
+        return (int(st.get("segment.all.allocated", 0)), int(st.get("segment.all.freed", 0)), int(gc.get_stats()[2]["collections"]))
+    c0 = counters()
     rows_before = int(pc._xyz.shape[0])
     per_gaussian = dict(per_gaussian or {})
     appends = [] if append is None else ([append] if isinstance(append, dict) else list(append))
@@ -74,6 +92,7 @@ def densification_event(pc, optimizer, *, append=None, prune=None, reset_opacity
             torch.cuda.synchronize(dev)
         return time.perf_counter()
     t1 = t2 = t3 = lap()
+    m1 = m2 = counters()[0]
     if shape_changed:
         if getattr(pc, "spatially_ordered", False):
             pc.spatially_ordered = False                     # (appended rows sit at the end: index neighbours are no longer spatial neighbours)
@@ -82,10 +101,13 @@ def densification_event(pc, optimizer, *, append=None, prune=None, reset_opacity
         if probe is not None:
             probe()
         t2 = t3 = lap()
+        m2 = counters()[0]
         if graphed is not None:
             graphed.recapture()
             recaptured = True
             t3 = lap()
+    c1 = counters()
     return {"rows_before": rows_before, "rows_after": int(pc._xyz.shape[0]), "recaptured": recaptured,
             "event_ms": round(1e3 * (t3 - t0), 3), "surgery_ms": round(1e3 * (t1 - t0), 3), "probe_ms": round(1e3 * (t2 - t1), 3),
-            "capture_ms": round(1e3 * (t3 - t2), 3), "per_gaussian": per_gaussian}
+            "capture_ms": round(1e3 * (t3 - t2), 3), "device_mallocs": c1[0] - c0[0], "device_mallocs_by_phase": [m1 - c0[0], m2 - m1, c1[0] - m2], "device_frees": c1[1] - c0[1],
+            "gc_full_collections": c1[2] - c0[2], "per_gaussian": per_gaussian}
