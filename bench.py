@@ -449,6 +449,25 @@ class Harness:
         return time.perf_counter() - t0, out
 
 
+def cpu_quota():
+    """CPUs this process may use: the cgroup's quota (cpu.max = "<quota> <period>" or "max"), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt and txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -477,6 +496,13 @@ def main(argv=None):
     # densification event, or -- before moss_amd.graphs.capturing held it off -- inside a graph capture, where freeing a dropped
     # GraphedStep aborts the process.  What exists now (the modules) is moved to the permanent generation: later passes look only at what
     # this program creates (a few ms at worst).  INTEGRATION.md recommends the same two lines to a training script.
+    # CPU threads: torch sizes its OpenMP team from the machine (128 of 256 hardware threads on the GPU boxes), the container's CPU QUOTA
+    # is 16.  A parallel CPU op -- anything over >= 32k elements: building a scene, a harness, a scripted event -- then burns the quota of
+    # the 100 ms scheduler period in a few ms and the kernel suspends the whole process, HIP runtime threads included, until the period
+    # ends: 10-90 ms stalls that land in whatever is being timed a moment later (scripts/micro/cpu_parallel_stall.py: 40.3 / 60.3 / 50.3 ms
+    # with 128 threads, none with 8).  The team is sized to the quota.
+    # (the ranks of one node share the quota)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     import gc
     import moss_amd.graphs, moss_amd.surgery, moss_amd.multiview, moss_amd.optim, moss_amd.loss, moss_amd.densify   # noqa: F401,E401
     gc.collect()
@@ -1395,7 +1421,7 @@ def cpu_baseline_autograd(budget_s=8.0):
     while time.perf_counter() - t0 < budget_s and n < 200:
         it(); n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "iters/s", "cores": torch.get_num_threads(), "host_cores_available": os.cpu_count(), "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "iters/s", "cores": torch.get_num_threads(), "host_cores_available": os.cpu_count(), "cpu_quota": cpu_quota(), "kind": "port",
             "workload": "BASELINE configs[0]: 256 Gaussians, 128x128, fwd+bwd", "sample": f"{n} iterations in {dt:.1f} s",
             "what": "naive PyTorch-autograd rasterizer (oracle/autograd_rasterizer.py, float64, torch intra-op threads as stated)"}
 

@@ -249,11 +249,11 @@ def scripted_densification(tensors, step, device, reset_opacity=False, clone_fra
     ``moss_amd.surgery.densification_event``: clones of a seeded selection (densify_and_clone: copies), two jittered children with
     scales / 1.6 for another selection whose sources are pruned (densify_and_split, N = 2: :466-475, :526-527), a few more pruned, and
     optionally the opacity reset.  Decisions depend on the parameters' SHAPES and the seed only: every replica takes the same one."""
-    # Everything is drawn ON ``device``.  (Round 6 drew on the CPU and copied: per event a dozen pageable host <-> device copies of
-    # 0.4-1 MB buffers that are allocated and freed around them.  At the bench frame's sizes every schedule then had one or two stalls of
-    # 60-100 ms at random places -- a capture, a step segment, this function -- which look like the driver's evict / restore cycle of the
-    # process's queues when host pages it had pinned for such a copy go away; configs[1]'s buffers are below malloc's mmap threshold and
-    # its schedule had none.  profiles/r06_notes.md section 10.)
+    # Everything is drawn ON ``device``.  (Round 6 first drew on the CPU and copied.  CPU torch ops on >= 32k elements run on an OpenMP team
+    # of torch.get_num_threads() threads -- 128 on the GPU boxes, whose containers have a CPU QUOTA of 16: the team burns the quota of
+    # the 100 ms period in a few milliseconds and the kernel then suspends the WHOLE process, HIP runtime threads included, until the
+    # period ends -- stalls of 10-90 ms at random places a moment later: scripts/micro/cpu_parallel_stall.py, profiles/r06_notes.md
+    # section 10.  configs[1]'s tensors are below the parallel grain and its schedule had none.)
     device = torch.device(device)
     g = torch.Generator(device=device).manual_seed(seed + step)
     P = tensors["xyz"].shape[0]
