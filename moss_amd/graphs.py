@@ -129,6 +129,7 @@ class GraphedStep:
         g = torch.cuda.CUDAGraph()
         with capturing(g, empty_cache=False, pool=self._pool, stream=self._side, capture_error_mode="thread_local"):
             t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            t[:16].zero_()                                   # (one node: torch warns about an empty graph)
         torch.cuda.synchronize(self.device)
         del t, g
 
