@@ -768,6 +768,16 @@ def main(argv=None):
             full = all_b[k] + R * (64 + 48 + 2)
             stages[k]["algorithmic_bytes_incl_record_gather"] = int(full)
             stages[k]["frac_incl_record_gather"] = round(full / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0
+        if k == "blend_bwd" and stages[k].get("traffic_writes"):
+            # SURVEY 8(d) prices this kernel's output at the reference's: 36 B per visible Gaussian, ADDED atomically (backward.cu:566-580).
+            # This design adds nothing atomically (bitwise reproducible gradients): the kernel WRITES one 48-byte record per (entry, 4x4
+            # block) pair that blended, and the per-Gaussian backward sums a Gaussian's records in a fixed order.  Its writes are those
+            # records -- `traffic` above the algorithmic bytes here is that choice, not a re-read: the READS are below the algorithmic ones.
+            stages[k]["gradient_records_written"] = int(stages[k]["traffic_writes"] // 48)
+            stages[k]["gradient_records_per_instance"] = round(stages[k]["traffic_writes"] / 48.0 / max(R, 1), 2)
+            stages[k]["algorithmic_bytes_with_the_records"] = int(44 * R + 28 * N + stages[k]["traffic_writes"])
+            stages[k]["traffic_note"] = ("writes = one 48 B gradient record per (entry, block) pair that blended, where the reference adds 36 B per visible "
+                                         "Gaussian atomically; reads (traffic_reads) are below the algorithmic 44 R + 28 N")
 
     result = {
         "metric": "train iters/sec (fwd+bwd, 512x512, ~100k Gaussians)" if args.config == "cfg3" else f"train iters/sec ({args.config})",
@@ -1349,6 +1359,8 @@ def _traffic_fields(rec):
     if rec.get("traffic_bound") == "upper" and rec.get("hbm_bytes_interval"):
         out["traffic_interval"] = rec["hbm_bytes_interval"]
         out["traffic_is"] = "upper bound (gather reads: FETCH_SIZE doubling uncalibrated)"
+    if rec.get("hbm_read_bytes") is not None:
+        out["traffic_reads"], out["traffic_writes"] = rec["hbm_read_bytes"], rec["hbm_write_bytes"]
     for k in ("valu_issue_frac", "wave_cycles_waiting_frac", "insts_valu_per_launch", "insts_salu_per_launch", "kernel_cycles"):
         if k in rec:
             out[k] = rec[k]

@@ -62,6 +62,10 @@ if stage_out:
                      "traffic_bound": "upper" if any(p["traffic_bound"] == "upper" for p in present) else present[0]["traffic_bound"],
                      "hbm_bytes_interval": [sum(p["hbm_bytes_raw"] if p["traffic_bound"] == "upper" else p["hbm_bytes_per_launch"] for p in present),
                                             sum(p["hbm_bytes_per_launch"] for p in present)],
+                     # reads and writes apart (a kernel can be well over its algorithmic bytes by DESIGN in one direction only: the
+                     # backward blend writes a 48-byte gradient record per (entry, block) pair where the reference adds atomically)
+                     "hbm_write_bytes": int(sum(p["WRITE_SIZE"] for p in present) * 1024),
+                     "hbm_read_bytes": int(sum(2 * p["FETCH_SIZE"] for p in present) * 1024),
                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), eager-launch bench.py --graph 0 --steps 30 --warmup 10"}
             # vector-instruction issue (round 6, what bench.py's per-stage `bound` is read from): a SIMD issues at most one VALU instruction
             # of a wave64 per 4 cycles, so SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles) is the share of the kernel's issue slots that
