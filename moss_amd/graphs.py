@@ -42,9 +42,9 @@ def capturing(graph, collect=False, empty_cache=True, pool=None, stream=None, ca
       ~45 ms of host time in a process that has torch loaded -- a first capture can afford it, the re-capture of a densification event
       (5 ms in all) cannot.
     * ``empty_cache=False`` skips the ``torch.cuda.empty_cache()`` that ``torch.cuda.graph`` performs on entry.  It returns every cached
-      segment to the driver (measured at a densification event of the bench frame: 9-11 hipFree and 14-17 hipMalloc per event, 6 ms when
-      the driver answers at once and 40-60 ms when it does not).  A first capture wants it (the private pool is carved out of what is
-      free); a RE-capture into the pool of the graph it replaces does not."""
+      segment to the driver (measured at a densification event of the bench frame: 9-11 hipFree and then 14-17 hipMalloc per event,
+      3 of its 6 ms).  A first capture wants it (the private pool is carved out of what is free); a RE-capture into the pool of the
+      graph it replaces does not."""
     was = gc.isenabled()
     if collect:
         gc.collect()
@@ -55,7 +55,7 @@ def capturing(graph, collect=False, empty_cache=True, pool=None, stream=None, ca
                 yield
         else:
             side = stream if stream is not None else torch.cuda.Stream()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(side.device)
             with torch.cuda.stream(side):
                 graph.capture_begin(*(() if pool is None else (pool,)), capture_error_mode=capture_error_mode)
                 try:
@@ -87,8 +87,8 @@ class GraphedStep:
         self.captured_capacity = (self.context or _C.DEFAULT).capacity   # the binning capacity is a kernel argument: baked into the graph
         # A RE-capture goes into the memory pool of the graph it replaces, and that graph is destroyed FIRST: its blocks -- the
         # rasterizer's scratch buffers, ~250 MB at the bench frame -- are then free in the pool and serve the new capture instead of
-        # hipMalloc (9-13 driver allocations per densification event while the old graph was kept alive until the new one existed;
-        # each now and then takes 40-60 ms).  A pool lives only as long as a graph uses it (torch asserts `use_count > 0`), so a
+        # hipMalloc (9-13 driver allocations per densification event while the old graph was kept alive until the new one existed:
+        # a capture of 3 ms instead of 1).  A pool lives only as long as a graph uses it (torch asserts `use_count > 0`), so a
         # one-element ANCHOR graph captured into the same pool keeps it alive across the gap.
         first = self.graph is None
         pool = None if first else self._pool
@@ -124,8 +124,8 @@ class GraphedStep:
         """Put ONE free block of ``nbytes`` into this step's graph memory pool (a throw-away capture allocates it; a private pool keeps
         what it has until it dies).  A re-capture after a densification event needs scratch a little larger than what the replaced
         graph freed -- the binning buffer follows the capacity, the gradient temporaries the number of Gaussians -- so without this
-        every one of those is a hipMalloc inside the capture (5-13 per event at the bench frame; one in eight takes 40-60 ms).  Twice the
-        scratch of the largest set expected is ample: ``RasterContext`` sizes ~0.4 KB per instance of capacity."""
+        every one of those is a hipMalloc inside the capture (5-13 per event at the bench frame: the first re-capture 7 ms instead of
+        1.5).  Twice the scratch of the largest set expected is ample: ``RasterContext`` sizes ~0.4 KB per instance of capacity."""
         g = torch.cuda.CUDAGraph()
         with capturing(g, empty_cache=False, pool=self._pool, stream=self._side, capture_error_mode="thread_local"):
             t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)

@@ -29,8 +29,8 @@ def reserve_workspace(nbytes, device):
     """Make torch's caching allocator hold ONE free segment of ``nbytes`` (allocate it, release it -- call after the first graph capture,
     which empties the cache).  A densification event builds new flat parameter / gradient / moment buffers and their gathered sources
     (seven tensors of 236 B per Gaussian) a little larger than the ones it frees, so none of them fits a cached block and every one
-    is a hipMalloc -- a few hundred microseconds each, and now and then 40-60 ms.  Blocks split off a large cached segment cost nothing
-    and merge back when they are freed.  3 KB per Gaussian of the LARGEST set expected is ample; an MI355X has 288 GB."""
+    is a hipMalloc (a few hundred microseconds each).  Blocks split off a large cached segment cost nothing and merge back when they
+    are freed.  3 KB per Gaussian of the LARGEST set expected is ample; an MI355X has 288 GB."""
     t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     del t
 
@@ -53,8 +53,9 @@ def densification_event(pc, optimizer, *, append=None, prune=None, reset_opacity
     t0 = time.perf_counter()
 
     def counters():
-        # what can make ONE event cost ten times the others: a segment allocated from / returned to the driver (hipMalloc / hipFree by
-        # torch's caching allocator), a full pass of Python's cyclic collector (45-55 ms in a process that has torch loaded)
+        # the usual suspects when ONE event costs ten times the others: segments allocated from / returned to the driver (hipMalloc /
+        # hipFree by torch's caching allocator), a full pass of Python's cyclic collector (45-55 ms in a process that has torch loaded).
+        # (Zero in every event since round 6 -- the 40-95 ms outliers were the container's CPU quota: profiles/r06_notes.md section 10)
         st = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
         return (int(st.get("segment.all.allocated", 0)), int(st.get("segment.all.freed", 0)), int(gc.get_stats()[2]["collections"]))
     c0 = counters()
