@@ -274,7 +274,8 @@ int moss_photometric_loss_weighted(int C, int H, int W, const float* image, cons
  *   rect:  FIVE int32 in DEVICE memory: x, y, w, h, and the number of non-zero bytes of `bound` (ignored when bound is NULL).  Device
  *          memory so that a step captured in a hipGraph changes view by rewriting them (and `bound`, `gt`, `mask`) in place.  The
  *          rectangle is clipped to the image.  Pixels of `bound` outside it count for nothing (MOSS's rectangle is the bounding box of
- *          the mask: there are none).  An empty mask gives NaN means, like torch's mean of an empty selection.
+ *          the mask: there are none).  An empty mask gives NaN means, like torch's mean of an empty selection (MOSS's own expression
+ *          raises there: its ssim() is handed a 0 x 0 crop).
  *   dL_dimage, dL_dalpha: written for the WHOLE image (zero off the crop / off the mask), so they are the gradients of `total`
  *          w.r.t. the full-size tensors the rasterizer produced.  Same workspace, same two launches, deterministic. */
 int moss_photometric_loss_roi(int C, int H, int W, const float* image, const float* gt, const float* alpha, const float* mask,

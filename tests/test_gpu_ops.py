@@ -184,6 +184,51 @@ def test_fused_moss_loss_matches_torch_expression(gpu, hip_lib, shape, rect):
     assert float(X.grad.cpu()[:, off].abs().sum()) == 0.0 and float(A.grad.cpu()[0][bound[0] == 0].abs().sum()) == 0.0
 
 
+def test_fused_moss_loss_edge_cases(gpu, hip_lib):
+    """An EMPTY bound_mask: the means over an empty selection are NaN (torch.mean of nothing) and so are the kernels' L1 / mask terms,
+    while no gradient element is written as anything but NaN or zero.  A rectangle handed in by the caller that sticks out of the frame is
+    clipped to it (the C ABI's contract): same value and gradients as the clipped rectangle.  A mask pixel OUTSIDE the caller's rectangle
+    counts for nothing."""
+    from moss_amd.loss import ViewRegion, training_loss_moss, training_loss_moss_fused
+    H, W = 80, 96
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(3, H, W, generator=g).to(gpu); gt = torch.rand(3, H, W, generator=g).to(gpu)
+    alpha = torch.rand(1, H, W, generator=g).to(gpu); bk = (torch.rand(1, H, W, generator=g) > 0.5).float().to(gpu)
+    # (1) empty mask
+    empty = ViewRegion(torch.zeros(1, H, W, dtype=torch.uint8, device=gpu))
+    assert empty.xywh == (0, 0, 0, 0) and int(empty.rect[4]) == 0
+    terms = torch.zeros(4, device=gpu)
+    X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
+    out = training_loss_moss_fused(X, A, gt, bk, empty, terms_out=terms)
+    (out * 1.0).backward()
+    assert bool(torch.isnan(terms[1])) and bool(torch.isnan(terms[3])) and bool(torch.isnan(out))
+    # (MOSS's own expression does not get that far: ssim() of the 0 x 0 crop raises inside conv2d)
+    with pytest.raises(RuntimeError):
+        training_loss_moss(img.cpu().double(), alpha.cpu().double(), gt.cpu().double(), bk.cpu().double(), torch.zeros(1, H, W, dtype=torch.uint8))
+    gx = X.grad.cpu()
+    assert bool(((gx == 0) | torch.isnan(gx)).all())
+    # (2) a rectangle that sticks out of the frame == the clipped rectangle
+    m = torch.zeros(1, H, W, dtype=torch.uint8); m[0, 50:, 60:] = 1; m[0, 55, 70] = 0
+    res = []
+    for rect in ((60, 50, 100, 100), (60, 50, W - 60, H - 50)):
+        region = ViewRegion(m.to(gpu), rect=rect)
+        X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
+        out = training_loss_moss_fused(X, A, gt, bk, region)
+        (out * 1.0).backward()
+        res.append((out.detach().clone(), X.grad.clone(), A.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    ref = training_loss_moss(img.cpu().double(), alpha.cpu().double(), gt.cpu().double(), bk.cpu().double(), m)
+    assert abs(float(res[1][0]) - float(ref)) < 2e-6
+    # (3) mask pixels outside the caller's rectangle count for nothing: the same as the mask cut to the rectangle
+    m2 = m.clone(); m2[0, 3:9, 4:30] = 1
+    r2 = ViewRegion(m2.to(gpu), rect=(60, 50, W - 60, H - 50))
+    assert int(r2.rect[4]) == int(m.sum())
+    X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
+    out = training_loss_moss_fused(X, A, gt, bk, r2)
+    (out * 1.0).backward()
+    assert torch.equal(out.detach(), res[1][0]) and torch.equal(X.grad, res[1][1]) and torch.equal(A.grad, res[1][2])
+
+
 def test_fused_moss_loss_changes_view_inside_a_captured_graph(gpu, hip_lib):
     """The rectangle, the mask and its pixel count live in device memory: a captured loss changes view by ``ViewRegion.copy_`` --
     the replay then equals an eager evaluation on the new view, bit for bit."""
