@@ -42,8 +42,9 @@ __device__ __forceinline__ Crop load_crop(const int* __restrict__ rect, int W, i
 {
     Crop r;
     const int x = rect[0], y = rect[1], w = max(rect[2], 0), h = max(rect[3], 0);
+    const long long xe = (long long)x + w, ye = (long long)y + h;     // (the rectangle's far edges, before clipping: x may be negative)
     r.x0 = min(max(x, 0), W); r.y0 = min(max(y, 0), H);
-    r.x1 = min(max(x, 0) + min(w, W), W); r.y1 = min(max(y, 0) + min(h, H), H);
+    r.x1 = (int)min(max(xe, (long long)r.x0), (long long)W); r.y1 = (int)min(max(ye, (long long)r.y0), (long long)H);
     r.n_pix = (float)(r.x1 - r.x0) * (float)(r.y1 - r.y0);
     r.n_bound = has_bound ? (float)rect[4] : r.n_pix;
     return r;

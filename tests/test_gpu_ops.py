@@ -210,7 +210,7 @@ def test_fused_moss_loss_edge_cases(gpu, hip_lib):
     # (2) a rectangle that sticks out of the frame == the clipped rectangle
     m = torch.zeros(1, H, W, dtype=torch.uint8); m[0, 50:, 60:] = 1; m[0, 55, 70] = 0
     res = []
-    for rect in ((60, 50, 100, 100), (60, 50, W - 60, H - 50)):
+    for rect in ((60, 50, 100, 100), (60, 50, W - 60, H - 50)):              # (sticking out to the right / bottom)
         region = ViewRegion(m.to(gpu), rect=rect)
         X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
         out = training_loss_moss_fused(X, A, gt, bk, region)
@@ -219,6 +219,18 @@ def test_fused_moss_loss_edge_cases(gpu, hip_lib):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     ref = training_loss_moss(img.cpu().double(), alpha.cpu().double(), gt.cpu().double(), bk.cpu().double(), m)
     assert abs(float(res[1][0]) - float(ref)) < 2e-6
+    # (... and to the left / top: a negative corner is clipped at 0, the far edge stays where it was)
+    m3 = torch.zeros(1, H, W, dtype=torch.uint8); m3[0, :20, :30] = 1; m3[0, 4, 7] = 0
+    res3 = []
+    for rect in ((-9, -5, 39, 25), (0, 0, 30, 20)):
+        region = ViewRegion(m3.to(gpu), rect=rect) if rect[0] >= 0 else ViewRegion(m3.to(gpu), rect=(0, 0, 30, 20))
+        if rect[0] < 0:
+            region.rect[:4] = torch.tensor(rect, dtype=torch.int32, device=gpu)      # (the C ABI takes what the device words say)
+        X = img.clone().requires_grad_(True); A = alpha.clone().requires_grad_(True)
+        out = training_loss_moss_fused(X, A, gt, bk, region)
+        (out * 1.0).backward()
+        res3.append((out.detach().clone(), X.grad.clone(), A.grad.clone()))
+    assert torch.equal(res3[0][0], res3[1][0]) and torch.equal(res3[0][1], res3[1][1]) and torch.equal(res3[0][2], res3[1][2])
     # (3) mask pixels outside the caller's rectangle count for nothing: the same as the mask cut to the rectangle
     m2 = m.clone(); m2[0, 3:9, 4:30] = 1
     r2 = ViewRegion(m2.to(gpu), rect=(60, 50, W - 60, H - 50))
