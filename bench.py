@@ -938,6 +938,10 @@ def caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_T, steps=100, wa
         # torch loss kept, eager launches
         "patched_moss_pattern": dict(mode="lbs", activations="fused", torch_activations=True, torch_adamw="moss_amd", forward="async", graph=0,
                                      fused_loss="ssim", caller_side="fused", raw_in_op=True),
+        # the same with train_ZJU.py:108-119 -- MOSS's bound_mask selection, crop and three loss terms: ~40 torch launches forward and
+        # backward -- replaced by the ONE call moss_amd.loss.training_loss_moss_fused (C ABI moss_photometric_loss_roi), INTEGRATION section 3
+        "patched_moss_pattern_one_call_loss": dict(mode="lbs", activations="fused", torch_activations=True, torch_adamw="moss_amd", forward="async",
+                                                   graph=0, fused_loss="moss", caller_side="fused", raw_in_op=True),
         # the op without per-Gaussian transforms (the reference's compute_cov3D_python=False path): rounds 1-3's headline
         "no_transforms": dict(mode="scale_rot", activations="in_op", torch_activations=False, torch_adamw=False, forward="async", graph=1),
         # MOSS's shipped input mode (compute_cov3D_python=True, arguments/__init__.py:60: the covariance built by torch ops from the
