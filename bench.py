@@ -870,6 +870,7 @@ def main(argv=None):
         result["callers"] = caller_variants(args, dev, scene, cam, gt, gt_mask, bg, lbs_transforms())
         result["value_dropin"] = result["callers"].get("dropin_unchanged", {}).get("value")
         result["value_patched_moss"] = result["callers"].get("patched_moss_pattern", {}).get("value")
+        result["value_patched_moss_one_call_loss"] = result["callers"].get("patched_moss_pattern_one_call_loss", {}).get("value")
         if "spatial_order" in result["callers"]:
             result["value_spatial_order"] = result["callers"]["spatial_order"].get("value")
         result["value_no_transforms"] = result["callers"].get("no_transforms", {}).get("value")

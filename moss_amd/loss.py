@@ -57,7 +57,8 @@ def ssim(img1, img2, window_size=11, size_average=True):
 def bounding_rect(bound_mask):
     """cv2.boundingRect(bound_mask) (train_ZJU.py:115) of a (1,H,W) / (H,W) 0/1 mask as (x, y, w, h) Python ints (a host read: do it once
     per view when the view is loaded, like the mask's pixel count)."""
-    m = bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) != 0
+    # (the script casts the mask to uint8 first -- a truncation -- and boundingRect takes the non-zero bytes)
+    m = bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]).to(torch.uint8) != 0
     ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
     if ys.numel() == 0:
         return 0, 0, 0, 0
@@ -68,7 +69,7 @@ def training_loss_moss(image, alpha, gt_image, bkgd_mask, bound_mask, rect=None,
     """MOSS's own expression, torch ops, line by line (train_ZJU.py:108-119,131): L1 and mask L2 over the pixels of ``bound_mask``
     (1,H,W), SSIM on the crop ``rect`` = boundingRect(bound_mask) of both images.  The reference form :func:`training_loss_moss_fused` is
     tested against."""
-    sel = bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) != 0
+    sel = bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) == 1          # (`bound_mask[0]==1`, :111)
     ll1 = l1_loss(image.permute(1, 2, 0)[sel], gt_image.permute(1, 2, 0)[sel])
     mask_loss = l2_loss(alpha.reshape(sel.shape)[sel], bkgd_mask.reshape(sel.shape)[sel])
     x, y, w, h = rect if rect is not None else bounding_rect(bound_mask)
@@ -200,9 +201,9 @@ class ViewRegion:
     rewrites both in place -- how a step captured in a hipGraph changes view."""
 
     def __init__(self, bound_mask, rect=None):
-        m = (bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) != 0)
+        m = (bound_mask.reshape(bound_mask.shape[-2], bound_mask.shape[-1]) == 1)      # the script's selection: `bound_mask[0]==1`
         self.bound = m.to(torch.uint8).contiguous()
-        x, y, w, h = rect if rect is not None else bounding_rect(m)
+        x, y, w, h = rect if rect is not None else bounding_rect(bound_mask)
         self.xywh = (x, y, w, h)
         inside = m[y:y + h, x:x + w]                          # (pixels of the mask outside a caller's rectangle count for nothing)
         self.rect = torch.tensor([x, y, w, h, int(inside.sum())], dtype=torch.int32, device=m.device)

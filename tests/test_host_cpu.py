@@ -636,7 +636,7 @@ def test_moss_side_patches_apply(tmp_path):
     shutil.copy(os.path.join(ref, "train_ZJU.py"), tmp_path / "train_ZJU.py")
     os.makedirs(tmp_path / "scene")
     shutil.copy(os.path.join(ref, "scene", "gaussian_model.py"), tmp_path / "scene" / "gaussian_model.py")
-    for name in ("gaussian_renderer.diff", "train_ZJU.diff", "gaussian_model.diff"):
+    for name in ("gaussian_renderer.diff", "train_ZJU.diff", "gaussian_model.diff", "train_ZJU_one_call_loss.diff"):
         with open(os.path.join(ROOT, "patches", name), "rb") as f:
             r = subprocess.run(["patch", "-p1", "--binary"], cwd=tmp_path, stdin=f, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -649,7 +649,11 @@ def test_moss_side_patches_apply(tmp_path):
     src = open(tmp_path / "scene" / "gaussian_model.py", newline="").read()
     compile(src, "scene/gaussian_model.py", "exec")
     assert "from moss_amd.optim import AdamW as _AdamW" in src and "torch.optim.AdamW(l, lr=0.0, eps=1e-15)" not in src
-    assert "ssim_fused as ssim" in open(tmp_path / "train_ZJU.py", newline="").read()
+    src = open(tmp_path / "train_ZJU.py", newline="").read()
+    assert "ssim_fused as ssim" in src
+    # the optional fourth diff (on top of train_ZJU.diff): lines 111-119 and the first three terms of :131 as ONE call
+    assert "training_loss_moss_fused(image, alpha, gt_image, bkgd_mask, viewpoint_cam.moss_region, terms_out=raster_terms)" in src
+    assert "loss = raster_loss +" in src and "cv2.boundingRect" not in src
     from moss_amd import optim as moptim
     import torch as _t
     assert issubclass(moptim.AdamW, _t.optim.Optimizer)
@@ -660,6 +664,9 @@ def test_moss_side_patches_apply(tmp_path):
     assert "context" in inspect.signature(GaussianRasterizer.__init__).parameters
     assert "transforms" in inspect.signature(GaussianRasterizer.forward).parameters
     assert list(inspect.signature(densify.densify_stats_update).parameters) == ["max_radii2D", "xyz_gradient_accum", "denom", "radii", "viewspace_grad"]
+    from moss_amd import loss as mloss
+    assert list(inspect.signature(mloss.training_loss_moss_fused).parameters)[:5] == ["image", "alpha", "gt_image", "bkgd_mask", "region"]
+    assert "terms_out" in inspect.signature(mloss.training_loss_moss_fused).parameters and hasattr(mloss.ViewRegion, "copy_")
 
 
 def test_graft_entry_build_passes(hip_lib):
