@@ -228,7 +228,7 @@ class Harness:
         self.sharded = None
         if torch_adamw == "moss_amd":
             # MOSS's optimizer construction with the class swapped (patches/gaussian_model.diff): same groups, same per-group lr, same
-            # state keys -- one kernel per parameter tensor instead of torch's nine multi-tensor launches per group
+            # state keys -- one kernel for the six single-tensor groups (moss_adamw_multi) instead of torch's nine multi-tensor launches per group
             from moss_amd.optim import AdamW as MossAdamW
             self.opt = MossAdamW(pc.param_groups(), lr=0.0, eps=1e-15)
         elif torch_adamw:

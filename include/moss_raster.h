@@ -366,6 +366,20 @@ typedef struct moss_adamw_flat_args {
 } moss_adamw_flat_args;
 int moss_adamw_flat_ex(const moss_adamw_flat_args* args, void* stream);
 
+/* Up to eight parameter tensors with buffers OF THEIR OWN in one launch (ABI 6): what a torch.optim-style optimizer holds -- MOSS's six
+ * single-tensor Gaussian groups (scene/gaussian_model.py:215-226), each with its `exp_avg` / `exp_avg_sq` state tensors and its own
+ * step count (densification surgery keeps them per tensor).  Per element the arithmetic of moss_adamw_flat with one segment and the
+ * tensor's `lr` and `step`: bit-identical to num_tensors calls of it.  Pointers 16-byte aligned; an entry with numel 0 is skipped.
+ * moss_amd.optim.AdamW -- the drop-in for `torch.optim.AdamW` of patches/gaussian_model.diff -- steps its single-tensor groups with it. */
+typedef struct moss_adamw_multi_args {
+    int32_t num_tensors;                     /* 1..8 */
+    long long numel[8];
+    float* params[8]; const float* grads[8]; float* exp_avg[8]; float* exp_avg_sq[8];
+    float lr[8]; int32_t step[8];            /* step counts from 1, like moss_adamw_flat */
+    double beta1, beta2; float eps, weight_decay;
+} moss_adamw_multi_args;
+int moss_adamw_multi(const moss_adamw_multi_args* args, void* stream);
+
 /*
  * k nearest reference points of every query point, 3-D, exact, k = 1..4: replaces the third-party
  * `knn_cuda.KNN(k, transpose_mode=True)(ref, query)` MOSS calls at scene/gaussian_model.py:85-86,586,657,759,827 (a CUDA-only

@@ -122,6 +122,8 @@ def _declare(lib):
     lib.moss_photometric_loss.argtypes = [_i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
     lib.moss_photometric_loss_weighted.restype = _i
     lib.moss_photometric_loss_weighted.argtypes = [_i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
+    lib.moss_adamw_multi.restype = _i
+    lib.moss_adamw_multi.argtypes = [_p, _p]
     lib.moss_photometric_loss_roi.restype = _i
     lib.moss_photometric_loss_roi.argtypes = [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, C.c_size_t, _p]
     lib.moss_adamw_flat.restype = _i
@@ -163,6 +165,13 @@ class AdamWFlatArgs(C.Structure):
                 ("inactive_zero", C.c_int), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float),
                 ("step", C.c_int), ("step_state", C.c_void_p), ("skip_word", C.c_void_p), ("skip_mask", C.c_uint32),
                 ("num_grads_extra", C.c_int), ("grads_extra", C.c_void_p * 3), ("grad_scale", C.c_float)]
+
+
+class AdamWMultiArgs(C.Structure):
+    """``moss_adamw_multi_args`` of include/moss_raster.h (``moss_adamw_multi``: up to eight tensors with buffers of their own, one launch)."""
+    _fields_ = [("num_tensors", C.c_int32), ("numel", C.c_longlong * 8), ("params", C.c_void_p * 8), ("grads", C.c_void_p * 8),
+                ("exp_avg", C.c_void_p * 8), ("exp_avg_sq", C.c_void_p * 8), ("lr", C.c_float * 8), ("step", C.c_int32 * 8),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
 
 OPT_BITS = {"means3D": 1, "sh": 2, "opacity": 4, "scales": 8, "rotations": 16}      # MOSS_OPT_*; position = index in the struct's arrays

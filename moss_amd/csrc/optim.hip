@@ -182,8 +182,82 @@ int launch_adamw(long long n, float* params, const float* grads, float* exp_avg,
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
 
+// ---- SEVERAL parameter tensors with buffers of their own in ONE launch (moss_adamw_multi): the torch-state drop-in optimizer
+// (moss_amd.optim.AdamW, MOSS's six single-tensor Gaussian groups -- scene/gaussian_model.py:215-226) took one launch per tensor: six
+// launches and six host calls per step of a call pattern that is bound by the host.  Same arithmetic per element as adamw_kernel
+// (adamw_element, the same bias corrections from the tensor's own step count): bit-identical to six moss_adamw_flat calls.
+struct MultiT {
+    int n;
+    float* p[8]; const float* g[8]; float* m[8]; float* v[8];
+    long long numel[8]; float lr[8], bc1[8], bc2_sqrt[8];
+    unsigned block_end[8];                                   // tensor t owns the blocks [block_end[t-1], block_end[t])
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+adamw_multi_kernel(MultiT T, AdamBetas betas, float eps, float weight_decay)
+{
+    // this block's tensor (static indices only: a run-time index into the kernel-argument tables would spill them to scratch)
+    float* p = nullptr; const float* g = nullptr; float* m = nullptr; float* v = nullptr;
+    long long n = 0; float lr = 0.f, bc1 = 1.f, bc2_sqrt = 1.f; unsigned b0 = 0u, b1 = 0u;
+#pragma unroll
+    for (int t = 7; t >= 0; t--) if (t < T.n && blockIdx.x < T.block_end[t]) {
+        p = T.p[t]; g = T.g[t]; m = T.m[t]; v = T.v[t]; n = T.numel[t]; lr = T.lr[t]; bc1 = T.bc1[t]; bc2_sqrt = T.bc2_sqrt[t];
+        b1 = T.block_end[t]; b0 = t > 0 ? T.block_end[t - 1] : 0u;
+    }
+    const float inv_bc1 = 1.0f / bc1, inv_bc2_sqrt = 1.0f / bc2_sqrt;
+    const long long stride = (long long)(b1 - b0) * blockDim.x;
+    for (long long i4 = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += stride) {
+        const long long i = i4 * 4;
+        float pv[4], gv[4], mv[4], vv[4];
+        const bool full = i + 4 <= n;
+        if (full) {
+            const float4 a = reinterpret_cast<const float4*>(p)[i4], b = reinterpret_cast<const float4*>(g)[i4];
+            const float4 c = reinterpret_cast<const float4*>(m)[i4], d = reinterpret_cast<const float4*>(v)[i4];
+            pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+        } else {
+            for (int k = 0; k < 4; k++) { const bool ok = i + k < n; pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) adamw_element(pv[k], gv[k], mv[k], vv[k], lr, betas, eps, weight_decay, inv_bc1, inv_bc2_sqrt);
+        if (full) {
+            reinterpret_cast<float4*>(p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            reinterpret_cast<float4*>(m)[i4] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            reinterpret_cast<float4*>(v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            for (int k = 0; k < 4; k++) if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace moss
+
+extern "C" int moss_adamw_multi(const moss_adamw_multi_args* a, void* stream)
+{
+    if (!a || a->num_tensors < 1 || a->num_tensors > 8) return MOSS_ERR_INVALID_ARG;
+    moss::MultiT T; T.n = 0;
+    unsigned blocks = 0u;
+    for (int t = 0; t < 8; t++) { T.p[t] = nullptr; T.g[t] = nullptr; T.m[t] = nullptr; T.v[t] = nullptr; T.numel[t] = 0; T.lr[t] = 0.f; T.bc1[t] = 1.f; T.bc2_sqrt[t] = 1.f; T.block_end[t] = 0u; }
+    for (int t = 0; t < a->num_tensors; t++) {
+        const long long n = a->numel[t];
+        if (n < 0 || a->step[t] < 1) return MOSS_ERR_INVALID_ARG;
+        if (n == 0) continue;                                // (an empty tensor takes no block)
+        if (!a->params[t] || !a->grads[t] || !a->exp_avg[t] || !a->exp_avg_sq[t]) return MOSS_ERR_INVALID_ARG;
+        if ((((uintptr_t)a->params[t]) | ((uintptr_t)a->grads[t]) | ((uintptr_t)a->exp_avg[t]) | ((uintptr_t)a->exp_avg_sq[t])) & 15u) return MOSS_ERR_INVALID_ARG;
+        const int k = T.n++;
+        T.p[k] = a->params[t]; T.g[k] = a->grads[t]; T.m[k] = a->exp_avg[t]; T.v[k] = a->exp_avg_sq[t]; T.numel[k] = n; T.lr[k] = a->lr[t];
+        // (the corrections exactly as moss_adamw_flat forms them: doubles, rounded once)
+        T.bc1[k] = (float)(1.0 - pow(a->beta1, a->step[t])); T.bc2_sqrt[k] = (float)sqrt(1.0 - pow(a->beta2, a->step[t]));
+        long long b = (n / 4 + 255) / 256;
+        if (b > 1024) b = 1024;
+        if (b < 1) b = 1;
+        blocks += (unsigned)b; T.block_end[k] = blocks;
+    }
+    if (T.n == 0) return 0;
+    hipLaunchKernelGGL(moss::adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, moss::AdamBetas(a->beta1, a->beta2), a->eps, a->weight_decay);
+    return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
+}
 
 extern "C" int moss_adamw_flat(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                int num_segments, const long long* segment_end, const float* segment_lr,

@@ -454,9 +454,11 @@ class FlatAdamW:
 
 class AdamW(torch.optim.Optimizer):
     """Drop-in for ``torch.optim.AdamW(params, lr, betas, eps, weight_decay)`` as MOSS builds it (scene/gaussian_model.py:226:
-    eight parameter groups, ``lr=0.0, eps=1e-15``): the same update rule, ONE kernel per parameter tensor (C ABI ``moss_adamw_flat``)
-    instead of torch's nine ``multi_tensor_apply`` launches per group -- with MOSS's six single-tensor Gaussian groups that is 54
-    launches of ~13 us per step, more than half of the patched call pattern's step (rocprofv3, ``profiles/r04_notes.md``).
+    eight parameter groups, ``lr=0.0, eps=1e-15``): the same update rule, ONE kernel for all the single-tensor groups (C ABI
+    ``moss_adamw_multi``: up to eight tensors with their own state tensors and step counts per launch; rounds 4-5: one launch per tensor,
+    ``moss_adamw_flat``, bit-identical) instead of torch's nine ``multi_tensor_apply`` launches per group -- with MOSS's six single-tensor
+    Gaussian groups that is 54 launches of ~13 us per step, more than half of the patched call pattern's step (rocprofv3,
+    ``profiles/r04_notes.md``).
 
     Everything MOSS does to its optimizer keeps working: ``param_groups`` with per-group ``lr`` rewritten every iteration
     (``update_learning_rate``), and the densification surgery on ``state[p]["exp_avg"] / ["exp_avg_sq"]`` (``cat_tensors_to_optimizer``,
@@ -467,10 +469,8 @@ class AdamW(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._one = (C.c_longlong * 1)()
-        self._lr = (C.c_float * 1)()
-        self._zero_i = (C.c_int * 1)(0)
-        self._zero_f = (C.c_float * 1)(0.0)
+        from ._lib import AdamWMultiArgs
+        self._multi = AdamWMultiArgs()
 
     # A group of MANY tensors (MOSS's two network groups, scene/gaussian_model.py:222-223: the parameters of `auto_regression` and
     # `cross_attention_lbs`) is stepped with torch's multi-tensor primitives -- nine launches for the whole group, where one kernel per
@@ -518,7 +518,9 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = lib()
+        # the single tensors of ALL groups that the kernel can take, batched by what a launch holds as scalars (device, betas, eps, weight
+        # decay): MOSS's six Gaussian groups share them, so its step is ONE launch (C ABI moss_adamw_multi; up to eight tensors each)
+        batches = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             if len(group["params"]) > self.FOREACH_ABOVE and self._foreach_group(group):
@@ -537,17 +539,26 @@ class AdamW(torch.optim.Optimizer):
                 if n == 0:
                     continue
                 if self._native_ok(p, g, m, v):
-                    self._one[0] = n
-                    self._lr[0] = float(group["lr"])
-                    with torch.cuda.device(p.device):
-                        rc = L.moss_adamw_flat(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1, self._one, self._lr,
-                                               self._zero_i, self._zero_i, self._zero_f, float(beta1), float(beta2), float(group["eps"]),
-                                               float(group["weight_decay"]), int(st["step"]), torch.cuda.current_stream(p.device).cuda_stream)
-                    check(rc, "adamw_flat")
+                    key = (p.device, float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]))
+                    batches.setdefault(key, []).append((p, g, m, v, float(group["lr"]), int(st["step"])))
                 else:                                        # torch's expressions (CPU tensors, other dtypes, views with odd alignment)
                     p.mul_(1 - group["lr"] * group["weight_decay"])
                     m.lerp_(g, 1 - beta1)
                     v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
                     bc1, bc2 = 1 - beta1 ** st["step"], 1 - beta2 ** st["step"]
                     p.addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(group["eps"]), value=-group["lr"] / bc1)
+        if batches:
+            L = lib()
+            a = self._multi
+            for (dev, beta1, beta2, eps, wd), items in batches.items():
+                a.beta1, a.beta2, a.eps, a.weight_decay = beta1, beta2, eps, wd
+                with torch.cuda.device(dev):
+                    stream = torch.cuda.current_stream(dev).cuda_stream
+                    for i0 in range(0, len(items), 8):
+                        part = items[i0:i0 + 8]
+                        a.num_tensors = len(part)
+                        for k, (p, g, m, v, lr, t) in enumerate(part):
+                            a.numel[k], a.params[k], a.grads[k], a.exp_avg[k], a.exp_avg_sq[k] = p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+                            a.lr[k], a.step[k] = lr, t
+                        check(L.moss_adamw_multi(C.addressof(a), stream), "adamw_multi")
         return loss

@@ -952,6 +952,50 @@ def test_adamw_drop_in_matches_torch_optim_adamw(gpu, hip_lib):
     assert float((p64 - r64).abs().max()) < 1e-12
 
 
+def test_adamw_multi_is_bit_identical_to_one_call_per_tensor(gpu, hip_lib):
+    """C ABI moss_adamw_multi (several tensors with buffers and step counts of their own, one launch) against moss_adamw_flat called once
+    per tensor: the same bits in every parameter and moment -- ragged sizes (not multiples of 4, one element, empty), different learning
+    rates and DIFFERENT step counts (MOSS's surgery keeps the step per tensor), two steps."""
+    import ctypes as C
+    from moss_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(17)
+    sizes = [3711, 1237 * 45, 1, 1237 * 4, 0, 1237 * 3 + 2, 262147]
+    lrs = [1.6e-4, 1.25e-4, 0.05, 1e-3, 0.3, 5e-3, 2.5e-3]
+    steps0 = [1, 7, 1, 300, 1, 2, 41]
+    def fresh():
+        g = torch.Generator().manual_seed(99)
+        return [[torch.randn(max(n, 0), generator=g).to(gpu) for n in sizes] for _ in range(2)] + \
+               [[(torch.rand(max(n, 0), generator=g) * 1e-3).to(gpu) for n in sizes]]
+    (pa, ma, va), (pb, mb, vb) = fresh(), fresh()
+    stream = torch.cuda.current_stream(gpu).cuda_stream
+    for it in range(2):
+        grads = [torch.randn(max(n, 0), generator=gen).to(gpu) for n in sizes]
+        a = _lib.AdamWMultiArgs()
+        a.num_tensors = len(sizes)
+        a.beta1, a.beta2, a.eps, a.weight_decay = 0.9, 0.999, 1e-15, 0.01
+        for k, n in enumerate(sizes):
+            a.numel[k], a.lr[k], a.step[k] = n, lrs[k], steps0[k] + it
+            a.params[k], a.grads[k], a.exp_avg[k], a.exp_avg_sq[k] = pa[k].data_ptr(), grads[k].data_ptr(), ma[k].data_ptr(), va[k].data_ptr()
+        assert L.moss_adamw_multi(C.addressof(a), stream) == 0
+        for k, n in enumerate(sizes):
+            if n == 0:
+                continue
+            one, lr, zi, zf = (C.c_longlong * 1)(n), (C.c_float * 1)(lrs[k]), (C.c_int * 1)(0), (C.c_float * 1)(0.0)
+            assert L.moss_adamw_flat(n, pb[k].data_ptr(), grads[k].data_ptr(), mb[k].data_ptr(), vb[k].data_ptr(), 1, one, lr, zi, zi, zf,
+                                     0.9, 0.999, 1e-15, 0.01, steps0[k] + it, stream) == 0
+        torch.cuda.synchronize(gpu)
+        for k in range(len(sizes)):
+            assert torch.equal(pa[k], pb[k]) and torch.equal(ma[k], mb[k]) and torch.equal(va[k], vb[k]), (it, k)
+    # refused: nine tensors, a misaligned pointer, a step count of zero
+    a.num_tensors = 9
+    assert L.moss_adamw_multi(C.addressof(a), stream) != 0
+    a.num_tensors = 1; a.numel[0] = 8; a.params[0] = pa[1].data_ptr() + 4
+    assert L.moss_adamw_multi(C.addressof(a), stream) != 0
+    a.params[0] = pa[1].data_ptr(); a.step[0] = 0
+    assert L.moss_adamw_multi(C.addressof(a), stream) != 0
+
+
 def test_partial_fusion_position_in_an_optimizer_of_its_own(gpu, hip_lib, async_mode):
     """The configuration INTEGRATION.md recommends for MOSS: features, opacity, scaling and rotation take their AdamW step inside the
     backward kernel; the POSITION -- whose gradient MOSS also feeds from its LBS network -- keeps its gradient (written by the op) and
