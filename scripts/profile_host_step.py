@@ -24,6 +24,7 @@ def spy(self, n, barrier=None):
     pr.disable()
     buf = io.StringIO()
     pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(28)
+    pstats.Stats(pr, stream=buf).sort_stats("cumtime").print_stats(45)
     print(f"==== {variant}: {n} eager steps in {1e3 * out[0]:.1f} ms ({1e3 * out[0] / n:.4f} ms per step; under the profiler)", file=sys.stderr)
     print(buf.getvalue(), file=sys.stderr)
     return out
