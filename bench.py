@@ -450,22 +450,9 @@ class Harness:
 
 
 def cpu_quota():
-    """CPUs this process may use: the cgroup's quota (cpu.max = "<quota> <period>" or "max"), else the affinity mask."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt and txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
+    """CPUs this process may use (cgroup quota / affinity): moss_amd.host.cpu_quota."""
+    from moss_amd.host import cpu_quota as q
+    return q()
 
 
 def main(argv=None):
@@ -501,8 +488,8 @@ def main(argv=None):
     # the 100 ms scheduler period in a few ms and the kernel suspends the whole process, HIP runtime threads included, until the period
     # ends: 10-90 ms stalls that land in whatever is being timed a moment later (scripts/micro/cpu_parallel_stall.py: 40.3 / 60.3 / 50.3 ms
     # with 128 threads, none with 8).  The team is sized to the quota.
-    # (the ranks of one node share the quota)
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+    from moss_amd.host import limit_cpu_threads
+    limit_cpu_threads()                                      # (the ranks of one node share the quota: LOCAL_WORLD_SIZE)
     import gc
     import moss_amd.graphs, moss_amd.surgery, moss_amd.multiview, moss_amd.optim, moss_amd.loss, moss_amd.densify   # noqa: F401,E401
     gc.collect()

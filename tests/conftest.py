@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
+    # torch's OpenMP team follows the machine (128 threads), the container's CPU quota is 16: every parallel CPU op of a test (the float64
+    # torch references, scene construction) would get the whole process suspended for the rest of a scheduler period (moss_amd/host.py)
+    from moss_amd.host import limit_cpu_threads
+    limit_cpu_threads()
 
 
 @pytest.fixture(scope="session", autouse=True)
