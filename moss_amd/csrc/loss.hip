@@ -267,7 +267,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
                   const float* __restrict__ mask_partials, float* __restrict__ loss_out, float lambda_l1,
                   unsigned long long* __restrict__ stamps, const unsigned char* __restrict__ bound, const int* __restrict__ rect)
 {
-    static_assert(!ROI || SKIP_EMPTY, "the crop instantiation takes the early-leave path");
+
     LSTAMP(0);
     __shared__ float s_d[3][LP][LP + 1];
     __shared__ float s_h[3][LP][LT + 1];
@@ -331,7 +331,7 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     // +0 + (+-0) = +0): skipped, same bits.
     bool tile_content = true;
     if constexpr (SKIP_EMPTY) tile_content = __syncthreads_or(content ? 1 : 0) != 0;
-    else __syncthreads();
+    else { __syncthreads(); if constexpr (ROI) tile_content = !off_crop; }      // (a tile off the crop loaded nothing: zeros are written below)
     LSTAMP(2);
     if (tile_content && tid < (LT / SEG) * LP) {         // horizontal pass of the three derivative maps (see pass 1)
         const int r = tid % LP, q0 = (tid / LP) * SEG;
@@ -513,9 +513,18 @@ extern "C" int moss_photometric_loss_roi(int C, int H, int W, const float* image
     float* mask_partials = carve<float>(p, (size_t)gx * gy);
     static const Win win = make_window();
     const dim3 grid(gx, gy, C);
-    hipLaunchKernelGGL((ssim_pass1_kernel<true, true>), grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha,
-                       mask_partials, (unsigned long long*)nullptr, bound, rect);
-    hipLaunchKernelGGL((ssim_pass2_kernel<true, true>), grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
-                       lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, (unsigned long long*)nullptr, bound, rect);
+    // (as for the full frame: the instantiations that let empty tiles leave early only where the grid takes more than one residency round --
+    // at 512 x 512 every workgroup is resident and the block-wide OR costs more than it saves: 19.2 -> 18.x us, scripts/loss_times_roi.py)
+    if ((size_t)gx * gy * C > (size_t)3 * loss_device_cus()) {
+        hipLaunchKernelGGL((ssim_pass1_kernel<true, true>), grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha,
+                           mask_partials, (unsigned long long*)nullptr, bound, rect);
+        hipLaunchKernelGGL((ssim_pass2_kernel<true, true>), grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, (unsigned long long*)nullptr, bound, rect);
+    } else {
+        hipLaunchKernelGGL((ssim_pass1_kernel<false, true>), grid, dim3(256), 0, s, C, H, W, image, gt, win, dmap, partials, alpha, mask, lambda_mask, dL_dalpha,
+                           mask_partials, (unsigned long long*)nullptr, bound, rect);
+        hipLaunchKernelGGL((ssim_pass2_kernel<false, true>), grid, dim3(256), 0, s, C, H, W, image, gt, alpha, mask, win, dmap, partials, gx * gy * C,
+                           lambda_dssim, lambda_mask, dL_dimage, dL_dalpha, mask_partials, loss_out, lambda_l1, (unsigned long long*)nullptr, bound, rect);
+    }
     return hipGetLastError() == hipSuccess ? 0 : MOSS_ERR_HIP;
 }
