@@ -135,6 +135,15 @@ class RasterContext:
             ev = torch.cuda.Event(); ev.record(s)
         self.pending = (status, ev)
 
+    def _clear_captured_status(self):
+        """After a graph CAPTURE: ``last_img_buffer`` is the captured forward's image buffer -- memory of the graph's pool that nothing has
+        written yet (a capture executes no kernel).  A ``check_status()`` before the first replay would read whatever the block held
+        before (seen: the bits of 1.0f in word [3] -> a "needed capacity" of 10^9 and an 800 GB allocation at the next capture).  Its
+        status words are zeroed here, eagerly: "nothing rendered, nothing needed" until a replay says otherwise."""
+        img = self.last_img_buffer
+        if img is not None and img.is_cuda and img.numel() * img.element_size() >= 32:
+            img.view(torch.uint8).reshape(-1)[:32].zero_()
+
     def check_status(self, img_buffer=None):
         """Synchronously verify the most recent asynchronous forward (call outside graph capture, e.g. every N steps)."""
         if img_buffer is None:

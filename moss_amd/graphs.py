@@ -71,8 +71,9 @@ class GraphedStep:
     """``step = GraphedStep(fn, warmup=3)``; ``out = step()`` replays the captured ``fn`` and returns the (static) outputs of the
     capture.  ``fn`` takes no arguments: it reads its inputs from tensors that are updated in place between replays."""
 
-    def __init__(self, fn, warmup: int = 3, device=None, context=None):
+    def __init__(self, fn, warmup: int = 3, device=None, context=None, extra_contexts=()):
         self.fn = fn
+        self.extra_contexts = list(extra_contexts)           # further RasterContexts whose forwards ``fn`` captures (B views per step)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.context = context                               # the RasterContext whose capacity is baked into the graph (None: the default one)
         self.recaptures = 0
@@ -119,6 +120,9 @@ class GraphedStep:
         # overflows of EAGER forwards on this context before (or during the warm-up of) this capture were raised to, or seen by, the
         # caller: only what the replays drop from here on is counted in ``dropped_frames``
         (self.context or _C.DEFAULT).read_dropped_frames(reset=True)
+        # (the captured forwards' image buffers have not been written by anybody yet: a check before the first replay must not read them)
+        for cx in [self.context or _C.DEFAULT] + self.extra_contexts:
+            cx._clear_captured_status()
 
     def reserve_pool(self, nbytes: int) -> None:
         """Put ONE free block of ``nbytes`` into this step's graph memory pool (a throw-away capture allocates it; a private pool keeps

@@ -128,7 +128,8 @@ class MultiViewStep:
     eager_step = compute
 
     def capture(self, warmup=2):
-        self.graphed = GraphedStep(self.compute, warmup=warmup, device=self.dev, context=self.views[0].ctx)
+        self.graphed = GraphedStep(self.compute, warmup=warmup, device=self.dev, context=self.views[0].ctx,
+                                   extra_contexts=[v.ctx for v in self.views[1:]])
         return self.graphed
 
     def step(self):
@@ -192,7 +193,8 @@ class MultiViewRender:
     def capture(self, warmup=2):
         self.compute()                                       # (the first, synchronous renders size the capacities)
         torch.cuda.synchronize(self.dev)
-        self.graphed = GraphedStep(self.compute, warmup=warmup, device=self.dev, context=self.views[0].ctx)
+        self.graphed = GraphedStep(self.compute, warmup=warmup, device=self.dev, context=self.views[0].ctx,
+                                   extra_contexts=[v.ctx for v in self.views[1:]])
         return self.graphed
 
     def __call__(self):

@@ -260,6 +260,34 @@ def test_densification_schedule_flat_fused_graph_equals_moss_style_surgery(gpu, 
     assert float(ma["f_dc"][0].abs().max()) > 0 and bool(torch.isfinite(A.opt.flat_params).all())
 
 
+def test_check_before_the_first_replay_reads_no_stale_status(gpu, hip_lib):
+    """A capture executes no kernel: the captured forward's image buffer -- where the status words live -- is pool memory nobody has
+    written.  ``GraphedStep.check()`` / ``RasterContext.check_status()`` straight after a capture or a re-capture must not take whatever
+    the block held before for a frame's report (seen: the bits of 1.0f as the "needed capacity", 10^9 instances, and an 800 GB
+    allocation at the next capture).  The pool is poisoned with 1.0f first so that stale words would be exactly that."""
+    scene = scenes.config2()
+    gt, mask = _target(scenes.config2, gpu)
+    T = torch.eye(3).repeat(scene.P, 1, 1)
+    junk = [torch.full((1 << 20,), 1.0, device=gpu) for _ in range(8)]      # (what freed blocks of the general pool hold)
+    del junk
+    a = FormA(scene, gpu, gt, mask, T, degree=3, graph=True)
+    a.graphed.reserve_pool(256 << 20)
+    cap = a.ctx.capacity
+    assert a.graphed.check() is False and a.ctx.capacity == cap         # straight after the first capture
+    for _ in range(3):
+        a.step()
+    assert a.graphed.check() is False and a.ctx.capacity == cap
+    ev = scripted_event(a.tensors(), 1, gpu, False)
+    a.event(ev)
+    cap2 = a.ctx.capacity
+    a.ctx.check_status()                                                  # straight after a RE-capture, before any replay
+    assert a.graphed.check() is False and a.ctx.capacity == cap2 and a.graphed.dropped_frames == 0
+    for _ in range(3):
+        a.step()
+    a.ctx.check_status()
+    assert a.ctx.capacity == cap2 and 0 < a.ctx.last_needed < cap2
+
+
 def test_opacity_reset_needs_no_recapture(gpu, hip_lib):
     """reset_opacity (scene/gaussian_model.py:314-317) changes no shape and no address: applied in place between two replays of the
     SAME captured graph, equal to the eager unfused step driven the same way."""
