@@ -9,6 +9,10 @@ then x 1/B: bitwise reproducible, and bit-identical to accumulating the same vie
 Every view runs the ordinary single-view chain -- ``render()`` -> fused loss -> backward -- on a ``RasterContext`` and a gradient buffer
 of its own; with ``parallel_streams`` the B chains are issued on B HIP streams and joined in front of the update, inside ONE captured
 hipGraph (parallel branches), so the kernels of different views overlap.  No kernel knows about views.
+
+After a densification event (``FlatAdamW.append_rows`` / ``prune_rows`` on ``MultiViewStep.opt``) build a NEW ``MultiViewStep`` on the model:
+the per-view gradient buffers, alias leaves and capacities all follow the row count (``moss_amd.surgery.densification_event`` re-captures
+one context and one ``GraphedStep``: the single-view step).
 """
 from __future__ import annotations
 
