@@ -24,3 +24,10 @@ for k in outs[0][1]:
     assert torch.isfinite(outs[0][1][k]).all(), k
     assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 print("finite and bit-identical across two runs; radii>0:", int((t.radii > 0).sum()))
+# the forward-only path (MOSS_FORWARD_ONLY: 62 B of binning buffer per instance) at this size: the same images, bit for bit
+del g, outs[1:]
+torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+t2 = hp.hip_forward(d, dev, debug=16)
+torch.cuda.synchronize()
+assert t2.R == t.R and torch.equal(t2.color, outs[0][0]) and torch.equal(t2.alpha, t.alpha) and torch.equal(t2.depth, t.depth)
+print(f"forward only: the same image bit for bit, binning buffer {t2.binning.numel() / max(t2.R, 1):.1f} B per instance (training forward: {t.binning.numel() / max(t.R, 1):.1f}), peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
