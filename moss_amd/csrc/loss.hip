@@ -73,6 +73,48 @@ __device__ __forceinline__ TileId xcd_tile()
     return id;
 }
 
+// The crop instantiations: the tiles that meet the crop FIRST.  Workgroups are dispatched in linear-id order as slots free up; at 1024 x 1024
+// the grid takes three residency rounds and, in image order, the crop's tiles (a person in the middle of the frame) are handed out behind
+// the empty ones in front of them.  Here XCD x (linear id % 8) is dealt, in its turns j = id / 8, first the x-th contiguous eighth of the
+// crop's tiles -- (channel, row, column) order inside the crop's tile rectangle: neighbours still share an L2 -- and then its share of the
+// tiles off the crop (which leave at once).
+__device__ __forceinline__ TileId roi_tile(const Crop& cr)
+{
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y, C = (int)gridDim.z;
+    const int total = gx * gy * C;
+    const int lin = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    const bool some = cr.x1 > cr.x0 && cr.y1 > cr.y0;
+    const int tx0 = cr.x0 / LT, ty0 = cr.y0 / LT;
+    const int ncx = some ? (cr.x1 - 1) / LT - tx0 + 1 : 0, ncy = some ? (cr.y1 - 1) / LT - ty0 + 1 : 0;
+    const int n_crop = ncx * ncy, n_in = n_crop * C;
+    const int x = lin % 8, j = lin / 8;
+    const int q = n_in / 8, r = n_in % 8, qt = total / 8, rt = total % 8;
+    const int cnt = q + (x < r ? 1 : 0);                     // crop tiles dealt to this XCD
+    TileId id;
+    if (j < cnt) {
+        const int ci = x * q + min(x, r) + j;
+        const int rem = ci % n_crop;
+        id.c = ci / n_crop; id.by = ty0 + rem / ncx; id.bx = tx0 + rem % ncx;
+        return id;
+    }
+    // the (oi)-th tile off the crop, in (channel, row, column) order: the rows above the crop, the crop's rows without its columns, the rows below
+    const int oi = (x * qt + min(x, rt)) - (x * q + min(x, r)) + (j - cnt);
+    const int n_off = gx * gy - n_crop;                      // per channel (> 0 here: some block is left over for this branch)
+    id.c = oi / n_off;
+    int k = oi % n_off;
+    const int above = ty0 * gx, side = gx - ncx;
+    if (!some || k < above) { id.by = k / gx; id.bx = k % gx; return id; }
+    k -= above;
+    if (side > 0 && k < ncy * side) {
+        const int cc = k % side;
+        id.by = ty0 + k / side; id.bx = cc < tx0 ? cc : cc + ncx;
+        return id;
+    }
+    k -= ncy * side;
+    id.by = ty0 + ncy + k / gx; id.bx = k % gx;
+    return id;
+}
+
 // Both passes are separable 11-tap filters through LDS with SLIDING WINDOWS in registers (round 2: one output per thread and pass,
 // 11 LDS reads per output and moment, products recomputed per tap -- 7.8 wave-instructions per pixel-channel, 30 % of the wave
 // cycles waiting on LDS).  Horizontal: a thread owns a run of SEG outputs of one row, walks its SEG + 10 inputs once and adds each
@@ -95,16 +137,16 @@ ssim_pass1_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __shared__ float s_h[4][LP][LT + 1];                 // (four moments, below: 36.7 KB of LDS in all -- FOUR workgroups per CU; five: 42.2 KB, three)
     __shared__ float s_red[3][4];
 
-    const TileId tile = xcd_tile();
+    Crop crop = {};
+    if constexpr (ROI) crop = load_crop(rect, W, H, bound != nullptr);
+    const TileId tile = ROI ? roi_tile(crop) : xcd_tile();
     const int c = tile.c;
     const int x0 = tile.bx * LT, y0 = tile.by * LT;
     const int tid = threadIdx.x;
     const float* xc = img + (size_t)c * H * W;
     const float* yc = gt + (size_t)c * H * W;
     bool nonzero = false;
-    Crop crop = {};
     if constexpr (ROI) {
-        crop = load_crop(rect, W, H, bound != nullptr);
         if (x0 >= crop.x1 || x0 + LT <= crop.x0 || y0 >= crop.y1 || y0 + LT <= crop.y0) {
             // a tile off the crop: no SSIM term, no pixel of the mask (MOSS's rectangle is the mask's bounding box; a mask pixel outside
             // the rectangle handed in here counts for nothing): zero sums, zero alpha gradient; pass 2 never reads its derivative maps
@@ -273,15 +315,15 @@ ssim_pass2_kernel(int C, int H, int W, const float* __restrict__ img, const floa
     __shared__ float s_h[3][LP][LT + 1];
     __shared__ float s_red[3][4];
 
-    const TileId tile = xcd_tile();
+    Crop crop = {};
+    if constexpr (ROI) crop = load_crop(rect, W, H, bound != nullptr);
+    const TileId tile = ROI ? roi_tile(crop) : xcd_tile();
     const int c = tile.c;
     const int x0 = tile.bx * LT, y0 = tile.by * LT;
     const int tid = threadIdx.x;
     const size_t plane3 = (size_t)C * H * W;
-    Crop crop = {};
     bool off_crop = false;                               // (block-uniform)
     if constexpr (ROI) {
-        crop = load_crop(rect, W, H, bound != nullptr);
         off_crop = x0 >= crop.x1 || x0 + LT <= crop.x0 || y0 >= crop.y1 || y0 + LT <= crop.y0;
     }
     const float N = ROI ? (float)C * crop.n_pix : (float)C * (float)H * (float)W;           // pixels-channels of the SSIM mean
