@@ -120,6 +120,10 @@ def parse_args(argv=None):
                     help="OR-ed into the op's `debug` argument (include/moss_raster.h MOSS_DEBUG_*): 8 = MOSS_DEBUG_TRACE, roctx ranges around "
                          "every stage launcher (use with --graph 0 under `rocprofv3 --kernel-trace --marker-trace`); 4 = "
                          "MOSS_DEBUG_EXACT_MATH (checking mode, slower blend kernels: not a valid `value`)")
+    ap.add_argument("--loss", default="full", choices=["full", "moss"],
+                    help="full (default, the metric's form since round 1: L1 / SSIM / mask L2 over the whole frame) or moss: MOSS's OWN expression "
+                         "(train_ZJU.py:108-119: L1 and mask L2 over the view's bound_mask, SSIM on its bounding rectangle; "
+                         "moss_photometric_loss_roi) -- an analysis aid: `config.loss` says which, the driver's default command is `full`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the drop-in / lbs-in-op caller variants reported beside the headline")
     ap.add_argument("--callers-only", default="", help="comma-separated names: measure only these caller variants (profiling aid, e.g. "
@@ -547,7 +551,7 @@ def main(argv=None):
     h = Harness(args, dev, rank, world, scene, cam, gt, gt_mask, bg, mode=args.mode, activations=args.activations,
                 torch_activations=args.torch_activations, torch_adamw=args.torch_adamw, forward=args.forward, graph=args.graph,
                 lbs_T=lbs_transforms() if args.mode in ("lbs", "lbs_python") else None, exchange=args.exchange,
-                fused_optimizer=bool(args.fused_optimizer))
+                fused_optimizer=bool(args.fused_optimizer), fused_loss=("moss" if args.loss == "moss" else True))
     opt, bucket, pc = h.opt, h.bucket, h.pc
     pc.spatially_ordered = args.order == "morton"
 
@@ -791,6 +795,8 @@ def main(argv=None):
                    # (was_fused: what the TIMED region ran -- the rasterizer-only pass above takes the step out of the backward afterwards)
                    "optimizer": ("AdamW step taken by the per-Gaussian backward kernel (moss_raster_backward_raw_adamw); bit-identical to the flat "
                                  "kernel, reported beside as callers.unfused_optimizer") if was_fused else "flat AdamW kernel over the gradient bucket",
+                   "loss": ("full frame: L1 + 0.2 (1 - SSIM) + 0.5 mask L2 (moss_photometric_loss)" if args.loss == "full" else
+                            "MOSS's own expression: L1 and mask L2 over the view's bound_mask, SSIM on its bounding rectangle (moss_photometric_loss_roi)"),
                    "glue": "compiled PyTorch-ROCm extension moss_amd/lib/_moss_C.so over the C ABI of libmoss_raster.so",
                    **({"debug_bits": int(args.debug_bits)} if args.debug_bits else {})},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
