@@ -36,7 +36,9 @@ extern "C" {
  * follows the slimmer gradient-record layout.  No signature changed. */
 /* ABI 6 (round 6): MOSS_FORWARD_ONLY (a bit of the forward entry points' `debug` argument) + moss_raster_binning_bytes_forward_only;
  * moss_fused_adamw gained sh_active_degree / sh_inactive_zero and moss_adamw_flat_ex takes the same two per segment (degree-aware SH
- * traffic: coefficients above the highest degree ever active are never read or written when they are known to be zero). */
+ * traffic: coefficients above the highest degree ever active are never read or written when they are known to be zero);
+ * moss_photometric_loss_roi (MOSS's own loss expression: bound_mask selection, bounding-rectangle crop) and moss_adamw_multi (up to eight
+ * tensors with buffers of their own in one launch) are new entry points. */
 #define MOSS_ABI_VERSION 6
 /* Version 3 (round 4): EVERY forward / backward entry point takes the `debug` bit set (version 2: only moss_raster_forward /
  * moss_raster_backward did, so MOSS_DEBUG_NO_BLOCK_CULL was silently dropped on the _async / _tf / _raw paths: last argument before
